@@ -1,0 +1,45 @@
+// Error plumbing + library identity for libdv3hip.so.
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void dv3_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* dv3_last_error(void) { return g_err; }
+extern "C" int dv3_abi_version(void) { return DV3_ABI_VERSION; }
+
+extern "C" int dv3_device_info(int dev, char* name, int name_len, int* n_cu) {
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) {
+    dv3_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e));
+    return DV3_ELAUNCH;
+  }
+  if (name && name_len > 0) {
+    strncpy(name, prop.gcnArchName, (size_t)name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  return DV3_OK;
+}
+
+// sizeof of every descriptor struct, so the ctypes mirror can be checked at load time
+extern "C" int dv3_sizeof(const char* name) {
+#define DV3_SZ(T) if (!strcmp(name, #T)) return (int)sizeof(T)
+  DV3_SZ(dv3_conv_desc);
+  DV3_SZ(dv3_wgrad_desc);
+  DV3_SZ(dv3_wn_desc);
+  DV3_SZ(dv3_wn_bwd_desc);
+  DV3_SZ(dv3_gate_bwd_desc);
+  DV3_SZ(dv3_softmax_desc);
+  DV3_SZ(dv3_softmax_bwd_desc);
+  DV3_SZ(dv3_spec_loss_desc);
+#undef DV3_SZ
+  return -1;
+}

@@ -1,0 +1,310 @@
+// dv3_conv_gemm_f32: im2col-free dilated 1-D convolution as a tap-GEMM on the gfx950 fp32
+// matrix cores, with the Conv1dGLU / HighwayConv1d tail fused into the epilogue.
+//
+// Reference semantics: deepvoice3_pytorch/modules.py:145-164 (Conv1dGLU._forward),
+// :205-226 (HighwayConv1d._forward), conv.py:7-16 (nn.Conv1d), plus the 1x1 convs /
+// Linear / ConvTranspose1d / torch.bmm call sites listed in include/dv3hip.h.
+//
+// Design (see DESIGN.md "conv_gemm"):
+//   * one workgroup = WM x WN waves; each wave owns a 64(M) x NI*32(N) accumulator block:
+//     two 32-row M sub-tiles (the `a` rows and their gate rows, so GLU is lane-local) times
+//     NI 32-column time sub-tiles, v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+//   * K loop over input-channel chunks of BKC; per chunk the packed weight tile
+//     [J][BKC][BM] and ONE haloed input tile [BKC][BN+(J-1)*dil] are staged in LDS; the J
+//     taps read the same input tile at shifted columns (no im2col, input read once per chunk).
+//   * dropout is applied while staging x (keep-bits from dv3_dropout_bits), bias / speaker
+//     bias / gate / residual / sqrt(.5) / activation in the epilogue.
+//   * fragment reads are ds_read_b32 with lanes along the contiguous axis: conflict-free,
+//     and at the fp32 MFMA rate (64 cycles per instruction) LDS bandwidth is <15% used.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  dv3_conv_desc d;
+  int m_tiles, n_tiles, n_blocks;
+};
+
+template <int WM, int WN, int NI, int BKC>
+__global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_kernel(const ConvArgs args) {
+  constexpr int BM = WM * 64;   // rows staged per chunk (two halves of BMH)
+  constexpr int BMH = WM * 32;  // rows per half
+  constexpr int BN = WN * NI * 32;
+  constexpr int NW = WM * WN;
+  constexpr int NT = NW * 64;
+  const dv3_conv_desc& p = args.d;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int J = p.J, dil = p.dil;
+  const int BNH = BN + (J - 1) * dil;
+  float* As = smem;                 // [J][BKC][BM]
+  float* Xs = smem + J * BKC * BM;  // [BKC][BNH]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  // ---- tile coordinates (XCD-aware: m fastest so blocks sharing an x tile share an L2) ----
+  const int pid = dv3_xcd_remap(blockIdx.x, args.n_blocks);
+  const int mt = pid % args.m_tiles;
+  const int nt = (pid / args.m_tiles) % args.n_tiles;
+  const int b = pid / (args.m_tiles * args.n_tiles);
+  const int n0 = nt * BN;
+
+  const bool gated = (p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY);
+  // column bases of the two row-halves inside a packed weight row, and their valid limits
+  int h0b, h1b, lim0, lim1;
+  if (gated) {
+    h0b = mt * BMH;
+    h1b = p.a_half + mt * BMH;
+    lim0 = p.a_half;  // a_half = Cg rounded up to 4, zero padded
+    lim1 = p.lda;
+  } else {
+    h0b = mt * BM;
+    h1b = mt * BM + BMH;
+    lim0 = lim1 = p.lda;
+  }
+
+  const float* __restrict__ Ag = p.a + (int64_t)b * p.a_bs;
+  const float* __restrict__ Xg = p.x + (int64_t)b * p.x_bs;
+  const uint32_t* __restrict__ xmask = p.xmask;
+  const float dscale = p.drop_scale;
+
+  f32x16 acc[2][NI];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][ni][r] = 0.f;
+
+  const int Cin = p.Cin, Tin = p.Tin, lda = p.lda;
+  const int tg0 = n0 - p.padL;  // global time of staged column 0
+
+  for (int c0 = 0; c0 < Cin; c0 += BKC) {
+    // ---------------- stage packed weights: J*BKC rows x BM floats ----------------
+    for (int idx = tid; idx < J * BKC * (BM / 4); idx += NT) {
+      const int c4 = idx % (BM / 4);
+      const int row = idx / (BM / 4);  // j*BKC + kc
+      const int j = row / BKC, kc = row % BKC;
+      const int c = c0 + kc;
+      const int col = c4 * 4;
+      const bool hi = col >= BMH;
+      const int gcol = (hi ? h1b : h0b) + (col - (hi ? BMH : 0));
+      const int lim = hi ? lim1 : lim0;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < Cin && gcol < lim)
+        v = *reinterpret_cast<const f32x4*>(Ag + ((int64_t)j * Cin + c) * lda + gcol);
+      *reinterpret_cast<f32x4*>(As + row * BM + col) = v;
+    }
+    // ---------------- stage haloed input tile: BKC rows x BNH floats ----------------
+    for (int kc = wave; kc < BKC; kc += NW) {
+      const int c = c0 + kc;
+      const float* __restrict__ xrow = Xg + (int64_t)c * p.x_rs;
+      const int64_t mrow = ((int64_t)b * Cin + c) * p.xmask_rs;
+      for (int q = lane; q < BNH; q += 64) {
+        const int tg = tg0 + q;
+        float v = 0.f;
+        if (c < Cin && tg >= 0 && tg < Tin) {
+          v = xrow[tg];
+          if (xmask) {
+            const uint32_t w = xmask[mrow + (tg >> 5)];
+            v = ((w >> (tg & 31)) & 1u) ? v * dscale : 0.f;
+          }
+        }
+        Xs[kc * BNH + q] = v;
+      }
+    }
+    __syncthreads();
+
+    // ---------------- MFMA over taps x channel pairs ----------------
+    const float* a_base = As + wm * 32 + l31 + lhi * BM;
+    const float* x_base = Xs + wn * (NI * 32) + l31 + lhi * BNH;
+    for (int j = 0; j < J; ++j) {
+      const float* aj = a_base + j * (BKC * BM);
+      const float* xj = x_base + j * dil;
+#pragma unroll
+      for (int kk = 0; kk < BKC; kk += 2) {
+        const float a0 = aj[kk * BM];
+        const float a1 = aj[kk * BM + BMH];
+        float bv[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bv[ni] = xj[kk * BNH + ni * 32];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[ni], acc[0][ni], 0, 0, 0);
+          acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[ni], acc[1][ni], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int Tout = p.Tout, M = p.M, Cg = p.Cg;
+  const float rs2 = 0.70710678118654752440f;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+    if (n >= Tout) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float v0 = acc[0][ni][r], v1 = acc[1][ni][r];
+      if (gated) {
+        const int ch = mt * BMH + i;
+        if (ch >= Cg) continue;
+        float a = v0, g = v1;
+        if (p.bias) {
+          a += p.bias[ch];
+          g += p.bias[Cg + ch];
+        }
+        if (p.spk) a += p.spk[(int64_t)b * p.spk_bs + (int64_t)ch * p.spk_rs + (int64_t)n * p.spk_ts];
+        if (p.ab) {
+          float* abp = p.ab + ((int64_t)b * M + ch) * Tout + n;
+          abp[0] = a;
+          abp[(int64_t)Cg * Tout] = g;
+        }
+        const float s = 1.0f / (1.0f + expf(-g));
+        float y;
+        if (p.mode == DV3_EPI_GLU) {
+          y = a * s;
+          if (p.residual) y = (y + p.r[(int64_t)b * p.r_bs + (int64_t)ch * p.r_rs + n]) * rs2;
+        } else {
+          const float xr = p.r[(int64_t)b * p.r_bs + (int64_t)ch * p.r_rs + n];
+          y = s * a + (1.0f - s) * xr;
+        }
+        p.y[(int64_t)b * p.y_bs + (int64_t)ch * p.y_rs + n] = y;
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = mt * BM + h * BMH + i;
+          if (m >= M) continue;
+          float v = h ? v1 : v0;
+          if (p.mode == DV3_EPI_DGRAD) {
+            if (p.ymask) {
+              const uint32_t w = p.ymask[((int64_t)b * M + m) * p.ymask_rs + (n >> 5)];
+              v = ((w >> (n & 31)) & 1u) ? v * dscale : 0.f;
+            }
+            if (p.r) v += p.r[(int64_t)b * p.r_bs + (int64_t)m * p.r_rs + n];
+          } else {
+            if (p.bias) v += p.bias[(p.store_mode == DV3_STORE_INTERLEAVE2) ? (m % (M >> 1)) : m];
+            if (p.mode == DV3_EPI_RELU) v = fmaxf(v, 0.f);
+            else if (p.mode == DV3_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+          }
+          if (p.store_mode == DV3_STORE_INTERLEAVE2) {
+            const int Mo = M >> 1;
+            p.y[(int64_t)b * p.y_bs + (int64_t)(m % Mo) * p.y_rs + 2 * n + (m / Mo)] = v;
+          } else {
+            p.y[(int64_t)b * p.y_bs + (int64_t)m * p.y_rs + n] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+struct TileCfg {
+  int id, wm, wn, ni;
+};
+// id is what dv3_conv_desc.tile_hint selects.
+const TileCfg kCfgs[] = {
+    {1, 2, 2, 2},  // 128 x 128
+    {2, 2, 2, 1},  // 128 x 64
+    {3, 4, 1, 1},  // 256 x 32
+    {4, 2, 1, 1},  // 128 x 32
+    {5, 1, 2, 2},  // 64 x 128
+    {6, 1, 2, 1},  // 64 x 64
+};
+
+template <int WM, int WN, int NI>
+int launch_cfg(const ConvArgs& a, int bkc, size_t lds, hipStream_t st) {
+  dim3 grid(a.n_blocks), block(WM * WN * 64);
+  if (bkc == 16) {
+    hipLaunchKernelGGL((conv_gemm_f32_kernel<WM, WN, NI, 16>), grid, block, lds, st, a);
+  } else {
+    hipLaunchKernelGGL((conv_gemm_f32_kernel<WM, WN, NI, 8>), grid, block, lds, st, a);
+  }
+  return dv3_check_launch("conv_gemm_f32");
+}
+
+}  // namespace
+
+extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
+  DV3_REQUIRE(d && d->x && d->a && d->y, "conv_gemm: null pointer");
+  DV3_REQUIRE(d->B > 0 && d->Cin > 0 && d->Tin > 0 && d->M > 0 && d->Tout > 0, "conv_gemm: bad dims");
+  DV3_REQUIRE(d->J >= 1 && d->J <= 16 && d->dil >= 1, "conv_gemm: bad taps J=%d dil=%d", d->J, d->dil);
+  DV3_REQUIRE((d->lda & 3) == 0 && (d->a_half & 3) == 0, "conv_gemm: lda/a_half must be multiples of 4");
+  const bool gated = d->mode == DV3_EPI_GLU || d->mode == DV3_EPI_HIGHWAY;
+  if (gated) {
+    DV3_REQUIRE(d->M == 2 * d->Cg, "conv_gemm: gated mode needs M == 2*Cg");
+    DV3_REQUIRE(d->a_half >= d->Cg && d->lda >= d->a_half + d->Cg, "conv_gemm: bad a_half/lda");
+    DV3_REQUIRE(d->mode == DV3_EPI_GLU ? (!d->residual || d->r) : (d->r != nullptr),
+                "conv_gemm: residual/highway input missing");
+    DV3_REQUIRE(d->store_mode == DV3_STORE_BCT, "conv_gemm: gated mode stores BCT only");
+  } else {
+    DV3_REQUIRE(d->lda >= d->M, "conv_gemm: lda < M");
+    DV3_REQUIRE(d->mode >= DV3_EPI_LINEAR && d->mode <= DV3_EPI_DGRAD, "conv_gemm: bad mode");
+    if (d->store_mode == DV3_STORE_INTERLEAVE2) DV3_REQUIRE((d->M & 1) == 0, "interleave2 needs even M");
+  }
+  if (d->xmask) DV3_REQUIRE(d->xmask_rs * 32 >= d->Tin, "conv_gemm: xmask row stride too small");
+  if (d->ymask) DV3_REQUIRE(d->ymask_rs * 32 >= d->Tout, "conv_gemm: ymask row stride too small");
+
+  const int rows_half = gated ? d->Cg : 0;
+  // ---- pick a tile config: minimise padded work with a mild small-tile penalty ----
+  const TileCfg* best = nullptr;
+  double best_cost = 0;
+  for (const TileCfg& c : kCfgs) {
+    if (d->tile_hint && c.id != d->tile_hint) continue;
+    const int BM = c.wm * 64, BMH = c.wm * 32, BN = c.wn * c.ni * 32;
+    const int mt = gated ? dv3_cdiv(rows_half, BMH) : dv3_cdiv(d->M, BM);
+    const int ntl = dv3_cdiv(d->Tout, BN);
+    double work = (double)mt * BM * (double)ntl * BN;
+    double pen = 1.0;
+    if (BN == 64) pen *= 1.04;
+    if (BN == 32) pen *= 1.10;
+    if (BM == 64) pen *= 1.06;
+    // too few blocks to fill 256 CUs: prefer finer tiles
+    const double blocks = (double)mt * ntl * d->B;
+    if (blocks < 512) pen *= 1.0 + 0.25 * (512 - blocks) / 512;
+    const double cost = work * pen;
+    if (!best || cost < best_cost) {
+      best = &c;
+      best_cost = cost;
+    }
+  }
+  DV3_REQUIRE(best, "conv_gemm: unknown tile_hint %d", d->tile_hint);
+
+  ConvArgs a;
+  a.d = *d;
+  const int BM = best->wm * 64, BMH = best->wm * 32, BN = best->wn * best->ni * 32;
+  a.m_tiles = gated ? dv3_cdiv(rows_half, BMH) : dv3_cdiv(d->M, BM);
+  a.n_tiles = dv3_cdiv(d->Tout, BN);
+  const int64_t nb = (int64_t)a.m_tiles * a.n_tiles * d->B;
+  DV3_REQUIRE(nb < (1ll << 31), "conv_gemm: grid too large");
+  a.n_blocks = (int)nb;
+
+  const int BNH = BN + (d->J - 1) * d->dil;
+  int bkc = 16;
+  size_t lds = (size_t)(d->J * bkc * BM + bkc * BNH) * 4;
+  if (lds > 64 * 1024) {
+    bkc = 8;
+    lds = (size_t)(d->J * bkc * BM + bkc * BNH) * 4;
+  }
+  DV3_REQUIRE(lds <= 64 * 1024, "conv_gemm: LDS tile %zu B too large (J=%d dil=%d)", lds, d->J, d->dil);
+
+  hipStream_t st = (hipStream_t)stream;
+  switch (best->id) {
+    case 1: return launch_cfg<2, 2, 2>(a, bkc, lds, st);
+    case 2: return launch_cfg<2, 2, 1>(a, bkc, lds, st);
+    case 3: return launch_cfg<4, 1, 1>(a, bkc, lds, st);
+    case 4: return launch_cfg<2, 1, 1>(a, bkc, lds, st);
+    case 5: return launch_cfg<1, 2, 2>(a, bkc, lds, st);
+    case 6: return launch_cfg<1, 2, 1>(a, bkc, lds, st);
+  }
+  dv3_set_error("conv_gemm: unreachable");
+  return DV3_EINVAL;
+}

@@ -1,0 +1,352 @@
+// HBM-bound helpers around the tap-GEMMs: gate/activation backward, dropout keep-bits,
+// layout changes, embedding gather / dense grad, sinusoidal position encodings.
+// Reference call sites are cited per kernel.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Gate backward.  One wave per (b, channel) row, lanes along time (coalesced); row sums of the
+// pre-activation gradients are written per (b, row) for the deterministic bias / speaker-bias
+// reduction.  Autograd of modules.py:157-164 (GLU) and :224-226 (highway).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // b*C + ch
+  const int C = p.C, T = p.T;
+  if (row >= (int64_t)p.B * C) return;
+  const int b = (int)(row / C), ch = (int)(row % C);
+  const float* dy = p.dy + row * T;
+  float sa = 0.f, sg = 0.f;
+  if (p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY) {
+    const float* a = p.ab_or_y + ((int64_t)b * 2 * C + ch) * T;
+    const float* g = a + (int64_t)C * T;
+    float* da = p.dab + ((int64_t)b * 2 * C + ch) * T;
+    float* dg = da + (int64_t)C * T;
+    const float k = (p.mode == DV3_EPI_GLU && p.residual) ? 0.70710678118654752440f : 1.0f;
+    const float* x = p.x ? p.x + row * T : nullptr;
+    float* dres = p.dres ? p.dres + row * T : nullptr;
+    for (int t = lane; t < T; t += 64) {
+      const float d = dy[t] * k;
+      const float s = 1.0f / (1.0f + expf(-g[t]));
+      float va, vg;
+      if (p.mode == DV3_EPI_GLU) {
+        va = d * s;
+        vg = d * a[t] * s * (1.0f - s);
+        if (dres) dres[t] = d;
+      } else {
+        va = d * s;
+        vg = d * (a[t] - x[t]) * s * (1.0f - s);
+        if (dres) dres[t] = d * (1.0f - s);
+      }
+      da[t] = va;
+      dg[t] = vg;
+      sa += va;
+      sg += vg;
+    }
+    sa = dv3_wave_sum(sa);
+    sg = dv3_wave_sum(sg);
+    if (lane == 0 && p.bias_part) {
+      p.bias_part[(int64_t)b * 2 * C + ch] = sa;
+      p.bias_part[(int64_t)b * 2 * C + C + ch] = sg;
+    }
+  } else {
+    const float* y = p.ab_or_y ? p.ab_or_y + row * T : nullptr;
+    float* dpre = p.dab ? p.dab + row * T : nullptr;
+    for (int t = lane; t < T; t += 64) {
+      float d = dy[t];
+      if (p.mode == DV3_EPI_RELU) d = y[t] > 0.f ? d : 0.f;
+      else if (p.mode == DV3_EPI_SIGMOID) d = d * y[t] * (1.0f - y[t]);
+      if (dpre) dpre[t] = d;
+      sa += d;
+    }
+    sa = dv3_wave_sum(sa);
+    if (lane == 0 && p.bias_part) p.bias_part[row] = sa;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 keep-bit generator (replaces F.dropout's bernoulli_: modules.py:147,210).
+// One thread per 32-bit mask word = 4 Philox calls x 8 sixteen-bit uniforms.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict__ bits,
+                                                           int64_t n_words, uint32_t thr,
+                                                           uint64_t seed, uint64_t site) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  uint32_t word = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint64_t ci = (uint64_t)w * 4 + q;
+    uint32_t o[4];
+    philox4x32_10((uint32_t)ci, (uint32_t)(ci >> 32), (uint32_t)site, (uint32_t)(site >> 32),
+                  (uint32_t)seed, (uint32_t)(seed >> 32), o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t lo = o[e] & 0xFFFFu, hi = o[e] >> 16;
+      word |= (uint32_t)(lo >= thr) << (8 * q + 2 * e);
+      word |= (uint32_t)(hi >= thr) << (8 * q + 2 * e + 1);
+    }
+  }
+  bits[w] = word;
+}
+
+// ------------------------------------------------------------------------------------------
+// y[b][c][r] = alpha * x[b][r][c] (+ add[b][c][r]) -- BTC <-> BCT (deepvoice3.py:85,92,318,324,
+// 352-356: the reference's .transpose(1,2)[.contiguous()] calls).  32x32 LDS tile.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x,
+                                                        float* __restrict__ y,
+                                                        const float* __restrict__ add, int R, int C,
+                                                        float alpha) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* xb = x + (int64_t)b * R * C;
+  float* yb = y + (int64_t)b * R * C;
+  const float* ab = add ? add + (int64_t)b * R * C : nullptr;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < R && c < C) ? xb[(int64_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < C && r < R) {
+      float v = alpha * tile[tx][ty + 8 * k];
+      if (ab) v += ab[(int64_t)c * R + r];
+      yb[(int64_t)c * R + r] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a,
+                                                    const float* __restrict__ b,
+                                                    float* __restrict__ out, int64_t n, float alpha) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < n; i += stride) out[i] = alpha * (a[i] + (b ? b[i] : 0.f));
+}
+
+// dy [B][O][2T] -> out [B][2*O][T] with out[b][j*O+o][t] = dy[b][o][2t+j]
+// (operand of the ConvTranspose1d k2 s2 backward GEMMs; deepvoice3.py:519-520,527-528)
+__global__ __launch_bounds__(256) void deinterleave2_kernel(const float* __restrict__ dy,
+                                                            float* __restrict__ out, int O, int T,
+                                                            int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < n; i += stride) {  // i over [B][O][2T]
+    const int tt = (int)(i % (2 * T));
+    const int64_t bo = i / (2 * T);
+    const int o = (int)(bo % O);
+    const int64_t b = bo / O;
+    const int j = tt & 1, t = tt >> 1;
+    out[((b * 2 + j) * O + o) * (int64_t)T + t] = dy[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Embedding gather straight into BCT (+dropout): deepvoice3.py:74-75, nyanko.py:63.
+// block = 32 time steps x 32 channels through an LDS tile so both sides are coalesced.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embedding_bct_kernel(const int64_t* __restrict__ idx,
+                                                            const float* __restrict__ w,
+                                                            float* __restrict__ out,
+                                                            const uint32_t* __restrict__ mask,
+                                                            int mask_rs, float dscale, int T, int C,
+                                                            int n_vocab) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = t0 + ty + 8 * k, c = c0 + tx;
+    float v = 0.f;
+    if (t < T && c < C) {
+      int64_t id = idx[(int64_t)b * T + t];
+      id = id < 0 ? 0 : (id >= n_vocab ? n_vocab - 1 : id);
+      v = w[id * C + c];
+    }
+    tile[ty + 8 * k][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, t = t0 + tx;
+    if (c < C && t < T) {
+      float v = tile[tx][ty + 8 * k];
+      if (mask) v = dv3_keep(mask, (int64_t)b * C + c, mask_rs, t) ? v * dscale : 0.f;
+      out[((int64_t)b * C + c) * T + t] = v;
+    }
+  }
+}
+
+// Dense embedding gradient, deterministic: one block per (vocab id, 64-channel tile) scans the
+// index array; dW[v][c] = sum_{(b,t): idx==v} dout[b][c][t]*keep*scale.  padding_idx row = 0.
+__global__ __launch_bounds__(64) void embedding_bct_bwd_kernel(const int64_t* __restrict__ idx,
+                                                               const float* __restrict__ dout,
+                                                               float* __restrict__ dw,
+                                                               const uint32_t* __restrict__ mask,
+                                                               int mask_rs, float dscale, int B, int T,
+                                                               int C, int padding_idx) {
+  const int v = blockIdx.x;
+  const int c = blockIdx.y * 64 + threadIdx.x;
+  float s = 0.f;
+  if (v != padding_idx) {
+    for (int64_t bt = 0; bt < (int64_t)B * T; ++bt) {
+      if (idx[bt] != v) continue;  // wave-uniform branch
+      if (c < C) {
+        const int b = (int)(bt / T), t = (int)(bt % T);
+        float g = dout[((int64_t)b * C + c) * T + t];
+        if (mask) g = dv3_keep(mask, (int64_t)b * C + c, mask_rs, t) ? g * dscale : 0.f;
+        s += g;
+      }
+    }
+  }
+  if (c < C) dw[(int64_t)v * C + c] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// SinusoidalEncoding.forward (modules.py:30-64): gather the raw-angle table at `pos`, scale
+// by the (per-batch) rate w, sin on even / cos on odd channels, row 0 (padding) untouched.
+//   out[b][c][t] = base[b][c][t] + enc    (base may be NULL)      -- BCT output
+// table: [n_pos][C] fp32 (the module's .weight, in the reference's state_dict).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sincos_pos_kernel(const int64_t* __restrict__ pos,
+                                                         const float* __restrict__ table,
+                                                         const float* __restrict__ w, int w_per_batch,
+                                                         const float* __restrict__ base,
+                                                         float* __restrict__ out, int T, int C,
+                                                         int n_pos, int apply_sincos) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float rate = w ? w[w_per_batch ? b : 0] : 1.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = t0 + ty + 8 * k, c = c0 + tx;
+    float v = 0.f;
+    if (t < T && c < C) {
+      int64_t p = pos[(int64_t)b * T + t];
+      p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+      const float ang = rate * table[p * C + c];
+      if (!apply_sincos || p == 0) v = ang;
+      else v = (c & 1) ? cosf(ang) : sinf(ang);
+    }
+    tile[ty + 8 * k][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, t = t0 + tx;
+    if (c < C && t < T) {
+      const int64_t o = ((int64_t)b * C + c) * T + t;
+      out[o] = tile[tx][ty + 8 * k] + (base ? base[o] : 0.f);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
+  DV3_REQUIRE(d && d->dy, "gate_bwd: null dy");
+  DV3_REQUIRE(d->B > 0 && d->C > 0 && d->T > 0, "gate_bwd: bad dims");
+  const bool gated = d->mode == DV3_EPI_GLU || d->mode == DV3_EPI_HIGHWAY;
+  if (gated) {
+    DV3_REQUIRE(d->ab_or_y && d->dab, "gate_bwd: gated mode needs ab and dab");
+    DV3_REQUIRE(d->mode != DV3_EPI_HIGHWAY || d->x, "gate_bwd: highway needs x");
+  } else {
+    DV3_REQUIRE(d->mode == DV3_EPI_LINEAR || d->ab_or_y, "gate_bwd: activation mode needs y");
+  }
+  const int64_t rows = (int64_t)d->B * d->C;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)dv3_cdiv64(rows, 4)), dim3(256), 0,
+                     (hipStream_t)stream, *d);
+  return dv3_check_launch("gate_bwd_f32");
+}
+
+extern "C" int dv3_dropout_bits(uint32_t* bits, int64_t n_words, float p, uint64_t seed,
+                                uint64_t site, void* stream) {
+  DV3_REQUIRE(bits && n_words > 0, "dropout_bits: bad args");
+  DV3_REQUIRE(p >= 0.f && p < 1.f, "dropout_bits: p out of range");
+  uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
+  hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)dv3_cdiv64(n_words, 256)), dim3(256), 0,
+                     (hipStream_t)stream, bits, n_words, thr, seed, site);
+  return dv3_check_launch("dropout_bits");
+}
+
+extern "C" int dv3_transpose_f32(const float* x, float* y, const float* add, int32_t B, int32_t R,
+                                 int32_t C, float alpha, void* stream) {
+  DV3_REQUIRE(x && y && B > 0 && R > 0 && C > 0, "transpose: bad args");
+  hipLaunchKernelGGL(transpose_kernel, dim3(dv3_cdiv(C, 32), dv3_cdiv(R, 32), B), dim3(256), 0,
+                     (hipStream_t)stream, x, y, add, R, C, alpha);
+  return dv3_check_launch("transpose_f32");
+}
+
+extern "C" int dv3_axpby_f32(const float* a, const float* b, float* out, int64_t n, float alpha,
+                             void* stream) {
+  DV3_REQUIRE(a && out && n > 0, "axpby: bad args");
+  int64_t blocks = dv3_cdiv64(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b,
+                     out, n, alpha);
+  return dv3_check_launch("axpby_f32");
+}
+
+extern "C" int dv3_deinterleave2_f32(const float* dy, float* out, int32_t B, int32_t O, int32_t T,
+                                     void* stream) {
+  DV3_REQUIRE(dy && out && B > 0 && O > 0 && T > 0, "deinterleave2: bad args");
+  const int64_t n = (int64_t)B * O * 2 * T;
+  int64_t blocks = dv3_cdiv64(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(deinterleave2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     dy, out, O, T, n);
+  return dv3_check_launch("deinterleave2_f32");
+}
+
+extern "C" int dv3_embedding_bct_f32(const int64_t* idx, const float* w, float* out,
+                                     const uint32_t* mask, int32_t mask_rs, float drop_scale,
+                                     int32_t B, int32_t T, int32_t C, int32_t n_vocab, void* stream) {
+  DV3_REQUIRE(idx && w && out && B > 0 && T > 0 && C > 0 && n_vocab > 0, "embedding: bad args");
+  hipLaunchKernelGGL(embedding_bct_kernel, dim3(dv3_cdiv(C, 32), dv3_cdiv(T, 32), B), dim3(256), 0,
+                     (hipStream_t)stream, idx, w, out, mask, mask_rs, drop_scale, T, C, n_vocab);
+  return dv3_check_launch("embedding_bct_f32");
+}
+
+extern "C" int dv3_embedding_bct_bwd_f32(const int64_t* idx, const float* dout, float* dw,
+                                         const uint32_t* mask, int32_t mask_rs, float drop_scale,
+                                         int32_t B, int32_t T, int32_t C, int32_t n_vocab,
+                                         int32_t padding_idx, void* stream) {
+  DV3_REQUIRE(idx && dout && dw && B > 0 && T > 0 && C > 0 && n_vocab > 0, "embedding_bwd: bad args");
+  hipLaunchKernelGGL(embedding_bct_bwd_kernel, dim3(n_vocab, dv3_cdiv(C, 64)), dim3(64), 0,
+                     (hipStream_t)stream, idx, dout, dw, mask, mask_rs, drop_scale, B, T, C,
+                     padding_idx);
+  return dv3_check_launch("embedding_bct_bwd_f32");
+}
+
+extern "C" int dv3_sincos_pos_bct_f32(const int64_t* pos, const float* table, const float* w,
+                                      int32_t w_per_batch, const float* base, float* out, int32_t B,
+                                      int32_t T, int32_t C, int32_t n_pos, int32_t apply_sincos,
+                                      void* stream) {
+  DV3_REQUIRE(pos && table && out && B > 0 && T > 0 && C > 0 && n_pos > 0, "sincos_pos: bad args");
+  hipLaunchKernelGGL(sincos_pos_kernel, dim3(dv3_cdiv(C, 32), dv3_cdiv(T, 32), B), dim3(256), 0,
+                     (hipStream_t)stream, pos, table, w, w_per_batch, base, out, T, C, n_pos,
+                     apply_sincos);
+  return dv3_check_launch("sincos_pos_bct_f32");
+}

@@ -1,0 +1,228 @@
+// Fused loss value + gradient kernels for the reference train step
+// (train.py:261-291 sequence_mask/MaskedL1Loss, :537-582 logit/masked_mean/spec_loss,
+//  :585-601 guided_attention(s), :614,:714 BCELoss, :733-740 attention loss).
+// All are HBM-bound single passes: read prediction + target once, write the gradient once,
+// block partial sums -> deterministic second-stage reduce (no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int kLossBlock = 256;
+
+__device__ __forceinline__ void block_reduce4(float v[4], float* out /* [4] per block */) {
+  __shared__ float red[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = dv3_wave_sum(v[k]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[w][k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) out[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] +
+                                          red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// mask_sum as train.py:286-290 computes it: sum over the expanded (B, T-r, D) mask
+__device__ __forceinline__ float spec_mask_sum(const dv3_spec_loss_desc& p) {
+  float ms = 0.f;
+  const int Tr = p.T - p.r;
+  for (int b = 0; b < p.B; ++b) {
+    int l = p.lengths[b] - p.r;
+    l = l < 0 ? 0 : (l > Tr ? Tr : l);
+    ms += (float)l;
+  }
+  return ms * (float)p.D;
+}
+
+__global__ __launch_bounds__(kLossBlock) void spec_loss_kernel(const dv3_spec_loss_desc p) {
+  const int Tr = p.T - p.r, D = p.D;
+  const int64_t n = (int64_t)p.B * Tr * D;
+  const bool use_mask = p.w_masked > 0.f && p.lengths;
+  const float msum = use_mask ? spec_mask_sum(p) : 1.f;
+  const float inv_n = 1.0f / (float)n;
+  const float wm = use_mask ? p.w_masked : 0.f;
+  const float c_all = (1.f - wm) * inv_n, c_msk = use_mask ? wm / msum : 0.f;
+  const float eps = 1e-8f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // l1, l1 masked, z, z masked
+  const int64_t stride = (int64_t)gridDim.x * kLossBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kLossBlock + threadIdx.x; i < n; i += stride) {
+    const int dd = (int)(i % D);
+    const int64_t bt = i / D;
+    const int t = (int)(bt % Tr);
+    const int b = (int)(bt / Tr);
+    const int64_t ih = ((int64_t)b * p.T + t) * D + dd;          // y_hat[:, :-r]
+    const int64_t iy = ((int64_t)b * p.T + t + p.r) * D + dd;    // y[:, r:]
+    const float yh = p.y_hat[ih], y = p.y[iy];
+    const float m = (use_mask && (t + p.r) < p.lengths[b]) ? 1.f : 0.f;
+    const float diff = yh - y;
+    const float ad = fabsf(diff);
+    acc[0] += ad;
+    acc[1] += m * ad;
+    float dz = 0.f;
+    if (p.w_bd > 0.f) {
+      const float L = logf(yh + eps) - logf(1.f - yh + eps);
+      const float z = -y * L + log1pf(expf(L));
+      acc[2] += z;
+      acc[3] += m * z;
+      const float sig = 1.0f / (1.0f + expf(-L));
+      dz = (sig - y) * (1.0f / (yh + eps) + 1.0f / (1.f - yh + eps));
+    }
+    if (p.dyh) {
+      const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+      const float coef = c_all + c_msk * m;
+      p.dyh[ih] = p.gscale * coef * ((1.f - p.w_bd) * sgn + p.w_bd * dz);
+    }
+  }
+  block_reduce4(acc, p.scratch + (int64_t)blockIdx.x * 4);
+}
+
+// the last r frames of y_hat take no part in the loss: their gradient is zero
+__global__ __launch_bounds__(256) void spec_loss_tail_zero_kernel(const dv3_spec_loss_desc p) {
+  const int64_t n = (int64_t)p.B * p.r * p.D;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int dd = (int)(i % p.D);
+  const int64_t bt = i / p.D;
+  const int t = p.T - p.r + (int)(bt % p.r);
+  const int b = (int)(bt / p.r);
+  p.dyh[((int64_t)b * p.T + t) * p.D + dd] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void spec_loss_finish_kernel(const dv3_spec_loss_desc p,
+                                                               int n_blocks) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < n_blocks; i += 256)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += p.scratch[(int64_t)i * 4 + k];
+  __shared__ float fin[4];
+  block_reduce4(acc, fin);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool use_mask = p.w_masked > 0.f && p.lengths;
+    const float msum = use_mask ? spec_mask_sum(p) : 1.f;
+    const float n = (float)((int64_t)p.B * (p.T - p.r) * p.D);
+    const float wm = use_mask ? p.w_masked : 0.f;
+    const float l1 = wm * (use_mask ? fin[1] / msum : 0.f) + (1.f - wm) * fin[0] / n;
+    const float bd = p.w_bd > 0.f ? wm * (use_mask ? fin[3] / msum : 0.f) + (1.f - wm) * fin[2] / n : 0.f;
+    p.out4[0] = l1;
+    p.out4[1] = bd;
+    p.out4[2] = (1.f - p.w_bd) * l1 + p.w_bd * bd;
+    p.out4[3] = msum;
+  }
+}
+
+// ---- guided attention ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void guided_attn_kernel(const float* __restrict__ attn,
+                                                          const int32_t* __restrict__ in_len,
+                                                          const int32_t* __restrict__ out_len,
+                                                          float* __restrict__ dattn,
+                                                          float* __restrict__ scratch, int L, int B,
+                                                          int Tq, int Tk, float g, float gscale) {
+  const int64_t per = (int64_t)B * Tq * Tk, n = per * L;
+  const float inv_n = 1.0f / (float)n;
+  const double inv2g2 = 1.0 / (2.0 * (double)g * (double)g);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += stride) {
+    const int nk = (int)(i % Tk);
+    const int64_t bt = i / Tk;
+    const int t = (int)(bt % Tq), b = (int)(bt / Tq);
+    const int N = in_len[b], T = out_len[b];
+    float w = 0.f;
+    if (nk < N && t < T) {
+      // train.py:585-591 evaluates this in float64 and stores float32
+      const double dlt = (double)nk / (double)N - (double)t / (double)T;
+      w = (float)(1.0 - exp(-dlt * dlt * inv2g2));
+    }
+    for (int l = 0; l < L; ++l) {
+      acc[0] += attn[(int64_t)l * per + i] * w;
+      if (dattn) dattn[(int64_t)l * per + i] = gscale * w * inv_n;
+    }
+  }
+  block_reduce4(acc, scratch + (int64_t)blockIdx.x * 4);
+}
+
+__global__ __launch_bounds__(256) void sum_finish_kernel(const float* __restrict__ scratch,
+                                                         int n_blocks, float scale,
+                                                         float* __restrict__ out1) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < n_blocks; i += 256) acc[0] += scratch[(int64_t)i * 4];
+  __shared__ float fin[4];
+  block_reduce4(acc, fin);
+  __syncthreads();
+  if (threadIdx.x == 0) out1[0] = fin[0] * scale;
+}
+
+// ---- BCE (nn.BCELoss, mean; log clamped at -100 as torch does) ------------------------------
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p,
+                                                  const float* __restrict__ t,
+                                                  float* __restrict__ dp, float* __restrict__ scratch,
+                                                  int64_t n, float gscale) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float inv_n = 1.0f / (float)n;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float x = p[i], y = t[i];
+    const float lx = fmaxf(logf(x), -100.f), l1x = fmaxf(logf(1.f - x), -100.f);
+    acc[0] += -(y * lx + (1.f - y) * l1x);
+    if (dp) dp[i] = gscale * inv_n * (x - y) / fmaxf((1.f - x) * x, 1e-12f);
+  }
+  block_reduce4(acc, scratch + (int64_t)blockIdx.x * 4);
+}
+
+inline int loss_blocks(int64_t n) {
+  int64_t b = dv3_cdiv64(n, (int64_t)kLossBlock * 4);
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int dv3_spec_loss_scratch_floats(int32_t B, int32_t T, int32_t D) {
+  return 4 * loss_blocks((int64_t)B * T * D) + 16;
+}
+
+extern "C" int dv3_spec_loss_f32(const dv3_spec_loss_desc* d, void* stream) {
+  DV3_REQUIRE(d && d->y_hat && d->y && d->out4 && d->scratch, "spec_loss: null pointer");
+  DV3_REQUIRE(d->B > 0 && d->D > 0 && d->r >= 0 && d->T > d->r, "spec_loss: bad dims");
+  DV3_REQUIRE(d->w_masked <= 0.f || d->lengths, "spec_loss: masked weight needs lengths");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = (int64_t)d->B * (d->T - d->r) * d->D;
+  const int nb = loss_blocks(n);
+  hipLaunchKernelGGL(spec_loss_kernel, dim3(nb), dim3(kLossBlock), 0, st, *d);
+  if (d->dyh && d->r > 0) {
+    const int64_t nt = (int64_t)d->B * d->r * d->D;
+    hipLaunchKernelGGL(spec_loss_tail_zero_kernel, dim3((unsigned)dv3_cdiv64(nt, 256)), dim3(256), 0,
+                       st, *d);
+  }
+  hipLaunchKernelGGL(spec_loss_finish_kernel, dim3(1), dim3(256), 0, st, *d, nb);
+  return dv3_check_launch("spec_loss_f32");
+}
+
+extern "C" int dv3_guided_attn_loss_f32(const float* attn, const int32_t* in_len,
+                                        const int32_t* out_len, float* dattn, float* out1,
+                                        float* scratch, int32_t L, int32_t B, int32_t Tq, int32_t Tk,
+                                        float g, float gscale, void* stream) {
+  DV3_REQUIRE(attn && in_len && out_len && out1 && scratch, "guided_attn: null pointer");
+  DV3_REQUIRE(L > 0 && B > 0 && Tq > 0 && Tk > 0 && g > 0.f, "guided_attn: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t per = (int64_t)B * Tq * Tk;
+  const int nb = loss_blocks(per);
+  hipLaunchKernelGGL(guided_attn_kernel, dim3(nb), dim3(256), 0, st, attn, in_len, out_len, dattn,
+                     scratch, L, B, Tq, Tk, g, gscale);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, scratch, nb,
+                     1.0f / (float)(per * L), out1);
+  return dv3_check_launch("guided_attn_loss_f32");
+}
+
+extern "C" int dv3_bce_loss_f32(const float* p, const float* t, float* dp, float* out1,
+                                float* scratch, int64_t n, float gscale, void* stream) {
+  DV3_REQUIRE(p && t && out1 && scratch && n > 0, "bce_loss: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = loss_blocks(n);
+  hipLaunchKernelGGL(bce_kernel, dim3(nb), dim3(256), 0, st, p, t, dp, scratch, n, gscale);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, scratch, nb, 1.0f / (float)n, out1);
+  return dv3_check_launch("bce_loss_f32");
+}

@@ -1,0 +1,215 @@
+// Weight normalisation (nn.utils.weight_norm as applied by the reference factories,
+// deepvoice3_pytorch/modules.py:80-109) fused with packing into the operand layouts of the
+// tap-GEMM kernels, and its backward from the wgrad slabs.
+//
+//   w = g * v / ||v||   (norm over every dim but 0)
+//   Conv1d / Linear      v [O][I][J]  norm per output channel o
+//   ConvTranspose1d      v [I][O][J]  norm per INPUT channel i (dim 0 of its weight)
+#include "common.h"
+
+namespace {
+
+// scale[r] = 1/||v[r]||  (1 when g == NULL: plain weight).  One block per row.
+__global__ __launch_bounds__(256) void wn_inv_norm_kernel(const float* __restrict__ v,
+                                                          const float* __restrict__ g,
+                                                          float* __restrict__ scale, int len) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  if (!g) {
+    if (threadIdx.x == 0) scale[r] = 1.0f;
+    return;
+  }
+  const float* row = v + (int64_t)r * len;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < len; i += 256) {
+    const float x = row[i];
+    s += x * x;
+  }
+  s = dv3_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) scale[r] = 1.0f / sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+
+// Forward pack, Conv1d/Linear: fwd[j][i][col(o)] = g[o]*scale[o]*v[o][i][j]
+// block: 32 output channels x 32 input channels, all taps.  LDS tile [32 o][32*J + 1].
+__global__ __launch_bounds__(256) void wn_pack_fwd_kernel(const dv3_wn_desc p) {
+  extern __shared__ float tile[];  // [32][32*J+1]
+  const int O = p.O, I = p.I, J = p.J;
+  const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+  const int W = 32 * J, LD = W + 1;
+  // load: rows o, contiguous (i,j) span of 32*J floats starting at i0*J
+  for (int idx = threadIdx.x; idx < 32 * W; idx += 256) {
+    const int ol = idx / W, q = idx % W;
+    const int o = o0 + ol, i = i0 + q / J;
+    float val = 0.f;
+    if (o < O && i < I) {
+      const float sc = p.g ? p.g[o] * p.scale[o] : 1.0f;
+      val = sc * p.v[((int64_t)o * I + i0) * J + q];
+    }
+    tile[ol * LD + q] = val;
+  }
+  __syncthreads();
+  // store: for each (j, i): 32 consecutive o
+  for (int idx = threadIdx.x; idx < 32 * W; idx += 256) {
+    const int ol = idx & 31, q = idx >> 5;  // q = il*J + j
+    const int il = q / J, j = q % J;
+    const int o = o0 + ol, i = i0 + il;
+    if (o < O && i < I) {
+      int col = o;
+      if (p.glu_cg > 0 && o >= p.glu_cg) col = p.a_half + (o - p.glu_cg);
+      p.fwd_pack[((int64_t)j * I + i) * p.lda + col] = tile[ol * LD + q];
+    }
+  }
+}
+
+// Backward (DGRAD operand) pack, Conv1d/Linear: bwd[J-1-j][o][i] = g[o]*scale[o]*v[o][i][j]
+// one block per o; zero-fills the pad columns [I, ldb).
+__global__ __launch_bounds__(256) void wn_pack_bwd_kernel(const dv3_wn_desc p) {
+  const int o = blockIdx.x, I = p.I, J = p.J;
+  const float sc = p.g ? p.g[o] * p.scale[o] : 1.0f;
+  const float* row = p.v + (int64_t)o * I * J;
+  for (int idx = threadIdx.x; idx < p.ldb * J; idx += 256) {
+    const int j = idx / p.ldb, i = idx % p.ldb;
+    const float val = (i < I) ? sc * row[i * J + j] : 0.f;
+    p.bwd_pack[((int64_t)(J - 1 - j) * p.O + o) * p.ldb + i] = val;
+  }
+}
+
+// ConvTranspose1d (v [I][O][J]): one block per input channel i.
+//   fwd[0][i][j*O + o] = g[i]*scale[i]*v[i][o][j]            (K = I rows, M' = J*O cols)
+//   bwd[0][j*O + o][i] = same value                          (K' = J*O rows, m = i cols)
+__global__ __launch_bounds__(256) void wn_pack_transposed_kernel(const dv3_wn_desc p) {
+  const int i = blockIdx.x, O = p.O, J = p.J;
+  const float sc = p.g ? p.g[i] * p.scale[i] : 1.0f;
+  const float* row = p.v + (int64_t)i * O * J;
+  for (int idx = threadIdx.x; idx < p.lda; idx += 256) {
+    float val = 0.f;
+    if (idx < J * O) {
+      const int j = idx / O, o = idx % O;
+      val = sc * row[o * J + j];
+      if (p.bwd_pack) p.bwd_pack[(int64_t)idx * p.ldb + i] = val;
+    }
+    p.fwd_pack[(int64_t)i * p.lda + idx] = val;
+  }
+}
+
+__global__ void zero_kernel(float* p, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = 0.f;
+}
+
+// ---- backward ------------------------------------------------------------------------
+// one block per normalised row r (o, or i when transposed).  dW row gathered from the slabs
+// into LDS, dot with v, then dv / dg.
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const dv3_wn_bwd_desc p) {
+  extern __shared__ float dw[];  // [len]
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const int O = p.O, I = p.I, J = p.J;
+  const int len = p.transposed ? O * J : I * J;
+  const float* vrow = p.v + (int64_t)r * len;
+  float dot = 0.f;
+  for (int idx = threadIdx.x; idx < len; idx += 256) {
+    // element idx of row r <-> (i,j) [plain: idx = i*J + j] or (o,j) [transposed: idx = o*J + j]
+    int64_t off;
+    if (!p.transposed) {
+      const int i = idx / J, j = idx % J;
+      off = ((int64_t)j * O + r) * p.ldo + i;  // slab[j][o=r][i]
+    } else {
+      const int o = idx / J, j = idx % J;
+      off = ((int64_t)j * O + o) * p.ldo + r;  // slab[0][j*O+o][i=r]
+    }
+    float s = 0.f;
+    for (int k = 0; k < p.n_slabs; ++k) s += p.slabs[(int64_t)k * p.slab_ss + off];
+    dw[idx] = s;
+    dot += s * vrow[idx];
+  }
+  dot = dv3_wave_sum(dot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  dot = red[0] + red[1] + red[2] + red[3];
+  float* dvrow = p.dv + (int64_t)r * len;
+  if (p.g) {
+    const float sc = p.scale[r], gg = p.g[r];
+    const float dg = dot * sc;
+    if (threadIdx.x == 0) p.dg[r] = dg;
+    const float c1 = gg * sc, c2 = gg * sc * sc * dg;
+    for (int idx = threadIdx.x; idx < len; idx += 256) dvrow[idx] = c1 * dw[idx] - c2 * vrow[idx];
+  } else {
+    for (int idx = threadIdx.x; idx < len; idx += 256) dvrow[idx] = dw[idx];
+  }
+}
+
+// dbias[o] = sum_p part[p][o]
+__global__ void bias_reduce_kernel(const float* __restrict__ part, int n_part, int n,
+                                   float* __restrict__ out) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < n_part; ++k) s += part[(int64_t)k * n + o];
+  out[o] = s;
+}
+
+}  // namespace
+
+extern "C" int dv3_weight_norm_pack_f32(const dv3_wn_desc* d, void* stream) {
+  DV3_REQUIRE(d && d->v && d->scale && d->fwd_pack, "wn_pack: null pointer");
+  DV3_REQUIRE(d->O > 0 && d->I > 0 && d->J > 0, "wn_pack: bad dims");
+  DV3_REQUIRE((d->lda & 3) == 0, "wn_pack: lda must be a multiple of 4");
+  hipStream_t st = (hipStream_t)stream;
+  const dv3_wn_desc p = *d;
+  if (!d->transposed) {
+    DV3_REQUIRE(d->glu_cg == 0 || (2 * d->glu_cg == d->O && d->a_half >= d->glu_cg &&
+                                   d->lda >= d->a_half + d->glu_cg),
+                "wn_pack: bad GLU layout");
+    DV3_REQUIRE(d->glu_cg > 0 || d->lda >= d->O, "wn_pack: lda < O");
+    hipLaunchKernelGGL(wn_inv_norm_kernel, dim3(d->O), dim3(256), 0, st, d->v, d->g, d->scale,
+                       d->I * d->J);
+    // pads must be zero: clear the packed buffer when it has pad columns
+    const bool has_pad = d->glu_cg > 0 ? (d->a_half != d->glu_cg || d->lda != 2 * d->glu_cg)
+                                       : (d->lda != d->O);
+    if (has_pad) {
+      const int64_t n = (int64_t)d->J * d->I * d->lda;
+      hipLaunchKernelGGL(zero_kernel, dim3((unsigned)dv3_cdiv64(n, 256 * 8)), dim3(256), 0, st,
+                         d->fwd_pack, n);
+    }
+    const size_t lds = (size_t)32 * (32 * d->J + 1) * 4;
+    hipLaunchKernelGGL(wn_pack_fwd_kernel, dim3(dv3_cdiv(d->O, 32), dv3_cdiv(d->I, 32)), dim3(256),
+                       lds, st, p);
+    if (d->bwd_pack) {
+      DV3_REQUIRE((d->ldb & 3) == 0 && d->ldb >= d->I, "wn_pack: bad ldb");
+      hipLaunchKernelGGL(wn_pack_bwd_kernel, dim3(d->O), dim3(256), 0, st, p);
+    }
+  } else {
+    DV3_REQUIRE(d->lda >= d->J * d->O, "wn_pack(T): lda < J*O");
+    if (d->bwd_pack) DV3_REQUIRE((d->ldb & 3) == 0 && d->ldb >= d->I, "wn_pack(T): bad ldb");
+    hipLaunchKernelGGL(wn_inv_norm_kernel, dim3(d->I), dim3(256), 0, st, d->v, d->g, d->scale,
+                       d->O * d->J);
+    if (d->bwd_pack && d->ldb != d->I) {
+      const int64_t n = (int64_t)d->J * d->O * d->ldb;
+      hipLaunchKernelGGL(zero_kernel, dim3((unsigned)dv3_cdiv64(n, 256 * 8)), dim3(256), 0, st,
+                         d->bwd_pack, n);
+    }
+    hipLaunchKernelGGL(wn_pack_transposed_kernel, dim3(d->I), dim3(256), 0, st, p);
+  }
+  return dv3_check_launch("weight_norm_pack_f32");
+}
+
+extern "C" int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream) {
+  DV3_REQUIRE(d && d->slabs && d->v && d->dv, "wn_bwd: null pointer");
+  DV3_REQUIRE(!d->g || (d->scale && d->dg), "wn_bwd: g given without scale/dg");
+  DV3_REQUIRE(d->O > 0 && d->I > 0 && d->J > 0 && d->n_slabs > 0, "wn_bwd: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = d->transposed ? d->I : d->O;
+  const int len = d->transposed ? d->O * d->J : d->I * d->J;
+  const size_t lds = (size_t)len * 4;
+  DV3_REQUIRE(lds <= 64 * 1024, "wn_bwd: row too long (%d)", len);
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(rows), dim3(256), lds, st, *d);
+  if (d->bias_part && d->dbias) {
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3(dv3_cdiv(d->O, 256)), dim3(256), 0, st, d->bias_part,
+                       d->n_part, d->O, d->dbias);
+  }
+  return dv3_check_launch("weight_norm_bwd_f32");
+}

@@ -1,0 +1,270 @@
+/*
+ * dv3hip.h -- C ABI of the MI355X (gfx950) DeepVoice3 hot-path library (libdv3hip.so).
+ *
+ * The reference (r9y9/deepvoice3_pytorch) has no FFI: its hot path is stock torch ops
+ * called from Python modules.  This header is the boundary a maintainer would bind
+ * (ctypes) to replace those torch calls; every entry point cites
+ * the reference lines it stands in for (paths relative to the reference repo root).
+ *
+ * Conventions
+ *  - plain C: device pointers + sizes only, no torch types.  All tensors are fp32
+ *    unless a name says otherwise; "BCT" = (batch, channel, time), time contiguous --
+ *    the layout the reference conv stacks use (deepvoice3_pytorch/modules.py:139-164).
+ *  - every call enqueues on `stream` (a hipStream_t passed as void*), never syncs,
+ *    never allocates, never frees, retains no pointer after returning.
+ *  - return value: 0 on success, a negative DV3_E* code otherwise;
+ *    dv3_last_error() returns a thread-local message for the last failure.
+ *  - strides are in ELEMENTS.  "bs" = batch stride, "rs" = row (channel) stride.
+ */
+#ifndef DV3HIP_H
+#define DV3HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DV3_OK 0
+#define DV3_EINVAL (-1)   /* bad argument / unsupported shape */
+#define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
+
+/* ABI version, bumped on any struct change; checked by the Python loader. */
+#define DV3_ABI_VERSION 7
+int dv3_abi_version(void);
+const char* dv3_last_error(void);
+/* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
+int dv3_device_info(int dev, char* name, int name_len, int* n_cu);
+/* sizeof(struct <name>) or -1: lets a foreign-language mirror of the descriptors self-check */
+int dv3_sizeof(const char* name);
+
+/* ------------------------------------------------------------------------------------
+ * Epilogue modes of the tap-GEMM (dv3_conv_gemm_f32).
+ * ------------------------------------------------------------------------------------ */
+enum {
+  DV3_EPI_LINEAR = 0,  /* y = acc + bias                      1x1 Conv1d / Linear          */
+  DV3_EPI_RELU = 1,    /* y = relu(acc + bias)                Conv1d + nn.ReLU             */
+  DV3_EPI_SIGMOID = 2, /* y = sigmoid(acc + bias)             last 1x1 + torch.sigmoid     */
+  DV3_EPI_GLU = 3,     /* Conv1dGLU:  modules.py:157-164                                   */
+  DV3_EPI_HIGHWAY = 4, /* HighwayConv1d: modules.py:224-226                                */
+  DV3_EPI_DGRAD = 5    /* y = acc * dropmask(y-site) + addend   (input-gradient pass)      */
+};
+
+enum {
+  DV3_STORE_BCT = 0,       /* y[b][m][n]                                                   */
+  DV3_STORE_INTERLEAVE2 = 1 /* y[b][m % Mo][2n + m / Mo], Mo = M/2: ConvTranspose1d k2 s2  */
+};
+
+/*
+ * dv3_conv_gemm_f32 -- the hot kernel.  im2col-free dilated 1-D convolution as a tap-GEMM
+ * on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), with the whole Conv1dGLU / HighwayConv1d
+ * tail fused in the epilogue.
+ *
+ *   acc[b][m][n] = sum_{j<J} sum_{c<Cin} A[b][j][c][m] * xd[b][c][n + j*dil - padL]
+ *   xd = x * bit(xmask) * drop_scale      (bit==1 everywhere when xmask == NULL)
+ *
+ * Replaces, per mode (reference file:line):
+ *   GLU      F.dropout -> conv -> trim -> split -> (+softsign speaker bias) -> a*sigmoid(b)
+ *            -> (x+residual)*sqrt(.5)                   deepvoice3_pytorch/modules.py:145-164
+ *   HIGHWAY  same conv, T=sigmoid(b); T*a+(1-T)*x       deepvoice3_pytorch/modules.py:205-226
+ *   LINEAR/RELU/SIGMOID  1x1 convs and Linear layers    deepvoice3.py:51-54,65-67,227-229,
+ *            262-264,360-363,517,565-567,578,604; nyanko.py:29-31,96-100,133,149-156,365-398
+ *   INTERLEAVE2 store     nn.ConvTranspose1d(k=2,s=2)   deepvoice3.py:519-520,527-528
+ *   per-batch A (a_bs!=0) torch.bmm(q, keys)            deepvoice3.py:143
+ *   DGRAD    input gradient of all of the above (autograd of F.conv1d + F.dropout)
+ *
+ * A is the PACKED weight: [J][Cin][lda], m contiguous, produced by dv3_weight_norm_pack_f32.
+ * For GLU/HIGHWAY the m axis holds the `a` half in [0,Cg) and the gate half at [a_half,
+ * a_half+Cg); M must equal 2*Cg and the output has Cg channels.
+ */
+typedef struct dv3_conv_desc {
+  const float* x;  int64_t x_bs, x_rs;      /* input  [B][Cin][Tin]                         */
+  const float* a;  int64_t a_bs; int32_t lda; int32_t a_half; /* packed weights            */
+  const float* bias;                         /* [M] (reference order) or NULL               */
+  const float* spk; int64_t spk_bs, spk_rs, spk_ts; /* additive on the `a` half (GLU) or NULL */
+  const float* r;  int64_t r_bs, r_rs;       /* residual / highway input / DGRAD addend     */
+  float* y;        int64_t y_bs, y_rs;       /* output                                      */
+  float* ab;                                 /* optional save of pre-gate (a,b): [B][M][Tout] */
+  const uint32_t* xmask; int32_t xmask_rs;   /* dropout keep-bits over x rows [B*Cin][rs]   */
+  const uint32_t* ymask; int32_t ymask_rs;   /* DGRAD: keep-bits over y rows [B*M][rs]      */
+  float drop_scale;                          /* 1/(1-p)                                     */
+  int32_t B, Cin, Tin, M, Cg, Tout, J, dil, padL;
+  int32_t mode, residual, store_mode;
+  int32_t tile_hint;                         /* 0 = auto; else forces a tile config (tests) */
+} dv3_conv_desc;
+int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
+
+/*
+ * dv3_wgrad_gemm_f32 -- weight-gradient GEMM (autograd of F.conv1d w.r.t. weight; also
+ * torch.bmm(p, values) of deepvoice3.py:167 when used batched with J=1).
+ *
+ *   out[s][j][m][c] = sum_{b in slab s} sum_t g[b][m][t] * xd[b][c][t + j*dil - padL]
+ *
+ * slab s covers batches {s, s+S, s+2S, ...}; S = n_slabs (S == B gives a per-batch
+ * result, S == 1 a full reduction).  The slabs are summed by dv3_weight_norm_bwd_f32.
+ */
+typedef struct dv3_wgrad_desc {
+  const float* g;  int64_t g_bs, g_rs;       /* [B][M][T]                                    */
+  const float* x;  int64_t x_bs, x_rs;       /* [B][Cin][Tin]                                */
+  const uint32_t* xmask; int32_t xmask_rs;   /* dropout keep-bits over x rows, or NULL       */
+  float drop_scale;
+  float* out;      int64_t out_ss;           /* [S][J][M][ldo]; slab stride                  */
+  int32_t ldo;
+  int32_t B, M, Cin, T, Tin, J, dil, padL, n_slabs;
+} dv3_wgrad_desc;
+int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Weight normalisation (nn.utils.weight_norm, modules.py:85,100,109) + packing.
+ *   v: [O][I][J] (Conv1d/Linear, norm over (I,J) per o)   transposed==0
+ *   v: [I][O][J] (ConvTranspose1d, norm over (O,J) per i) transposed==1
+ * fwd_pack  [J'][K][lda]  operand of the forward tap-GEMM
+ * bwd_pack  [J'][K'][ldb] operand of the DGRAD tap-GEMM (transposed, taps reversed)
+ * scale     [O or I] = 1/||v||  (saved for backward; w = g*scale*v)
+ * For GLU layers (glu_cg > 0) fwd_pack puts the `a` half at [0,Cg) and the gate half at
+ * [a_half, a_half+Cg).
+ * ------------------------------------------------------------------------------------ */
+typedef struct dv3_wn_desc {
+  const float* v; const float* g;            /* g NULL => plain weight (no weight norm)     */
+  float* scale;
+  float* fwd_pack; int32_t lda; int32_t a_half;
+  float* bwd_pack; int32_t ldb;
+  int32_t O, I, J, transposed, glu_cg;
+} dv3_wn_desc;
+int dv3_weight_norm_pack_f32(const dv3_wn_desc* d, void* stream);
+
+/*
+ * Backward of weight norm from wgrad slabs: dW = sum_s slab[s]; dg, dv.
+ *   slabs: [S][J][M][ldo] as written by dv3_wgrad_gemm_f32 (M = O rows; c = I cols;
+ *   for transposed (ConvTranspose) layers M = J*O rows and the tap is folded in m).
+ *   bias_part: [P][O] partial bias sums (or NULL), reduced into dbias.
+ */
+typedef struct dv3_wn_bwd_desc {
+  const float* slabs; int64_t slab_ss; int32_t ldo; int32_t n_slabs;
+  const float* v; const float* g; const float* scale;
+  float* dv; float* dg;                      /* dg NULL when g NULL (plain weight: dv = dW) */
+  const float* bias_part; int32_t n_part; float* dbias;
+  int32_t O, I, J, transposed;
+} dv3_wn_bwd_desc;
+int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Gate / activation backward (autograd of modules.py:157-164, 224-226 and of ReLU/sigmoid).
+ *   mode GLU/HIGHWAY: in dy [B][Cg][T], ab [B][2Cg][T], x (highway input) ->
+ *        dab [B][2Cg][T], dres [B][Cg][T] (gradient flowing to the residual / highway
+ *        carry; NULL when residual==0), bias_part [B][2Cg] row sums of dab,
+ *        dspk [B][Cg] (row sums of d a, = bias_part's first half; written when non-NULL)
+ *   mode RELU/SIGMOID/LINEAR: in dy, y [B][M][T] -> dpre [B][M][T], bias_part [B][M]
+ * ------------------------------------------------------------------------------------ */
+typedef struct dv3_gate_bwd_desc {
+  const float* dy; const float* ab_or_y; const float* x;
+  float* dab; float* dres; float* bias_part;
+  int32_t B, C, T, mode, residual;
+} dv3_gate_bwd_desc;
+int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Dropout keep-bit generator (F.dropout's bernoulli_, modules.py:147,210; deepvoice3.py:
+ * 75,80,165,290,321).  Philox4x32-10, counter = (word index, site), key = seed.
+ * bits[w] bit i == 1  <=>  element 32*w+i of the row is kept; p quantised to 1/65536.
+ * ------------------------------------------------------------------------------------ */
+int dv3_dropout_bits(uint32_t* bits, int64_t n_words, float p, uint64_t seed,
+                     uint64_t site, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Attention (deepvoice3.py:132-176): masked softmax over the key axis + dropout.
+ *   s [B][Tq][Tk] scores (in place -> probabilities p, returned PRE-dropout as the
+ *   reference does, deepvoice3.py:163); pd (optional) = dropout(p) for the context GEMM.
+ *   key_len [B] (int32, use_memory_mask) or NULL; last_attended (device scalar) with
+ *   win_back/win_ahead: monotonic window [last-back, last+ahead) (deepvoice3.py:150-156).
+ * ------------------------------------------------------------------------------------ */
+typedef struct dv3_softmax_desc {
+  float* s; float* pd;
+  const int32_t* key_len;
+  const int32_t* last_attended;              /* device int32[1] or NULL (no window)        */
+  const uint32_t* mask; int32_t mask_rs; float drop_scale;
+  int32_t B, Tq, Tk, win_back, win_ahead;
+} dv3_softmax_desc;
+int dv3_attn_softmax_f32(const dv3_softmax_desc* d, void* stream);
+/* backward: ds = p * (dp_total - sum_k(dp_total*p)); dp_total = dpd*bit*scale + dp_direct */
+typedef struct dv3_softmax_bwd_desc {
+  const float* p; const float* dpd; const float* dp_direct; float* ds;
+  const uint32_t* mask; int32_t mask_rs; float drop_scale;
+  int32_t B, Tq, Tk;
+} dv3_softmax_bwd_desc;
+int dv3_attn_softmax_bwd_f32(const dv3_softmax_bwd_desc* d, void* stream);
+/* argmax over keys of one probability row -> last_attended (deepvoice3.py:445)          */
+int dv3_attn_argmax_i32(const float* p_row, int32_t Tk, int32_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Small layout / elementwise helpers.
+ * ------------------------------------------------------------------------------------ */
+/* y[b][c][r] = alpha * x[b][r][c] (+ beta_add[b][c][r] if non-NULL) : BTC <-> BCT      */
+int dv3_transpose_f32(const float* x, float* y, const float* add, int32_t B, int32_t R,
+                      int32_t C, float alpha, void* stream);
+/* out[i] = alpha * (a[i] + b[i]) ; b may be NULL                                       */
+int dv3_axpby_f32(const float* a, const float* b, float* out, int64_t n, float alpha,
+                  void* stream);
+/* Embedding gather into BCT with optional dropout: out[b][c][t] = W[idx[b][t]][c]
+ * (deepvoice3.py:74-75, nyanko.py:63).  Backward: dense scatter-add into dW.           */
+int dv3_embedding_bct_f32(const int64_t* idx, const float* w, float* out,
+                          const uint32_t* mask, int32_t mask_rs, float drop_scale,
+                          int32_t B, int32_t T, int32_t C, int32_t n_vocab, void* stream);
+int dv3_embedding_bct_bwd_f32(const int64_t* idx, const float* dout, float* dw,
+                              const uint32_t* mask, int32_t mask_rs, float drop_scale,
+                              int32_t B, int32_t T, int32_t C, int32_t n_vocab,
+                              int32_t padding_idx, void* stream);
+/* SinusoidalEncoding.forward (modules.py:30-64) at gathered positions only, BCT output:
+ * out[b][c][t] = base[b][c][t] + enc, enc = (pos==0 || !apply_sincos) ? w*table[pos][c]
+ *              : (c odd ? cos : sin)(w*table[pos][c]);  w = w[b] (w_per_batch) or w[0] or 1 */
+int dv3_sincos_pos_bct_f32(const int64_t* pos, const float* table, const float* w,
+                           int32_t w_per_batch, const float* base, float* out, int32_t B,
+                           int32_t T, int32_t C, int32_t n_pos, int32_t apply_sincos,
+                           void* stream);
+/* dy [B][O][2T] -> out[b][j*O+o][t] = dy[b][o][2t+j]: operand of the ConvTranspose1d(k2,s2)
+ * backward GEMMs (deepvoice3.py:519-520,527-528)                                          */
+int dv3_deinterleave2_f32(const float* dy, float* out, int32_t B, int32_t O, int32_t T,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Losses (train.py:261-291,537-601,704-740), fused value + gradient.
+ * ------------------------------------------------------------------------------------ */
+/* spec_loss on y_hat[:, :-r] vs y[:, r:]  (BTC tensors [B][T][D]).
+ *   loss = (1-wbd)*(wm*maskedL1 + (1-wm)*L1) + wbd*(wm*masked_mean(z) + (1-wm)*mean(z))
+ *   z = -y*logit(yh) + log1p(exp(logit(yh))), logit eps 1e-8 (train.py:537-582).
+ * out4 = {l1_loss, binary_div, total, mask_sum}; dyh gets d total / d y_hat * gscale.   */
+typedef struct dv3_spec_loss_desc {
+  const float* y_hat; const float* y; const int32_t* lengths; /* mask: t < lengths[b] (shifted by r) */
+  float* dyh; float* out4; float* scratch;  /* scratch: >= 4*n_blocks floats                */
+  int32_t B, T, D, r; float w_masked, w_bd, gscale;
+} dv3_spec_loss_desc;
+int dv3_spec_loss_f32(const dv3_spec_loss_desc* d, void* stream);
+int dv3_spec_loss_scratch_floats(int32_t B, int32_t T, int32_t D);
+
+/* guided attention (train.py:585-601,733-740): loss = mean(attn * W),
+ * W[b][t][n] = 1-exp(-(n/N_b - t/T_b)^2/(2 g^2)) inside (T_b,N_b), 0 outside.
+ * attn [L][B][Tq][Tk]; dattn (optional) = W/(L*B*Tq*Tk) * gscale                        */
+int dv3_guided_attn_loss_f32(const float* attn, const int32_t* in_len, const int32_t* out_len,
+                             float* dattn, float* out1, float* scratch, int32_t L, int32_t B,
+                             int32_t Tq, int32_t Tk, float g, float gscale, void* stream);
+/* BCELoss(done_hat, done) mean (train.py:614,714) + gradient                            */
+int dv3_bce_loss_f32(const float* p, const float* t, float* dp, float* out1, float* scratch,
+                     int64_t n, float gscale, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimiser tail (train.py:755-759): clip_grad_norm_ + Adam over ONE flat fp32 arena
+ * (all trainable parameters / gradients / moments are views into four flat buffers).
+ *   out2 = {||g||_2, ||g||_2^2};  hyper (device) = {lr, 1-beta1^t, sqrt(1-beta2^t)};
+ *   grad_prescale multiplies g first (1/world_size after a sum all-reduce).
+ * ------------------------------------------------------------------------------------ */
+int dv3_grad_sqnorm_f32(const float* g, int64_t n, float* partial, int32_t n_partial,
+                        float* out2, void* stream);
+int dv3_clip_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
+                      const float* grad_norm, float clip, const float* hyper, float beta1,
+                      float beta2, float eps, float weight_decay, float grad_prescale,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DV3HIP_H */

@@ -1,0 +1,276 @@
+# coding: utf-8
+"""Generate tests/golden/*.npz from the UNMODIFIED reference (build container only).
+
+    python -m oracle.make_golden            # rewrites tests/golden/
+
+TEST INFRASTRUCTURE ONLY.  Imports /root/reference through oracle/refimport.py, builds small
+models with fixed seeds, runs the reference's own forward / incremental decode / loss / train
+step on CPU, and stores inputs + state_dict + outputs.  tests/test_oracle_golden.py pins
+oracle/dv3_oracle.py against these files; the -m gpu tests pin the HIP path against the oracle
+and, through the same files, against the reference itself.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import refimport  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+# (name, builder, hyper-parameters).  Shapes are tiny so the fixtures stay small, but every
+# structural feature of the presets is present: k=3 dilations 1..27, downsample_step 4 with two
+# ConvTranspose1d, key/value projections, memory mask, multi-speaker softsign biases.
+MODELS = [
+    ("dv3_tiny", "deepvoice3", dict(
+        n_vocab=40, embed_dim=32, mel_dim=80, linear_dim=65, r=4, padding_idx=0, dropout=0.05,
+        kernel_size=5, encoder_channels=16, decoder_channels=32, converter_channels=32,
+        force_monotonic_attention=False, use_decoder_state_for_postnet_input=False)),
+    ("dv3_preset_like", "deepvoice3", dict(
+        n_vocab=40, embed_dim=24, mel_dim=20, linear_dim=33, r=1, downsample_step=4, padding_idx=0,
+        dropout=0.05, kernel_size=3, encoder_channels=48, decoder_channels=32,
+        converter_channels=32, query_position_rate=1.0, key_position_rate=1.385,
+        use_memory_mask=True, force_monotonic_attention=True,
+        use_decoder_state_for_postnet_input=True, key_projection=True, value_projection=True)),
+    ("dv3_multispeaker", "deepvoice3_multispeaker", dict(
+        n_vocab=40, embed_dim=24, mel_dim=20, linear_dim=33, r=1, downsample_step=4, padding_idx=0,
+        n_speakers=5, speaker_embed_dim=8, dropout=0.05, kernel_size=3, encoder_channels=48,
+        decoder_channels=32, converter_channels=32, query_position_rate=2.0,
+        key_position_rate=7.6, use_memory_mask=True, force_monotonic_attention=True,
+        use_decoder_state_for_postnet_input=True, max_positions=128,
+        speaker_embedding_weight_std=0.05)),
+    ("nyanko_tiny", "nyanko", dict(
+        n_vocab=40, embed_dim=16, mel_dim=20, linear_dim=33, r=1, downsample_step=4, padding_idx=0,
+        dropout=0.05, kernel_size=3, encoder_channels=32, decoder_channels=32,
+        converter_channels=32, use_memory_mask=True, force_monotonic_attention=True,
+        use_decoder_state_for_postnet_input=True, max_positions=128)),
+]
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def make_batch(rng, hp, B, Tt_max, Td, n_speakers=1):
+    """Random padded batch in the conventions of train.collate_fn (train.py:293-360)."""
+    r = hp.get("r", 4)
+    ds = hp.get("downsample_step", 1)
+    in_len = rng.randint(max(3, Tt_max // 2), Tt_max + 1, size=B)
+    in_len[0] = Tt_max
+    text = np.zeros((B, Tt_max), dtype=np.int64)
+    text_pos = np.zeros((B, Tt_max), dtype=np.int64)
+    for b in range(B):
+        text[b, :in_len[b]] = rng.randint(2, hp["n_vocab"], size=in_len[b])
+        text_pos[b, :in_len[b]] = np.arange(1, in_len[b] + 1)
+    mel = rng.rand(B, Td * r, hp["mel_dim"]).astype(np.float32)
+    frame_pos = np.tile(np.arange(1, Td + 1, dtype=np.int64)[None, :], (B, 1))
+    spk = rng.randint(0, n_speakers, size=B).astype(np.int64) if n_speakers > 1 else None
+    return dict(text=text, text_positions=text_pos, frame_positions=frame_pos, mel=mel,
+                input_lengths=in_len.astype(np.int64), speaker_ids=spk)
+
+
+def ref_forward(model, text, mel=None, speaker_ids=None, text_positions=None, frame_positions=None,
+                input_lengths=None):
+    """model(...) of the reference.  Under torch >= 2 the reference's own glue
+    (`mel_outputs.view(B, -1, mel_dim)`, __init__.py:83) raises for r > 1 because sigmoid now
+    preserves the transposed strides of its input; in that case the same glue is replayed here
+    with .reshape (identical values -- it is what older torch computed)."""
+    try:
+        return model(text, mel, speaker_ids=speaker_ids, text_positions=text_positions,
+                     frame_positions=frame_positions, input_lengths=input_lengths)
+    except RuntimeError as e:
+        if "view size is not compatible" not in str(e):
+            raise
+    B = text.size(0)
+    se = model.embed_speakers(speaker_ids) if speaker_ids is not None else None
+    mo, al, dn, st = model.seq2seq(text, mel, se, text_positions, frame_positions, input_lengths)
+    mo = mo.reshape(B, -1, model.mel_dim)
+    pin = st.reshape(B, mo.size(1), -1) if model.use_decoder_state_for_postnet_input else mo
+    return mo, model.postnet(pin, se), al, dn
+
+
+def gen_model(name, builder_name, hp):
+    pkg = refimport.load_model_package()
+    from deepvoice3_pytorch import builder
+    torch.manual_seed(1234)
+    model = getattr(builder, builder_name)(**hp)
+    # make biases / speaker tables non-trivial so a swapped or dropped bias cannot pass
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith(".bias"):
+                p.uniform_(-0.1, 0.1)
+            if n.endswith("weight_g"):
+                p.mul_(torch.empty_like(p).uniform_(0.8, 1.2))
+    model.eval()
+    rng = np.random.RandomState(7)
+    nspk = hp.get("n_speakers", 1)
+    B, Tt, Td = 3, 13, 9
+    batch = make_batch(rng, hp, B, Tt, Td, nspk)
+    out = {"hp": json.dumps(hp), "builder": builder_name}
+    sd = {k: _np(v) for k, v in model.state_dict().items()}
+    for k, v in sd.items():
+        out["sd/" + k] = v
+    for k, v in batch.items():
+        if v is not None:
+            out["in/" + k] = v
+    text = torch.from_numpy(batch["text"])
+    mel = torch.from_numpy(batch["mel"])
+    tp = torch.from_numpy(batch["text_positions"])
+    fp = torch.from_numpy(batch["frame_positions"])
+    spk = torch.from_numpy(batch["speaker_ids"]) if nspk > 1 else None
+    with torch.no_grad():
+        mo, lo, al, dn = ref_forward(model, text, mel, speaker_ids=spk, text_positions=tp,
+                                     frame_positions=fp, input_lengths=batch["input_lengths"])
+    out.update({"out/mel": _np(mo), "out/linear": _np(lo), "out/alignments": _np(al),
+                "out/done": _np(dn)})
+    # encoder outputs (intermediate pin)
+    with torch.no_grad():
+        se = model.embed_speakers(spk) if nspk > 1 else None
+        keys, values = model.seq2seq.encoder(text, lengths=batch["input_lengths"], speaker_embed=se)
+    out.update({"out/enc_keys": _np(keys), "out/enc_values": _np(values)})
+    # incremental decode, teacher forced (tests/test_deepvoice3.py:184-235 logic)
+    dec = model.seq2seq.decoder
+    r = hp.get("r", 4)
+    if nspk > 1:
+        # the reference's multi-speaker incremental path only works for B == 1: with B > 1
+        # `a + softsign(speaker_proj(speaker_embed))` broadcasts (B,1,C)+(B,C) -> (B,B,C)
+        # (modules.py:158-162 with the 2-D speaker_embed of deepvoice3.py:417).  Use item 0.
+        B = 1
+        text, mel, tp, fp, spk = text[:1], mel[:1], tp[:1], fp[:1], spk[:1]
+        keys, values, se = keys[:1], values[:1], se[:1]
+    out["inc_batch"] = np.int64(B)
+    mel_r = mel.view(B, mel.size(1) // r, -1)
+    with torch.no_grad():
+        dec.start_fresh_sequence()
+        if builder_name == "nyanko":
+            io, ia, idn, ist = dec.incremental_forward((keys, values), tp, test_inputs=mel_r)
+        else:
+            io, ia, idn, ist = dec.incremental_forward((keys, values), tp, speaker_embed=se,
+                                                       test_inputs=mel_r)
+    out.update({"inc_tf/mel": _np(io), "inc_tf/alignments": _np(ia), "inc_tf/states": _np(ist),
+                "inc_tf/done": _np(torch.stack(idn))})
+    # free-running generation with a fixed number of steps (issue38 path)
+    dec.max_decoder_steps = 12
+    dec.min_decoder_steps = 12
+    with torch.no_grad():
+        g_mo, g_lo, g_al, g_dn = ref_forward(model, text, speaker_ids=spk, text_positions=tp)
+        g_mo2, _, _, _ = ref_forward(model, text, speaker_ids=spk, text_positions=tp)
+    assert (g_mo == g_mo2).all()
+    out.update({"gen/mel": _np(g_mo), "gen/linear": _np(g_lo), "gen/alignments": _np(g_al),
+                "gen/done": _np(torch.stack(g_dn))})
+    np.savez_compressed(os.path.join(OUT, "model_%s.npz" % name), **out)
+    print("wrote model_%s.npz: %d tensors, mel %s linear %s" % (name, len(sd), tuple(mo.shape), tuple(lo.shape)))
+
+
+def gen_losses():
+    train, hparams, _ = refimport.load_train_module()
+    rng = np.random.RandomState(3)
+    B, T, D, r = 3, 11, 7, 1
+    y_hat = torch.from_numpy(rng.uniform(0.02, 0.98, size=(B, T, D)).astype(np.float32))
+    y = torch.from_numpy(rng.rand(B, T, D).astype(np.float32))
+    lengths = torch.tensor([11, 7, 4]).long()
+    mask = train.sequence_mask(lengths, max_len=T).unsqueeze(-1)[:, r:, :]
+    out = {}
+    for wm, wbd in [(0.5, 0.1), (0.0, 0.1), (0.5, 0.0)]:
+        hparams.masked_loss_weight = wm
+        hparams.binary_divergence_weight = wbd
+        yh = y_hat.clone().requires_grad_(True)
+        l1, bd = train.spec_loss(yh[:, :-r, :], y[:, r:, :], mask if wm > 0 else None)
+        total = (1 - wbd) * l1 + wbd * bd
+        total.sum().backward()
+        tag = "spec_wm%g_wbd%g" % (wm, wbd)
+        out[tag + "/l1"] = _np(l1)
+        out[tag + "/bd"] = _np(bd.reshape(-1)[0])
+        out[tag + "/grad"] = _np(yh.grad)
+    out.update({"spec/y_hat": _np(y_hat), "spec/y": _np(y), "spec/lengths": _np(lengths)})
+    hparams.masked_loss_weight = 0.5
+    hparams.binary_divergence_weight = 0.1
+    il, tl = np.array([9, 5, 7]), np.array([12, 8, 3])
+    for g in (0.2, 0.4):
+        out["guided_g%g" % g] = train.guided_attentions(il, tl, 12, g=g)
+    out["guided/in_len"], out["guided/out_len"] = il, tl
+    p = torch.from_numpy(rng.uniform(0.01, 0.99, size=(4, 6, 1)).astype(np.float32)).requires_grad_(True)
+    t = torch.from_numpy((rng.rand(4, 6, 1) > 0.5).astype(np.float32))
+    l = torch.nn.BCELoss()(p, t)
+    l.backward()
+    out.update({"bce/p": _np(p), "bce/t": _np(t), "bce/loss": _np(l), "bce/grad": _np(p.grad)})
+    for step in (0, 10, 3999, 4000, 100000):
+        out["noam/%d" % step] = np.float64(__import__("lrschedule").noam_learning_rate_decay(5e-4, step))
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
+    print("wrote losses.npz")
+
+
+def gen_trainstep():
+    """Two steps of the reference's own train.train() on CPU with dropout=0 (deterministic)."""
+    train, hparams, Writer = refimport.load_train_module()
+    import deepvoice3_pytorch.frontend as fe
+    hparams.parse_json(open(os.path.join(refimport.REF_ROOT, "presets", "deepvoice3_ljspeech.json")).read())
+    hp_over = dict(dropout=0.0, text_embed_dim=24, encoder_channels=48, decoder_channels=32,
+                   converter_channels=32, num_mels=20, fft_size=64, batch_size=3, max_positions=128)
+    for k, v in hp_over.items():
+        setattr(hparams, k, v)
+    train._frontend = fe.en
+    torch.manual_seed(4321)
+    model = train.build_model()
+    sd0 = {k: _np(v).copy() for k, v in model.state_dict().items()}
+    rng = np.random.RandomState(11)
+    items = []
+    for n_frames, n_text in [(37, 9), (52, 13), (44, 11)]:
+        text = np.concatenate([rng.randint(2, 149, size=n_text - 1), [1]]).astype(np.int32)
+        items.append((text, rng.rand(n_frames, 20).astype(np.float32),
+                      rng.rand(n_frames, 33).astype(np.float32)))
+    batch = train.collate_fn(items)
+    optimizer = torch.optim.Adam(model.get_trainable_parameters(), lr=hparams.initial_learning_rate,
+                                 betas=(hparams.adam_beta1, hparams.adam_beta2), eps=hparams.adam_eps,
+                                 weight_decay=hparams.weight_decay, amsgrad=hparams.amsgrad)
+    writer = Writer()
+    # start at the top of the Noam warm-up so the two Adam updates are well above fp32 noise
+    train.global_step, train.global_epoch = 3999, 0
+    train.train(torch.device("cpu"), model, [batch, batch], optimizer, writer,
+                init_lr=hparams.initial_learning_rate, checkpoint_dir="/tmp",
+                checkpoint_interval=10 ** 9, nepochs=1, clip_thresh=hparams.clip_thresh)
+    out = {"hp_over": json.dumps(hp_over), "global_step0": np.int64(3999)}
+    for k, v in sd0.items():
+        out["sd0/" + k] = v
+    for k, v in model.state_dict().items():
+        out["sd2/" + k] = _np(v)
+    x, in_len, mel, y, (tp, fp), done, tgt_len, _ = batch
+    out.update({"in/text": _np(x), "in/input_lengths": _np(in_len), "in/mel": _np(mel), "in/y": _np(y),
+                "in/text_positions": _np(tp), "in/frame_positions": _np(fp), "in/done": _np(done),
+                "in/target_lengths": _np(tgt_len)})
+    for k, v in writer.scalars.items():
+        out["scalar/" + k.replace(" ", "_")] = np.array([s[1] for s in v], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "trainstep.npz"), **out)
+    print("wrote trainstep.npz; scalars:", {k: [round(s[1], 6) for s in v] for k, v in writer.scalars.items()})
+
+
+def gen_misc():
+    pkg = refimport.load_model_package()
+    from deepvoice3_pytorch.modules import position_encoding_init, SinusoidalEncoding
+    out = {"pe/table_r1.0": _np(position_encoding_init(64, 24, position_rate=1.0)),
+           "pe/table_r1.385": _np(position_encoding_init(64, 24, position_rate=1.385)),
+           "pe/raw": _np(position_encoding_init(64, 24, position_rate=1.0, sinusoidal=False))}
+    se = SinusoidalEncoding(64, 24)
+    pos = torch.tensor([[1, 2, 3, 0], [5, 60, 7, 8]]).long()
+    out["pe/pos"] = _np(pos)
+    out["pe/enc_w1.385"] = _np(se(pos, 1.385))
+    out["pe/enc_wvec"] = _np(se(pos, torch.tensor([0.7, 2.3])))
+    np.savez_compressed(os.path.join(OUT, "misc.npz"), **out)
+    print("wrote misc.npz")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name, b, hp in MODELS:
+        gen_model(name, b, hp)
+    gen_losses()
+    gen_misc()
+    gen_trainstep()
+
+
+if __name__ == "__main__":
+    main()
