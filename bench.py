@@ -1,0 +1,266 @@
+# coding: utf-8
+"""bench.py -- mel-frames/sec/node of the DeepVoice3 training step on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full optimisation step (forward + losses + backward + [all-reduce] + clip + Adam,
+train.py:604-785) of builder=deepvoice3 preset=deepvoice3_ljspeech, fp32, on a synthetic
+LJSpeech-shaped batch resident in HBM.  value = sum over ranks of un-padded target frames per
+step / wall time per step (max over ranks).  Prints ONE JSON line on rank 0 with two extra
+objects:
+  roofline      the dominant kernel (conv_gemm_f32, Conv1dGLU forward at the north-star shape
+                B=64 x 256ch x 1024T, k=3) timed with HIP events on its launch stream;
+                bound "mfma": algorithmic FLOPs / time vs the fp32 matrix peak (157.3 TF);
+                hbm_frac reports the same launch against the 8 TB/s HBM roof for the record.
+  cpu_baseline  the CPU oracle port of the same train step (oracle/dv3_oracle.py: the reference's
+                own torch-CPU ops) on this host's cores, a bounded sample of the same workload.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# presets/deepvoice3_ljspeech.json of the reference, as train.build_model() forwards it
+# (train.py:812-840: key_position_rate / query_position_rate / embedding_weight_std are NOT
+# forwarded, so the builder defaults apply).
+DV3_LJ = dict(n_vocab=149, embed_dim=256, mel_dim=80, linear_dim=513, r=1, downsample_step=4,
+              n_speakers=1, speaker_embed_dim=16, padding_idx=0, dropout=1 - 0.95, kernel_size=3,
+              encoder_channels=512, decoder_channels=256, converter_channels=256, use_memory_mask=True,
+              trainable_positional_encodings=False, force_monotonic_attention=True,
+              use_decoder_state_for_postnet_input=True, max_positions=512,
+              speaker_embedding_weight_std=0.01, freeze_embedding=False, window_ahead=3,
+              window_backward=1, key_projection=True, value_projection=True)
+PEAK_F32_MFMA_TF = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak (= vector peak)
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_batch(rng, B, Tt, n_frames, hp, fixed=True):
+    """Synthetic LJSpeech-shaped items padded exactly as train.collate_fn does (train.py:293-360):
+    target length rounded up to r and downsample_step, plus b_pad*downsample_step leading frames."""
+    r, ds = hp["r"], hp["downsample_step"]
+    if fixed:
+        text_lens = np.full(B, Tt)
+        frame_lens = np.full(B, n_frames)
+    else:
+        text_lens = np.clip(rng.normal(100, 30, B), 20, 187).astype(np.int64)
+        frame_lens = np.clip(rng.normal(566, 180, B), 120, 870).astype(np.int64)
+    max_in = int(text_lens.max())
+    max_t = int(frame_lens.max())
+    if max_t % r:
+        max_t += r - max_t % r
+    if max_t % ds:
+        max_t += ds - max_t % ds
+    b_pad = r
+    max_t += b_pad * ds
+    text = np.zeros((B, max_in), dtype=np.int64)
+    tpos = np.zeros((B, max_in), dtype=np.int64)
+    mel = np.zeros((B, max_t, hp["mel_dim"]), dtype=np.float32)
+    y = np.zeros((B, max_t, hp["linear_dim"]), dtype=np.float32)
+    Td = max_t // r // ds
+    done = np.ones((B, Td, 1), dtype=np.float32)
+    for b in range(B):
+        L, n = int(text_lens[b]), int(frame_lens[b])
+        text[b, :L - 1] = rng.randint(2, hp["n_vocab"], L - 1)
+        text[b, L - 1] = 1
+        tpos[b, :L] = np.arange(1, L + 1)
+        mel[b, b_pad:b_pad + n] = rng.rand(n, hp["mel_dim"])
+        y[b, b_pad:b_pad + n] = rng.rand(n, hp["linear_dim"])
+        done[b, :n // r // ds - 1] = 0
+    fpos = np.tile(np.arange(1, Td + 1, dtype=np.int64)[None], (B, 1))
+    return dict(text=torch.from_numpy(text), input_lengths=text_lens, mel=torch.from_numpy(mel),
+                y=torch.from_numpy(y), text_positions=torch.from_numpy(tpos),
+                frame_positions=torch.from_numpy(fpos), done=torch.from_numpy(done),
+                target_lengths=frame_lens)
+
+
+def conv_roofline(dev, iters=30):
+    """Conv1dGLU forward at the north-star shape, one conv_gemm_f32 launch per iteration, timed with
+    HIP events on the stream it is launched on."""
+    from deepvoice3_pytorch_amd import ops
+    B, C, T, k, d = 64, 256, 1024, 3, 1
+    torch.manual_seed(0)
+    x = torch.randn(B, C, T, device=dev)
+    v = torch.randn(2 * C, C, k, device=dev) * math.sqrt(4.0 * 0.95 / (k * C))
+    g = v.reshape(2 * C, -1).norm(dim=1).view(-1, 1, 1).clone()
+    bias = torch.zeros(2 * C, device=dev)
+    pk = ops.pack_weights(v, g, glu_cg=C, need_bwd=False)
+    y = torch.empty(B, C, T, device=dev)
+
+    def launch():
+        ops.conv_gemm(x, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
+                      padL=(k - 1) // 2 * d, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x, residual=1, y=y)
+    for _ in range(5):
+        launch()
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(iters):
+        launch()
+    e1.record(s)
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    flops = 2.0 * B * T * (2 * C) * (k * C)                     # 51.54 GFLOP
+    byts = 4.0 * (B * C * T * 2 + 2 * C * C * k + 2 * C)         # x + y + weights + bias: 135.8 MB
+    tf = flops / (us * 1e-6) / 1e12
+    return dict(bound="mfma", kernel="conv_gemm_f32_kernel<2,2,2,16> (Conv1dGLU fwd B=64 C=256 T=1024 k=3)",
+                achieved=round(tf, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=round(tf / PEAK_F32_MFMA_TF, 4),
+                traffic=None, us_per_launch=round(us, 2), alg_flops=flops, alg_bytes=byts,
+                hbm_gbs=round(byts / (us * 1e-6) / 1e9, 1),
+                hbm_frac=round(byts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4))
+
+
+def cpu_baseline(B, Tt, n_frames, max_seconds=25.0):
+    """The oracle port of the reference train step on the host cores (bounded sample)."""
+    from oracle import dv3_oracle as O
+    hp = dict(DV3_LJ)
+    spec = O.build_spec("deepvoice3", **hp)
+    from deepvoice3_pytorch_amd import builder
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in builder.deepvoice3(**hp).state_dict().items()}
+    frozen = ("seq2seq.decoder.embed_query_positions.weight", "seq2seq.decoder.embed_keys_positions.weight")
+    names = [k for k in sd if k not in frozen]
+    for k in names:
+        sd[k].requires_grad_(True)
+    m = {k: torch.zeros_like(sd[k]) for k in names}
+    v = {k: torch.zeros_like(sd[k]) for k in names}
+    rng = np.random.RandomState(1234)
+    bt = synth_batch(rng, B, Tt, n_frames, hp)
+    mel = bt["mel"][:, 0::4, :].contiguous()
+    lhp = dict(outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5, binary_divergence_weight=0.1,
+               use_guided_attention=True, guided_attention_sigma=0.2)
+    g = torch.Generator().manual_seed(0)
+
+    def drop(site, t, p, layout):     # F.dropout stand-in with the same cost profile (bernoulli_ + mul)
+        return torch.nn.functional.dropout(t, p, True)
+
+    def one(it):
+        for k in names:
+            sd[k].grad = None
+        out = O.model_forward(sd, spec, bt["text"], mel, None, bt["text_positions"], bt["frame_positions"],
+                              bt["input_lengths"], drop=drop)
+        loss, _ = O.train_losses(spec, lhp, out, mel, bt["y"], bt["done"], bt["input_lengths"], bt["target_lengths"])
+        loss.backward()
+        with torch.no_grad():
+            O.clip_and_adam([sd[k] for k in names], [sd[k].grad for k in names], [m[k] for k in names],
+                            [v[k] for k in names], it + 1, 5e-4)
+    one(0)
+    t0 = time.time()
+    n = 0
+    while n < 20 and (time.time() - t0) < max_seconds:
+        one(n + 1)
+        n += 1
+    dt = (time.time() - t0) / n
+    frames = float(bt["target_lengths"].sum())
+    return dict(value=round(frames / dt, 1), unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d train steps of the same workload (B=%d, Tt=%d, %d frames/item) through "
+                       "oracle/dv3_oracle.py on the host, %.2f s/step" % (n, B, Tt, n_frames, dt),
+                host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (preset batch_size = 16)")
+    ap.add_argument("--text-len", type=int, default=150)
+    ap.add_argument("--frames", type=int, default=800)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "conv"])
+    args = ap.parse_args()
+
+    from deepvoice3_pytorch_amd import builder, train_step, dist as dv3dist
+    pg, rank, world, local_rank = dv3dist.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torchrun for --gpus > 1"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    if args.mode == "conv":
+        rf = conv_roofline(dev, iters=max(args.steps, 10))
+        print(json.dumps(dict(metric="conv1dglu_fwd_tflops", value=rf["achieved"], unit="TFLOP/s", n_gpus=1,
+                              steps=args.steps, warmup=5, ms_per_step=rf["us_per_launch"] / 1e3,
+                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                              data="synthetic", config=dict(workload="Conv1dGLU fwd B=64 C=256 T=1024 k=3"),
+                              roofline=rf)))
+        return
+
+    hp = dict(DV3_LJ)
+    torch.manual_seed(0)            # identical initial weights on every rank
+    model = builder.deepvoice3(**hp).to(dev)
+    cfg = train_step.TrainConfig(max_positions=hp["max_positions"])
+    trainer = train_step.Trainer(model, cfg, process_group=pg)
+    rng = np.random.RandomState(1234 + rank)
+    bt = synth_batch(rng, args.batch, args.text_len, args.frames, hp)
+    batch = train_step.Batch.from_collate(bt["text"], bt["input_lengths"], bt["mel"], bt["y"],
+                                          bt["text_positions"], bt["frame_positions"], bt["done"],
+                                          bt["target_lengths"], None, downsample_step=4, device=dev)
+    trainer.check_lengths(batch)
+    use_graph = not args.no_graph
+    runner = None
+    if use_graph:
+        try:
+            runner = train_step.GraphedTrainer(trainer, batch, warmup=max(1, min(args.warmup, 3)))
+        except Exception as e:      # capture not possible (e.g. collective not capturable): say so, go eager
+            if rank == 0:
+                print("hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
+            use_graph = False
+            torch.cuda.synchronize()
+
+    def do_step():
+        return runner.step() if use_graph else trainer.step(batch)
+
+    for _ in range(args.warmup):
+        scal = do_step()
+    if pg is not None:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scal = do_step()
+    torch.cuda.synchronize()
+    if pg is not None:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    frames = torch.tensor([float(batch.n_frames)], dtype=torch.float64, device=dev)
+    if pg is not None:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(frames, op=torch.distributed.ReduceOp.SUM)
+    dt = float(tmax.item())
+    loss = float(scal["loss"])
+    if rank != 0:
+        return
+    ms = dt / args.steps * 1e3
+    value = float(frames.item()) / (dt / args.steps)
+    out = dict(metric="mel-frames/sec/node (train step, deepvoice3_ljspeech)", value=round(value, 1),
+               unit="mel-frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f32", data="synthetic (fixed-shape LJSpeech-like: Tt=%d, %d frames/item; random-init weights)"
+               % (args.text_len, args.frames),
+               config=dict(workload="builder=deepvoice3 preset=deepvoice3_ljspeech fp32 train step "
+                                    "(fwd+losses+bwd+clip+Adam), synthetic LJSpeech-shaped batches",
+                           per_gpu_batch=args.batch, global_batch=args.batch * world, text_len=args.text_len,
+                           frames_per_item=args.frames, parallelism="dp%d" % world,
+                           hipgraph=bool(use_graph), final_loss=round(loss, 5)))
+    if not args.no_roofline:
+        out["roofline"] = conv_roofline(dev)
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.batch, args.text_len, args.frames)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(const dv3_softmax_des
     if (pd) {
       float d = v;
       if (p.mask) d = dv3_keep(p.mask, row, p.mask_rs, n) ? v * p.drop_scale : 0.f;
-      pd[n] = d;
+      pd[n] = d * p.pd_scale;
     }
   }
 }

@@ -23,6 +23,7 @@ namespace {
 struct ConvArgs {
   dv3_conv_desc d;
   int m_tiles, n_tiles, n_blocks;
+  int a_scalar;  // packed operand not 16-byte aligned (per-batch A = an activation): scalar staging
 };
 
 template <int WM, int WN, int NI, int BKC>
@@ -85,6 +86,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_kernel(const ConvAr
 
   for (int c0 = 0; c0 < Cin; c0 += BKC) {
     // ---------------- stage packed weights: J*BKC rows x BM floats ----------------
+    if (args.a_scalar) {
+      for (int idx = tid; idx < J * BKC * BM; idx += NT) {
+        const int col = idx % BM;
+        const int row = idx / BM;
+        const int j = row / BKC, kc = row % BKC;
+        const int c = c0 + kc;
+        const bool hi = col >= BMH;
+        const int gcol = (hi ? h1b : h0b) + (col - (hi ? BMH : 0));
+        const int lim = hi ? lim1 : lim0;
+        float v = 0.f;
+        if (c < Cin && gcol < lim) v = Ag[((int64_t)j * Cin + c) * lda + gcol];
+        As[row * BM + col] = v;
+      }
+    } else
     for (int idx = tid; idx < J * BKC * (BM / 4); idx += NT) {
       const int c4 = idx % (BM / 4);
       const int row = idx / (BM / 4);  // j*BKC + kc
@@ -194,6 +209,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_kernel(const ConvAr
             if (p.bias) v += p.bias[(p.store_mode == DV3_STORE_INTERLEAVE2) ? (m % (M >> 1)) : m];
             if (p.mode == DV3_EPI_RELU) v = fmaxf(v, 0.f);
             else if (p.mode == DV3_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+            else if (p.mode == DV3_EPI_SOFTSIGN) v = v / (1.0f + fabsf(v));
+            if (p.r) v = (v + p.r[(int64_t)b * p.r_bs + (int64_t)m * p.r_rs + n]) * rs2;
+            if (p.r2) v = (v + p.r2[(int64_t)b * p.r2_bs + (int64_t)m * p.r2_rs + n]) * rs2;
           }
           if (p.store_mode == DV3_STORE_INTERLEAVE2) {
             const int Mo = M >> 1;
@@ -237,7 +255,7 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
   DV3_REQUIRE(d && d->x && d->a && d->y, "conv_gemm: null pointer");
   DV3_REQUIRE(d->B > 0 && d->Cin > 0 && d->Tin > 0 && d->M > 0 && d->Tout > 0, "conv_gemm: bad dims");
   DV3_REQUIRE(d->J >= 1 && d->J <= 16 && d->dil >= 1, "conv_gemm: bad taps J=%d dil=%d", d->J, d->dil);
-  DV3_REQUIRE((d->lda & 3) == 0 && (d->a_half & 3) == 0, "conv_gemm: lda/a_half must be multiples of 4");
+  const bool a_scalar = (d->lda & 3) || (d->a_half & 3) || (d->a_bs & 3) || ((uintptr_t)d->a & 15);
   const bool gated = d->mode == DV3_EPI_GLU || d->mode == DV3_EPI_HIGHWAY;
   if (gated) {
     DV3_REQUIRE(d->M == 2 * d->Cg, "conv_gemm: gated mode needs M == 2*Cg");
@@ -247,7 +265,7 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
     DV3_REQUIRE(d->store_mode == DV3_STORE_BCT, "conv_gemm: gated mode stores BCT only");
   } else {
     DV3_REQUIRE(d->lda >= d->M, "conv_gemm: lda < M");
-    DV3_REQUIRE(d->mode >= DV3_EPI_LINEAR && d->mode <= DV3_EPI_DGRAD, "conv_gemm: bad mode");
+    DV3_REQUIRE(d->mode >= DV3_EPI_LINEAR && d->mode <= DV3_EPI_SOFTSIGN, "conv_gemm: bad mode");
     if (d->store_mode == DV3_STORE_INTERLEAVE2) DV3_REQUIRE((d->M & 1) == 0, "interleave2 needs even M");
   }
   if (d->xmask) DV3_REQUIRE(d->xmask_rs * 32 >= d->Tin, "conv_gemm: xmask row stride too small");
@@ -280,6 +298,7 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
 
   ConvArgs a;
   a.d = *d;
+  a.a_scalar = a_scalar ? 1 : 0;
   const int BM = best->wm * 64, BMH = best->wm * 32, BN = best->wn * best->ni * 32;
   a.m_tiles = gated ? dv3_cdiv(rows_half, BMH) : dv3_cdiv(d->M, BM);
   a.n_tiles = dv3_cdiv(d->Tout, BN);

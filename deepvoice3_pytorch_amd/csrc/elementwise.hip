@@ -54,9 +54,10 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
     const float* y = p.ab_or_y ? p.ab_or_y + row * T : nullptr;
     float* dpre = p.dab ? p.dab + row * T : nullptr;
     for (int t = lane; t < T; t += 64) {
-      float d = dy[t];
+      float d = dy[t] * p.alpha;
       if (p.mode == DV3_EPI_RELU) d = y[t] > 0.f ? d : 0.f;
       else if (p.mode == DV3_EPI_SIGMOID) d = d * y[t] * (1.0f - y[t]);
+      else if (p.mode == DV3_EPI_SOFTSIGN) { const float q = 1.0f - fabsf(y[t]); d = d * q * q; }
       if (dpre) dpre[t] = d;
       sa += d;
     }
@@ -85,9 +86,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict__ bits,
                                                            int64_t n_words, uint32_t thr,
-                                                           uint64_t seed, uint64_t site) {
+                                                           uint64_t seed, uint64_t site,
+                                                           const uint64_t* __restrict__ dev_off) {
   const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (w >= n_words) return;
+  if (dev_off) seed += dev_off[0];
   uint32_t word = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -143,6 +146,17 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a,
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (; i < n; i += stride) out[i] = alpha * (a[i] + (b ? b[i] : 0.f));
+}
+
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x,
+                                                            const uint32_t* __restrict__ bits, int rs,
+                                                            float scale, float* __restrict__ out,
+                                                            int64_t rows, int T) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  for (int t = lane; t < T; t += 64)
+    out[row * T + t] = dv3_keep(bits, row, rs, t) ? x[row * T + t] * scale : 0.f;
 }
 
 // dy [B][O][2T] -> out [B][2*O][T] with out[b][j*O+o][t] = dy[b][o][2t+j]
@@ -263,7 +277,44 @@ __global__ __launch_bounds__(256) void sincos_pos_kernel(const int64_t* __restri
   }
 }
 
+// dw[b] = sum_{c,t} dout[b][c][t] * a * (c even ? cos(w a) : -sin(w a)), a = table[pos][c], pos != 0
+__global__ __launch_bounds__(256) void sincos_pos_bwd_kernel(const int64_t* __restrict__ pos,
+                                                             const float* __restrict__ table,
+                                                             const float* __restrict__ w, int w_per_batch,
+                                                             const float* __restrict__ dout,
+                                                             float* __restrict__ dw, int T, int C,
+                                                             int n_pos) {
+  const int b = blockIdx.x;
+  const float rate = w[w_per_batch ? b : 0];
+  float s = 0.f;
+  for (int idx = threadIdx.x; idx < C * T; idx += 256) {
+    const int c = idx / T, t = idx % T;
+    int64_t p = pos[(int64_t)b * T + t];
+    p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+    const float a = table[p * C + c];
+    const float d = dout[((int64_t)b * C + c) * T + t];
+    float de;
+    if (p == 0) de = a;
+    else de = (c & 1) ? -sinf(rate * a) * a : cosf(rate * a) * a;
+    s += d * de;
+  }
+  __shared__ float red[4];
+  s = dv3_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dw[b] = red[0] + red[1] + red[2] + red[3];
+}
+
 }  // namespace
+
+extern "C" int dv3_sincos_pos_bwd_f32(const int64_t* pos, const float* table, const float* w,
+                                      int32_t w_per_batch, const float* dout, float* dw, int32_t B,
+                                      int32_t T, int32_t C, int32_t n_pos, void* stream) {
+  DV3_REQUIRE(pos && table && w && dout && dw && B > 0 && T > 0 && C > 0 && n_pos > 0, "sincos_pos_bwd: bad args");
+  hipLaunchKernelGGL(sincos_pos_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pos, table, w,
+                     w_per_batch, dout, dw, T, C, n_pos);
+  return dv3_check_launch("sincos_pos_bwd_f32");
+}
 
 extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
   DV3_REQUIRE(d && d->dy, "gate_bwd: null dy");
@@ -274,6 +325,7 @@ extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
     DV3_REQUIRE(d->mode != DV3_EPI_HIGHWAY || d->x, "gate_bwd: highway needs x");
   } else {
     DV3_REQUIRE(d->mode == DV3_EPI_LINEAR || d->ab_or_y, "gate_bwd: activation mode needs y");
+    DV3_REQUIRE(d->mode != DV3_EPI_DGRAD, "gate_bwd: bad mode");
   }
   const int64_t rows = (int64_t)d->B * d->C;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)dv3_cdiv64(rows, 4)), dim3(256), 0,
@@ -282,13 +334,21 @@ extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
 }
 
 extern "C" int dv3_dropout_bits(uint32_t* bits, int64_t n_words, float p, uint64_t seed,
-                                uint64_t site, void* stream) {
+                                uint64_t site, const uint64_t* dev_seed_offset, void* stream) {
   DV3_REQUIRE(bits && n_words > 0, "dropout_bits: bad args");
   DV3_REQUIRE(p >= 0.f && p < 1.f, "dropout_bits: p out of range");
   uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
   hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)dv3_cdiv64(n_words, 256)), dim3(256), 0,
-                     (hipStream_t)stream, bits, n_words, thr, seed, site);
+                     (hipStream_t)stream, bits, n_words, thr, seed, site, dev_seed_offset);
   return dv3_check_launch("dropout_bits");
+}
+
+extern "C" int dv3_dropout_apply_f32(const float* x, const uint32_t* bits, int32_t bits_rs,
+                                     float scale, float* out, int64_t rows, int32_t T, void* stream) {
+  DV3_REQUIRE(x && bits && out && rows > 0 && T > 0 && bits_rs * 32 >= T, "dropout_apply: bad args");
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)dv3_cdiv64(rows, 4)), dim3(256), 0,
+                     (hipStream_t)stream, x, bits, bits_rs, scale, out, rows, T);
+  return dv3_check_launch("dropout_apply_f32");
 }
 
 extern "C" int dv3_transpose_f32(const float* x, float* y, const float* add, int32_t B, int32_t R,

@@ -46,13 +46,23 @@ __global__ __launch_bounds__(kLossBlock) void spec_loss_kernel(const dv3_spec_lo
   const float eps = 1e-8f;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};  // l1, l1 masked, z, z masked
   const int64_t stride = (int64_t)gridDim.x * kLossBlock;
+  // iterate with the faster-varying axis of y_hat innermost so its accesses coalesce
+  const bool t_fast = p.yh_ts < p.yh_ds;
   for (int64_t i = (int64_t)blockIdx.x * kLossBlock + threadIdx.x; i < n; i += stride) {
-    const int dd = (int)(i % D);
-    const int64_t bt = i / D;
-    const int t = (int)(bt % Tr);
-    const int b = (int)(bt / Tr);
-    const int64_t ih = ((int64_t)b * p.T + t) * D + dd;          // y_hat[:, :-r]
-    const int64_t iy = ((int64_t)b * p.T + t + p.r) * D + dd;    // y[:, r:]
+    int dd, t, b;
+    if (t_fast) {
+      t = (int)(i % Tr);
+      const int64_t bd = i / Tr;
+      dd = (int)(bd % D);
+      b = (int)(bd / D);
+    } else {
+      dd = (int)(i % D);
+      const int64_t bt = i / D;
+      t = (int)(bt % Tr);
+      b = (int)(bt / Tr);
+    }
+    const int64_t ih = b * p.yh_bs + t * p.yh_ts + dd * p.yh_ds;          // y_hat[:, :-r]
+    const int64_t iy = b * p.y_bs + (int64_t)(t + p.r) * p.y_ts + dd * p.y_ds;  // y[:, r:]
     const float yh = p.y_hat[ih], y = p.y[iy];
     const float m = (use_mask && (t + p.r) < p.lengths[b]) ? 1.f : 0.f;
     const float diff = yh - y;
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(256) void spec_loss_tail_zero_kernel(const dv3_spec
   const int64_t bt = i / p.D;
   const int t = p.T - p.r + (int)(bt % p.r);
   const int b = (int)(bt / p.r);
-  p.dyh[((int64_t)b * p.T + t) * p.D + dd] = 0.f;
+  p.dyh[b * p.yh_bs + t * p.yh_ts + dd * p.yh_ds] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void spec_loss_finish_kernel(const dv3_spec_loss_desc p,

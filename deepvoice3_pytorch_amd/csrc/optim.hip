@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p,
   float coef = grad_prescale;
   if (clip > 0.f && grad_norm) {
     // clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
-    const float c = clip / (grad_norm[0] + 1e-6f);
+    // grad_norm is the norm of the (summed) arena; the averaged gradient's norm is prescale * that
+    const float c = clip / (grad_norm[0] * grad_prescale + 1e-6f);
     coef *= fminf(c, 1.0f);
   }
   const float lr = hyper[0], bc1 = hyper[1], bc2s = hyper[2];

@@ -1,0 +1,302 @@
+# coding: utf-8
+"""Nyanko (DCTTS-style) blocks on HIP kernels: HighwayConv1d stacks with dilations 1,3,9,27.
+
+API mirror of the reference's deepvoice3_pytorch/nyanko.py (class names, constructor arguments,
+module and parameter names, forward signatures).  BCT activations, one fused tap-GEMM launch
+per HighwayConv1d / Conv1d(+ReLU / +Sigmoid).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from . import conv as _conv
+from .modules import Embedding, Linear, Conv1d, ConvTranspose1d
+from .modules import HighwayConv1d, get_mask_from_lengths
+from .modules import position_encoding_init
+from .deepvoice3 import AttentionLayer
+
+
+def _run_seq(mods, x):
+    """nn.Sequential / ModuleList of {Conv1d, ReLU, Sigmoid, HighwayConv1d, ConvTranspose1d} on
+    BCT x with Conv1d+ReLU / Conv1d+Sigmoid fused."""
+    mods = list(mods)
+    n = len(mods)
+    i = 0
+    while i < n:
+        f = mods[i]
+        if isinstance(f, _conv.Conv1d):
+            nxt = mods[i + 1] if i + 1 < n else None
+            if isinstance(nxt, nn.ReLU):
+                x = f(x, mode=ops.EPI_RELU)
+                i += 1
+            elif isinstance(nxt, nn.Sigmoid):
+                x = f(x, mode=ops.EPI_SIGMOID)
+                i += 1
+            else:
+                x = f(x)
+        elif isinstance(f, nn.ReLU):
+            x = torch.relu(x)
+        elif isinstance(f, nn.Sigmoid):
+            x = torch.sigmoid(x)
+        else:
+            x = f(x)
+        i += 1
+    return x
+
+
+def _run_seq_incremental(mods, x):
+    mods = list(mods)
+    n = len(mods)
+    i = 0
+    while i < n:
+        f = mods[i]
+        if isinstance(f, _conv.Conv1d):
+            if i + 1 < n and isinstance(mods[i + 1], nn.ReLU):
+                x = f.incremental_forward(x, _gate=dict(mode=ops.EPI_RELU))
+                i += 1
+            else:
+                x = f.incremental_forward(x)
+        elif isinstance(f, HighwayConv1d):
+            x = f.incremental_forward(x)
+        else:
+            x = f(x)
+        i += 1
+    return x
+
+
+class Encoder(nn.Module):
+    def __init__(self, n_vocab, embed_dim, channels, kernel_size=3, n_speakers=1, speaker_embed_dim=16,
+                 embedding_weight_std=0.01, padding_idx=None, dropout=0.1):
+        super(Encoder, self).__init__()
+        self.dropout = dropout
+        self.embed_tokens = Embedding(n_vocab, embed_dim, padding_idx, embedding_weight_std)
+        E, D = embed_dim, channels
+
+        def hw(k, d):
+            return HighwayConv1d(2 * D, 2 * D, kernel_size=k, padding=None, dilation=d, std_mul=1.0,
+                                 dropout=dropout)
+
+        self.convnet = nn.Sequential(
+            Conv1d(E, 2 * D, kernel_size=1, padding=0, dilation=1, std_mul=1.0),
+            nn.ReLU(inplace=True),
+            Conv1d(2 * D, 2 * D, kernel_size=1, padding=0, dilation=1, std_mul=2.0),
+            hw(kernel_size, 1), hw(kernel_size, 3), hw(kernel_size, 9), hw(kernel_size, 27),
+            hw(kernel_size, 1), hw(kernel_size, 3), hw(kernel_size, 9), hw(kernel_size, 27),
+            hw(kernel_size, 1), hw(kernel_size, 1),
+            HighwayConv1d(2 * D, 2 * D, kernel_size=1, padding=0, dilation=1, std_mul=1.0,
+                          dropout=dropout),
+        )
+
+    def forward(self, text_sequences, text_positions=None, lengths=None, speaker_embed=None):
+        x = ops.embedding_bct(text_sequences, self.embed_tokens.weight, 0.0, False,
+                              self.embed_tokens.padding_idx)
+        x = _run_seq(self.convnet, x)                       # (B, 2D, T)
+        D = x.size(1) // 2
+        keys, values = x[:, :D, :], x[:, D:, :]             # channel halves (nyanko.py:69)
+        return keys.transpose(1, 2), values.transpose(1, 2)
+
+
+class Decoder(nn.Module):
+    def __init__(self, embed_dim, in_dim=80, r=5, channels=256, kernel_size=3, n_speakers=1,
+                 speaker_embed_dim=16, max_positions=512, padding_idx=None, dropout=0.1,
+                 use_memory_mask=False, force_monotonic_attention=False, query_position_rate=1.0,
+                 key_position_rate=1.29, window_ahead=3, window_backward=1, key_projection=False,
+                 value_projection=False):
+        super(Decoder, self).__init__()
+        self.dropout = dropout
+        self.in_dim = in_dim
+        self.r = r
+        D = channels
+        F = in_dim * r
+
+        def hw(d):
+            return HighwayConv1d(D, D, kernel_size=kernel_size, padding=None, dilation=d, causal=True,
+                                 std_mul=1.0, dropout=dropout)
+
+        self.audio_encoder_modules = nn.ModuleList([
+            Conv1d(F, D, kernel_size=1, padding=0, dilation=1, std_mul=1.0),
+            nn.ReLU(inplace=True),
+            Conv1d(D, D, kernel_size=1, padding=0, dilation=1, std_mul=2.0),
+            nn.ReLU(inplace=True),
+            Conv1d(D, D, kernel_size=1, padding=0, dilation=1, std_mul=2.0),
+            hw(1), hw(3), hw(9), hw(27), hw(1), hw(3), hw(9), hw(27), hw(3), hw(3),
+        ])
+        self.attention = AttentionLayer(D, D, dropout=dropout, window_ahead=window_ahead,
+                                        window_backward=window_backward, key_projection=key_projection,
+                                        value_projection=value_projection)
+        self.audio_decoder_modules = nn.ModuleList([
+            Conv1d(2 * D, D, kernel_size=1, padding=0, dilation=1, std_mul=1.0),
+            hw(1), hw(3), hw(9), hw(27), hw(1), hw(1),
+            Conv1d(D, D, kernel_size=1, padding=0, dilation=1, std_mul=1.0),
+            nn.ReLU(inplace=True),
+            Conv1d(D, D, kernel_size=1, padding=0, dilation=1, std_mul=2.0),
+            nn.ReLU(inplace=True),
+            Conv1d(D, D, kernel_size=1, padding=0, dilation=1, std_mul=2.0),
+            nn.ReLU(inplace=True),
+        ])
+        self.last_conv = Conv1d(D, F, kernel_size=1, padding=0, dilation=1, std_mul=2.0)
+        self.fc = Linear(F, 1)
+
+        # Position encodings: frozen tables with the rate baked in (nyanko.py:161-169)
+        self.embed_query_positions = Embedding(max_positions, D, padding_idx)
+        self.embed_query_positions.weight.data = position_encoding_init(
+            max_positions, D, position_rate=query_position_rate, sinusoidal=True)
+        self.embed_keys_positions = Embedding(max_positions, D, padding_idx)
+        self.embed_keys_positions.weight.data = position_encoding_init(
+            max_positions, D, position_rate=key_position_rate, sinusoidal=True)
+
+        self.max_decoder_steps = 200
+        self.min_decoder_steps = 10
+        self.use_memory_mask = use_memory_mask
+        self.force_monotonic_attention = force_monotonic_attention
+
+    def forward(self, encoder_out, inputs=None, text_positions=None, frame_positions=None,
+                speaker_embed=None, lengths=None):
+        if inputs is None:
+            assert text_positions is not None
+            self.start_fresh_sequence()
+            return self.incremental_forward(encoder_out, text_positions)
+
+        if inputs.size(-1) == self.in_dim:
+            inputs = inputs.reshape(inputs.size(0), inputs.size(1) // self.r, -1)
+        assert inputs.size(-1) == self.in_dim * self.r
+
+        keys, values = encoder_out
+        keys_bct, values_bct = keys.transpose(1, 2), values.transpose(1, 2)
+        key_len = None
+        if self.use_memory_mask and lengths is not None:
+            key_len = torch.as_tensor(np.asarray(lengths), dtype=torch.int32).to(keys_bct.device)
+
+        if text_positions is not None:
+            keys_bct = ops.add_position_encoding(keys_bct.contiguous(), text_positions,
+                                                 self.embed_keys_positions.weight, None, False)
+
+        x = _run_seq(self.audio_encoder_modules, inputs.transpose(1, 2).contiguous())
+        Q = x
+        if frame_positions is not None:
+            x = ops.add_position_encoding(x, frame_positions, self.embed_query_positions.weight, None, False)
+        R, alignments = self.attention.forward_bct(x, keys_bct, values_bct, key_len)
+
+        x = torch.cat((R, Q), dim=1)
+        x = _run_seq(self.audio_decoder_modules, x)
+        decoder_states = x.transpose(1, 2).contiguous()
+        decoder_states._dv3_bct = x
+        outputs = self.last_conv(x, mode=ops.EPI_SIGMOID).transpose(1, 2)
+        done = self.fc.forward_bct(self.last_conv(x), ops.EPI_SIGMOID).transpose(1, 2)
+        return outputs, alignments.unsqueeze(0), done, decoder_states
+
+    def incremental_forward(self, encoder_out, text_positions, initial_input=None, test_inputs=None):
+        """nyanko.py:250-338."""
+        keys, values = encoder_out
+        B = keys.size(0)
+        dev = keys.device
+        keys_bct = keys.transpose(1, 2).contiguous()
+        if text_positions is not None:
+            keys_bct = ops.add_position_encoding(keys_bct, text_positions, self.embed_keys_positions.weight,
+                                                 None, False)
+        values_bct = values.transpose(1, 2).contiguous()
+        Tk = keys_bct.size(-1)
+        att = self.attention
+        k = att.key_projection.forward_bct(keys_bct) if att.key_projection is not None else keys_bct
+        v = att.value_projection.forward_bct(values_bct) if att.value_projection is not None else values_bct
+
+        decoder_states, outputs, alignments, dones = [], [], [], []
+        last_attended = torch.zeros(1, dtype=torch.int32, device=dev) if self.force_monotonic_attention else None
+        t = 0
+        if initial_input is None:
+            initial_input = keys.new_zeros(B, 1, self.in_dim * self.r)
+        current_input = initial_input
+        while True:
+            frame_pos = torch.full((B, 1), t + 1, dtype=torch.long, device=dev)
+            if test_inputs is not None:
+                if t >= test_inputs.size(1):
+                    break
+                current_input = test_inputs[:, t, :].unsqueeze(1)
+            else:
+                if t > 0:
+                    current_input = outputs[-1]
+            x = _run_seq_incremental(self.audio_encoder_modules, current_input)      # (B, 1, D)
+            Q = x
+            xq = ops.add_position_encoding(x.transpose(1, 2).contiguous(), frame_pos,
+                                           self.embed_query_positions.weight, None, False)
+            q = att.query_projection.forward_bct(xq)
+            ctx, alignment = ops.attention_core(q, k, v, None, last_attended, 0.0, False,
+                                                att.window_backward, att.window_ahead)
+            R = att.out_projection.forward_bct(ctx, r=xq).transpose(1, 2)
+            if self.force_monotonic_attention:
+                ops._lib.call("dv3_attn_argmax_i32", alignment.data_ptr(), Tk, last_attended.data_ptr(),
+                              ops._stream())
+            x = torch.cat((R, Q), dim=-1)
+            x = _run_seq_incremental(self.audio_decoder_modules, x)
+            decoder_state = x
+            x = self.last_conv.incremental_forward(x)
+            output = torch.sigmoid(x)
+            done = torch.sigmoid(self.fc(x))
+            decoder_states += [decoder_state]
+            outputs += [output]
+            alignments += [alignment]
+            dones += [done]
+            t += 1
+            if test_inputs is None:
+                if (done > 0.5).all() and t > self.min_decoder_steps:
+                    break
+                elif t > self.max_decoder_steps:
+                    break
+
+        alignments = list(map(lambda x: x.squeeze(1), alignments))
+        decoder_states = list(map(lambda x: x.squeeze(1), decoder_states))
+        outputs = list(map(lambda x: x.squeeze(1), outputs))
+        alignments = torch.stack(alignments).transpose(0, 1)
+        decoder_states = torch.stack(decoder_states).transpose(0, 1).contiguous()
+        outputs = torch.stack(outputs).transpose(0, 1).contiguous()
+        return outputs, alignments, dones, decoder_states
+
+    def start_fresh_sequence(self):
+        _clear_modules(self.audio_encoder_modules)
+        _clear_modules(self.audio_decoder_modules)
+        self.last_conv.clear_buffer()
+
+
+def _clear_modules(modules):
+    for m in modules:
+        try:
+            m.clear_buffer()
+        except AttributeError:
+            pass
+
+
+class Converter(nn.Module):
+    def __init__(self, in_dim, out_dim, channels=512, kernel_size=3, dropout=0.1):
+        super(Converter, self).__init__()
+        self.dropout = dropout
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        F, Fd, C = in_dim, out_dim, channels
+
+        def hw(c, d):
+            return HighwayConv1d(c, c, kernel_size=kernel_size, padding=None, dilation=d, std_mul=1.0,
+                                 dropout=dropout)
+
+        def c11(i, o, std_mul):
+            return Conv1d(i, o, kernel_size=1, padding=0, dilation=1, std_mul=std_mul)
+
+        self.convnet = nn.Sequential(
+            c11(F, C, 1.0),
+            hw(C, 1), hw(C, 3),
+            ConvTranspose1d(C, C, kernel_size=2, padding=0, stride=2, std_mul=1.0),
+            hw(C, 1), hw(C, 3),
+            ConvTranspose1d(C, C, kernel_size=2, padding=0, stride=2, std_mul=1.0),
+            hw(C, 1), hw(C, 3),
+            c11(C, 2 * C, 1.0),
+            hw(2 * C, 1), hw(2 * C, 1),
+            c11(2 * C, Fd, 1.0),
+            c11(Fd, Fd, 1.0), nn.ReLU(inplace=True),
+            c11(Fd, Fd, 2.0), nn.ReLU(inplace=True),
+            c11(Fd, Fd, 2.0), nn.Sigmoid(),
+        )
+
+    def forward(self, x, speaker_embed=None):
+        bct = getattr(x, "_dv3_bct", None)
+        x = bct if bct is not None else x.transpose(1, 2).contiguous()
+        return _run_seq(self.convnet, x).transpose(1, 2)

@@ -1,0 +1,716 @@
+# coding: utf-8
+"""Host-side operators over the libdv3hip C ABI (include/dv3hip.h).
+
+Every function here enqueues hand-written HIP kernels on torch's *current* stream through
+ctypes; torch is used only for device memory (caching allocator), streams and autograd
+bookkeeping.  There is no fallback: a non-CUDA tensor or a missing library raises.
+
+Layout convention inside the package: activations are BCT (batch, channel, time), fp32,
+contiguous -- the layout of the reference conv stacks (deepvoice3_pytorch/modules.py:139-164).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import CONSTS, STRUCTS
+
+EPI_LINEAR = CONSTS["DV3_EPI_LINEAR"]
+EPI_RELU = CONSTS["DV3_EPI_RELU"]
+EPI_SIGMOID = CONSTS["DV3_EPI_SIGMOID"]
+EPI_GLU = CONSTS["DV3_EPI_GLU"]
+EPI_HIGHWAY = CONSTS["DV3_EPI_HIGHWAY"]
+EPI_DGRAD = CONSTS["DV3_EPI_DGRAD"]
+EPI_SOFTSIGN = CONSTS["DV3_EPI_SOFTSIGN"]
+STORE_BCT = CONSTS["DV3_STORE_BCT"]
+STORE_INTERLEAVE2 = CONSTS["DV3_STORE_INTERLEAVE2"]
+
+_conv_desc = STRUCTS["dv3_conv_desc"]
+_wgrad_desc = STRUCTS["dv3_wgrad_desc"]
+_wn_desc = STRUCTS["dv3_wn_desc"]
+_wn_bwd_desc = STRUCTS["dv3_wn_bwd_desc"]
+_gate_bwd_desc = STRUCTS["dv3_gate_bwd_desc"]
+_softmax_desc = STRUCTS["dv3_softmax_desc"]
+_softmax_bwd_desc = STRUCTS["dv3_softmax_bwd_desc"]
+_spec_loss_desc = STRUCTS["dv3_spec_loss_desc"]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError("dv3hip op got a non-GPU tensor for %s: the HIP path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+# ----------------------------------------------------------------------------------------------
+# dropout keep-bits
+# ----------------------------------------------------------------------------------------------
+class DropoutState(object):
+    """Seed / site bookkeeping for dv3_dropout_bits.  `dev_offset` (uint64 on the device) is
+    added to the seed inside the kernel so a replayed hipGraph draws fresh masks each step."""
+
+    def __init__(self):
+        self.seed = None
+        self.site = 0
+        self.dev_offset = None   # optional torch.int64 tensor [1] on the device
+        self.record = None       # tests: dict site_name -> (bits tensor, rows, T)
+
+    def manual_seed(self, seed):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.site = 0
+
+    def next_site(self):
+        if self.seed is None:
+            self.manual_seed(torch.initial_seed())
+        self.site += 1
+        return self.site
+
+
+dropout_state = DropoutState()
+
+
+def dropout_bits(rows, T, p, device, name=None):
+    """-> (bits int32 [rows][ceil(T/32)], row_stride_words). One Philox launch."""
+    rs = (T + 31) // 32
+    bits = torch.empty(rows * rs, dtype=torch.int32, device=device)
+    site = dropout_state.next_site()
+    off = dropout_state.dev_offset
+    _lib.call("dv3_dropout_bits", bits.data_ptr(), rows * rs, float(p), dropout_state.seed, site,
+              _ptr(off), _stream())
+    if dropout_state.record is not None and name is not None:
+        dropout_state.record[name] = (bits, rows, T)
+    return bits, rs
+
+
+# ----------------------------------------------------------------------------------------------
+# weight norm + packing
+# ----------------------------------------------------------------------------------------------
+class Packed(object):
+    __slots__ = ("fwd", "bwd", "scale", "lda", "a_half", "ldb", "O", "I", "J", "transposed", "glu_cg")
+
+
+def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True):
+    """dv3_weight_norm_pack_f32.  v: (O,I,J) / (O,I) [Conv1d / Linear] or (I,O,J) [ConvTranspose1d]."""
+    _chk(v, "weight_v")
+    v = _c(v)
+    if v.dim() == 2:
+        v = v.unsqueeze(-1)
+    pk = Packed()
+    if transposed:
+        I, O, J = v.shape
+    else:
+        O, I, J = v.shape
+    pk.O, pk.I, pk.J, pk.transposed, pk.glu_cg = O, I, J, transposed, glu_cg
+    dev = v.device
+    if transposed:
+        pk.lda, pk.a_half = _round_up(J * O, 4), 0
+        pk.fwd = torch.empty(I * pk.lda, dtype=torch.float32, device=dev)
+        pk.scale = torch.empty(I, dtype=torch.float32, device=dev)
+        pk.ldb = _round_up(I, 4)
+        pk.bwd = torch.empty(J * O * pk.ldb, dtype=torch.float32, device=dev) if need_bwd else None
+    else:
+        if glu_cg:
+            pk.a_half = _round_up(glu_cg, 4)
+            pk.lda = 2 * pk.a_half
+        else:
+            pk.a_half, pk.lda = 0, _round_up(O, 4)
+        pk.fwd = torch.empty(J * I * pk.lda, dtype=torch.float32, device=dev)
+        pk.scale = torch.empty(O, dtype=torch.float32, device=dev)
+        pk.ldb = _round_up(I, 4)
+        pk.bwd = torch.empty(J * O * pk.ldb, dtype=torch.float32, device=dev) if need_bwd else None
+    d = _wn_desc()
+    d.v, d.g, d.scale = v.data_ptr(), _ptr(_c(g) if g is not None else None), pk.scale.data_ptr()
+    d.fwd_pack, d.lda, d.a_half = pk.fwd.data_ptr(), pk.lda, pk.a_half
+    d.bwd_pack, d.ldb = _ptr(pk.bwd), pk.ldb
+    d.O, d.I, d.J, d.transposed, d.glu_cg = O, I, J, int(transposed), glu_cg
+    _lib.call("dv3_weight_norm_pack_f32", ctypes.byref(d), _stream())
+    return pk
+
+
+# ----------------------------------------------------------------------------------------------
+# raw kernel wrappers
+# ----------------------------------------------------------------------------------------------
+def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mode=EPI_LINEAR,
+              Cg=0, bias=None, spk=None, spk_strides=(0, 0, 0), r=None, r2=None, residual=0,
+              y=None, y_rs=None, ab=None, xmask=None, xmask_rs=0, ymask=None, ymask_rs=0,
+              drop_scale=1.0, a_bs=0, store_mode=STORE_BCT, x_bs=None, x_rs=None, tile_hint=0):
+    """dv3_conv_gemm_f32.  x: [B][Cin][Tin] (strides overridable); returns y."""
+    gated = mode in (EPI_GLU, EPI_HIGHWAY)
+    Cout = Cg if gated else (M // 2 if store_mode == STORE_INTERLEAVE2 else M)
+    To = 2 * Tout if store_mode == STORE_INTERLEAVE2 else Tout
+    if y is None:
+        y = torch.empty((B, Cout, To), dtype=torch.float32, device=x.device)
+        y_bs, y_rs_ = Cout * To, To
+    else:
+        y_rs_ = y_rs if y_rs is not None else y.stride(1)
+        y_bs = y.stride(0)
+    d = _conv_desc()
+    d.x = x.data_ptr()
+    d.x_bs = x_bs if x_bs is not None else x.stride(0)
+    d.x_rs = x_rs if x_rs is not None else x.stride(1)
+    d.a, d.a_bs, d.lda, d.a_half = a.data_ptr(), a_bs, lda, a_half
+    d.bias = _ptr(bias)
+    d.spk = _ptr(spk)
+    d.spk_bs, d.spk_rs, d.spk_ts = spk_strides
+    if r is not None:
+        d.r, d.r_bs, d.r_rs = r.data_ptr(), r.stride(0), r.stride(1)
+    if r2 is not None:
+        d.r2, d.r2_bs, d.r2_rs = r2.data_ptr(), r2.stride(0), r2.stride(1)
+    d.y, d.y_bs, d.y_rs = y.data_ptr(), y_bs, y_rs_
+    d.ab = _ptr(ab)
+    d.xmask, d.xmask_rs = _ptr(xmask), xmask_rs
+    d.ymask, d.ymask_rs = _ptr(ymask), ymask_rs
+    d.drop_scale = drop_scale
+    d.B, d.Cin, d.Tin, d.M, d.Cg, d.Tout, d.J, d.dil, d.padL = B, Cin, Tin, M, Cg, Tout, J, dil, padL
+    d.mode, d.residual, d.store_mode, d.tile_hint = mode, residual, store_mode, tile_hint
+    _lib.call("dv3_conv_gemm_f32", ctypes.byref(d), _stream())
+    return y
+
+
+def wgrad_gemm(g, x, *, B, M, Cin, T, Tin, J=1, dil=1, padL=0, n_slabs=1, xmask=None, xmask_rs=0,
+               drop_scale=1.0, out=None, ldo=None, g_bs=None, g_rs=None, x_bs=None, x_rs=None):
+    """dv3_wgrad_gemm_f32 -> out [S][J][M][ldo]."""
+    if ldo is None:
+        ldo = Cin
+    if out is None:
+        out = torch.empty((n_slabs, J, M, ldo), dtype=torch.float32, device=g.device)
+    d = _wgrad_desc()
+    d.g, d.g_bs, d.g_rs = g.data_ptr(), (g_bs if g_bs is not None else g.stride(0)), \
+        (g_rs if g_rs is not None else g.stride(1))
+    d.x, d.x_bs, d.x_rs = x.data_ptr(), (x_bs if x_bs is not None else x.stride(0)), \
+        (x_rs if x_rs is not None else x.stride(1))
+    d.xmask, d.xmask_rs, d.drop_scale = _ptr(xmask), xmask_rs, drop_scale
+    d.out, d.out_ss, d.ldo = out.data_ptr(), J * M * ldo, ldo
+    d.B, d.M, d.Cin, d.T, d.Tin, d.J, d.dil, d.padL, d.n_slabs = B, M, Cin, T, Tin, J, dil, padL, n_slabs
+    _lib.call("dv3_wgrad_gemm_f32", ctypes.byref(d), _stream())
+    return out
+
+
+def gate_bwd(dy, ab_or_y, x, *, B, C, T, mode, residual=0, alpha=1.0, want_dres=False,
+             want_dpre=True):
+    """dv3_gate_bwd_f32 -> (dab_or_dpre, dres, bias_part)."""
+    gated = mode in (EPI_GLU, EPI_HIGHWAY)
+    dev = dy.device
+    rows = 2 * C if gated else C
+    dab = torch.empty((B, rows, T), dtype=torch.float32, device=dev) if (gated or want_dpre) else None
+    dres = torch.empty((B, C, T), dtype=torch.float32, device=dev) if (gated and want_dres) else None
+    part = torch.empty((B, rows), dtype=torch.float32, device=dev)
+    d = _gate_bwd_desc()
+    d.dy, d.ab_or_y, d.x = dy.data_ptr(), _ptr(ab_or_y), _ptr(x)
+    d.dab, d.dres, d.bias_part = _ptr(dab), _ptr(dres), part.data_ptr()
+    d.alpha = alpha
+    d.B, d.C, d.T, d.mode, d.residual = B, C, T, mode, residual
+    _lib.call("dv3_gate_bwd_f32", ctypes.byref(d), _stream())
+    return dab, dres, part
+
+
+def weight_norm_bwd(slabs, n_slabs, ldo, v, g, scale, bias_part, n_part, O, I, J, transposed=False,
+                    want_bias=True):
+    dev = v.device
+    dv = torch.empty_like(v)
+    dg = torch.empty_like(g) if g is not None else None
+    dbias = torch.empty(O, dtype=torch.float32, device=dev) if (want_bias and bias_part is not None) else None
+    d = _wn_bwd_desc()
+    M = J * O if transposed else O
+    Jk = 1 if transposed else J
+    d.slabs, d.slab_ss, d.ldo, d.n_slabs = slabs.data_ptr(), Jk * M * ldo, ldo, n_slabs
+    d.v, d.g, d.scale = v.data_ptr(), _ptr(g), _ptr(scale)
+    d.dv, d.dg = dv.data_ptr(), _ptr(dg)
+    d.bias_part, d.n_part, d.dbias = _ptr(bias_part) if dbias is not None else None, n_part, _ptr(dbias)
+    d.O, d.I, d.J, d.transposed = O, I, J, int(transposed)
+    _lib.call("dv3_weight_norm_bwd_f32", ctypes.byref(d), _stream())
+    return dv, dg, dbias
+
+
+def transpose(x, add=None, alpha=1.0):
+    """(B,R,C) -> (B,C,R): y = alpha * x^T (+ add)."""
+    x = _c(_chk(x, "x"))
+    B, R, C = x.shape
+    y = torch.empty((B, C, R), dtype=torch.float32, device=x.device)
+    _lib.call("dv3_transpose_f32", x.data_ptr(), y.data_ptr(), _ptr(add), B, R, C, float(alpha), _stream())
+    return y
+
+
+def axpby(a, b, alpha):
+    a = _c(a)
+    out = torch.empty_like(a)
+    _lib.call("dv3_axpby_f32", a.data_ptr(), _ptr(_c(b) if b is not None else None), out.data_ptr(),
+              a.numel(), float(alpha), _stream())
+    return out
+
+
+def _slab_count(B, tiles):
+    """Split-K factor for wgrad: enough blocks to fill 256 CUs ~2x, at most B."""
+    want = max(1, (512 + tiles - 1) // tiles)
+    s = min(B, want)
+    while B % s:  # equal-sized slabs keep the reduction balanced
+        s -= 1
+    return max(s, 1)
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd: one conv-like layer (Conv1dGLU / HighwayConv1d / 1x1 Conv1d(+act) / Linear /
+# ConvTranspose1d) = pack -> tap-GEMM(+fused tail); backward = gate_bwd -> DGRAD tap-GEMM ->
+# wgrad GEMM -> weight-norm backward.
+# ----------------------------------------------------------------------------------------------
+class LayerCfg(object):
+    __slots__ = ("k", "dil", "causal", "mode", "residual", "p", "training", "transposed", "site",
+                 "pad_left", "t_out")
+
+    def __init__(self, k=1, dil=1, causal=False, mode=EPI_LINEAR, residual=False, p=0.0,
+                 training=False, transposed=False, site=None, pad_left=None, t_out=None):
+        self.k, self.dil, self.causal, self.mode = k, dil, causal, mode
+        self.residual, self.p, self.training, self.transposed, self.site = residual, p, training, transposed, site
+        self.pad_left, self.t_out = pad_left, t_out   # None: "same" length output (all model layers)
+
+
+def _pad_left(k, dil, causal):
+    # modules.py:123-128 (the causal conv pads (k-1)*d on both sides and trims the right)
+    return (k - 1) * dil if causal else (k - 1) // 2 * dil
+
+
+class ConvLayerFn(torch.autograd.Function):
+    """y = layer(x; v, g, bias[, spk][, r][, r2]).  See LayerCfg.  `packed` may carry a cached
+    Packed (eval mode); spk is the additive per-(b,channel[,t]) term on the `a` half (already
+    softsign'ed); r / r2 are residual inputs for non-gated modes (each: y = (y + r)*sqrt(.5))."""
+
+    @staticmethod
+    def forward(ctx, x, v, g, bias, spk, r, r2, cfg, packed):
+        _chk(x, "x")
+        x = _c(x)
+        B, Cin, T = x.shape
+        mode = cfg.mode
+        gated = mode in (EPI_GLU, EPI_HIGHWAY)
+        need_grad = any(ctx.needs_input_grad[:7])
+        if cfg.transposed:
+            I, O, J = v.shape
+            M, Cg = J * O, 0
+        else:
+            O = v.shape[0]
+            J = v.shape[2] if v.dim() == 3 else 1
+            M, Cg = O, (O // 2 if gated else 0)
+        if packed is not None and need_grad and packed.bwd is None:
+            packed = None
+        pk = packed if packed is not None else pack_weights(v, g, glu_cg=Cg, transposed=cfg.transposed,
+                                                            need_bwd=need_grad)
+        bits, bits_rs, dscale = None, 0, 1.0
+        if cfg.training and cfg.p > 0:
+            bits, bits_rs = dropout_bits(B * Cin, T, cfg.p, x.device, cfg.site)
+            dscale = 1.0 / (1.0 - cfg.p)
+        padL = _pad_left(J, cfg.dil, cfg.causal) if not cfg.transposed else 0
+        if cfg.pad_left is not None:
+            padL = cfg.pad_left
+        Tout = cfg.t_out if cfg.t_out is not None else T
+        if gated and Tout != T:
+            raise ValueError("gated layers keep the sequence length")
+        ab = torch.empty((B, M, T), dtype=torch.float32, device=x.device) if (gated and need_grad) else None
+        spk_strides = (0, 0, 0)
+        if spk is not None:
+            spk = _c(spk)
+            if spk.dim() == 2:      # (B, Cg): constant over time
+                spk_strides = (spk.stride(0), 1, 0)
+            else:                   # (B, Cg, T)
+                spk_strides = (spk.stride(0), spk.stride(1), 1)
+        res_in = x if gated else (_c(r) if r is not None else None)
+        r2c = _c(r2) if r2 is not None else None
+        y = conv_gemm(x, pk.fwd, pk.lda, pk.a_half, B=B, Cin=Cin, Tin=T, M=M, Tout=Tout,
+                      J=(1 if cfg.transposed else J), dil=cfg.dil, padL=padL, mode=mode, Cg=Cg,
+                      bias=bias, spk=spk, spk_strides=spk_strides,
+                      r=res_in if (mode == EPI_HIGHWAY or cfg.residual or not gated) else None,
+                      r2=r2c, residual=int(cfg.residual), ab=ab, xmask=bits, xmask_rs=bits_rs,
+                      drop_scale=dscale,
+                      store_mode=STORE_INTERLEAVE2 if cfg.transposed else STORE_BCT)
+        if need_grad:
+            ctx.cfg, ctx.pk, ctx.dims = cfg, pk, (B, Cin, T, Tout, M, Cg, J, padL)
+            ctx.bits, ctx.bits_rs, ctx.dscale = bits, bits_rs, dscale
+            ctx.spk_dim = spk.dim() if spk is not None else 0
+            ctx.has_r, ctx.has_r2 = (r is not None), (r2 is not None)
+            ctx.has_bias = bias is not None
+            ctx.save_for_backward(x, v, g, ab if gated else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg, pk = ctx.cfg, ctx.pk
+        B, Cin, T, Tout, M, Cg, J, padL = ctx.dims
+        x, v, g, saved = ctx.saved_tensors
+        mode = cfg.mode
+        gated = mode in (EPI_GLU, EPI_HIGHWAY)
+        dy = _c(dy)
+        rs2 = math.sqrt(0.5)
+        dr = dr2 = dspk = None
+        if gated:
+            dab, dres, part = gate_bwd(dy, saved, x if mode == EPI_HIGHWAY else None, B=B, C=Cg, T=T,
+                                       mode=mode, residual=int(cfg.residual),
+                                       want_dres=(mode == EPI_HIGHWAY or cfg.residual))
+            if ctx.spk_dim == 2:
+                dspk = part[:, :Cg].contiguous()
+            elif ctx.spk_dim == 3:
+                dspk = dab[:, :Cg, :]
+            gmat, Tg = dab, T
+        elif cfg.transposed:
+            # dy (B,O,2T): bias sums over the interleaved rows, operand de-interleaved to (B,2O,T)
+            O = pk.O
+            _, _, part = gate_bwd(dy, None, None, B=B, C=O, T=2 * T, mode=EPI_LINEAR, want_dpre=False)
+            gmat = torch.empty((B, 2 * O, T), dtype=torch.float32, device=dy.device)
+            _lib.call("dv3_deinterleave2_f32", dy.data_ptr(), gmat.data_ptr(), B, O, T, _stream())
+            dres, Tg = None, T
+        else:
+            # non-gated: y = ((act(pre) + r)*s + r2)*s ; strip the residual scalings first
+            alpha = 1.0
+            if ctx.has_r2:
+                dr2 = axpby(dy, None, rs2)
+                alpha *= rs2
+            if ctx.has_r:
+                dr = axpby(dy, None, alpha * rs2)
+                alpha *= rs2
+            need_y = mode in (EPI_RELU, EPI_SIGMOID, EPI_SOFTSIGN)
+            if need_y and (ctx.has_r or ctx.has_r2):
+                raise RuntimeError("activation + fused residual is not used by any layer")
+            if mode == EPI_LINEAR and alpha == 1.0:
+                _, _, part = gate_bwd(dy, None, None, B=B, C=M, T=Tout, mode=EPI_LINEAR, want_dpre=False)
+                gmat = dy
+            else:
+                gmat, _, part = gate_bwd(dy, saved if need_y else None, None, B=B, C=M, T=Tout, mode=mode,
+                                         alpha=alpha)
+            dres, Tg = None, Tout
+        dx = dv = dg = dbias = None
+        Mg = gmat.shape[1]
+        if ctx.needs_input_grad[0]:
+            # input gradient: transposed, tap-reversed weights; dropout mask on the output side
+            Jd = 1 if cfg.transposed else J
+            dx = conv_gemm(gmat, pk.bwd, pk.ldb, 0, B=B, Cin=Mg, Tin=Tg, M=Cin, Tout=T, J=Jd,
+                           dil=cfg.dil, padL=(Jd - 1) * cfg.dil - padL, mode=EPI_DGRAD, r=dres,
+                           ymask=ctx.bits, ymask_rs=ctx.bits_rs, drop_scale=ctx.dscale)
+        if ctx.needs_input_grad[1]:
+            Jd = 1 if cfg.transposed else J
+            tiles = ((Mg + 127) // 128) * ((Cin + 127) // 128) * Jd
+            S = _slab_count(B, tiles)
+            slabs = wgrad_gemm(gmat, x, B=B, M=Mg, Cin=Cin, T=Tg, Tin=T, J=Jd, dil=cfg.dil, padL=padL,
+                               n_slabs=S, xmask=ctx.bits, xmask_rs=ctx.bits_rs, drop_scale=ctx.dscale)
+            v3 = v if v.dim() == 3 else v.unsqueeze(-1)
+            dv, dg, dbias = weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None,
+                                            pk.scale, part, B, pk.O, pk.I, pk.J, cfg.transposed,
+                                            want_bias=ctx.has_bias)
+            dv = dv.view_as(v)
+        return dx, dv, dg, dbias, dspk, dr, dr2, None, None
+
+
+def conv_layer(x, v, g, bias, cfg, spk=None, r=None, r2=None, packed=None):
+    return ConvLayerFn.apply(x, v, g, bias, spk, r, r2, cfg, packed)
+
+
+# ----------------------------------------------------------------------------------------------
+# attention core (deepvoice3.py:143-171): S = q^T k -> mask/softmax/dropout -> ctx = v Pd^T sqrt(Tk)
+# q (B,E,Tq), k (B,E,Tk), v (B,E,Tk) all BCT; returns ctx (B,E,Tq) BCT and P (B,Tq,Tk).
+# ----------------------------------------------------------------------------------------------
+class AttnCoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, key_len, last_attended, cfg):
+        q, k, v = _c(_chk(q, "q")), _c(_chk(k, "k")), _c(_chk(v, "v"))
+        B, E, Tq = q.shape
+        Tk = k.shape[2]
+        p_drop, training, win_back, win_ahead, site = cfg
+        dev = q.device
+        # scores: per-batch operand A = q[b] as [Cin=E][lda=Tq]
+        S = conv_gemm(k, q, Tq, 0, B=B, Cin=E, Tin=Tk, M=Tq, Tout=Tk, a_bs=E * Tq)
+        bits, bits_rs, dscale = None, 0, 1.0
+        if training and p_drop > 0:
+            bits, bits_rs = dropout_bits(B * Tq, Tk, p_drop, dev, site)
+            dscale = 1.0 / (1.0 - p_drop)
+        pd = torch.empty_like(S)
+        d = _softmax_desc()
+        d.s, d.pd, d.key_len, d.last_attended = S.data_ptr(), pd.data_ptr(), _ptr(key_len), _ptr(last_attended)
+        d.mask, d.mask_rs, d.drop_scale = _ptr(bits), bits_rs, dscale
+        d.pd_scale = Tk * math.sqrt(1.0 / Tk)   # deepvoice3.py:170-171: s * sqrt(1/s)
+        d.B, d.Tq, d.Tk, d.win_back, d.win_ahead = B, Tq, Tk, win_back, win_ahead
+        _lib.call("dv3_attn_softmax_f32", ctypes.byref(d), _stream())
+        P = S
+        # context: out[b][e][t] = sum_n v[b][e][n] * pd[b][t][n]
+        ctxv = wgrad_gemm(v, pd, B=B, M=E, Cin=Tq, T=Tk, Tin=Tk, n_slabs=B).view(B, E, Tq)
+        if any(ctx.needs_input_grad[:3]):
+            ctx.save_for_backward(q, k, v, P, pd)
+            ctx.bits, ctx.bits_rs, ctx.dscale, ctx.pd_scale = bits, bits_rs, dscale, d.pd_scale
+        return ctxv, P
+
+    @staticmethod
+    def backward(ctx, dctx, dP):
+        q, k, v, P, pd = ctx.saved_tensors
+        B, E, Tq = q.shape
+        Tk = k.shape[2]
+        dctx = _c(dctx)
+        # dv[b][e][n] = sum_t dctx[b][e][t] * pd[b][t][n]  -> needs pd^T (B,Tk,Tq)
+        pdT = transpose(pd)
+        dv = wgrad_gemm(dctx, pdT, B=B, M=E, Cin=Tk, T=Tq, Tin=Tq, n_slabs=B).view(B, E, Tk)
+        # dpd[b][t][n] = sum_e dctx[b][e][t] * v[b][e][n]   (per-batch operand A = dctx[b])
+        dpd = conv_gemm(v, dctx, Tq, 0, B=B, Cin=E, Tin=Tk, M=Tq, Tout=Tk, a_bs=E * Tq)
+        dS = torch.empty_like(P)
+        d = _softmax_bwd_desc()
+        d.p, d.dpd, d.ds = P.data_ptr(), dpd.data_ptr(), dS.data_ptr()
+        d.dp_direct = _ptr(_c(dP)) if dP is not None else None
+        d.mask, d.mask_rs, d.drop_scale = _ptr(ctx.bits), ctx.bits_rs, ctx.dscale * ctx.pd_scale
+        d.B, d.Tq, d.Tk = B, Tq, Tk
+        _lib.call("dv3_attn_softmax_bwd_f32", ctypes.byref(d), _stream())
+        # dq[b][e][t] = sum_n k[b][e][n] * dS[b][t][n]
+        dq = wgrad_gemm(k, dS, B=B, M=E, Cin=Tq, T=Tk, Tin=Tk, n_slabs=B).view(B, E, Tq)
+        # dk[b][e][n] = sum_t q[b][e][t] * dS[b][t][n]  -> needs dS^T
+        dST = transpose(dS)
+        dk = wgrad_gemm(q, dST, B=B, M=E, Cin=Tk, T=Tq, Tin=Tq, n_slabs=B).view(B, E, Tk)
+        return dq, dk, dv, None, None, None
+
+
+def attention_core(q, k, v, key_len=None, last_attended=None, p=0.0, training=False, win_back=1,
+                   win_ahead=3, site=None):
+    return AttnCoreFn.apply(q, k, v, key_len, last_attended, (p, training, win_back, win_ahead, site))
+
+
+# ----------------------------------------------------------------------------------------------
+# embedding gather (+dropout) straight into BCT, dense deterministic gradient
+# ----------------------------------------------------------------------------------------------
+class EmbeddingBCTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, weight, p, training, padding_idx, site):
+        _chk(weight, "embedding weight")
+        idx = _c(idx.long())
+        B, T = idx.shape
+        n_vocab, C = weight.shape
+        out = torch.empty((B, C, T), dtype=torch.float32, device=weight.device)
+        bits, rs, dscale = None, 0, 1.0
+        if training and p > 0:
+            bits, rs = dropout_bits(B * C, T, p, weight.device, site)
+            dscale = 1.0 / (1.0 - p)
+        _lib.call("dv3_embedding_bct_f32", idx.data_ptr(), _c(weight).data_ptr(), out.data_ptr(), _ptr(bits),
+                  rs, dscale, B, T, C, n_vocab, _stream())
+        ctx.save_for_backward(idx)
+        ctx.info = (bits, rs, dscale, B, T, C, n_vocab, -1 if padding_idx is None else padding_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        bits, rs, dscale, B, T, C, n_vocab, pad = ctx.info
+        dout = _c(dout)
+        dw = torch.empty((n_vocab, C), dtype=torch.float32, device=dout.device)
+        _lib.call("dv3_embedding_bct_bwd_f32", idx.data_ptr(), dout.data_ptr(), dw.data_ptr(), _ptr(bits),
+                  rs, dscale, B, T, C, n_vocab, pad, _stream())
+        return None, dw, None, None, None, None
+
+
+def embedding_bct(idx, weight, p=0.0, training=False, padding_idx=None, site=None):
+    return EmbeddingBCTFn.apply(idx, weight, p, training, padding_idx, site)
+
+
+class DropoutFn(torch.autograd.Function):
+    """Standalone dropout on a (..., T)-last tensor viewed as [rows][T] (shared-mask sites)."""
+
+    @staticmethod
+    def forward(ctx, x, p, site):
+        x = _c(_chk(x, "x"))
+        T = x.shape[-1]
+        rows = x.numel() // T
+        bits, rs = dropout_bits(rows, T, p, x.device, site)
+        scale = 1.0 / (1.0 - p)
+        out = torch.empty_like(x)
+        _lib.call("dv3_dropout_apply_f32", x.data_ptr(), bits.data_ptr(), rs, scale, out.data_ptr(), rows, T,
+                  _stream())
+        ctx.info = (bits, rs, scale, rows, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        bits, rs, scale, rows, T = ctx.info
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        _lib.call("dv3_dropout_apply_f32", dy.data_ptr(), bits.data_ptr(), rs, scale, dx.data_ptr(), rows, T,
+                  _stream())
+        return dx, None, None
+
+
+def dropout(x, p, training, site=None):
+    if not training or p <= 0:
+        return x
+    return DropoutFn.apply(x, p, site)
+
+
+def sincos_pos_bct(pos, table, w=None, base=None, apply_sincos=True):
+    """SinusoidalEncoding.forward (modules.py:45-64) -> BCT; w: None | float | tensor[B]; the
+    (frozen) table gets no gradient; `base` is added (gradient passes straight through)."""
+    pos = _c(pos.long())
+    B, T = pos.shape
+    n_pos, C = table.shape
+    wt, per_batch = None, 0
+    if w is not None:
+        if torch.is_tensor(w):
+            wt = _c(w.detach().float().view(-1))
+            per_batch = 1 if wt.numel() > 1 else 0
+        else:
+            wt = torch.full((1,), float(w), dtype=torch.float32, device=table.device)
+    out = torch.empty((B, C, T), dtype=torch.float32, device=table.device)
+    _lib.call("dv3_sincos_pos_bct_f32", pos.data_ptr(), _c(table).data_ptr(), _ptr(wt), per_batch,
+              _ptr(_c(base.detach()) if base is not None else None), out.data_ptr(), B, T, C, n_pos,
+              int(apply_sincos), _stream())
+    return out
+
+
+class _PosEncFn(torch.autograd.Function):
+    """out = base + PE(pos; table, w).  Gradient flows to `base` (identity) and to the rate `w`
+    when it is a tensor (multi-speaker: deepvoice3.py:304-315); the table is frozen."""
+
+    @staticmethod
+    def forward(ctx, base, pos, table, w, apply_sincos):
+        out = sincos_pos_bct(pos, table, w, base, apply_sincos)
+        ctx.has_base = base is not None
+        if torch.is_tensor(w) and w.requires_grad:
+            if not apply_sincos:
+                raise RuntimeError("a learnable rate needs the raw-angle table")
+            ctx.save_for_backward(pos, table, w)
+            ctx.w_shape = w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dw = None
+        if ctx.needs_input_grad[3]:
+            pos, table, w = ctx.saved_tensors
+            dout_c = _c(dout)
+            B, C, T = dout_c.shape
+            wt = _c(w.detach().float().view(-1))
+            per_batch = 1 if wt.numel() > 1 else 0
+            dwb = torch.empty(B, dtype=torch.float32, device=dout.device)
+            _lib.call("dv3_sincos_pos_bwd_f32", _c(pos.long()).data_ptr(), _c(table).data_ptr(), wt.data_ptr(),
+                      per_batch, dout_c.data_ptr(), dwb.data_ptr(), B, T, C, table.shape[0], _stream())
+            dw = (dwb if per_batch else dwb.sum(0, keepdim=True)).view(ctx.w_shape)
+        return (dout if ctx.has_base else None), None, None, dw, None
+
+
+def add_position_encoding(base, pos, table, w=None, apply_sincos=True):
+    return _PosEncFn.apply(base, pos, table, w, apply_sincos)
+
+
+def position_encoding(pos, table, w=None, apply_sincos=True):
+    return _PosEncFn.apply(None, pos, table, w, apply_sincos)
+
+
+# ----------------------------------------------------------------------------------------------
+# losses (fused value + gradient; train.py:537-601,704-740)
+# ----------------------------------------------------------------------------------------------
+def _dense_or_copy(t):
+    """Keep a (B,T,D)-shaped tensor whose memory is dense in either BTC or BCT order."""
+    B, T, D = t.shape
+    st = t.stride()
+    if st == (T * D, D, 1) or st == (D * T, 1, T):
+        return t
+    return t.contiguous()
+
+
+class SpecLossFn(torch.autograd.Function):
+    """-> tensor[4] = {l1_loss, binary_div, (1-w_bd)*l1 + w_bd*bd, mask_sum}; only [2] carries
+    gradient.  y_hat, y: logical (B,T,D) (memory BTC or a transposed view of BCT); compares
+    y_hat[:, :-r] with y[:, r:]."""
+
+    @staticmethod
+    def forward(ctx, y_hat, y, lengths, r, w_masked, w_bd):
+        y_hat, y = _dense_or_copy(_chk(y_hat, "y_hat")), _dense_or_copy(_chk(y, "y"))
+        B, T, D = y_hat.shape
+        dev = y_hat.device
+        out4 = torch.empty(4, dtype=torch.float32, device=dev)
+        n_scr = _lib.lib().dv3_spec_loss_scratch_floats(B, T, D)
+        scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
+        dyh = torch.empty_strided(y_hat.shape, y_hat.stride(), dtype=torch.float32, device=dev) \
+            if ctx.needs_input_grad[0] else None
+        d = _spec_loss_desc()
+        d.y_hat, d.y, d.lengths = y_hat.data_ptr(), y.data_ptr(), _ptr(lengths)
+        d.yh_bs, d.yh_ts, d.yh_ds = y_hat.stride()
+        d.y_bs, d.y_ts, d.y_ds = y.stride()
+        d.dyh, d.out4, d.scratch = _ptr(dyh), out4.data_ptr(), scratch.data_ptr()
+        d.B, d.T, d.D, d.r = B, T, D, r
+        d.w_masked, d.w_bd, d.gscale = w_masked, w_bd, 1.0
+        _lib.call("dv3_spec_loss_f32", ctypes.byref(d), _stream())
+        ctx.dyh = dyh
+        return out4
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = ctx.dyh * dout[2] if ctx.dyh is not None else None
+        return g, None, None, None, None, None
+
+
+def spec_loss(y_hat, y, lengths, r=1, w_masked=0.5, w_bd=0.1):
+    return SpecLossFn.apply(y_hat, y, lengths, r, w_masked, w_bd)
+
+
+class GuidedAttnLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attn, in_len, out_len, g):
+        attn = _c(_chk(attn, "attn"))
+        L, B, Tq, Tk = attn.shape
+        dev = attn.device
+        out1 = torch.empty(1, dtype=torch.float32, device=dev)
+        scratch = torch.empty(4 * 1024 + 16, dtype=torch.float32, device=dev)
+        dattn = torch.empty_like(attn) if ctx.needs_input_grad[0] else None
+        _lib.call("dv3_guided_attn_loss_f32", attn.data_ptr(), in_len.data_ptr(), out_len.data_ptr(),
+                  _ptr(dattn), out1.data_ptr(), scratch.data_ptr(), L, B, Tq, Tk, float(g), 1.0, _stream())
+        ctx.dattn = dattn
+        return out1
+
+    @staticmethod
+    def backward(ctx, dout):
+        return (ctx.dattn * dout if ctx.dattn is not None else None), None, None, None
+
+
+def guided_attention_loss(attn, in_len, out_len, g=0.2):
+    return GuidedAttnLossFn.apply(attn, in_len, out_len, g)
+
+
+class BCELossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, t):
+        p, t = _c(_chk(p, "p")), _c(_chk(t, "t"))
+        dev = p.device
+        out1 = torch.empty(1, dtype=torch.float32, device=dev)
+        scratch = torch.empty(4 * 1024 + 16, dtype=torch.float32, device=dev)
+        dp = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        _lib.call("dv3_bce_loss_f32", p.data_ptr(), t.data_ptr(), _ptr(dp), out1.data_ptr(),
+                  scratch.data_ptr(), p.numel(), 1.0, _stream())
+        ctx.dp = dp
+        return out1
+
+    @staticmethod
+    def backward(ctx, dout):
+        return (ctx.dp * dout if ctx.dp is not None else None), None
+
+
+def bce_loss(p, t):
+    return BCELossFn.apply(p, t)
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser tail on flat arenas
+# ----------------------------------------------------------------------------------------------
+def grad_sqnorm(flat_grad, partial, out2):
+    _lib.call("dv3_grad_sqnorm_f32", flat_grad.data_ptr(), flat_grad.numel(), partial.data_ptr(),
+              partial.numel(), out2.data_ptr(), _stream())
+
+
+def clip_adam(p, g, m, v, grad_norm, clip, hyper, beta1, beta2, eps, weight_decay=0.0, grad_prescale=1.0):
+    _lib.call("dv3_clip_adam_f32", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+              _ptr(grad_norm), float(clip), hyper.data_ptr(), float(beta1), float(beta2), float(eps),
+              float(weight_decay), float(grad_prescale), _stream())

@@ -1,0 +1,260 @@
+# coding: utf-8
+"""One optimisation step of the reference's train.train() (train.py:604-785) on the HIP path.
+
+What the reference does on the host per step -- numpy guided-attention masks (train.py:594-601),
+sequence masks, ~12 .item() syncs, per-tensor Adam -- is done here on the device:
+    model forward (fused tap-GEMM layers)
+    spec_loss (mel) + spec_loss (linear) + BCE(done) + guided attention loss, each ONE fused
+        value+gradient kernel (csrc/loss.hip)
+    backward (dgrad / wgrad tap-GEMMs, weight-norm backward)
+    [data parallel: RCCL all-reduce of the flat gradient arena in reverse-layer buckets,
+     launched on a side stream as soon as each bucket's gradients are final]
+    global-norm clip + Adam over ONE flat parameter arena (csrc/optim.hip)
+Scalars stay on the device; nothing in step() synchronises with the host.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class TrainConfig(object):
+    """The hparams train.train() reads (hparams.py:96-121; presets/*.json)."""
+
+    def __init__(self, outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5,
+                 binary_divergence_weight=0.1, priority_freq_weight=0.0, use_guided_attention=True,
+                 guided_attention_sigma=0.2, clip_thresh=0.1, adam_beta1=0.5, adam_beta2=0.9,
+                 adam_eps=1e-6, weight_decay=0.0, initial_learning_rate=5e-4,
+                 lr_schedule="noam_learning_rate_decay", lr_schedule_kwargs=None, max_positions=512):
+        self.outputs_per_step = outputs_per_step
+        self.downsample_step = downsample_step
+        self.masked_loss_weight = masked_loss_weight
+        self.binary_divergence_weight = binary_divergence_weight
+        if priority_freq_weight > 0:
+            raise NotImplementedError("priority_freq_weight > 0 (0 in every reference preset)")
+        self.use_guided_attention = use_guided_attention
+        self.guided_attention_sigma = guided_attention_sigma
+        self.clip_thresh = clip_thresh
+        self.adam_beta1, self.adam_beta2, self.adam_eps = adam_beta1, adam_beta2, adam_eps
+        self.weight_decay = weight_decay
+        self.initial_learning_rate = initial_learning_rate
+        self.lr_schedule = lr_schedule
+        self.lr_schedule_kwargs = lr_schedule_kwargs or {}
+        self.max_positions = max_positions
+
+
+def noam_learning_rate_decay(init_lr, global_step, warmup_steps=4000):
+    """lrschedule.py:5-11."""
+    warmup_steps = float(warmup_steps)
+    step = global_step + 1.
+    return init_lr * warmup_steps ** 0.5 * min(step * warmup_steps ** -1.5, step ** -0.5)
+
+
+def step_learning_rate_decay(init_lr, global_step, anneal_rate=0.98, anneal_interval=30000):
+    return init_lr * anneal_rate ** (global_step // anneal_interval)
+
+
+def cyclic_cosine_annealing(init_lr, global_step, T, M):
+    TdivM = T // M
+    return init_lr / 2.0 * (math.cos(math.pi * ((global_step - 1) % TdivM) / TdivM) + 1.0)
+
+
+_SCHEDULES = dict(noam_learning_rate_decay=noam_learning_rate_decay,
+                  step_learning_rate_decay=step_learning_rate_decay,
+                  cyclic_cosine_annealing=cyclic_cosine_annealing)
+
+
+class Batch(object):
+    """Device-resident training batch in the conventions of train.collate_fn (train.py:293-360):
+    mel already time-downsampled (train.py:639-640), lengths as int32 device vectors."""
+
+    def __init__(self, text, text_positions, frame_positions, mel, y, done, input_lengths_host,
+                 target_lengths_host, speaker_ids, r, downsample_step, device):
+        self.text, self.text_positions, self.frame_positions = text, text_positions, frame_positions
+        self.mel, self.y, self.done, self.speaker_ids = mel, y, done, speaker_ids
+        self.input_lengths_host = np.asarray(input_lengths_host)
+        self.target_lengths_host = np.asarray(target_lengths_host)
+        dl = self.target_lengths_host // r // downsample_step
+        self.decoder_lengths_host = dl
+        i32 = dict(dtype=torch.int32, device=device)
+        self.input_lengths = torch.as_tensor(self.input_lengths_host.astype(np.int32), **i32)
+        self.target_lengths = torch.as_tensor(self.target_lengths_host.astype(np.int32), **i32)
+        self.decoder_lengths = torch.as_tensor(dl.astype(np.int32), **i32)
+        # what the linear-domain mask is built from (train.py:669-677)
+        self.linear_mask_lengths = self.target_lengths if downsample_step > 1 else self.decoder_lengths
+        self.n_frames = int(self.target_lengths_host.sum())
+
+    @staticmethod
+    def from_collate(x, input_lengths, mel, y, text_positions, frame_positions, done, target_lengths,
+                     speaker_ids, downsample_step, device, r=1):
+        if downsample_step > 1:
+            mel = mel[:, 0::downsample_step, :].contiguous()
+        f = lambda t: t.to(device, non_blocking=True) if t is not None else None
+        return Batch(f(x.long()), f(text_positions.long()), f(frame_positions.long()), f(mel.float()),
+                     f(y.float()), f(done.float()), input_lengths.numpy() if torch.is_tensor(input_lengths) else input_lengths,
+                     target_lengths.numpy() if torch.is_tensor(target_lengths) else target_lengths,
+                     f(speaker_ids), r, downsample_step, device)
+
+
+class FlatArena(object):
+    """All trainable parameters as views into one flat fp32 buffer; same for gradients and the
+    Adam moments.  Order = reverse of first use in forward would be ideal for bucketing; we keep
+    registration order and bucket from the tail (converter -> decoder -> encoder), which is the
+    order backward produces gradients in."""
+
+    def __init__(self, params):
+        params = list(params)
+        self.params = params
+        dev = params[0].device
+        sizes = [p.numel() for p in params]
+        # 4-element alignment per tensor keeps every view 16-byte aligned
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 3) // 4 * 4
+        self.offsets, self.sizes, self.total = offs, sizes, total
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o, n in zip(params, offs, sizes):
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+
+
+class Trainer(object):
+    def __init__(self, model, cfg, global_step=0, process_group=None, bucket_mb=25.0):
+        self.model, self.cfg = model, cfg
+        self.global_step = global_step
+        self.adam_step = 0
+        params = list(model.get_trainable_parameters())
+        self.arena = FlatArena(params)
+        dev = self.arena.flat.device
+        self.device = dev
+        self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(3)
+        self.norm_partial = torch.empty(1024, dtype=torch.float32, device=dev)
+        self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.pg = process_group
+        self.world = 1
+        self.comm = None
+        if process_group is not None:
+            from . import dist as _dist
+            self.world = torch.distributed.get_world_size(process_group)
+            self.comm = _dist.BucketedAllReduce(self.arena, process_group, bucket_mb)
+
+    # ------------------------------------------------------------------------------------
+    def current_lr(self):
+        c = self.cfg
+        if c.lr_schedule is None:
+            return c.initial_learning_rate
+        return _SCHEDULES[c.lr_schedule](c.initial_learning_rate, self.global_step, **c.lr_schedule_kwargs)
+
+    def _set_hyper(self):
+        c = self.cfg
+        self.adam_step += 1
+        t = self.adam_step
+        self._hyper_host[0] = float(self.current_lr())
+        self._hyper_host[1] = 1.0 - c.adam_beta1 ** t
+        self._hyper_host[2] = math.sqrt(1.0 - c.adam_beta2 ** t)
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
+
+    def check_lengths(self, batch):
+        """train.py:646-652."""
+        max_seq_len = max(batch.input_lengths_host.max(), batch.decoder_lengths_host.max())
+        if max_seq_len >= self.cfg.max_positions:
+            raise RuntimeError(
+                """max_seq_len ({}) >= max_posision ({})
+Input text or decoder targget length exceeded the maximum length.
+Please set a larger value for ``max_position`` in hyper parameters.""".format(max_seq_len, self.cfg.max_positions))
+
+    # ------------------------------------------------------------------------------------
+    def forward_backward(self, batch):
+        """model forward + losses + backward.  Returns the scalars as device tensors."""
+        c = self.cfg
+        r = c.outputs_per_step
+        self.model.train()
+        mel_out, lin_out, attn, done_hat = self.model(
+            batch.text, batch.mel, speaker_ids=batch.speaker_ids, text_positions=batch.text_positions,
+            frame_positions=batch.frame_positions, input_lengths=batch.input_lengths_host)
+        wm, w = c.masked_loss_weight, c.binary_divergence_weight
+        m4 = ops.spec_loss(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w)
+        l4 = ops.spec_loss(lin_out, batch.y, batch.linear_mask_lengths if wm > 0 else None, r, wm, w)
+        done_loss = ops.bce_loss(done_hat, batch.done)
+        loss = m4[2] + l4[2] + done_loss[0]
+        scal = dict(mel_l1_loss=m4[0], mel_binary_div_loss=m4[1], mel_loss=m4[2], linear_l1_loss=l4[0],
+                    linear_binary_div_loss=l4[1], linear_loss=l4[2], done_loss=done_loss[0])
+        if c.use_guided_attention:
+            attn_loss = ops.guided_attention_loss(attn, batch.input_lengths, batch.decoder_lengths,
+                                                  c.guided_attention_sigma)
+            loss = loss + attn_loss[0]
+            scal["attn_loss"] = attn_loss[0]
+        scal["loss"] = loss
+        if self.comm is not None:
+            self.comm.arm()
+        loss.backward()
+        return {k: v.detach() for k, v in scal.items()}
+
+    def optimizer_step(self):
+        c, a = self.cfg, self.arena
+        if self.comm is not None:
+            self.comm.finish()           # all buckets reduced (sum); 1/world folded into grad_prescale
+        prescale = 1.0 / self.world
+        if c.clip_thresh > 0:
+            ops.grad_sqnorm(a.grad, self.norm_partial, self.norm_out)   # norm of the SUMMED gradient
+        ops.clip_adam(a.flat, a.grad, a.exp_avg, a.exp_avg_sq, self.norm_out if c.clip_thresh > 0 else None,
+                      c.clip_thresh, self.hyper, c.adam_beta1, c.adam_beta2, c.adam_eps, c.weight_decay,
+                      prescale)
+
+    def step(self, batch):
+        """One full optimisation step; returns device scalars (loss terms, grad_norm, lr)."""
+        self._set_hyper()
+        self.arena.grad.zero_()
+        scal = self.forward_backward(batch)
+        self.optimizer_step()
+        scal["grad_norm"] = self.norm_out[0] * (1.0 / self.world)
+        scal["learning_rate"] = self.hyper[0].clone()
+        self.global_step += 1
+        return scal
+
+
+class GraphedTrainer(object):
+    """Whole-step hipGraph: forward + losses + backward + (all-reduce) + clip/Adam captured once per
+    batch shape and replayed -- removes the per-kernel host launch cost (~300 launches/step).
+    Dropout masks still change every replay: the Philox seed offset lives on the device."""
+
+    def __init__(self, trainer, static_batch, warmup=3):
+        self.t = trainer
+        self.batch = static_batch
+        dev = trainer.device
+        self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
+        ops.dropout_state.dev_offset = self.seed_offset
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        site0 = ops.dropout_state.site
+        with torch.cuda.graph(self.graph):
+            self.scal = self._body()
+        ops.dropout_state.site = site0
+
+    def _body(self):
+        t = self.t
+        t.arena.grad.zero_()
+        scal = t.forward_backward(self.batch)
+        t.optimizer_step()
+        scal["grad_norm"] = t.norm_out[0] * (1.0 / t.world)
+        self.seed_offset.add_(1)
+        return scal
+
+    def step(self):
+        self.t._set_hyper()
+        self.graph.replay()
+        self.t.global_step += 1
+        return self.scal

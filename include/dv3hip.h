@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 7
+#define DV3_ABI_VERSION 10
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -47,8 +47,13 @@ enum {
   DV3_EPI_SIGMOID = 2, /* y = sigmoid(acc + bias)             last 1x1 + torch.sigmoid     */
   DV3_EPI_GLU = 3,     /* Conv1dGLU:  modules.py:157-164                                   */
   DV3_EPI_HIGHWAY = 4, /* HighwayConv1d: modules.py:224-226                                */
-  DV3_EPI_DGRAD = 5    /* y = acc * dropmask(y-site) + addend   (input-gradient pass)      */
+  DV3_EPI_DGRAD = 5,   /* y = acc * dropmask(y-site) + addend   (input-gradient pass)      */
+  DV3_EPI_SOFTSIGN = 6 /* y = v/(1+|v|), v = acc + bias       F.softsign(Linear(spk))      */
 };
+/* LINEAR/RELU/SIGMOID/SOFTSIGN: after the activation, if r  != NULL: y = (y + r ) * sqrt(.5)
+ *                                               then if r2 != NULL: y = (y + r2) * sqrt(.5)
+ * (AttentionLayer's `(x + residual) * sqrt(0.5)`, deepvoice3.py:175, and the decoder's outer
+ *  residual, deepvoice3.py:348-349).                                                      */
 
 enum {
   DV3_STORE_BCT = 0,       /* y[b][m][n]                                                   */
@@ -83,6 +88,7 @@ typedef struct dv3_conv_desc {
   const float* bias;                         /* [M] (reference order) or NULL               */
   const float* spk; int64_t spk_bs, spk_rs, spk_ts; /* additive on the `a` half (GLU) or NULL */
   const float* r;  int64_t r_bs, r_rs;       /* residual / highway input / DGRAD addend     */
+  const float* r2; int64_t r2_bs, r2_rs;     /* second residual (non-gated modes) or NULL   */
   float* y;        int64_t y_bs, y_rs;       /* output                                      */
   float* ab;                                 /* optional save of pre-gate (a,b): [B][M][Tout] */
   const uint32_t* xmask; int32_t xmask_rs;   /* dropout keep-bits over x rows [B*Cin][rs]   */
@@ -159,6 +165,7 @@ int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream);
 typedef struct dv3_gate_bwd_desc {
   const float* dy; const float* ab_or_y; const float* x;
   float* dab; float* dres; float* bias_part;
+  float alpha;                               /* non-gated modes: dy is scaled by alpha first */
   int32_t B, C, T, mode, residual;
 } dv3_gate_bwd_desc;
 int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream);
@@ -167,9 +174,17 @@ int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream);
  * Dropout keep-bit generator (F.dropout's bernoulli_, modules.py:147,210; deepvoice3.py:
  * 75,80,165,290,321).  Philox4x32-10, counter = (word index, site), key = seed.
  * bits[w] bit i == 1  <=>  element 32*w+i of the row is kept; p quantised to 1/65536.
+ * dev_seed_offset: a device-resident step counter, so a replayed hipGraph draws new masks.
  * ------------------------------------------------------------------------------------ */
 int dv3_dropout_bits(uint32_t* bits, int64_t n_words, float p, uint64_t seed,
-                     uint64_t site, void* stream);
+                     uint64_t site, const uint64_t* dev_seed_offset /* added to seed; NULL = 0 */,
+                     void* stream);
+
+/* out[row][t] = x[row][t] * keep(bits,row,t) * scale -- a standalone F.dropout for the few
+ * sites whose dropped tensor is shared by several consumers (deepvoice3.py:78-80,290,321:
+ * the time-expanded speaker embedding and the decoder input).  Its own backward.          */
+int dv3_dropout_apply_f32(const float* x, const uint32_t* bits, int32_t bits_rs, float scale,
+                          float* out, int64_t rows, int32_t T, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Attention (deepvoice3.py:132-176): masked softmax over the key axis + dropout.
@@ -183,6 +198,7 @@ typedef struct dv3_softmax_desc {
   const int32_t* key_len;
   const int32_t* last_attended;              /* device int32[1] or NULL (no window)        */
   const uint32_t* mask; int32_t mask_rs; float drop_scale;
+  float pd_scale;                            /* pd = dropout(p) * pd_scale (the sqrt(Tk) of deepvoice3.py:170-171) */
   int32_t B, Tq, Tk, win_back, win_ahead;
 } dv3_softmax_desc;
 int dv3_attn_softmax_f32(const dv3_softmax_desc* d, void* stream);
@@ -221,6 +237,11 @@ int dv3_sincos_pos_bct_f32(const int64_t* pos, const float* table, const float* 
                            int32_t w_per_batch, const float* base, float* out, int32_t B,
                            int32_t T, int32_t C, int32_t n_pos, int32_t apply_sincos,
                            void* stream);
+/* gradient of the encoding w.r.t. the rate: dw[b] = sum_{c,t} dout[b][c][t] * d enc/d w
+ * (multi-speaker models learn the rate through speaker_proj1/2, deepvoice3.py:304-315).   */
+int dv3_sincos_pos_bwd_f32(const int64_t* pos, const float* table, const float* w,
+                           int32_t w_per_batch, const float* dout, float* dw, int32_t B, int32_t T,
+                           int32_t C, int32_t n_pos, void* stream);
 /* dy [B][O][2T] -> out[b][j*O+o][t] = dy[b][o][2t+j]: operand of the ConvTranspose1d(k2,s2)
  * backward GEMMs (deepvoice3.py:519-520,527-528)                                          */
 int dv3_deinterleave2_f32(const float* dy, float* out, int32_t B, int32_t O, int32_t T,
@@ -236,6 +257,8 @@ int dv3_deinterleave2_f32(const float* dy, float* out, int32_t B, int32_t O, int
 typedef struct dv3_spec_loss_desc {
   const float* y_hat; const float* y; const int32_t* lengths; /* mask: t < lengths[b] (shifted by r) */
   float* dyh; float* out4; float* scratch;  /* scratch: >= 4*n_blocks floats                */
+  int64_t yh_bs, yh_ts, yh_ds;              /* element strides of y_hat / dyh over (b,t,d):  */
+  int64_t y_bs, y_ts, y_ds;                 /* BTC (T*D, D, 1) or BCT (D*T, 1, T) both fine  */
   int32_t B, T, D, r; float w_masked, w_bd, gscale;
 } dv3_spec_loss_desc;
 int dv3_spec_loss_f32(const dv3_spec_loss_desc* d, void* stream);

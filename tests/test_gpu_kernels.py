@@ -1,0 +1,415 @@
+# coding: utf-8
+"""-m gpu: kernel-level parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerance: BASELINE.json's north_star asks for 1e-4 relative fp32 on the model outputs; single
+kernels are held to 2e-5 (fp32 MFMA is an exact fma chain; only the summation order differs from
+the CPU's blocked GEMMs).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dv3_oracle as O
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+KTOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from deepvoice3_pytorch_amd import ops
+    return ops
+
+
+def test_library_loads_on_gpu_box(dev):
+    from deepvoice3_pytorch_amd import _lib
+    h = _lib.lib()
+    name = torch.zeros(1)  # placeholder to keep torch imported first
+    import ctypes
+    buf = ctypes.create_string_buffer(256)
+    ncu = ctypes.c_int(0)
+    _lib.call("dv3_device_info", 0, buf, 256, ctypes.byref(ncu))
+    assert buf.value.decode().startswith("gfx950"), buf.value
+    assert ncu.value == 256
+
+
+def test_ops_refuse_cpu_tensors():
+    ops = _ops()
+    with pytest.raises(RuntimeError):
+        ops.conv_layer(torch.zeros(1, 4, 8), torch.zeros(8, 4, 3), None, None, ops.LayerCfg(k=3))
+
+
+def _glu_sd(C, k, rng, n_spk=0):
+    sd = {"l.conv.weight_v": torch.from_numpy(rng.randn(2 * C, C, k).astype(np.float32) * 0.2),
+          "l.conv.weight_g": torch.from_numpy(rng.uniform(0.5, 1.5, (2 * C, 1, 1)).astype(np.float32)),
+          "l.conv.bias": torch.from_numpy(rng.uniform(-0.2, 0.2, 2 * C).astype(np.float32))}
+    return sd
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("C,T,k,d,causal", [(64, 200, 3, 1, False), (96, 150, 3, 27, True),
+                                            (20, 37, 5, 3, False), (128, 513, 3, 9, True)])
+def test_conv_gemm_glu_forward(dev, tile, C, T, k, d, causal):
+    """Conv1dGLU forward, eval mode, every tile configuration (asymmetric random data)."""
+    ops = _ops()
+    rng = np.random.RandomState(C + T + k + d)
+    B = 3
+    sd = _glu_sd(C, k, rng)
+    x = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
+    for residual in (True, False):
+        want = O.conv1d_glu(sd, "l", x, k, d, causal, residual)
+        pk = ops.pack_weights(sd["l.conv.weight_v"].to(dev), sd["l.conv.weight_g"].to(dev), glu_cg=C,
+                              need_bwd=False)
+        padL = (k - 1) * d if causal else (k - 1) // 2 * d
+        xg = x.to(dev)
+        y = ops.conv_gemm(xg, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
+                          padL=padL, mode=ops.EPI_GLU, Cg=C, bias=sd["l.conv.bias"].to(dev),
+                          r=xg if residual else None, residual=int(residual), tile_hint=tile)
+        assert rel_err(y.cpu(), want) < KTOL
+
+
+def test_conv_gemm_highway_and_activations(dev):
+    ops = _ops()
+    rng = np.random.RandomState(5)
+    B, C, T, k, d = 2, 48, 77, 3, 3
+    sd = _glu_sd(C, k, rng)
+    x = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
+    want = O.highway_conv1d(sd, "l", x, k, d, True)
+    xg = x.to(dev)
+    pk = ops.pack_weights(sd["l.conv.weight_v"].to(dev), sd["l.conv.weight_g"].to(dev), glu_cg=C, need_bwd=False)
+    y = ops.conv_gemm(xg, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
+                      padL=(k - 1) * d, mode=ops.EPI_HIGHWAY, Cg=C, bias=sd["l.conv.bias"].to(dev), r=xg)
+    assert rel_err(y.cpu(), want) < KTOL
+    # 1x1 conv with odd channel counts (80 -> 513, the converter's last layer shape class)
+    w = torch.from_numpy(rng.randn(513, 80, 1).astype(np.float32) * 0.1)
+    b = torch.from_numpy(rng.randn(513).astype(np.float32) * 0.1)
+    x2 = torch.from_numpy(rng.randn(B, 80, 203).astype(np.float32))
+    pk2 = ops.pack_weights(w.to(dev), None, need_bwd=False)
+    for mode, fn in [(ops.EPI_LINEAR, lambda v: v), (ops.EPI_RELU, torch.relu), (ops.EPI_SIGMOID, torch.sigmoid),
+                     (ops.EPI_SOFTSIGN, F.softsign)]:
+        y2 = ops.conv_gemm(x2.to(dev), pk2.fwd, pk2.lda, 0, B=B, Cin=80, Tin=203, M=513, Tout=203, mode=mode,
+                           bias=b.to(dev))
+        assert rel_err(y2.cpu(), fn(F.conv1d(x2, w, b))) < KTOL
+
+
+def _grads(outs, ins):
+    return torch.autograd.grad(outs, ins, allow_unused=True)
+
+
+@pytest.mark.parametrize("kind", ["glu_res", "glu", "highway", "relu1x1", "linear", "sigmoid", "convT"])
+def test_conv_layer_backward(dev, kind):
+    """ConvLayerFn forward+backward (pack -> tap-GEMM -> gate bwd -> dgrad -> wgrad -> weight-norm
+    bwd) against torch autograd of the oracle's formulation."""
+    ops = _ops()
+    rng = np.random.RandomState(sum(ord(c) for c in kind))
+    B, C, T, k, d = 4, 40, 61, 3, 3
+    if kind in ("glu_res", "glu", "highway"):
+        v = torch.from_numpy(rng.randn(2 * C, C, k).astype(np.float32) * 0.2)
+        g = torch.from_numpy(rng.uniform(0.5, 1.5, (2 * C, 1, 1)).astype(np.float32))
+        bias = torch.from_numpy(rng.uniform(-0.2, 0.2, 2 * C).astype(np.float32))
+    elif kind == "convT":
+        v = torch.from_numpy(rng.randn(C, 24, 2).astype(np.float32) * 0.2)
+        g = torch.from_numpy(rng.uniform(0.5, 1.5, (C, 1, 1)).astype(np.float32))
+        bias = torch.from_numpy(rng.uniform(-0.2, 0.2, 24).astype(np.float32))
+    else:
+        v = torch.from_numpy(rng.randn(33, C, 1).astype(np.float32) * 0.2)
+        g = torch.from_numpy(rng.uniform(0.5, 1.5, (33, 1, 1)).astype(np.float32))
+        bias = torch.from_numpy(rng.uniform(-0.2, 0.2, 33).astype(np.float32))
+    x = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
+
+    def cpu_forward(x, v, g, bias):
+        sd = {"l.conv.weight_v": v, "l.conv.weight_g": g, "l.conv.bias": bias,
+              "c.weight_v": v, "c.weight_g": g, "c.bias": bias}
+        if kind == "glu_res":
+            return O.conv1d_glu(sd, "l", x, k, d, True, True)
+        if kind == "glu":
+            return O.conv1d_glu(sd, "l", x, k, d, False, False)
+        if kind == "highway":
+            return O.highway_conv1d(sd, "l", x, k, d, True)
+        if kind == "convT":
+            return O.conv_transpose1d_k2s2(sd, "c", x)
+        y = O.conv1d(sd, "c", x)
+        return {"relu1x1": torch.relu, "linear": lambda t: t, "sigmoid": torch.sigmoid}[kind](y)
+
+    cfg = {"glu_res": ops.LayerCfg(k=k, dil=d, causal=True, mode=ops.EPI_GLU, residual=True),
+           "glu": ops.LayerCfg(k=k, dil=d, causal=False, mode=ops.EPI_GLU, residual=False),
+           "highway": ops.LayerCfg(k=k, dil=d, causal=True, mode=ops.EPI_HIGHWAY),
+           "relu1x1": ops.LayerCfg(mode=ops.EPI_RELU), "linear": ops.LayerCfg(mode=ops.EPI_LINEAR),
+           "sigmoid": ops.LayerCfg(mode=ops.EPI_SIGMOID),
+           "convT": ops.LayerCfg(k=2, mode=ops.EPI_LINEAR, transposed=True)}[kind]
+
+    cin = [t.clone().requires_grad_(True) for t in (x, v, g, bias)]
+    yc = cpu_forward(*cin)
+    wgt = torch.from_numpy(rng.randn(*yc.shape).astype(np.float32))
+    gc = _grads((yc * wgt).sum(), cin)
+
+    gin = [t.clone().to(dev).requires_grad_(True) for t in (x, v, g, bias)]
+    yg = ops.conv_layer(gin[0], gin[1], gin[2], gin[3], cfg)
+    assert rel_err(yg.detach().cpu(), yc.detach()) < KTOL
+    gg = _grads((yg * wgt.to(dev)).sum(), gin)
+    for name, a, b in zip(("dx", "dv", "dg", "dbias"), gg, gc):
+        assert rel_err(a.cpu(), b) < 5e-5, name
+
+
+def test_conv_layer_dropout_and_residuals(dev):
+    """Training-mode dropout (Philox keep-bits replayed into the oracle) + fused r / r2 residuals."""
+    ops = _ops()
+    rng = np.random.RandomState(9)
+    B, C, T, k, d, p = 3, 32, 100, 3, 1, 0.25
+    v = torch.from_numpy(rng.randn(2 * C, C, k).astype(np.float32) * 0.2)
+    g = torch.from_numpy(rng.uniform(0.5, 1.5, (2 * C, 1, 1)).astype(np.float32))
+    bias = torch.from_numpy(rng.uniform(-0.2, 0.2, 2 * C).astype(np.float32))
+    x = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
+    ops.dropout_state.manual_seed(77)
+    ops.dropout_state.record = {}
+    gin = [t.clone().to(dev).requires_grad_(True) for t in (x, v, g, bias)]
+    cfg = ops.LayerCfg(k=k, dil=d, causal=False, mode=ops.EPI_GLU, residual=True, p=p, training=True, site="s0")
+    yg = ops.conv_layer(gin[0], gin[1], gin[2], gin[3], cfg)
+    bits, rows, TT = ops.dropout_state.record["s0"]
+    ops.dropout_state.record = None
+    keep = torch.from_numpy(O.unpack_keep_bits(bits.cpu().numpy().view(np.uint32), rows, (TT + 31) // 32, TT))
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
+    # bit-exact agreement of the generator with the numpy Philox
+    want_bits = O.philox_keep_bits(bits.numel(), p, 77, 1)
+    assert np.array_equal(bits.cpu().numpy().view(np.uint32), want_bits)
+
+    def drop(site, t, pp, layout):
+        return t * keep.view(B, C, T).float() / (1 - pp)
+    cin = [t.clone().requires_grad_(True) for t in (x, v, g, bias)]
+    sd = {"l.conv.weight_v": cin[1], "l.conv.weight_g": cin[2], "l.conv.bias": cin[3]}
+    yc = O.conv1d_glu(sd, "l", cin[0], k, d, False, True, p, drop)
+    assert rel_err(yg.detach().cpu(), yc.detach()) < KTOL
+    wgt = torch.from_numpy(rng.randn(*yc.shape).astype(np.float32))
+    gc = _grads((yc * wgt).sum(), cin)
+    gg = _grads((yg * wgt.to(dev)).sum(), gin)
+    for name, a, b in zip(("dx", "dv", "dg", "dbias"), gg, gc):
+        assert rel_err(a.cpu(), b) < 5e-5, name
+    # linear + two fused residuals: y = ((Wx+b + r)*s + r2)*s
+    w = torch.from_numpy(rng.randn(C, C, 1).astype(np.float32) * 0.2)
+    r = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
+    r2 = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
+    b1 = bias[:C].clone()
+    cin = [t.clone().requires_grad_(True) for t in (x, w, b1, r, r2)]
+    s = math.sqrt(0.5)
+    yc = ((F.conv1d(cin[0], cin[1], cin[2]) + cin[3]) * s + cin[4]) * s
+    gin = [t.clone().to(dev).requires_grad_(True) for t in (x, w, b1, r, r2)]
+    yg = ops.conv_layer(gin[0], gin[1], None, gin[2], ops.LayerCfg(), r=gin[3], r2=gin[4])
+    assert rel_err(yg.detach().cpu(), yc.detach()) < KTOL
+    gc = _grads((yc * wgt).sum(), cin)
+    gg = _grads((yg * wgt.to(dev)).sum(), gin)
+    for name, a, b in zip(("dx", "dw", "db", "dr", "dr2"), gg, gc):
+        assert rel_err(a.cpu(), b) < 5e-5, name
+
+
+def test_speaker_bias_paths(dev):
+    ops = _ops()
+    rng = np.random.RandomState(21)
+    B, C, T, k = 3, 24, 50, 3
+    v = torch.from_numpy(rng.randn(2 * C, C, k).astype(np.float32) * 0.2)
+    bias = torch.from_numpy(rng.uniform(-0.2, 0.2, 2 * C).astype(np.float32))
+    x = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
+    for shape in [(B, C), (B, C, T)]:
+        spk = torch.from_numpy(rng.randn(*shape).astype(np.float32))
+        cin = [t.clone().requires_grad_(True) for t in (x, v, bias, spk)]
+        y = F.conv1d(cin[0], cin[1], cin[2], padding=1)
+        a, b = y.split(C, dim=1)
+        a = a + (cin[3].unsqueeze(-1) if len(shape) == 2 else cin[3])
+        yc = a * torch.sigmoid(b)
+        gin = [t.clone().to(dev).requires_grad_(True) for t in (x, v, bias, spk)]
+        yg = ops.conv_layer(gin[0], gin[1], None, gin[2], ops.LayerCfg(k=k, mode=ops.EPI_GLU), spk=gin[3])
+        assert rel_err(yg.detach().cpu(), yc.detach()) < KTOL
+        wgt = torch.from_numpy(rng.randn(*yc.shape).astype(np.float32))
+        gc = _grads((yc * wgt).sum(), cin)
+        gg = _grads((yg * wgt.to(dev)).sum(), gin)
+        for name, u, w_ in zip(("dx", "dv", "db", "dspk"), gg, gc):
+            assert rel_err(u.cpu(), w_) < 5e-5, name
+
+
+@pytest.mark.parametrize("Tq,Tk,E", [(50, 37, 32), (203, 150, 64), (1, 29, 48)])
+def test_attention_core(dev, Tq, Tk, E):
+    """q^T k -> mask -> softmax -> dropout(off) -> context * sqrt(Tk), forward and backward."""
+    ops = _ops()
+    rng = np.random.RandomState(Tq + Tk)
+    B = 3
+    q, k, v = [torch.from_numpy(rng.randn(B, E, t).astype(np.float32) * 0.5) for t in (Tq, Tk, Tk)]
+    lens = torch.tensor([Tk, max(1, Tk - 5), max(1, Tk // 2)], dtype=torch.int32)
+    cin = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    S = torch.bmm(cin[0].transpose(1, 2), cin[1])
+    mask = torch.arange(Tk)[None, :] >= lens[:, None]
+    S = S.masked_fill(mask[:, None, :], -float("inf"))
+    P = F.softmax(S, dim=-1)
+    ctx = torch.bmm(P, cin[2].transpose(1, 2)) * (Tk * math.sqrt(1.0 / Tk))   # (B,Tq,E)
+    ctx = ctx.transpose(1, 2)
+    gin = [t.clone().to(dev).requires_grad_(True) for t in (q, k, v)]
+    cg, Pg = ops.attention_core(gin[0], gin[1], gin[2], lens.to(dev))
+    assert rel_err(Pg.detach().cpu(), P.detach()) < KTOL
+    assert rel_err(cg.detach().cpu(), ctx.detach()) < KTOL
+    w1 = torch.from_numpy(rng.randn(*ctx.shape).astype(np.float32))
+    w2 = torch.from_numpy(rng.randn(*P.shape).astype(np.float32))
+    gc = _grads((ctx * w1).sum() + (P * w2).sum(), cin)
+    gg = _grads((cg * w1.to(dev)).sum() + (Pg * w2.to(dev)).sum(), gin)
+    for name, a, b in zip(("dq", "dk", "dv"), gg, gc):
+        assert rel_err(a.cpu(), b) < 1e-4, name
+
+
+def test_attention_window_and_argmax(dev):
+    ops = _ops()
+    rng = np.random.RandomState(3)
+    B, E, Tk = 2, 16, 40
+    q = torch.from_numpy(rng.randn(B, E, 1).astype(np.float32))
+    k = torch.from_numpy(rng.randn(B, E, Tk).astype(np.float32))
+    v = torch.from_numpy(rng.randn(B, E, Tk).astype(np.float32))
+    for la in (0, 5, 38):
+        S = torch.bmm(q.transpose(1, 2), k)
+        lo, hi = la - 1, la + 3
+        if lo > 0:
+            S[:, :, :lo] = -float("inf")
+        if hi < Tk:
+            S[:, :, hi:] = -float("inf")
+        P = F.softmax(S, dim=-1)
+        lat = torch.tensor([la], dtype=torch.int32, device=dev)
+        _, Pg = ops.attention_core(q.to(dev), k.to(dev), v.to(dev), None, lat, win_back=1, win_ahead=3)
+        assert rel_err(Pg.cpu(), P) < KTOL
+        out = torch.zeros(1, dtype=torch.int32, device=dev)
+        from deepvoice3_pytorch_amd import _lib
+        _lib.call("dv3_attn_argmax_i32", Pg.data_ptr(), Tk, out.data_ptr(), ops._stream())
+        assert int(out.item()) == int(P[0, 0].argmax())
+
+
+def test_embedding_and_positions(dev):
+    ops = _ops()
+    rng = np.random.RandomState(4)
+    B, T, C, V = 3, 45, 40, 30
+    idx = torch.from_numpy(rng.randint(0, V, (B, T)))
+    idx[:, -5:] = 0
+    W = torch.from_numpy(rng.randn(V, C).astype(np.float32))
+    wc = W.clone().requires_grad_(True)
+    yc = F.embedding(idx, wc, padding_idx=0).transpose(1, 2)
+    wg = W.clone().to(dev).requires_grad_(True)
+    yg = ops.embedding_bct(idx.to(dev), wg, padding_idx=0)
+    assert torch.equal(yg.detach().cpu(), yc.detach())
+    wgt = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
+    (gc,) = _grads((yc * wgt).sum(), [wc])
+    (gg,) = _grads((yg * wgt.to(dev)).sum(), [wg])
+    assert rel_err(gg.cpu(), gc) < 1e-6
+    # sinusoidal encodings: scalar and per-batch rate, padding position 0
+    table = O.position_encoding_table(64, C, 1.0, sinusoidal=False)
+    pos = torch.from_numpy(rng.randint(0, 64, (B, T)))
+    pos[:, -3:] = 0
+    for w in (1.385, torch.tensor([0.7, 2.3, 7.6])):
+        want = O.sinusoidal_encoding(table, pos, w).transpose(1, 2)
+        got = ops.sincos_pos_bct(pos.to(dev), table.to(dev), w.to(dev) if torch.is_tensor(w) else w)
+        assert np.abs(got.cpu().numpy() - want.numpy()).max() < 2e-5   # sin/cos of angles up to ~500 rad
+    base = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
+    got = ops.add_position_encoding(base.to(dev), pos.to(dev), table.to(dev), 1.0, True)
+    assert np.abs(got.cpu().numpy() - (base + O.sinusoidal_encoding(table, pos, 1.0).transpose(1, 2)).numpy()).max() < 2e-5
+
+
+def test_losses(dev):
+    ops = _ops()
+    from tests.util import load_golden
+    fx = load_golden("losses")
+    y_hat, y = torch.from_numpy(fx["spec/y_hat"]), torch.from_numpy(fx["spec/y"])
+    lengths = torch.from_numpy(fx["spec/lengths"]).to(torch.int32)
+    for wm, wbd in [(0.5, 0.1), (0.0, 0.1), (0.5, 0.0)]:
+        tag = "spec_wm%g_wbd%g" % (wm, wbd)
+        for layout in ("btc", "bct"):
+            yh = y_hat.clone().to(dev)
+            if layout == "bct":
+                yh = yh.transpose(1, 2).contiguous().transpose(1, 2)
+            yh.requires_grad_(True)
+            out4 = ops.spec_loss(yh, y.to(dev), lengths.to(dev) if wm > 0 else None, 1, wm, wbd)
+            out4[2].backward()
+            assert rel_err(out4[0].detach().cpu(), fx[tag + "/l1"]) < 1e-5
+            if wbd > 0:
+                assert rel_err(out4[1].detach().cpu(), fx[tag + "/bd"]) < 1e-5
+            assert rel_err(yh.grad.cpu(), fx[tag + "/grad"]) < 1e-5
+    # guided attention: mean(attn * W) and its gradient W / N
+    il, tl = fx["guided/in_len"], fx["guided/out_len"]
+    rng = np.random.RandomState(1)
+    attn = torch.from_numpy(rng.rand(2, 3, 12, 9).astype(np.float32))
+    for g in (0.2, 0.4):
+        W = torch.from_numpy(fx["guided_g%g" % g])
+        a = attn.clone().to(dev).requires_grad_(True)
+        loss = ops.guided_attention_loss(a, torch.from_numpy(il).to(torch.int32).to(dev),
+                                         torch.from_numpy(tl).to(torch.int32).to(dev), g)
+        loss.backward()
+        assert rel_err(loss.detach().cpu(), (attn * W).mean()) < 1e-5
+        assert rel_err(a.grad.cpu(), (W / attn.numel()).expand_as(attn)) < 1e-5
+    p = torch.from_numpy(fx["bce/p"]).to(dev).requires_grad_(True)
+    l = ops.bce_loss(p, torch.from_numpy(fx["bce/t"]).to(dev))
+    l.backward()
+    assert rel_err(l.detach().cpu(), fx["bce/loss"]) < 1e-5
+    assert rel_err(p.grad.cpu(), fx["bce/grad"]) < 1e-5
+
+
+def test_clip_adam(dev):
+    ops = _ops()
+    rng = np.random.RandomState(8)
+    n = 100003
+    p0 = torch.from_numpy(rng.randn(n).astype(np.float32))
+    g0 = torch.from_numpy(rng.randn(n).astype(np.float32) * 0.01)
+    pc, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
+    pg, mg, vg = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    partial = torch.empty(1024, device=dev)
+    out2 = torch.empty(2, device=dev)
+    hyper = torch.empty(3, device=dev)
+    for step in (1, 2, 3):
+        grad = g0 * step
+        gn = O.clip_and_adam([pc], [grad], [m], [v], step, 5e-4)
+        gg = grad.clone().to(dev)
+        ops.grad_sqnorm(gg, partial, out2)
+        hyper.copy_(torch.tensor([5e-4, 1 - 0.5 ** step, math.sqrt(1 - 0.9 ** step)]))
+        ops.clip_adam(pg, gg, mg, vg, out2, 0.1, hyper, 0.5, 0.9, 1e-6)
+        assert rel_err(out2[0].cpu(), gn) < 1e-5
+        assert rel_err(pg.cpu(), pc) < 1e-6
+        assert rel_err(mg.cpu(), m) < 1e-5 and rel_err(vg.cpu(), v) < 1e-5
+
+
+def test_conv_gemm_full_size_properties(dev):
+    """BASELINE north-star shape (B=64, C=256, T=1024, k=3): too big for the CPU oracle in a unit
+    test, so check size-independent properties: linearity in x of the pre-gate (a,b) outputs,
+    shift-equivariance in time away from the borders, and a sampled direct dot-product check."""
+    ops = _ops()
+    torch.manual_seed(0)
+    B, C, T, k, d = 64, 256, 1024, 3, 3
+    v = torch.randn(2 * C, C, k, device=dev) * 0.05
+    g = torch.rand(2 * C, 1, 1, device=dev) + 0.5
+    bias = torch.zeros(2 * C, device=dev)
+    pk = ops.pack_weights(v, g, glu_cg=C, need_bwd=False)
+    padL = d
+
+    def pre_gate(x):
+        ab = torch.empty(B, 2 * C, T, device=dev)
+        ops.conv_gemm(x, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d, padL=padL,
+                      mode=ops.EPI_GLU, Cg=C, bias=bias, ab=ab)
+        return ab
+    x1, x2 = torch.randn(B, C, T, device=dev), torch.randn(B, C, T, device=dev)
+    a1, a2, a12 = pre_gate(x1), pre_gate(x2), pre_gate(x1 + 2 * x2)
+    assert rel_err((a1 + 2 * a2).cpu(), a12.cpu()) < 1e-5
+    xs = torch.roll(x1, 7, dims=2)
+    a_s = pre_gate(xs)
+    assert rel_err(a_s[:, :, 32:-32].cpu(), torch.roll(a1, 7, dims=2)[:, :, 32:-32].cpu()) < 1e-6
+    # sampled direct check in float64
+    w = (g * v / v.reshape(2 * C, -1).norm(dim=1).view(-1, 1, 1)).double().cpu()
+    xc = x1.double().cpu()
+    rng = np.random.RandomState(0)
+    for _ in range(64):
+        b, o, t = rng.randint(B), rng.randint(2 * C), rng.randint(T)
+        acc = 0.0
+        for j in range(k):
+            tt = t + j * d - padL
+            if 0 <= tt < T:
+                acc += float((w[o, :, j] * xc[b, :, tt]).sum())
+        assert abs(acc - float(a1[b, o, t])) < 1e-4 * max(1.0, abs(acc))

@@ -1,0 +1,264 @@
+# coding: utf-8
+"""-m gpu: model-level parity of the HIP-backed module tree.
+
+  * against tests/golden/*.npz = outputs of the UNMODIFIED reference (forward, encoder,
+    incremental decode teacher-forced and free-running), 1e-4 relative fp32 as BASELINE.json's
+    north_star states;
+  * against the CPU oracle for what the reference cannot fix (training mode with dropout: the
+    HIP path's Philox keep-bits are replayed into the oracle) and for gradients;
+  * the reference's own self-consistency tests restated (tests/test_deepvoice3.py:152-235,
+    tests/test_nyanko.py:59-133, tests/test_conv.py:10-63).
+"""
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dv3_oracle as O
+from tests.util import MODEL_FIXTURES, load_golden, split_model_fixture, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4   # north_star: "within 1e-4 rel fp32 on identical inputs"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _build(name, dev):
+    from deepvoice3_pytorch_amd import builder
+    fx = load_golden("model_" + name)
+    b, hp, sd, x = split_model_fixture(fx)
+    model = getattr(builder, b)(**hp)
+    model.load_state_dict(sd)
+    return fx, b, hp, sd, x, model.to(dev)
+
+
+def _to(x, dev):
+    return {k: v.to(dev) for k, v in x.items()}
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_forward_matches_reference_golden(dev, name):
+    fx, b, hp, sd, x, model = _build(name, dev)
+    model.eval()
+    xg = _to(x, dev)
+    with torch.no_grad():
+        mel, lin, align, done = model(xg["text"], xg["mel"], xg.get("speaker_ids"), xg["text_positions"],
+                                      xg["frame_positions"], x["input_lengths"].numpy())
+    assert mel.shape == fx["out/mel"].shape and lin.shape == fx["out/linear"].shape
+    assert rel_err(mel.cpu(), fx["out/mel"]) < TOL
+    assert rel_err(lin.cpu(), fx["out/linear"]) < TOL
+    assert rel_err(align.cpu(), fx["out/alignments"]) < TOL
+    assert rel_err(done.cpu(), fx["out/done"]) < TOL
+    # encoder outputs in the reference's (B, T, C) layout
+    se = model.embed_speakers(xg["speaker_ids"]) if "speaker_ids" in xg else None
+    with torch.no_grad():
+        keys, values = model.seq2seq.encoder(xg["text"], lengths=x["input_lengths"].numpy(), speaker_embed=se)
+    assert rel_err(keys.cpu(), fx["out/enc_keys"]) < TOL
+    assert rel_err(values.cpu(), fx["out/enc_values"]) < TOL
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_make_generation_fast_keeps_outputs(dev, name):
+    """remove_weight_norm (reference __init__.py:39-46) must not change the function."""
+    fx, b, hp, sd, x, model = _build(name, dev)
+    model.eval()
+    model.make_generation_fast_()
+    assert not any(k.endswith("weight_g") for k in model.state_dict())
+    xg = _to(x, dev)
+    with torch.no_grad():
+        mel, lin, _, _ = model(xg["text"], xg["mel"], xg.get("speaker_ids"), xg["text_positions"],
+                               xg["frame_positions"], x["input_lengths"].numpy())
+    assert rel_err(mel.cpu(), fx["out/mel"]) < TOL
+    assert rel_err(lin.cpu(), fx["out/linear"]) < TOL
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_incremental_decode_matches_reference_golden(dev, name):
+    fx, b, hp, sd, x, model = _build(name, dev)
+    model.eval()
+    B = int(fx["inc_batch"])
+    xg = _to(x, dev)
+    text, tp, mel = xg["text"][:B], xg["text_positions"][:B], xg["mel"][:B]
+    spk = xg["speaker_ids"][:B] if "speaker_ids" in xg else None
+    r = hp.get("r", 4)
+    mel_r = mel.view(B, mel.size(1) // r, -1)
+    dec = model.seq2seq.decoder
+    with torch.no_grad():
+        se = model.embed_speakers(spk) if spk is not None else None
+        enc = model.seq2seq.encoder(text, lengths=None, speaker_embed=se)
+        dec.start_fresh_sequence()
+        if b == "nyanko":
+            io, ia, idn, ist = dec.incremental_forward(enc, tp, test_inputs=mel_r)
+        else:
+            io, ia, idn, ist = dec.incremental_forward(enc, tp, speaker_embed=se, test_inputs=mel_r)
+    assert rel_err(io.cpu(), fx["inc_tf/mel"]) < TOL
+    assert rel_err(ist.cpu(), fx["inc_tf/states"]) < TOL
+    assert rel_err(ia.cpu(), fx["inc_tf/alignments"]) < TOL
+    # free running twice with a fixed step count: identical to the reference and to itself
+    # (issue38 test, tests/test_deepvoice3.py:152-181: start_fresh_sequence clears every buffer)
+    dec.max_decoder_steps = 12
+    dec.min_decoder_steps = 12
+    with torch.no_grad():
+        m1, l1, a1, d1 = model(text, speaker_ids=spk, text_positions=tp)
+        m2, l2, a2, d2 = model(text, speaker_ids=spk, text_positions=tp)
+    assert torch.equal(m1, m2)
+    assert m1.shape == fx["gen/mel"].shape
+    assert rel_err(m1.cpu(), fx["gen/mel"]) < 5e-4     # 13 autoregressive steps compound round-off
+    assert rel_err(l1.cpu(), fx["gen/linear"]) < 5e-4
+    assert rel_err(a1.cpu(), fx["gen/alignments"]) < 5e-4
+
+
+def test_incremental_equals_teacher_forced(dev):
+    """tests/test_deepvoice3.py:184-235 restated: Decoder.forward == incremental_forward(test_inputs)
+    within atol 1e-5 (no monotonic window forced)."""
+    fx, b, hp, sd, x, model = _build("dv3_tiny", dev)
+    model.eval()
+    xg = _to(x, dev)
+    dec = model.seq2seq.decoder
+    with torch.no_grad():
+        enc = model.seq2seq.encoder(xg["text"])
+        mel_tf, _, _, _ = dec(enc, xg["mel"], text_positions=xg["text_positions"],
+                              frame_positions=xg["frame_positions"])
+        dec.start_fresh_sequence()
+        mel_r = xg["mel"].view(xg["mel"].size(0), -1, hp["mel_dim"] * hp["r"])
+        mel_inc, _, _, _ = dec.incremental_forward(enc, xg["text_positions"], test_inputs=mel_r)
+    assert (mel_tf - mel_inc).abs().max().item() < 1e-5
+
+
+def test_conv1d_incremental_kat(dev):
+    """tests/test_conv.py:10-63 restated on the HIP Conv1d: all-ones weights, time-ramp input,
+    incremental_forward step by step == causal conv output, exactly."""
+    from deepvoice3_pytorch_amd.conv import Conv1d
+    for B in (1, 4):
+        for T in (5, 10):
+            for C in (1, 2, 4):
+                for k in (2, 3):
+                    for d in (1, 2, 3, 4, 5, 9, 27):
+                        pad = (k - 1) * d
+                        conv = Conv1d(C, 2 * C, kernel_size=k, padding=pad, dilation=d).to(dev).eval()
+                        conv.weight.data.fill_(1.0)
+                        conv.bias.data.zero_()
+                        bct = (torch.zeros(B, C, T) + torch.arange(0, T).float()).to(dev)
+                        with torch.no_grad():
+                            ref = conv(bct)[:, :, :T]
+                            btc = bct.transpose(1, 2).contiguous()
+                            outs = [conv.incremental_forward(btc[:, t, :].contiguous().view(B, -1, C))
+                                    for t in range(T)]
+                        got = torch.stack(outs).squeeze(2).transpose(0, 1).transpose(1, 2)
+                        assert (ref == got).all(), (B, T, C, k, d)
+                        want = torch.nn.functional.conv1d(bct.cpu(), torch.ones(2 * C, C, k), None,
+                                                          padding=pad, dilation=d)[:, :, :T]
+                        assert (ref.cpu() == want).all()
+
+
+def _record_drop(ops):
+    rec = ops.dropout_state.record
+
+    def drop(site, t, p, layout):
+        bits, rows, T = rec["model." + site]
+        keep = torch.from_numpy(O.unpack_keep_bits(bits.cpu().numpy().view(np.uint32), rows,
+                                                   (T + 31) // 32, T)).float()
+        if layout == "bct":
+            m = keep.view(t.shape)
+        elif layout == "btc":       # bits live on the (B, C, T) image
+            m = keep.view(t.size(0), t.size(2), t.size(1)).transpose(1, 2)
+        else:                       # attention: rows = (b, tq), bits along keys
+            m = keep.view(t.shape)
+        return t * m / (1 - p)
+    return drop
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_training_forward_backward_matches_oracle(dev, name):
+    """model.train(): dropout active.  The keep-bits the HIP kernels drew are replayed into the CPU
+    oracle; outputs and every parameter gradient must agree."""
+    from deepvoice3_pytorch_amd import ops
+    fx, b, hp, sd, x, model = _build(name, dev)
+    spec = O.build_spec(b, **hp)
+    model.train()
+    xg = _to(x, dev)
+    ops.dropout_state.manual_seed(2024)
+    ops.dropout_state.record = {}
+    try:
+        mel, lin, align, done = model(xg["text"], xg["mel"], xg.get("speaker_ids"), xg["text_positions"],
+                                      xg["frame_positions"], x["input_lengths"].numpy())
+        rng = np.random.RandomState(0)
+        ws = [torch.from_numpy(rng.randn(*t.shape).astype(np.float32)) for t in (mel, lin, align, done)]
+        loss = sum((t * w.to(dev)).sum() for t, w in zip((mel, lin, align, done), ws))
+        loss.backward()
+        drop = _record_drop(ops)
+        sdc = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+        out = O.model_forward(sdc, spec, x["text"], x["mel"], x.get("speaker_ids"), x["text_positions"],
+                              x["frame_positions"], x["input_lengths"].numpy(), drop=drop)
+    finally:
+        ops.dropout_state.record = None
+    for got, want, nm in zip((mel, lin, align, done), out, ("mel", "linear", "align", "done")):
+        assert rel_err(got.detach().cpu(), want.detach()) < TOL, nm
+    lc = sum((t * w).sum() for t, w in zip(out, ws))
+    lc.backward()
+    frozen = ("embed_query_positions.weight", "embed_keys_positions.weight")
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        if k.endswith(frozen):
+            continue
+        gc = sdc[k].grad
+        if gc is None or float(gc.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-6, k
+            continue
+        assert p.grad is not None, k
+        e = rel_err(p.grad.cpu(), gc)
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 5e-4, worst
+
+
+def test_train_step_matches_reference_golden(dev):
+    """Two optimisation steps of the reference's own train.train() (tests/golden/trainstep.npz,
+    dropout 0): HIP forward + fused losses + backward + fused clip/Adam on the flat arena."""
+    from deepvoice3_pytorch_amd import builder, train_step
+    fx = load_golden("trainstep")
+    hpo = json.loads(str(fx["hp_over"]))
+    hp = dict(n_vocab=149, embed_dim=hpo["text_embed_dim"], mel_dim=hpo["num_mels"],
+              linear_dim=hpo["fft_size"] // 2 + 1, r=1, downsample_step=4, padding_idx=0, dropout=0.0,
+              kernel_size=3, encoder_channels=hpo["encoder_channels"],
+              decoder_channels=hpo["decoder_channels"], converter_channels=hpo["converter_channels"],
+              use_memory_mask=True, force_monotonic_attention=True,
+              use_decoder_state_for_postnet_input=True, max_positions=hpo["max_positions"],
+              key_projection=True, value_projection=True)
+    model = builder.deepvoice3(**hp)
+    model.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("sd0/")})
+    model.to(dev)
+    x = {k[3:]: torch.from_numpy(val) for k, val in fx.items() if k.startswith("in/")}
+    trainer = train_step.Trainer(model, train_step.TrainConfig(
+        outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5, binary_divergence_weight=0.1,
+        use_guided_attention=True, guided_attention_sigma=0.2, clip_thresh=0.1, adam_beta1=0.5,
+        adam_beta2=0.9, adam_eps=1e-6, initial_learning_rate=5e-4, lr_schedule="noam_learning_rate_decay"),
+        global_step=int(fx["global_step0"]))
+    batch = train_step.Batch.from_collate(x["text"], x["input_lengths"], x["mel"], x["y"],
+                                          x["text_positions"], x["frame_positions"], x["done"],
+                                          x["target_lengths"], None, downsample_step=4, device=dev)
+    for it in range(2):
+        scal = trainer.step(batch)
+        scal = {k: float(v) for k, v in scal.items()}
+        tol = 2e-5 if it == 0 else 2e-4
+        assert abs(scal["loss"] - fx["scalar/loss"][it]) < tol * fx["scalar/loss"][it]
+        assert abs(scal["attn_loss"] - fx["scalar/attn_loss"][it]) < 2e-4 * fx["scalar/attn_loss"][it]
+        assert abs(scal["done_loss"] - fx["scalar/done_loss"][it]) < 2e-4 * fx["scalar/done_loss"][it]
+        assert abs(scal["mel_l1_loss"] - fx["scalar/mel_l1_loss"][it]) < 2e-4 * fx["scalar/mel_l1_loss"][it]
+        assert abs(scal["linear_binary_div_loss"] - fx["scalar/linear_binary_div_loss"][it]) < \
+            2e-4 * fx["scalar/linear_binary_div_loss"][it]
+        assert abs(scal["grad_norm"] - fx["scalar/gradient_norm"][it]) < 2e-3 * fx["scalar/gradient_norm"][it]
+    sdn = model.state_dict()
+    for k in sdn:
+        if k.endswith("positions.weight"):
+            continue
+        moved = float(np.abs(fx["sd2/" + k] - fx["sd0/" + k]).max())
+        diff = float(np.abs(sdn[k].cpu().numpy() - fx["sd2/" + k]).max())
+        assert diff < 0.1 * max(moved, 1e-6) + 1e-6, (k, diff, moved)
