@@ -83,11 +83,11 @@ def synth_batch(rng, B, Tt, n_frames, hp, fixed=True):
                 target_lengths=frame_lens)
 
 
-def conv_roofline(dev, iters=30):
+def conv_roofline(dev, iters=30, tile_hint=0, dil=1):
     """Conv1dGLU forward at the north-star shape, one conv_gemm_f32 launch per iteration, timed with
     HIP events on the stream it is launched on."""
     from deepvoice3_pytorch_amd import ops
-    B, C, T, k, d = 64, 256, 1024, 3, 1
+    B, C, T, k, d = 64, 256, 1024, 3, dil
     torch.manual_seed(0)
     x = torch.randn(B, C, T, device=dev)
     v = torch.randn(2 * C, C, k, device=dev) * math.sqrt(4.0 * 0.95 / (k * C))
@@ -98,7 +98,8 @@ def conv_roofline(dev, iters=30):
 
     def launch():
         ops.conv_gemm(x, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
-                      padL=(k - 1) // 2 * d, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x, residual=1, y=y)
+                      padL=(k - 1) // 2 * d, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x, residual=1, y=y,
+                      tile_hint=tile_hint)
     for _ in range(5):
         launch()
     torch.cuda.synchronize()
@@ -113,7 +114,8 @@ def conv_roofline(dev, iters=30):
     flops = 2.0 * B * T * (2 * C) * (k * C)                     # 51.54 GFLOP
     byts = 4.0 * (B * C * T * 2 + 2 * C * C * k + 2 * C)         # x + y + weights + bias: 135.8 MB
     tf = flops / (us * 1e-6) / 1e12
-    return dict(bound="mfma", kernel="conv_gemm_f32_kernel<2,2,2,16> (Conv1dGLU fwd B=64 C=256 T=1024 k=3)",
+    return dict(bound="mfma", kernel="conv_gemm_f32_stream_kernel<2,2,2> (Conv1dGLU fwd B=64 C=256 T=1024 k=3)"
+                if tile_hint < 10 else "conv_gemm_f32_kernel (LDS-staged, tile %d)" % (tile_hint - 10),
                 achieved=round(tf, 2), peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=round(tf / PEAK_F32_MFMA_TF, 4),
                 traffic=None, us_per_launch=round(us, 2), alg_flops=flops, alg_bytes=byts,
                 hbm_gbs=round(byts / (us * 1e-6) / 1e9, 1),
@@ -179,7 +181,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--mode", default="train", choices=["train", "conv"])
+    ap.add_argument("--mode", default="train", choices=["train", "conv", "conv-ab"])
     args = ap.parse_args()
 
     from deepvoice3_pytorch_amd import builder, train_step, dist as dv3dist
@@ -188,6 +190,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.mode == "conv-ab":     # A/B of kernel variants / tiles at the north-star shape
+        for hint in (0, 1, 2, 3, 4, 11, 12):
+            for dil in (1, 27):
+                rf = conv_roofline(dev, iters=10, tile_hint=hint, dil=dil)
+                print("tile_hint=%2d dil=%2d  %8.1f us  %6.1f TFLOP/s  frac %.3f" % (hint, dil, rf["us_per_launch"], rf["achieved"], rf["frac"]))
+        return
     if args.mode == "conv":
         rf = conv_roofline(dev, iters=max(args.steps, 10))
         print(json.dumps(dict(metric="conv1dglu_fwd_tflops", value=rf["achieved"], unit="TFLOP/s", n_gpus=1,

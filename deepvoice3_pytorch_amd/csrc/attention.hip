@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const dv3_softmax
   for (int n = lane; n < Tk; n += 64) {
     float d = 0.f;
     if (dpd) {
-      d = dpd[n];
-      if (p.mask) d = dv3_keep(p.mask, row, p.mask_rs, n) ? d * p.drop_scale : 0.f;
+      d = dpd[n] * p.drop_scale;   // drop_scale carries 1/(1-p) AND the forward's pd_scale
+      if (p.mask && !dv3_keep(p.mask, row, p.mask_rs, n)) d = 0.f;
     }
     if (dpx) d += dpx[n];
     dot += d * pr[n];
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const dv3_softmax
   for (int n = lane; n < Tk; n += 64) {
     float d = 0.f;
     if (dpd) {
-      d = dpd[n];
-      if (p.mask) d = dv3_keep(p.mask, row, p.mask_rs, n) ? d * p.drop_scale : 0.f;
+      d = dpd[n] * p.drop_scale;   // drop_scale carries 1/(1-p) AND the forward's pd_scale
+      if (p.mask && !dv3_keep(p.mask, row, p.mask_rs, n)) d = 0.f;
     }
     if (dpx) d += dpx[n];
     ds[n] = pr[n] * (d - dot);

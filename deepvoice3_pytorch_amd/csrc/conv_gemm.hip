@@ -26,6 +26,78 @@ struct ConvArgs {
   int a_scalar;  // packed operand not 16-byte aligned (per-batch A = an activation): scalar staging
 };
 
+// Shared epilogue: acc[h][ni] is the 32x32 fp32 tile of row-half h, column sub-tile ni.
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int BM, int BMH, int NI>
+__device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], bool gated,
+                                              int b, int mt, int n0, int wm, int wn, int l31, int lhi) {
+  const float dscale = p.drop_scale;
+  const int Tout = p.Tout, M = p.M, Cg = p.Cg;
+  const float rs2 = 0.70710678118654752440f;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+    if (n >= Tout) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float v0 = acc[0][ni][r], v1 = acc[1][ni][r];
+      if (gated) {
+        const int ch = mt * BMH + i;
+        if (ch >= Cg) continue;
+        float a = v0, g = v1;
+        if (p.bias) {
+          a += p.bias[ch];
+          g += p.bias[Cg + ch];
+        }
+        if (p.spk) a += p.spk[(int64_t)b * p.spk_bs + (int64_t)ch * p.spk_rs + (int64_t)n * p.spk_ts];
+        if (p.ab) {
+          float* abp = p.ab + ((int64_t)b * M + ch) * Tout + n;
+          abp[0] = a;
+          abp[(int64_t)Cg * Tout] = g;
+        }
+        const float s = 1.0f / (1.0f + expf(-g));
+        float y;
+        if (p.mode == DV3_EPI_GLU) {
+          y = a * s;
+          if (p.residual) y = (y + p.r[(int64_t)b * p.r_bs + (int64_t)ch * p.r_rs + n]) * rs2;
+        } else {
+          const float xr = p.r[(int64_t)b * p.r_bs + (int64_t)ch * p.r_rs + n];
+          y = s * a + (1.0f - s) * xr;
+        }
+        p.y[(int64_t)b * p.y_bs + (int64_t)ch * p.y_rs + n] = y;
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = mt * BM + h * BMH + i;
+          if (m >= M) continue;
+          float v = h ? v1 : v0;
+          if (p.mode == DV3_EPI_DGRAD) {
+            if (p.ymask) {
+              const uint32_t w = p.ymask[((int64_t)b * M + m) * p.ymask_rs + (n >> 5)];
+              v = ((w >> (n & 31)) & 1u) ? v * dscale : 0.f;
+            }
+            if (p.r) v += p.r[(int64_t)b * p.r_bs + (int64_t)m * p.r_rs + n];
+          } else {
+            if (p.bias) v += p.bias[(p.store_mode == DV3_STORE_INTERLEAVE2) ? (m % (M >> 1)) : m];
+            if (p.mode == DV3_EPI_RELU) v = fmaxf(v, 0.f);
+            else if (p.mode == DV3_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+            else if (p.mode == DV3_EPI_SOFTSIGN) v = v / (1.0f + fabsf(v));
+            if (p.r) v = (v + p.r[(int64_t)b * p.r_bs + (int64_t)m * p.r_rs + n]) * rs2;
+            if (p.r2) v = (v + p.r2[(int64_t)b * p.r2_bs + (int64_t)m * p.r2_rs + n]) * rs2;
+          }
+          if (p.store_mode == DV3_STORE_INTERLEAVE2) {
+            const int Mo = M >> 1;
+            p.y[(int64_t)b * p.y_bs + (int64_t)(m % Mo) * p.y_rs + 2 * n + (m / Mo)] = v;
+          } else {
+            p.y[(int64_t)b * p.y_bs + (int64_t)m * p.y_rs + n] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int WM, int WN, int NI, int BKC>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_kernel(const ConvArgs args) {
   constexpr int BM = WM * 64;   // rows staged per chunk (two halves of BMH)
@@ -157,72 +229,123 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_kernel(const ConvAr
     __syncthreads();
   }
 
-  // ---------------- epilogue ----------------
-  // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int Tout = p.Tout, M = p.M, Cg = p.Cg;
-  const float rs2 = 0.70710678118654752440f;
+  conv_epilogue<BM, BMH, NI>(p, acc, gated, b, mt, n0, wm, wn, l31, lhi);
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming variant: no LDS, no barriers.  At the fp32 MFMA rate (64 cycles per 32x32x2
+// instruction) a wave needs only ~4 B/clk of operands, so each wave fetches its own A/B
+// fragments coalesced from L1/L2 (128-B row segments per half-wave) through a PF-deep software
+// prefetch ring and never synchronises with its neighbours.  rocprofv3 on the LDS-staged kernel
+// showed the matrix pipe 52% busy with waves parked 34% of their life at s_waitcnt/s_barrier
+// (profiles/r01_conv_gemm_pmc.md); this removes every such wait.
+// K order: channel pairs outer, taps inner, so the J shifted re-reads of an x row hit L1.
+// ------------------------------------------------------------------------------------------
+template <int WM, int WN, int NI, bool MASK>
+__global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_stream_kernel(const ConvArgs args) {
+  constexpr int BM = WM * 64, BMH = WM * 32, BN = WN * NI * 32;
+  constexpr int PF = 4;  // k-steps in flight
+  const dv3_conv_desc& p = args.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int pid = dv3_xcd_remap(blockIdx.x, args.n_blocks);
+  const int mt = pid % args.m_tiles;
+  const int nt = (pid / args.m_tiles) % args.n_tiles;
+  const int b = pid / (args.m_tiles * args.n_tiles);
+  const int n0 = nt * BN;
+
+  const bool gated = (p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY);
+  int h0b, h1b, lim0, lim1;
+  if (gated) {
+    h0b = mt * BMH; h1b = p.a_half + mt * BMH; lim0 = p.a_half; lim1 = p.lda;
+  } else {
+    h0b = mt * BM; h1b = mt * BM + BMH; lim0 = lim1 = p.lda;
+  }
+  const int J = p.J, dil = p.dil, Cin = p.Cin, Tin = p.Tin, lda = p.lda;
+  const int colA0 = h0b + wm * 32 + l31, colA1 = h1b + wm * 32 + l31;
+  const bool okA0 = colA0 < lim0, okA1 = colA1 < lim1;
+  const float* __restrict__ Xg = p.x + (int64_t)b * p.x_bs;
+  const uint32_t* __restrict__ xmask = p.xmask;
+  const float dscale = p.drop_scale;
+  int tgb[NI];
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
-    if (n >= Tout) continue;
+  for (int ni = 0; ni < NI; ++ni) tgb[ni] = n0 + wn * (NI * 32) + ni * 32 + l31 - p.padL;
+
+  f32x16 acc[2][NI];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      const float v0 = acc[0][ni][r], v1 = acc[1][ni][r];
-      if (gated) {
-        const int ch = mt * BMH + i;
-        if (ch >= Cg) continue;
-        float a = v0, g = v1;
-        if (p.bias) {
-          a += p.bias[ch];
-          g += p.bias[Cg + ch];
-        }
-        if (p.spk) a += p.spk[(int64_t)b * p.spk_bs + (int64_t)ch * p.spk_rs + (int64_t)n * p.spk_ts];
-        if (p.ab) {
-          float* abp = p.ab + ((int64_t)b * M + ch) * Tout + n;
-          abp[0] = a;
-          abp[(int64_t)Cg * Tout] = g;
-        }
-        const float s = 1.0f / (1.0f + expf(-g));
-        float y;
-        if (p.mode == DV3_EPI_GLU) {
-          y = a * s;
-          if (p.residual) y = (y + p.r[(int64_t)b * p.r_bs + (int64_t)ch * p.r_rs + n]) * rs2;
-        } else {
-          const float xr = p.r[(int64_t)b * p.r_bs + (int64_t)ch * p.r_rs + n];
-          y = s * a + (1.0f - s) * xr;
-        }
-        p.y[(int64_t)b * p.y_bs + (int64_t)ch * p.y_rs + n] = y;
-      } else {
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int m = mt * BM + h * BMH + i;
-          if (m >= M) continue;
-          float v = h ? v1 : v0;
-          if (p.mode == DV3_EPI_DGRAD) {
-            if (p.ymask) {
-              const uint32_t w = p.ymask[((int64_t)b * M + m) * p.ymask_rs + (n >> 5)];
-              v = ((w >> (n & 31)) & 1u) ? v * dscale : 0.f;
-            }
-            if (p.r) v += p.r[(int64_t)b * p.r_bs + (int64_t)m * p.r_rs + n];
-          } else {
-            if (p.bias) v += p.bias[(p.store_mode == DV3_STORE_INTERLEAVE2) ? (m % (M >> 1)) : m];
-            if (p.mode == DV3_EPI_RELU) v = fmaxf(v, 0.f);
-            else if (p.mode == DV3_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-            else if (p.mode == DV3_EPI_SOFTSIGN) v = v / (1.0f + fabsf(v));
-            if (p.r) v = (v + p.r[(int64_t)b * p.r_bs + (int64_t)m * p.r_rs + n]) * rs2;
-            if (p.r2) v = (v + p.r2[(int64_t)b * p.r2_bs + (int64_t)m * p.r2_rs + n]) * rs2;
-          }
-          if (p.store_mode == DV3_STORE_INTERLEAVE2) {
-            const int Mo = M >> 1;
-            p.y[(int64_t)b * p.y_bs + (int64_t)(m % Mo) * p.y_rs + 2 * n + (m / Mo)] = v;
-          } else {
-            p.y[(int64_t)b * p.y_bs + (int64_t)m * p.y_rs + n] = v;
-          }
-        }
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][ni][r] = 0.f;
+
+  const int nks = ((Cin + 1) >> 1) * J;
+  float ra0[PF], ra1[PF], rb[PF][NI];
+  int lc = lhi, lj = 0;  // (channel, tap) of the next k-step to LOAD (this lane's half)
+
+  // Loads are UNCONDITIONAL on clamped (always valid) addresses; the ring holds the RAW values
+  // and the validity predicate is recomputed and applied (bitwise AND with an optimiser-opaque
+  // mask) right before the MFMA that consumes them.  A predicated load, or a select on the loaded
+  // value at load time, makes hipcc branch around the load and drain vmcnt(0) -- or wait for the
+  // data a few instructions after issuing it -- which serialises the prefetch ring
+  // (cdna_hip_programming.md, ".s-level traps" (c)).
+  const int colA0c = okA0 ? colA0 : 0, colA1c = okA1 ? colA1 : 0;
+  const float* __restrict__ Ab = p.a + (int64_t)b * p.a_bs;
+  auto load_step = [&](float& a0, float& a1, float (&bv)[NI]) {
+    const int cc = min(lc, Cin - 1);
+    const int arow = (lj * Cin + cc) * lda;          // packed weights are < 2^31 elements
+    a0 = Ab[arow + colA0c];
+    a1 = Ab[arow + colA1c];
+    const float* __restrict__ xrow = Xg + (int64_t)cc * p.x_rs;
+    const int sh = lj * dil;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int tgc = min(max(tgb[ni] + sh, 0), Tin - 1);
+      float v = xrow[tgc];
+      if (MASK) {
+        const uint32_t w = xmask[((int64_t)b * Cin + cc) * p.xmask_rs + (tgc >> 5)];
+        uint32_t mk = (uint32_t)(-(int)((w >> (tgc & 31)) & 1u));
+        v = __uint_as_float(__float_as_uint(v * dscale) & mk);
       }
+      bv[ni] = v;
+    }
+    if (++lj == J) { lj = 0; lc += 2; }
+  };
+  int uc = lhi, uj = 0;  // (channel, tap) of the next k-step to USE
+  auto use_step = [&](float ra0_, float ra1_, const float (&rbv)[NI]) {
+    const bool live = uc < Cin;   // steps past nks have uc >= Cin as well
+    uint32_t m0 = (uint32_t)(-(int)(live && okA0)), m1 = (uint32_t)(-(int)(live && okA1));
+    asm volatile("" : "+v"(m0), "+v"(m1));
+    const float a0 = __uint_as_float(__float_as_uint(ra0_) & m0);
+    const float a1 = __uint_as_float(__float_as_uint(ra1_) & m1);
+    const int sh = uj * dil;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int tg = tgb[ni] + sh;
+      uint32_t mb = (uint32_t)(-(int)(live && tg >= 0 && tg < Tin));
+      asm volatile("" : "+v"(mb));
+      const float bvv = __uint_as_float(__float_as_uint(rbv[ni]) & mb);
+      acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bvv, acc[0][ni], 0, 0, 0);
+      acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bvv, acc[1][ni], 0, 0, 0);
+    }
+    if (++uj == J) { uj = 0; uc += 2; }
+  };
+
+#pragma unroll
+  for (int s = 0; s < PF; ++s) load_step(ra0[s], ra1[s], rb[s]);
+
+  for (int ks = 0; ks < nks; ks += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      use_step(ra0[s], ra1[s], rb[s]);
+      load_step(ra0[s], ra1[s], rb[s]);   // refill this ring slot for step ks + s + PF
     }
   }
+  conv_epilogue<BM, BMH, NI>(p, acc, gated, b, mt, n0, wm, wn, l31, lhi);
 }
 
 struct TileCfg {
@@ -237,6 +360,17 @@ const TileCfg kCfgs[] = {
     {5, 1, 2, 2},  // 64 x 128
     {6, 1, 2, 1},  // 64 x 64
 };
+
+template <int WM, int WN, int NI>
+int launch_stream(const ConvArgs& a, hipStream_t st) {
+  dim3 grid(a.n_blocks), block(WM * WN * 64);
+  if (a.d.xmask) {
+    hipLaunchKernelGGL((conv_gemm_f32_stream_kernel<WM, WN, NI, true>), grid, block, 0, st, a);
+  } else {
+    hipLaunchKernelGGL((conv_gemm_f32_stream_kernel<WM, WN, NI, false>), grid, block, 0, st, a);
+  }
+  return dv3_check_launch("conv_gemm_f32(stream)");
+}
 
 template <int WM, int WN, int NI>
 int launch_cfg(const ConvArgs& a, int bkc, size_t lds, hipStream_t st) {
@@ -272,11 +406,15 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
   if (d->ymask) DV3_REQUIRE(d->ymask_rs * 32 >= d->Tout, "conv_gemm: ymask row stride too small");
 
   const int rows_half = gated ? d->Cg : 0;
+  // tile_hint: 0 auto (streaming kernel), 1..6 streaming kernel with that tile, 11..16 the
+  // LDS-staged kernel with tile (hint-10) -- kept for A/B measurements
+  const bool use_lds = d->tile_hint > 10;
+  const int want_tile = use_lds ? d->tile_hint - 10 : d->tile_hint;
   // ---- pick a tile config: minimise padded work with a mild small-tile penalty ----
   const TileCfg* best = nullptr;
   double best_cost = 0;
   for (const TileCfg& c : kCfgs) {
-    if (d->tile_hint && c.id != d->tile_hint) continue;
+    if (want_tile && c.id != want_tile) continue;
     const int BM = c.wm * 64, BMH = c.wm * 32, BN = c.wn * c.ni * 32;
     const int mt = gated ? dv3_cdiv(rows_half, BMH) : dv3_cdiv(d->M, BM);
     const int ntl = dv3_cdiv(d->Tout, BN);
@@ -313,9 +451,19 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
     bkc = 8;
     lds = (size_t)(d->J * bkc * BM + bkc * BNH) * 4;
   }
-  DV3_REQUIRE(lds <= 64 * 1024, "conv_gemm: LDS tile %zu B too large (J=%d dil=%d)", lds, d->J, d->dil);
+  if (use_lds) DV3_REQUIRE(lds <= 64 * 1024, "conv_gemm: LDS tile %zu B too large (J=%d dil=%d)", lds, d->J, d->dil);
 
   hipStream_t st = (hipStream_t)stream;
+  if (!use_lds) {
+    switch (best->id) {
+      case 1: return launch_stream<2, 2, 2>(a, st);
+      case 2: return launch_stream<2, 2, 1>(a, st);
+      case 3: return launch_stream<4, 1, 1>(a, st);
+      case 4: return launch_stream<2, 1, 1>(a, st);
+      case 5: return launch_stream<1, 2, 2>(a, st);
+      case 6: return launch_stream<1, 2, 1>(a, st);
+    }
+  }
   switch (best->id) {
     case 1: return launch_cfg<2, 2, 2>(a, bkc, lds, st);
     case 2: return launch_cfg<2, 2, 1>(a, bkc, lds, st);

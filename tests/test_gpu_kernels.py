@@ -57,7 +57,7 @@ def _glu_sd(C, k, rng, n_spk=0):
     return sd
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("C,T,k,d,causal", [(64, 200, 3, 1, False), (96, 150, 3, 27, True),
                                             (20, 37, 5, 3, False), (128, 513, 3, 9, True)])
 def test_conv_gemm_glu_forward(dev, tile, C, T, k, d, causal):

@@ -204,13 +204,17 @@ def test_training_forward_backward_matches_oracle(dev, name):
     lc = sum((t * w).sum() for t, w in zip(out, ws))
     lc.backward()
     frozen = ("embed_query_positions.weight", "embed_keys_positions.weight")
+    scale = max(float(v.grad.abs().max()) for k, v in sdc.items() if v.grad is not None)
     worst = ("", 0.0)
     for k, p in model.named_parameters():
         if k.endswith(frozen):
             continue
         gc = sdc[k].grad
-        if gc is None or float(gc.abs().max()) == 0.0:
-            assert p.grad is None or float(p.grad.abs().max()) < 1e-6, k
+        gmax = 0.0 if gc is None else float(gc.abs().max())
+        if gmax < 1e-5 * scale:
+            # mathematically-zero gradients (e.g. key_projection.bias: a constant added to every key
+            # shifts all scores of a row equally and softmax is shift invariant): pure round-off
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-4 * scale, k
             continue
         assert p.grad is not None, k
         e = rel_err(p.grad.cpu(), gc)
