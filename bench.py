@@ -223,7 +223,9 @@ def main():
             runner = train_step.GraphedTrainer(trainer, batch, warmup=max(1, min(args.warmup, 3)))
         except Exception as e:      # capture not possible (e.g. collective not capturable): say so, go eager
             if rank == 0:
-                print("hipGraph capture failed (%s: %s); running eager" % (type(e).__name__, e), file=sys.stderr)
+                import traceback
+                traceback.print_exc()
+                print("hipGraph capture failed (%s); running eager" % type(e).__name__, file=sys.stderr)
             use_graph = False
             torch.cuda.synchronize()
 

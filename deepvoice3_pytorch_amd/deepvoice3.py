@@ -18,7 +18,7 @@ from torch import nn
 
 from . import ops
 from .modules import Conv1d, ConvTranspose1d, Embedding, Linear
-from .modules import get_mask_from_lengths, SinusoidalEncoding, Conv1dGLU
+from .modules import key_lengths_i32, get_mask_from_lengths, SinusoidalEncoding, Conv1dGLU
 from . import conv as _conv
 
 
@@ -294,7 +294,7 @@ class Decoder(nn.Module):
 
         key_len = None
         if self.use_memory_mask and lengths is not None:
-            key_len = torch.as_tensor(np.asarray(lengths), dtype=torch.int32).to(keys_bct.device)
+            key_len = key_lengths_i32(lengths, keys_bct.device)
 
         if text_positions is not None:
             w = self._rate(self.key_position_rate, self.speaker_proj1, speaker_embed)

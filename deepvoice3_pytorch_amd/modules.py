@@ -208,6 +208,14 @@ class HighwayConv1d(_GatedConv):
         return self.conv.incremental_forward(x, _gate=dict(mode=self.mode, r=r, residual=self.glu))
 
 
+def key_lengths_i32(lengths, device):
+    """`input_lengths` as the int32 device vector the attention kernels read.  A tensor already on
+    the device is used as is (no host round trip: keeps the step hipGraph-capturable)."""
+    if torch.is_tensor(lengths):
+        return lengths.to(device=device, dtype=torch.int32)
+    return torch.as_tensor(np.asarray(lengths), dtype=torch.int32).to(device)
+
+
 def get_mask_from_lengths(memory, memory_lengths):
     """Mask tensor from a list of lengths, True where PADDED (modules.py:232-241)."""
     max_len = max(memory_lengths)

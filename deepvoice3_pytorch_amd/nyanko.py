@@ -12,7 +12,7 @@ from torch import nn
 from . import ops
 from . import conv as _conv
 from .modules import Embedding, Linear, Conv1d, ConvTranspose1d
-from .modules import HighwayConv1d, get_mask_from_lengths
+from .modules import HighwayConv1d, get_mask_from_lengths, key_lengths_i32
 from .modules import position_encoding_init
 from .deepvoice3 import AttentionLayer
 
@@ -166,7 +166,7 @@ class Decoder(nn.Module):
         keys_bct, values_bct = keys.transpose(1, 2), values.transpose(1, 2)
         key_len = None
         if self.use_memory_mask and lengths is not None:
-            key_len = torch.as_tensor(np.asarray(lengths), dtype=torch.int32).to(keys_bct.device)
+            key_len = key_lengths_i32(lengths, keys_bct.device)
 
         if text_positions is not None:
             keys_bct = ops.add_position_encoding(keys_bct.contiguous(), text_positions,

@@ -179,7 +179,7 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         self.model.train()
         mel_out, lin_out, attn, done_hat = self.model(
             batch.text, batch.mel, speaker_ids=batch.speaker_ids, text_positions=batch.text_positions,
-            frame_positions=batch.frame_positions, input_lengths=batch.input_lengths_host)
+            frame_positions=batch.frame_positions, input_lengths=batch.input_lengths)
         wm, w = c.masked_loss_weight, c.binary_divergence_weight
         m4 = ops.spec_loss(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w)
         l4 = ops.spec_loss(lin_out, batch.y, batch.linear_mask_lengths if wm > 0 else None, r, wm, w)
