@@ -1,0 +1,225 @@
+// Shared pieces of the tap-GEMM kernels (conv_gemm.hip: exact fp32 MFMA; conv_gemm_bf16x3.hip:
+// split-bf16 MFMA): launch arguments, the fused epilogue and the tile table.
+#pragma once
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  dv3_conv_desc d;
+  int m_tiles, n_tiles, n_blocks;
+  int a_scalar;  // packed operand not 16-byte aligned (per-batch A = an activation): scalar staging
+  int kp;        // bf16x3: K extent of the split weight image (Cin rounded up to 32)
+};
+
+template <typename T>
+__device__ __forceinline__ T dv3_ld(const void* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void dv3_st(void* base, uint32_t byte_off, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// Shared epilogue: acc[h][ni] is the 32x32 fp32 tile of row-half h, column sub-tile ni.
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// The lane's output column of sub-tile ni is (batch bcol[ni], time tcol[ni]), live when okc[ni]
+// (per column, so a tile may span several batch items: the bf16x3 kernel flattens (b,t)).
+// All addressing is uniform base + 32-bit byte offset (the host checks every tensor < 4 GB):
+// the straightforward 64-bit form made this fully unrolled tail ~10k instructions -- more than
+// the instruction cache, i.e. a fixed ~40 us of fetch stalls per launch at the north-star shape.
+//
+// PRE (gated modes): the residual / highway input `r` was prefetched into pre[r][ni] by
+// conv_prefetch_residual (issued a K step before the end of the main loop, so its HBM latency is
+// hidden behind MFMAs instead of heading the tail).
+template <int BM, int BMH, int NI, bool PRE = false>
+__device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], bool gated,
+                                              int mt, int wm, int lhi, const int (&bcol)[NI],
+                                              const int (&tcol)[NI], const bool (&okc)[NI],
+                                              const float (*pre)[NI] = nullptr) {
+  const float dscale = p.drop_scale;
+  const uint32_t Tout = (uint32_t)p.Tout, M = (uint32_t)p.M, Cg = (uint32_t)p.Cg;
+  const float rs2 = 0.70710678118654752440f;
+  const uint32_t y_rs = (uint32_t)p.y_rs * 4u, r_rs = (uint32_t)p.r_rs * 4u, r2_rs = (uint32_t)p.r2_rs * 4u;
+  const bool il2 = p.store_mode == DV3_STORE_INTERLEAVE2;
+  uint32_t yb[NI], rb[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const uint32_t b = (uint32_t)bcol[ni], t = (uint32_t)tcol[ni];
+    yb[ni] = (b * (uint32_t)p.y_bs + (il2 ? 2u * t : t)) * 4u;
+    rb[ni] = (b * (uint32_t)p.r_bs + t) * 4u;
+  }
+  if (gated) {
+    const bool glu = p.mode == DV3_EPI_GLU;
+    const bool has_r = !glu || p.residual;
+    const float oscale = (glu && p.residual) ? rs2 : 1.0f;
+    const uint32_t spk_rs = (uint32_t)p.spk_rs * 4u;
+    uint32_t abb[NI], sb[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const uint32_t b = (uint32_t)bcol[ni], t = (uint32_t)tcol[ni];
+      abb[ni] = (b * M * Tout + t) * 4u;
+      sb[ni] = (b * (uint32_t)p.spk_bs + t * (uint32_t)p.spk_ts) * 4u;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t ch = (uint32_t)(mt * BMH + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
+      if (ch >= Cg) continue;
+      float ba = 0.f, bg = 0.f;
+      if (p.bias) {
+        ba = p.bias[ch];
+        bg = p.bias[Cg + ch];
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if (!okc[ni]) continue;
+        float a = acc[0][ni][r] + ba;
+        const float g = acc[1][ni][r] + bg;
+        if (p.spk) a += dv3_ld<float>(p.spk, sb[ni] + ch * spk_rs);
+        if (p.ab) {
+          const uint32_t o = abb[ni] + ch * Tout * 4u;
+          dv3_st(p.ab, o, a);
+          dv3_st(p.ab, o + Cg * Tout * 4u, g);
+        }
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+        const float xr = has_r ? (PRE ? pre[r][ni] : dv3_ld<float>(p.r, rb[ni] + ch * r_rs)) : 0.f;
+        // GLU: (a*s [+ x]) * (sqrt(.5) | 1)      HIGHWAY: s*a + (1-s)*x
+        const float y = glu ? (a * s + xr) * oscale : s * a + (1.0f - s) * xr;
+        dv3_st(p.y, yb[ni] + ch * y_rs, y);
+      }
+    }
+    return;
+  }
+  if (p.mode == DV3_EPI_DGRAD) {
+    const uint32_t ym_rs = (uint32_t)p.ymask_rs * 4u;
+    uint32_t ymb[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      ymb[ni] = ((uint32_t)bcol[ni] * M * (uint32_t)p.ymask_rs + ((uint32_t)tcol[ni] >> 5)) * 4u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t m = (uint32_t)(mt * BM + h * BMH + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
+        if (m >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if (!okc[ni]) continue;
+          float v = acc[h][ni][r];
+          if (p.ymask) {
+            const uint32_t w = dv3_ld<uint32_t>(p.ymask, ymb[ni] + m * ym_rs);
+            v = ((w >> (tcol[ni] & 31)) & 1u) ? v * dscale : 0.f;
+          }
+          if (p.r) v += dv3_ld<float>(p.r, rb[ni] + m * r_rs);
+          dv3_st(p.y, yb[ni] + m * y_rs, v);
+        }
+      }
+    return;
+  }
+  // LINEAR / RELU / SIGMOID / SOFTSIGN (+ up to two fused residuals, + interleaved store)
+  uint32_t r2b[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) r2b[ni] = ((uint32_t)bcol[ni] * (uint32_t)p.r2_bs + (uint32_t)tcol[ni]) * 4u;
+  const uint32_t Mo = M >> 1;
+  const int mode = p.mode;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t m = (uint32_t)(mt * BM + h * BMH + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
+      if (m >= M) continue;
+      const uint32_t mo = (il2 && m >= Mo) ? m - Mo : m;   // ConvTranspose: row m -> channel m % Mo
+      const uint32_t odd = (il2 && m >= Mo) ? 4u : 0u;      // ... and output column 2t + m / Mo
+      const float bv = p.bias ? p.bias[mo] : 0.f;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if (!okc[ni]) continue;
+        float v = acc[h][ni][r] + bv;
+        if (mode == DV3_EPI_RELU) v = fmaxf(v, 0.f);
+        else if (mode == DV3_EPI_SIGMOID) v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        else if (mode == DV3_EPI_SOFTSIGN) v = v * __builtin_amdgcn_rcpf(1.0f + fabsf(v));
+        if (p.r) v = (v + dv3_ld<float>(p.r, rb[ni] + m * r_rs)) * rs2;
+        if (p.r2) v = (v + dv3_ld<float>(p.r2, r2b[ni] + m * r2_rs)) * rs2;
+        dv3_st(p.y, yb[ni] + mo * y_rs + odd, v);
+      }
+    }
+}
+
+
+// Issue the loads of the gated epilogue's `r` operand (residual / highway input) early.
+// Rows / columns that the epilogue drops are clamped to a valid address and never used.
+template <int BM, int BMH, int NI>
+__device__ __forceinline__ void conv_prefetch_residual(const dv3_conv_desc& p, bool gated, int mt, int wm,
+                                                       int lhi, const int (&bcol)[NI],
+                                                       const int (&tcol)[NI], const bool (&okc)[NI],
+                                                       float (*pre)[NI]) {
+  if (!gated || !(p.mode == DV3_EPI_HIGHWAY || p.residual)) return;
+  const uint32_t r_rs = (uint32_t)p.r_rs * 4u;
+  const uint32_t rows = (uint32_t)p.Cg;
+  uint32_t rb[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+    rb[ni] = okc[ni] ? ((uint32_t)bcol[ni] * (uint32_t)p.r_bs + (uint32_t)tcol[ni]) * 4u : 0u;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    uint32_t m = (uint32_t)(mt * BMH + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
+    m = m < rows ? m : rows - 1;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) pre[r][ni] = dv3_ld<float>(p.r, rb[ni] + m * r_rs);
+  }
+}
+
+// the epilogue addresses every tensor with 32-bit byte offsets
+static inline bool dv3_conv_fits32(const dv3_conv_desc* d) {
+  const int64_t lim = (1ll << 30);  // elements (4-byte)
+  const int64_t B = d->B;
+  const int64_t To = d->store_mode == DV3_STORE_INTERLEAVE2 ? 2ll * d->Tout : d->Tout;
+  if (B * d->y_bs + To >= lim || (int64_t)d->M * d->y_rs >= lim) return false;
+  if (d->r && (B * d->r_bs + d->Tout >= lim || (int64_t)d->M * d->r_rs >= lim)) return false;
+  if (d->r2 && (B * d->r2_bs + d->Tout >= lim || (int64_t)d->M * d->r2_rs >= lim)) return false;
+  if (d->ab && B * d->M * d->Tout >= lim) return false;
+  if (d->spk && (B * d->spk_bs + (int64_t)d->Cg * d->spk_rs + (int64_t)d->Tout * d->spk_ts >= lim)) return false;
+  if (d->ymask && B * d->M * d->ymask_rs >= lim) return false;
+  return true;
+}
+
+struct TileCfg {
+  int id, wm, wn, ni;
+};
+// id is what dv3_conv_desc.tile_hint selects.
+static const TileCfg kCfgs[] = {
+    {1, 2, 2, 2},  // 128 x 128
+    {2, 2, 2, 1},  // 128 x 64
+    {3, 4, 1, 1},  // 256 x 32
+    {4, 2, 1, 1},  // 128 x 32
+    {5, 1, 2, 2},  // 64 x 128
+    {6, 1, 2, 1},  // 64 x 64
+};
+
+// pick a tile config: minimise padded work with a mild small-tile penalty
+static inline const TileCfg* dv3_pick_tile(const dv3_conv_desc* d, bool gated, int want_tile) {
+  const int rows_half = gated ? d->Cg : 0;
+  const TileCfg* best = nullptr;
+  double best_cost = 0;
+  for (const TileCfg& c : kCfgs) {
+    if (want_tile && c.id != want_tile) continue;
+    const int BM = c.wm * 64, BMH = c.wm * 32, BN = c.wn * c.ni * 32;
+    const int mt = gated ? dv3_cdiv(rows_half, BMH) : dv3_cdiv(d->M, BM);
+    const int ntl = dv3_cdiv(d->Tout, BN);
+    double work = (double)mt * BM * (double)ntl * BN;
+    double pen = 1.0;
+    if (BN == 64) pen *= 1.04;
+    if (BN == 32) pen *= 1.10;
+    if (BM == 64) pen *= 1.06;
+    // too few blocks to fill 256 CUs: prefer finer tiles
+    const double blocks = (double)mt * ntl * d->B;
+    if (blocks < 512) pen *= 1.0 + 0.25 * (512 - blocks) / 512;
+    const double cost = work * pen;
+    if (!best || cost < best_cost) {
+      best = &c;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
+}  // namespace

@@ -16,87 +16,9 @@
 //     bias / gate / residual / sqrt(.5) / activation in the epilogue.
 //   * fragment reads are ds_read_b32 with lanes along the contiguous axis: conflict-free,
 //     and at the fp32 MFMA rate (64 cycles per instruction) LDS bandwidth is <15% used.
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
-
-struct ConvArgs {
-  dv3_conv_desc d;
-  int m_tiles, n_tiles, n_blocks;
-  int a_scalar;  // packed operand not 16-byte aligned (per-batch A = an activation): scalar staging
-};
-
-// Shared epilogue: acc[h][ni] is the 32x32 fp32 tile of row-half h, column sub-tile ni.
-// C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <int BM, int BMH, int NI>
-__device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], bool gated,
-                                              int b, int mt, int n0, int wm, int wn, int l31, int lhi) {
-  const float dscale = p.drop_scale;
-  const int Tout = p.Tout, M = p.M, Cg = p.Cg;
-  const float rs2 = 0.70710678118654752440f;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
-    if (n >= Tout) continue;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      const float v0 = acc[0][ni][r], v1 = acc[1][ni][r];
-      if (gated) {
-        const int ch = mt * BMH + i;
-        if (ch >= Cg) continue;
-        float a = v0, g = v1;
-        if (p.bias) {
-          a += p.bias[ch];
-          g += p.bias[Cg + ch];
-        }
-        if (p.spk) a += p.spk[(int64_t)b * p.spk_bs + (int64_t)ch * p.spk_rs + (int64_t)n * p.spk_ts];
-        if (p.ab) {
-          float* abp = p.ab + ((int64_t)b * M + ch) * Tout + n;
-          abp[0] = a;
-          abp[(int64_t)Cg * Tout] = g;
-        }
-        const float s = 1.0f / (1.0f + expf(-g));
-        float y;
-        if (p.mode == DV3_EPI_GLU) {
-          y = a * s;
-          if (p.residual) y = (y + p.r[(int64_t)b * p.r_bs + (int64_t)ch * p.r_rs + n]) * rs2;
-        } else {
-          const float xr = p.r[(int64_t)b * p.r_bs + (int64_t)ch * p.r_rs + n];
-          y = s * a + (1.0f - s) * xr;
-        }
-        p.y[(int64_t)b * p.y_bs + (int64_t)ch * p.y_rs + n] = y;
-      } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int m = mt * BM + h * BMH + i;
-          if (m >= M) continue;
-          float v = h ? v1 : v0;
-          if (p.mode == DV3_EPI_DGRAD) {
-            if (p.ymask) {
-              const uint32_t w = p.ymask[((int64_t)b * M + m) * p.ymask_rs + (n >> 5)];
-              v = ((w >> (n & 31)) & 1u) ? v * dscale : 0.f;
-            }
-            if (p.r) v += p.r[(int64_t)b * p.r_bs + (int64_t)m * p.r_rs + n];
-          } else {
-            if (p.bias) v += p.bias[(p.store_mode == DV3_STORE_INTERLEAVE2) ? (m % (M >> 1)) : m];
-            if (p.mode == DV3_EPI_RELU) v = fmaxf(v, 0.f);
-            else if (p.mode == DV3_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-            else if (p.mode == DV3_EPI_SOFTSIGN) v = v / (1.0f + fabsf(v));
-            if (p.r) v = (v + p.r[(int64_t)b * p.r_bs + (int64_t)m * p.r_rs + n]) * rs2;
-            if (p.r2) v = (v + p.r2[(int64_t)b * p.r2_bs + (int64_t)m * p.r2_rs + n]) * rs2;
-          }
-          if (p.store_mode == DV3_STORE_INTERLEAVE2) {
-            const int Mo = M >> 1;
-            p.y[(int64_t)b * p.y_bs + (int64_t)(m % Mo) * p.y_rs + 2 * n + (m / Mo)] = v;
-          } else {
-            p.y[(int64_t)b * p.y_bs + (int64_t)m * p.y_rs + n] = v;
-          }
-        }
-      }
-    }
-  }
-}
 
 template <int WM, int WN, int NI, int BKC>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_kernel(const ConvArgs args) {
@@ -229,7 +151,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_kernel(const ConvAr
     __syncthreads();
   }
 
-  conv_epilogue<BM, BMH, NI>(p, acc, gated, b, mt, n0, wm, wn, l31, lhi);
+  int bcol[NI], tcol[NI];
+  bool okc[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    bcol[ni] = b;
+    tcol[ni] = n0 + wn * (NI * 32) + ni * 32 + l31;
+    okc[ni] = tcol[ni] < p.Tout;
+  }
+  conv_epilogue<BM, BMH, NI>(p, acc, gated, mt, wm, lhi, bcol, tcol, okc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -345,21 +275,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_stream_kernel(const
       load_step(ra0[s], ra1[s], rb[s]);   // refill this ring slot for step ks + s + PF
     }
   }
-  conv_epilogue<BM, BMH, NI>(p, acc, gated, b, mt, n0, wm, wn, l31, lhi);
+  int bcol[NI], tcol[NI];
+  bool okc[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    bcol[ni] = b;
+    tcol[ni] = n0 + wn * (NI * 32) + ni * 32 + l31;
+    okc[ni] = tcol[ni] < p.Tout;
+  }
+  conv_epilogue<BM, BMH, NI>(p, acc, gated, mt, wm, lhi, bcol, tcol, okc);
 }
-
-struct TileCfg {
-  int id, wm, wn, ni;
-};
-// id is what dv3_conv_desc.tile_hint selects.
-const TileCfg kCfgs[] = {
-    {1, 2, 2, 2},  // 128 x 128
-    {2, 2, 2, 1},  // 128 x 64
-    {3, 4, 1, 1},  // 256 x 32
-    {4, 2, 1, 1},  // 128 x 32
-    {5, 1, 2, 2},  // 64 x 128
-    {6, 1, 2, 1},  // 64 x 64
-};
 
 template <int WM, int WN, int NI>
 int launch_stream(const ConvArgs& a, hipStream_t st) {
@@ -385,6 +310,8 @@ int launch_cfg(const ConvArgs& a, int bkc, size_t lds, hipStream_t st) {
 
 }  // namespace
 
+int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st);  // conv_gemm_bf16x3.hip
+
 extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
   DV3_REQUIRE(d && d->x && d->a && d->y, "conv_gemm: null pointer");
   DV3_REQUIRE(d->B > 0 && d->Cin > 0 && d->Tin > 0 && d->M > 0 && d->Tout > 0, "conv_gemm: bad dims");
@@ -405,33 +332,20 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
   if (d->xmask) DV3_REQUIRE(d->xmask_rs * 32 >= d->Tin, "conv_gemm: xmask row stride too small");
   if (d->ymask) DV3_REQUIRE(d->ymask_rs * 32 >= d->Tout, "conv_gemm: ymask row stride too small");
 
+  DV3_REQUIRE(dv3_conv_fits32(d), "conv_gemm: a tensor exceeds the 4 GB the epilogue can address");
+  // split-bf16 operands given: the bf16x3 kernel (tile_hint 0 = auto, 21..26 = forced tile);
+  // hints 1..16 keep the exact fp32 kernels for A/B runs; ineligible shapes fall through
+  if (d->a_split && (d->tile_hint == 0 || d->tile_hint > 20)) {
+    const int rc = dv3_conv_gemm_bf16x3_dispatch(d, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
+  DV3_REQUIRE(d->tile_hint <= 20, "conv_gemm: tile_hint %d needs split-bf16 operands", d->tile_hint);
   const int rows_half = gated ? d->Cg : 0;
   // tile_hint: 0 auto (streaming kernel), 1..6 streaming kernel with that tile, 11..16 the
   // LDS-staged kernel with tile (hint-10) -- kept for A/B measurements
   const bool use_lds = d->tile_hint > 10;
   const int want_tile = use_lds ? d->tile_hint - 10 : d->tile_hint;
-  // ---- pick a tile config: minimise padded work with a mild small-tile penalty ----
-  const TileCfg* best = nullptr;
-  double best_cost = 0;
-  for (const TileCfg& c : kCfgs) {
-    if (want_tile && c.id != want_tile) continue;
-    const int BM = c.wm * 64, BMH = c.wm * 32, BN = c.wn * c.ni * 32;
-    const int mt = gated ? dv3_cdiv(rows_half, BMH) : dv3_cdiv(d->M, BM);
-    const int ntl = dv3_cdiv(d->Tout, BN);
-    double work = (double)mt * BM * (double)ntl * BN;
-    double pen = 1.0;
-    if (BN == 64) pen *= 1.04;
-    if (BN == 32) pen *= 1.10;
-    if (BM == 64) pen *= 1.06;
-    // too few blocks to fill 256 CUs: prefer finer tiles
-    const double blocks = (double)mt * ntl * d->B;
-    if (blocks < 512) pen *= 1.0 + 0.25 * (512 - blocks) / 512;
-    const double cost = work * pen;
-    if (!best || cost < best_cost) {
-      best = &c;
-      best_cost = cost;
-    }
-  }
+  const TileCfg* best = dv3_pick_tile(d, gated, want_tile);
   DV3_REQUIRE(best, "conv_gemm: unknown tile_hint %d", d->tile_hint);
 
   ConvArgs a;

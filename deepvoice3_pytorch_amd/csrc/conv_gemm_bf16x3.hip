@@ -1,0 +1,460 @@
+// Split-bf16 ("bf16x3") tap-GEMM: the same im2col-free dilated 1-D convolution + fused
+// Conv1dGLU / HighwayConv1d tail as conv_gemm.hip (reference semantics:
+// deepvoice3_pytorch/modules.py:145-164, 205-226), but the contraction runs on the bf16 matrix
+// cores.  Every fp32 operand v is written as hi + lo, hi = bf16_rn(v), lo = bf16_rn(v - hi), and
+//     acc += A_lo*B_hi + A_hi*B_lo + A_hi*B_hi        (fp32 accumulate, v_mfma_f32_32x32x16_bf16)
+// Three bf16 MFMAs per product block cost 3/16 of the fp32-MFMA cycles for ~2^-18 relative
+// operand error (include/dv3hip.h, "Split-bf16").
+//
+// Structure (DESIGN.md "conv_gemm_bf16x3"):
+//   * GEMM view: M = output channels, N = B*T flattened (a column tile may span several batch
+//     items, so short sequences -- T = 150 text, 200 decoder steps -- fill 128-column tiles), K =
+//     (input-channel chunk of 32) x (tap).  One K step = one (chunk, tap) pair.
+//   * weights arrive pre-split from dv3_split_pack_bf16 as [plane][j][k8][m][8]: the (tap, k8)
+//     panel of the block's BM rows is one contiguous run of 16-byte units, staged with straight
+//     coalesced 16-byte copies into the identical LDS image, double buffered per step.
+//   * activations stay fp32 BCT in HBM.  Per chunk a block stages a haloed [32 ch][BN+(J-1)*dil]
+//     tile over the FLAT (b,t) axis: each thread reads 8 channels of one column (8 row-coalesced
+//     loads), applies the dropout keep-bit, splits into hi/lo and writes two 16-byte units: LDS
+//     image [plane][k8][column][8 ch], double buffered per chunk; the J taps read it at shifted
+//     columns (no im2col, one HBM read).  Where a shifted read leaves the column's own batch item
+//     (the conv's zero padding) the fragment is zeroed in registers -- only waves whose 32..64
+//     columns touch a sequence edge for that tap take that path (wave-uniform test).
+//   * next step's operands are fetched into registers BEFORE the step's MFMAs and written to the
+//     other LDS buffer after them: global latency hides behind 24..72 MFMAs, one barrier per step.
+//   * an MFMA fragment (lane = one row/column, 8 consecutive k) is ONE ds_read_b128 whose 32
+//     lanes of a half-wave cover 512 contiguous bytes: conflict free for both operands.
+//   * wave tile 64(M: the `a` rows + their gate rows) x NI*32(N), same accumulator layout as the
+//     fp32 kernel, so the epilogue (conv_common.h) is shared verbatim.
+#include "conv_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BKC = 32;        // channels per K chunk
+constexpr int KB = 4;          // k8 blocks per chunk
+constexpr int HALO_MAX = 64;   // (J-1)*dil supported by the register staging (model max: 2*27)
+
+// split 8 floats into hi / lo bf16x8
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const f32x2 f = {v[i], v[i + 1]};
+    const bf16x2 h = __builtin_convertvector(f, bf16x2);
+    const f32x2 r = f - __builtin_convertvector(h, f32x2);
+    const bf16x2 l = __builtin_convertvector(r, bf16x2);
+    hi[i] = h[0]; hi[i + 1] = h[1];
+    lo[i] = l[0]; lo[i + 1] = l[1];
+  }
+}
+
+// uniform base + zero-extended 32-bit byte offset: selects the SGPR-base global_load form (one
+// VALU add per load instead of a 64-bit address build)
+template <typename T>
+__device__ __forceinline__ T ldg_off(const void* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+template <int WM, int WN, int NI, bool MASK, int ABL = 0>
+__global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const ConvArgs args) {
+  constexpr int BM = WM * 64, BMH = WM * 32, BN = WN * NI * 32;
+  constexpr int NT = WM * WN * 64;
+  constexpr int AU = KB * BM / NT;                          // A units per plane per thread per step
+  constexpr int XI = (KB * (BN + HALO_MAX) + NT - 1) / NT;  // X items per thread per chunk
+  static_assert(KB * BM % NT == 0, "A panel must split evenly");
+  const dv3_conv_desc& p = args.d;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int J = p.J, dil = p.dil;
+  const int BNH = BN + (J - 1) * dil;
+  // [2 buffers] x { A hi [KB][BM], A lo [KB][BM] } then [2 buffers] x { X hi [KB][BNH], X lo }
+  bf16x8* const As = reinterpret_cast<bf16x8*>(smem_raw);
+  bf16x8* const Xs = As + 2 * 2 * KB * BM;
+  const int xbuf = 2 * KB * BNH;  // units per X buffer (hi + lo)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int pid = dv3_xcd_remap(blockIdx.x, args.n_blocks);
+  const int mt = pid % args.m_tiles;
+  const int nt = pid / args.m_tiles;
+  const int n0 = nt * BN;
+
+  const bool gated = (p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY);
+  int h0b, h1b, lim0, lim1;
+  if (gated) {
+    h0b = mt * BMH; h1b = p.a_half + mt * BMH; lim0 = p.a_half; lim1 = p.lda;
+  } else {
+    h0b = mt * BM; h1b = mt * BM + BMH; lim0 = lim1 = p.lda;
+  }
+
+  const int Cin = p.Cin, T = p.Tout, lda = p.lda, B = p.B;
+  const int Ntot = B * T;
+  const int k8_total = args.kp >> 3;
+  const bf16x8* __restrict__ Wh = reinterpret_cast<const bf16x8*>(p.a_split);
+  const int64_t plane = (int64_t)J * k8_total * lda;  // 16-byte units per plane
+  const uint32_t* __restrict__ xmask = p.xmask;
+  const float dscale = p.drop_scale;
+
+  // ---- this lane's output columns: (batch, time) and per-tap validity of the shifted read ----
+  int bcol[NI], tcol[NI];
+  bool okc[NI];
+  uint32_t vbits = 0;  // bit j*NI+ni: the tap-j input of column ni lies inside its batch item
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+    okc[ni] = n < Ntot;
+    bcol[ni] = n / T;
+    tcol[ni] = n - bcol[ni] * T;
+    for (int j = 0; j < J; ++j) {
+      const int ts = tcol[ni] + j * dil - p.padL;
+      if (okc[ni] && ts >= 0 && ts < T) vbits |= 1u << (j * NI + ni);
+    }
+  }
+  uint32_t need = 0;  // wave-uniform: taps for which some lane of this wave must zero its fragment
+  for (int j = 0; j < J; ++j) {
+    const uint32_t all = ((1u << NI) - 1u) << (j * NI);
+    if (!__all((vbits & all) == all)) need |= 1u << j;
+  }
+  need = __builtin_amdgcn_readfirstlane(need);
+
+  // ---- this thread's X staging items: flat column -> (batch, time), fixed over chunks ----
+  // Nothing staged needs zeroing: columns outside the tensor or outside an output column's own
+  // batch item are zeroed per fragment (vbits), channels >= Cin meet zero weight rows (Cin % 8 == 0
+  // is required, so a k8 block is either inside or clamped to the last real block), and weight
+  // rows beyond the tile's valid range only feed output rows the epilogue drops.
+  uint32_t xoff[XI];                // byte offset of (b, 0, t) from p.x  (< 2^32, host-checked)
+  uint32_t xmo[MASK ? XI : 1];      // byte offset of word (b*Cin, t>>5) in xmask
+  int xsh[MASK ? XI : 1];           // bit position t & 31
+  int xk8[XI];
+  const int n_items = KB * BNH;
+  const uint32_t x_rsb = (uint32_t)p.x_rs * 4u, m_rsb = (uint32_t)p.xmask_rs * 4u;
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int idx = tid + i * NT;
+    const int k8 = idx / BNH, q = idx - k8 * BNH;
+    const int f = n0 - p.padL + q;
+    int bf = 0, tf = 0;
+    if (idx < n_items && f >= 0 && f < Ntot) {
+      bf = f / T;
+      tf = f - bf * T;
+    }
+    xk8[i] = k8 < KB ? k8 * 8 : 0;
+    xoff[i] = ((uint32_t)bf * (uint32_t)p.x_bs + (uint32_t)tf) * 4u;
+    if (MASK) {
+      xmo[i] = ((uint32_t)(bf * Cin) * (uint32_t)p.xmask_rs + (uint32_t)(tf >> 5)) * 4u;
+      xsh[i] = tf & 31;
+    }
+  }
+  // weight panel: per-unit column offset inside a (tap, k8) row of the split image
+  uint32_t aoff[AU];   // bytes
+#pragma unroll
+  for (int u = 0; u < AU; ++u) {
+    const int idx = tid + u * NT;  // k8 * BM + col
+    const int col = idx % BM, k8 = idx / BM;
+    const bool hi_half = col >= BMH;
+    const int gcol = (hi_half ? h1b : h0b) + (col - (hi_half ? BMH : 0));
+    aoff[u] = (uint32_t)(k8 * lda + (gcol < lda ? gcol : 0)) * 16u;
+  }
+
+  // ---- register staging ----
+  bf16x8 ra[2][AU];
+  float rx[XI][8];
+  uint32_t rm[MASK ? XI : 1][8];
+
+  auto load_A = [&](int chunk, int j) {
+    const bf16x8* srch = Wh + (int64_t)(j * k8_total + chunk * KB) * lda;  // uniform
+    const bf16x8* srcl = srch + plane;
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      ra[0][u] = ldg_off<bf16x8>(srch, aoff[u]);
+      ra[1][u] = ldg_off<bf16x8>(srcl, aoff[u]);
+    }
+  };
+  auto write_A = [&](int buf) {
+    bf16x8* dst = As + buf * (2 * KB * BM);
+#pragma unroll
+    for (int u = 0; u < AU; ++u) {
+      dst[tid + u * NT] = ra[0][u];
+      dst[KB * BM + tid + u * NT] = ra[1][u];
+    }
+  };
+  auto load_X = [&](int chunk) {
+    const int c0 = chunk * BKC;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const uint32_t cb = (uint32_t)min(c0 + xk8[i], Cin - 8);
+      const uint32_t o = xoff[i] + cb * x_rsb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rx[i][e] = ldg_off<float>(p.x, o + e * x_rsb);
+      if (MASK) {
+        const uint32_t mo = xmo[i] + cb * m_rsb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rm[i][e] = ldg_off<uint32_t>(xmask, mo + e * m_rsb);
+      }
+    }
+  };
+  auto write_X = [&](int buf) {
+    bf16x8* dst = Xs + buf * xbuf;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < n_items) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = rx[i][e];
+          if (MASK) v[e] *= ((rm[i][e] >> xsh[i]) & 1u) ? dscale : 0.f;
+        }
+        bf16x8 hi, lo;
+        split8(v, hi, lo);
+        dst[idx] = hi;
+        dst[KB * BNH + idx] = lo;
+      }
+    }
+  };
+
+  f32x16 acc[2][NI];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][ni][r] = 0.f;
+
+  const int nchunks = (Cin + BKC - 1) / BKC;
+  const int nsteps = (ABL == 5) ? 0 : nchunks * J;
+  const int a_off = wm * 32 + l31;
+  const int x_off = wn * (NI * 32) + l31;
+
+  load_A(0, 0);
+  load_X(0);
+  write_A(0);
+  write_X(0);
+  __syncthreads();
+
+  int c = 0, j = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    int jn = j + 1, cn = c;
+    if (jn == J) { jn = 0; cn = c + 1; }
+    const bool has_next = step + 1 < nsteps;
+    const bool new_chunk = has_next && jn == 0;
+    if (ABL != 1 && ABL != 2 && ABL != 3) {
+      if (has_next) load_A(cn, jn);
+      if (new_chunk) load_X(cn);
+    }
+
+    // ---------------- MFMA: two k16 steps of tap j ----------------
+    {
+      const bf16x8* AsH = As + cur * (2 * KB * BM);
+      const bf16x8* AsL = AsH + KB * BM;
+      const bf16x8* XsH = Xs + (c & 1) * xbuf;
+      const bf16x8* XsL = XsH + KB * BNH;
+      const bool fix = (need >> j) & 1u;
+      const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int k8 = 2 * s + lhi;
+        const int ai = k8 * BM + a_off;
+        const bf16x8 ah0 = AsH[ai], ah1 = AsH[ai + BMH];
+        const bf16x8 al0 = AsL[ai], al1 = AsL[ai + BMH];
+        bf16x8 bh[NI], bl[NI];
+        const int xi = k8 * BNH + x_off + j * dil;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          bh[ni] = XsH[xi + ni * 32];
+          bl[ni] = XsL[xi + ni * 32];
+        }
+        if (fix) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const bool ok = (vbits >> (j * NI + ni)) & 1u;
+            bh[ni] = ok ? bh[ni] : zero8;
+            bl[ni] = ok ? bl[ni] : zero8;
+          }
+        }
+        if (ABL == 4) {
+          asm volatile("" ::"v"(ah0), "v"(ah1), "v"(al0), "v"(al1));
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(bh[ni]), "v"(bl[ni]));
+          continue;
+        }
+        // small terms first; each accumulator is touched once per pass (no back-to-back RAW)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[ni], acc[0][ni], 0, 0, 0);
+          acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[ni], acc[1][ni], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[ni], acc[0][ni], 0, 0, 0);
+          acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[ni], acc[1][ni], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[ni], acc[0][ni], 0, 0, 0);
+          acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[ni], acc[1][ni], 0, 0, 0);
+        }
+      }
+    }
+
+    if (ABL != 2 && ABL != 3) {
+      if (has_next) write_A(cur ^ 1);
+      if (new_chunk) write_X((c + 1) & 1);
+    }
+    if (ABL != 3) __syncthreads();
+    j = jn;
+    c = cn;
+  }
+
+  // ABL 6: skip the epilogue but keep the accumulators live
+  if (ABL != 6 || acc[0][0][0] + acc[1][0][0] + acc[0][NI - 1][5] + acc[1][NI - 1][7] == 1.2345e30f)
+    conv_epilogue<BM, BMH, NI>(p, acc, gated, mt, wm, lhi, bcol, tcol, okc);
+}
+
+// packed fp32 [J][K][lda] -> split image [plane][j][k8][m][8]
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ src,
+                                                         bf16x8* __restrict__ dst, int J, int K,
+                                                         int lda, int k8_total) {
+  const int64_t n = (int64_t)J * k8_total * lda;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const int m = (int)(idx % lda);
+  const int64_t row = idx / lda;  // j*k8_total + k8
+  const int j = (int)(row / k8_total), k8 = (int)(row % k8_total);
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = k8 * 8 + i;
+    v[i] = (k < K) ? src[((int64_t)j * K + k) * lda + m] : 0.f;
+  }
+  bf16x8 hi, lo;
+  split8(v, hi, lo);
+  dst[idx] = hi;
+  dst[n + idx] = lo;
+}
+
+template <int WM, int WN, int NI, bool MASK>
+int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
+  static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      dv3_set_error("conv_gemm_bf16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DV3_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  dim3 grid(a.n_blocks), block(WM * WN * 64);
+  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK>), grid, block, lds, st, a);
+  return dv3_check_launch("conv_gemm_bf16x3");
+}
+int g_x3_ablate = 0;   // debug: dv3_debug_set(); ablation variants of the 128x128 unmasked tile
+template <int ABL>
+int launch_x3_abl(const ConvArgs& a, size_t lds, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<2, 2, 2, false, ABL>,
+                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<2, 2, 2, false, ABL>), dim3(a.n_blocks), dim3(256), lds, st, a);
+  return dv3_check_launch("conv_gemm_bf16x3(abl)");
+}
+template <int WM, int WN, int NI>
+int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
+  if (g_x3_ablate && WM == 2 && WN == 2 && NI == 2 && !a.d.xmask) {
+    switch (g_x3_ablate) {
+      case 1: return launch_x3_abl<1>(a, lds, st);
+      case 2: return launch_x3_abl<2>(a, lds, st);
+      case 3: return launch_x3_abl<3>(a, lds, st);
+      case 4: return launch_x3_abl<4>(a, lds, st);
+      case 5: return launch_x3_abl<5>(a, lds, st);
+      case 6: return launch_x3_abl<6>(a, lds, st);
+    }
+  }
+  return a.d.xmask ? launch_x3_m<WM, WN, NI, true>(a, lds, st) : launch_x3_m<WM, WN, NI, false>(a, lds, st);
+}
+
+// bf16x3 tile choice: padded work over the FLAT column axis, weight-panel traffic penalised
+// (a block re-reads its A panel every K step, so narrow column tiles starve the matrix pipe).
+const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
+  const TileCfg* best = nullptr;
+  double best_cost = 0;
+  const int64_t ntot = (int64_t)d->B * d->Tout;
+  for (const TileCfg& c : kCfgs) {
+    if (want_tile && c.id != want_tile) continue;
+    const int BM = c.wm * 64, BMH = c.wm * 32, BN = c.wn * c.ni * 32;
+    const int64_t mt = gated ? dv3_cdiv(d->Cg, BMH) : dv3_cdiv(d->M, BM);
+    const int64_t ntl = dv3_cdiv64(ntot, BN);
+    const double work = (double)mt * BM * (double)ntl * BN;
+    double pen = 1.0 + 24.0 / BN + 8.0 / BM;   // operand traffic per MFMA ~ 1/BN (weights) + 1/BM
+    const double blocks = (double)mt * ntl;
+    if (blocks < 512) pen *= 1.0 + 0.25 * (512 - blocks) / 512;
+    const double cost = work * pen;
+    if (!best || cost < best_cost) {
+      best = &c;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
+}  // namespace
+
+// called by dv3_conv_gemm_f32 (conv_gemm.hip) when d->a_split != NULL; returns 1 when the shape
+// is not eligible (caller falls back to the exact kernel), else a DV3_* code.
+int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
+  const bool gated = d->mode == DV3_EPI_GLU || d->mode == DV3_EPI_HIGHWAY;
+  if (d->a_bs != 0 || (d->lda & 3) || d->Tin != d->Tout || (d->Cin & 7)) return 1;
+  if ((d->J - 1) * d->dil > HALO_MAX || d->J * 2 > 32) return 1;
+  // 32-bit byte offsets inside the kernel
+  if ((int64_t)d->B * d->Tout >= (1ll << 30) || (int64_t)d->B * d->x_bs >= (1ll << 30)) return 1;
+  if (d->xmask && (int64_t)d->B * d->Cin * d->xmask_rs >= (1ll << 30)) return 1;
+  if ((int64_t)d->J * ((d->Cin + 31) / 32 * 4) * d->lda >= (1ll << 27)) return 1;
+  // the flat column axis needs batch-strided tensors only through (b, t) addressing: fine for all
+  const TileCfg* best = pick_tile_x3(d, gated, d->tile_hint > 20 ? d->tile_hint - 20 : 0);
+  if (!best) return 1;
+  const int BM = best->wm * 64, BMH = best->wm * 32, BN = best->wn * best->ni * 32;
+  const int BNH = BN + (d->J - 1) * d->dil;
+  const size_t lds = (size_t)(2 * 2 * KB * BM + 2 * 2 * KB * BNH) * 16;
+  if (lds > 160 * 1024) return 1;
+  ConvArgs a;
+  a.d = *d;
+  a.a_scalar = 0;
+  a.kp = (d->Cin + 31) / 32 * 32;
+  a.m_tiles = gated ? dv3_cdiv(d->Cg, BMH) : dv3_cdiv(d->M, BM);
+  a.n_tiles = (int)dv3_cdiv64((int64_t)d->B * d->Tout, BN);
+  const int64_t nb = (int64_t)a.m_tiles * a.n_tiles;
+  DV3_REQUIRE(nb < (1ll << 31), "conv_gemm: grid too large");
+  a.n_blocks = (int)nb;
+  switch (best->id) {
+    case 1: return launch_x3<2, 2, 2>(a, lds, st);
+    case 2: return launch_x3<2, 2, 1>(a, lds, st);
+    case 3: return launch_x3<4, 1, 1>(a, lds, st);
+    case 4: return launch_x3<2, 1, 1>(a, lds, st);
+    case 5: return launch_x3<1, 2, 2>(a, lds, st);
+    case 6: return launch_x3<1, 2, 1>(a, lds, st);
+  }
+  return 1;
+}
+
+extern "C" int dv3_debug_set(int what, int value) {
+  if (what == 1) g_x3_ablate = value;
+  return DV3_OK;
+}
+
+extern "C" int dv3_split_pack_bf16(const float* packed, uint16_t* out, int32_t J, int32_t K,
+                                   int32_t lda, void* stream) {
+  DV3_REQUIRE(packed && out, "split_pack: null pointer");
+  DV3_REQUIRE(J >= 1 && K >= 1 && lda >= 1 && ((uintptr_t)out & 15) == 0, "split_pack: bad arguments");
+  const int k8_total = (K + 31) / 32 * 4;
+  const int64_t n = (int64_t)J * k8_total * lda;
+  hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)dv3_cdiv64(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, packed, reinterpret_cast<bf16x8*>(out), J, K, lda, k8_total);
+  return dv3_check_launch("split_pack_bf16");
+}

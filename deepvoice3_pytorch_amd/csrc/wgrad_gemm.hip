@@ -112,6 +112,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_gemm_f32_kernel(const Wgrad
 
 }  // namespace
 
+int dv3_wgrad_gemm_bf16x3_dispatch(const dv3_wgrad_desc* d, hipStream_t st);  // wgrad_gemm_bf16x3.hip
+
 extern "C" int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream) {
   DV3_REQUIRE(d && d->g && d->x && d->out, "wgrad_gemm: null pointer");
   DV3_REQUIRE(d->B > 0 && d->M > 0 && d->Cin > 0 && d->T > 0 && d->Tin > 0, "wgrad_gemm: bad dims");
@@ -122,6 +124,7 @@ extern "C" int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream) {
   a.d = *d;
   hipStream_t st = (hipStream_t)stream;
   const bool small = (d->M <= 64 && d->Cin <= 64);
+  if (d->split_bf16 && !small) return dv3_wgrad_gemm_bf16x3_dispatch(d, st);
   if (small) {
     a.m_tiles = dv3_cdiv(d->M, 64);
     a.c_tiles = dv3_cdiv(d->Cin, 64);

@@ -36,6 +36,32 @@ _softmax_bwd_desc = STRUCTS["dv3_softmax_bwd_desc"]
 _spec_loss_desc = STRUCTS["dv3_spec_loss_desc"]
 
 
+# ----------------------------------------------------------------------------------------------
+# GEMM arithmetic: "bf16x3" = split-bf16 operands on the bf16 matrix cores with fp32 accumulate
+# (include/dv3hip.h, "Split-bf16"; ~3e-6 relative error, 16/3 x the fp32-MFMA rate) -- the
+# default; "f32" = the exact fp32 MFMA chain (v_mfma_f32_32x32x2_f32).  DV3_GEMM=f32 selects it.
+# ----------------------------------------------------------------------------------------------
+import os as _os
+
+_GEMM_MODES = ("bf16x3", "f32")
+_gemm_mode = _os.environ.get("DV3_GEMM", "bf16x3")
+if _gemm_mode not in _GEMM_MODES:
+    raise RuntimeError("DV3_GEMM must be one of %s" % (_GEMM_MODES,))
+
+
+def set_gemm_precision(mode):
+    """'bf16x3' (default) or 'f32'; returns the previous mode."""
+    global _gemm_mode
+    if mode not in _GEMM_MODES:
+        raise ValueError("gemm precision must be one of %s" % (_GEMM_MODES,))
+    prev, _gemm_mode = _gemm_mode, mode
+    return prev
+
+
+def gemm_precision():
+    return _gemm_mode
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -104,7 +130,16 @@ def dropout_bits(rows, T, p, device, name=None):
 # weight norm + packing
 # ----------------------------------------------------------------------------------------------
 class Packed(object):
-    __slots__ = ("fwd", "bwd", "scale", "lda", "a_half", "ldb", "O", "I", "J", "transposed", "glu_cg")
+    __slots__ = ("fwd", "bwd", "scale", "lda", "a_half", "ldb", "O", "I", "J", "transposed", "glu_cg",
+                 "fwd_s", "bwd_s")
+
+
+def split_pack(packed, J, K, ld):
+    """dv3_split_pack_bf16: fp32 packed image [J][K][ld] -> split-bf16 image (int16 storage)."""
+    kp = _round_up(K, 32)
+    out = torch.empty(2 * J * kp * ld, dtype=torch.int16, device=packed.device)
+    _lib.call("dv3_split_pack_bf16", packed.data_ptr(), out.data_ptr(), J, K, ld, _stream())
+    return out
 
 
 def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True):
@@ -142,6 +177,17 @@ def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True):
     d.bwd_pack, d.ldb = _ptr(pk.bwd), pk.ldb
     d.O, d.I, d.J, d.transposed, d.glu_cg = O, I, J, int(transposed), glu_cg
     _lib.call("dv3_weight_norm_pack_f32", ctypes.byref(d), _stream())
+    pk.fwd_s = pk.bwd_s = None
+    if _gemm_mode == "bf16x3":
+        # operand K/M extents of the two tap-GEMMs: fwd [J'][K=I][lda], bwd [J'][K'][ldb]
+        if transposed:
+            pk.fwd_s = split_pack(pk.fwd, 1, I, pk.lda)
+            if need_bwd:
+                pk.bwd_s = split_pack(pk.bwd, 1, J * O, pk.ldb)
+        else:
+            pk.fwd_s = split_pack(pk.fwd, J, I, pk.lda)
+            if need_bwd:
+                pk.bwd_s = split_pack(pk.bwd, J, O, pk.ldb)
     return pk
 
 
@@ -151,7 +197,8 @@ def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True):
 def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mode=EPI_LINEAR,
               Cg=0, bias=None, spk=None, spk_strides=(0, 0, 0), r=None, r2=None, residual=0,
               y=None, y_rs=None, ab=None, xmask=None, xmask_rs=0, ymask=None, ymask_rs=0,
-              drop_scale=1.0, a_bs=0, store_mode=STORE_BCT, x_bs=None, x_rs=None, tile_hint=0):
+              drop_scale=1.0, a_bs=0, store_mode=STORE_BCT, x_bs=None, x_rs=None, tile_hint=0,
+              a_split=None):
     """dv3_conv_gemm_f32.  x: [B][Cin][Tin] (strides overridable); returns y."""
     gated = mode in (EPI_GLU, EPI_HIGHWAY)
     Cout = Cg if gated else (M // 2 if store_mode == STORE_INTERLEAVE2 else M)
@@ -181,12 +228,14 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
     d.drop_scale = drop_scale
     d.B, d.Cin, d.Tin, d.M, d.Cg, d.Tout, d.J, d.dil, d.padL = B, Cin, Tin, M, Cg, Tout, J, dil, padL
     d.mode, d.residual, d.store_mode, d.tile_hint = mode, residual, store_mode, tile_hint
+    d.a_split = _ptr(a_split)
     _lib.call("dv3_conv_gemm_f32", ctypes.byref(d), _stream())
     return y
 
 
 def wgrad_gemm(g, x, *, B, M, Cin, T, Tin, J=1, dil=1, padL=0, n_slabs=1, xmask=None, xmask_rs=0,
-               drop_scale=1.0, out=None, ldo=None, g_bs=None, g_rs=None, x_bs=None, x_rs=None):
+               drop_scale=1.0, out=None, ldo=None, g_bs=None, g_rs=None, x_bs=None, x_rs=None,
+               split_bf16=False):
     """dv3_wgrad_gemm_f32 -> out [S][J][M][ldo]."""
     if ldo is None:
         ldo = Cin
@@ -200,6 +249,7 @@ def wgrad_gemm(g, x, *, B, M, Cin, T, Tin, J=1, dil=1, padL=0, n_slabs=1, xmask=
     d.xmask, d.xmask_rs, d.drop_scale = _ptr(xmask), xmask_rs, drop_scale
     d.out, d.out_ss, d.ldo = out.data_ptr(), J * M * ldo, ldo
     d.B, d.M, d.Cin, d.T, d.Tin, d.J, d.dil, d.padL, d.n_slabs = B, M, Cin, T, Tin, J, dil, padL, n_slabs
+    d.split_bf16 = int(bool(split_bf16))
     _lib.call("dv3_wgrad_gemm_f32", ctypes.byref(d), _stream())
     return out
 
@@ -336,7 +386,7 @@ class ConvLayerFn(torch.autograd.Function):
                       bias=bias, spk=spk, spk_strides=spk_strides,
                       r=res_in if (mode == EPI_HIGHWAY or cfg.residual or not gated) else None,
                       r2=r2c, residual=int(cfg.residual), ab=ab, xmask=bits, xmask_rs=bits_rs,
-                      drop_scale=dscale,
+                      drop_scale=dscale, a_split=pk.fwd_s if _gemm_mode == "bf16x3" else None,
                       store_mode=STORE_INTERLEAVE2 if cfg.transposed else STORE_BCT)
         if need_grad:
             ctx.cfg, ctx.pk, ctx.dims = cfg, pk, (B, Cin, T, Tout, M, Cg, J, padL)
@@ -399,13 +449,15 @@ class ConvLayerFn(torch.autograd.Function):
             Jd = 1 if cfg.transposed else J
             dx = conv_gemm(gmat, pk.bwd, pk.ldb, 0, B=B, Cin=Mg, Tin=Tg, M=Cin, Tout=T, J=Jd,
                            dil=cfg.dil, padL=(Jd - 1) * cfg.dil - padL, mode=EPI_DGRAD, r=dres,
-                           ymask=ctx.bits, ymask_rs=ctx.bits_rs, drop_scale=ctx.dscale)
+                           ymask=ctx.bits, ymask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
+                           a_split=pk.bwd_s if _gemm_mode == "bf16x3" else None)
         if ctx.needs_input_grad[1]:
             Jd = 1 if cfg.transposed else J
             tiles = ((Mg + 127) // 128) * ((Cin + 127) // 128) * Jd
             S = _slab_count(B, tiles)
             slabs = wgrad_gemm(gmat, x, B=B, M=Mg, Cin=Cin, T=Tg, Tin=T, J=Jd, dil=cfg.dil, padL=padL,
-                               n_slabs=S, xmask=ctx.bits, xmask_rs=ctx.bits_rs, drop_scale=ctx.dscale)
+                               n_slabs=S, xmask=ctx.bits, xmask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
+                               split_bf16=(_gemm_mode == "bf16x3"))
             v3 = v if v.dim() == 3 else v.unsqueeze(-1)
             dv, dg, dbias = weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None,
                                             pk.scale, part, B, pk.O, pk.I, pk.J, cfg.transposed,

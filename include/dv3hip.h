@@ -30,13 +30,15 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 10
+#define DV3_ABI_VERSION 11
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
 int dv3_device_info(int dev, char* name, int name_len, int* n_cu);
 /* sizeof(struct <name>) or -1: lets a foreign-language mirror of the descriptors self-check */
 int dv3_sizeof(const char* name);
+/* Developer knobs for measurements (what = 1: ablation variant of the bf16x3 tap-GEMM; 0 = off). */
+int dv3_debug_set(int what, int value);
 
 /* ------------------------------------------------------------------------------------
  * Epilogue modes of the tap-GEMM (dv3_conv_gemm_f32).
@@ -97,8 +99,28 @@ typedef struct dv3_conv_desc {
   int32_t B, Cin, Tin, M, Cg, Tout, J, dil, padL;
   int32_t mode, residual, store_mode;
   int32_t tile_hint;                         /* 0 = auto; else forces a tile config (tests) */
+  const uint16_t* a_split;                   /* split-bf16 image of `a` (dv3_split_pack_bf16) or
+                                                NULL.  Non-NULL selects the bf16x3 kernel (below) */
 } dv3_conv_desc;
 int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
+
+/*
+ * Split-bf16 ("bf16x3") operand form.  The fp32 matrix cores run at 1/16 of the bf16 rate on
+ * gfx950, so the GEMM kernels can instead write every fp32 operand as hi + lo with
+ *   hi = bf16_rn(v), lo = bf16_rn(v - hi)        (|v - hi - lo| <= 2^-18 |v|)
+ * and accumulate  A_lo*B_hi + A_hi*B_lo + A_hi*B_hi  in fp32 on v_mfma_f32_32x32x16_bf16:
+ * three bf16 MFMAs per product block = 16/3 x the fp32-MFMA rate; the dropped terms bound the
+ * relative error of a dot product by ~3*2^-18 of sum|a||b| -- inside the 1e-4 relative parity
+ * bar of the reference comparison (tests/ measure it against fp64).
+ *
+ * dv3_split_pack_bf16 converts a packed fp32 weight image [J][K][lda] (dv3_weight_norm_pack_f32's
+ * fwd_pack / bwd_pack) into the layout the bf16x3 tap-GEMM stages with straight 16-byte copies:
+ *   out[plane][j][k8][m][8]   plane 0 = hi, 1 = lo; k8 = k/8 over Kp = round_up(K,32) (zero rows
+ *   beyond K); m < lda; 8 consecutive k per 16-byte unit (one MFMA A-fragment lane).
+ * `out` holds 2*J*Kp*lda uint16 elements.
+ */
+int dv3_split_pack_bf16(const float* packed, uint16_t* out, int32_t J, int32_t K, int32_t lda,
+                        void* stream);
 
 /*
  * dv3_wgrad_gemm_f32 -- weight-gradient GEMM (autograd of F.conv1d w.r.t. weight; also
@@ -117,6 +139,7 @@ typedef struct dv3_wgrad_desc {
   float* out;      int64_t out_ss;           /* [S][J][M][ldo]; slab stride                  */
   int32_t ldo;
   int32_t B, M, Cin, T, Tin, J, dil, padL, n_slabs;
+  int32_t split_bf16;                        /* 1: bf16x3 split-operand MFMA; 0: exact fp32 MFMA */
 } dv3_wgrad_desc;
 int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream);
 

@@ -23,6 +23,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4   # north_star: "within 1e-4 rel fp32 on identical inputs"
 
 
+@pytest.fixture(autouse=True, params=["bf16x3", "f32"])
+def gemm_mode(request):
+    """every model-level parity test runs under both GEMM arithmetic modes (same 1e-4 bar)"""
+    from deepvoice3_pytorch_amd import ops
+    prev = ops.set_gemm_precision(request.param)
+    yield request.param
+    ops.set_gemm_precision(prev)
+
+
 @pytest.fixture(scope="module")
 def dev():
     if not torch.cuda.is_available():
