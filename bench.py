@@ -272,6 +272,8 @@ def main():
         torch.distributed.all_reduce(frames, op=torch.distributed.ReduceOp.SUM)
     dt = float(tmax.item())
     loss = float(scal["loss"])
+    if not math.isfinite(loss):
+        raise RuntimeError("non-finite training loss (%r): the measurement is void" % loss)
     if rank != 0:
         return
     ms = dt / args.steps * 1e3

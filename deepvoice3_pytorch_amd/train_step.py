@@ -235,8 +235,10 @@ class GraphedTrainer(object):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(warmup):
+            for _ in range(warmup):      # real optimisation steps (lr / bias corrections set first)
+                trainer._set_hyper()
                 self._body()
+                trainer.global_step += 1
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
         site0 = ops.dropout_state.site

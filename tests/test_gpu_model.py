@@ -275,3 +275,39 @@ def test_train_step_matches_reference_golden(dev):
         moved = float(np.abs(fx["sd2/" + k] - fx["sd0/" + k]).max())
         diff = float(np.abs(sdn[k].cpu().numpy() - fx["sd2/" + k]).max())
         assert diff < 0.1 * max(moved, 1e-6) + 1e-6, (k, diff, moved)
+
+
+def test_graphed_train_step_matches_reference_golden(dev):
+    """the whole-step hipGraph (what bench.py times): one warm-up step + one captured replay must
+    land on the reference's step-2 scalars, i.e. capture changes nothing numerically"""
+    from deepvoice3_pytorch_amd import builder, train_step
+    fx = load_golden("trainstep")
+    hpo = json.loads(str(fx["hp_over"]))
+    hp = dict(n_vocab=149, embed_dim=hpo["text_embed_dim"], mel_dim=hpo["num_mels"],
+              linear_dim=hpo["fft_size"] // 2 + 1, r=1, downsample_step=4, padding_idx=0, dropout=0.0,
+              kernel_size=3, encoder_channels=hpo["encoder_channels"],
+              decoder_channels=hpo["decoder_channels"], converter_channels=hpo["converter_channels"],
+              use_memory_mask=True, force_monotonic_attention=True,
+              use_decoder_state_for_postnet_input=True, max_positions=hpo["max_positions"],
+              key_projection=True, value_projection=True)
+    model = builder.deepvoice3(**hp)
+    model.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("sd0/")})
+    model.to(dev)
+    x = {k[3:]: torch.from_numpy(val) for k, val in fx.items() if k.startswith("in/")}
+    trainer = train_step.Trainer(model, train_step.TrainConfig(
+        outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5, binary_divergence_weight=0.1,
+        use_guided_attention=True, guided_attention_sigma=0.2, clip_thresh=0.1, adam_beta1=0.5,
+        adam_beta2=0.9, adam_eps=1e-6, initial_learning_rate=5e-4, lr_schedule="noam_learning_rate_decay"),
+        global_step=int(fx["global_step0"]))
+    batch = train_step.Batch.from_collate(x["text"], x["input_lengths"], x["mel"], x["y"],
+                                          x["text_positions"], x["frame_positions"], x["done"],
+                                          x["target_lengths"], None, downsample_step=4, device=dev)
+    runner = train_step.GraphedTrainer(trainer, batch, warmup=1)     # step 1 (eager, on a side stream)
+    scal = {k: float(v) for k, v in runner.step().items()}          # step 2 (graph replay)
+    assert np.isfinite(scal["loss"])
+    assert abs(scal["loss"] - fx["scalar/loss"][1]) < 2e-4 * fx["scalar/loss"][1]
+    assert abs(scal["attn_loss"] - fx["scalar/attn_loss"][1]) < 2e-4 * fx["scalar/attn_loss"][1]
+    assert abs(scal["grad_norm"] - fx["scalar/gradient_norm"][1]) < 2e-3 * fx["scalar/gradient_norm"][1]
+    for _ in range(3):
+        scal = runner.step()
+    assert np.isfinite(float(scal["loss"]))
