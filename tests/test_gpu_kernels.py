@@ -424,7 +424,8 @@ def test_clip_adam(dev):
 def test_conv_gemm_full_size_properties(dev):
     """BASELINE north-star shape (B=64, C=256, T=1024, k=3): too big for the CPU oracle in a unit
     test, so check size-independent properties: linearity in x of the pre-gate (a,b) outputs,
-    shift-equivariance in time away from the borders, and a sampled direct dot-product check."""
+    shift-equivariance in time away from the borders, and a sampled direct dot-product check
+    (fp64).  Runs on the kernel of the active GEMM mode."""
     ops = _ops()
     torch.manual_seed(0)
     B, C, T, k, d = 64, 256, 1024, 3, 3
@@ -437,11 +438,11 @@ def test_conv_gemm_full_size_properties(dev):
     def pre_gate(x):
         ab = torch.empty(B, 2 * C, T, device=dev)
         ops.conv_gemm(x, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d, padL=padL,
-                      mode=ops.EPI_GLU, Cg=C, bias=bias, ab=ab)
+                      mode=ops.EPI_GLU, Cg=C, bias=bias, ab=ab, a_split=pk.fwd_s)   # fwd_s: None in f32 mode
         return ab
     x1, x2 = torch.randn(B, C, T, device=dev), torch.randn(B, C, T, device=dev)
     a1, a2, a12 = pre_gate(x1), pre_gate(x2), pre_gate(x1 + 2 * x2)
-    assert rel_err((a1 + 2 * a2).cpu(), a12.cpu()) < 1e-5
+    assert rel_err((a1 + 2 * a2).cpu(), a12.cpu()) < (1e-5 if pk.fwd_s is None else 4e-5)
     xs = torch.roll(x1, 7, dims=2)
     a_s = pre_gate(xs)
     assert rel_err(a_s[:, :, 32:-32].cpu(), torch.roll(a1, 7, dims=2)[:, :, 32:-32].cpu()) < 1e-6
@@ -456,4 +457,4 @@ def test_conv_gemm_full_size_properties(dev):
             tt = t + j * d - padL
             if 0 <= tt < T:
                 acc += float((w[o, :, j] * xc[b, :, tt]).sum())
-        assert abs(acc - float(a1[b, o, t])) < 1e-4 * max(1.0, abs(acc))
+        assert abs(acc - float(a1[b, o, t])) < (1e-5 if pk.fwd_s is None else 5e-5) * max(1.0, abs(acc))
