@@ -20,8 +20,9 @@
 //     columns (no im2col, one HBM read).  Where a shifted read leaves the column's own batch item
 //     (the conv's zero padding) the fragment is zeroed in registers -- only waves whose 32..64
 //     columns touch a sequence edge for that tap take that path (wave-uniform test).
-//   * next step's operands are fetched into registers BEFORE the step's MFMAs and written to the
-//     other LDS buffer after them: global latency hides behind 24..72 MFMAs, one barrier per step.
+//   * next step's weight panel is fetched into registers BEFORE the step's MFMAs and written to the
+//     other LDS buffer after them; the next chunk's activation tile (HBM latency) is fetched J
+//     steps ahead.  One barrier per step.
 //   * an MFMA fragment (lane = one row/column, 8 consecutive k) is ONE ds_read_b128 whose 32
 //     lanes of a half-wave cover 512 contiguous bytes: conflict free for both operands.
 //   * wave tile 64(M: the `a` rows + their gate rows) x NI*32(N), same accumulator layout as the
@@ -126,9 +127,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
 
   // ---- this thread's X staging items: flat column -> (batch, time), fixed over chunks ----
   // Nothing staged needs zeroing: columns outside the tensor or outside an output column's own
-  // batch item are zeroed per fragment (vbits), channels >= Cin meet zero weight rows (Cin % 8 == 0
-  // is required, so a k8 block is either inside or clamped to the last real block), and weight
-  // rows beyond the tile's valid range only feed output rows the epilogue drops.
+  // batch item are zeroed per fragment (vbits), channels >= Cin (clamped reads) meet zero weight
+  // rows, and weight rows beyond the tile's valid range only feed output rows the epilogue drops.
   uint32_t xoff[XI];                // byte offset of (b, 0, t) from p.x  (< 2^32, host-checked)
   uint32_t xmo[MASK ? XI : 1];      // byte offset of word (b*Cin, t>>5) in xmask
   int xsh[MASK ? XI : 1];           // bit position t & 31
@@ -189,14 +189,24 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
     const int c0 = chunk * BKC;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const uint32_t cb = (uint32_t)min(c0 + xk8[i], Cin - 8);
-      const uint32_t o = xoff[i] + cb * x_rsb;
+      // channels >= Cin are clamped to the last real row: they meet zero weight rows
+      const int cbi = c0 + xk8[i];
+      if (cbi + 8 <= Cin) {
+        const uint32_t o = xoff[i] + (uint32_t)cbi * x_rsb;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) rx[i][e] = ldg_off<float>(p.x, o + e * x_rsb);
-      if (MASK) {
-        const uint32_t mo = xmo[i] + cb * m_rsb;
+        for (int e = 0; e < 8; ++e) rx[i][e] = ldg_off<float>(p.x, o + e * x_rsb);
+        if (MASK) {
+          const uint32_t mo = xmo[i] + (uint32_t)cbi * m_rsb;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rm[i][e] = ldg_off<uint32_t>(xmask, mo + e * m_rsb);
+          for (int e = 0; e < 8; ++e) rm[i][e] = ldg_off<uint32_t>(xmask, mo + e * m_rsb);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t c = (uint32_t)min(cbi + e, Cin - 1);
+          rx[i][e] = ldg_off<float>(p.x, xoff[i] + c * x_rsb);
+          if (MASK) rm[i][e] = ldg_off<uint32_t>(xmask, xmo[i] + c * m_rsb);
+        }
       }
     }
   };
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
       for (int r = 0; r < 16; ++r) acc[h][ni][r] = 0.f;
 
   const int nchunks = (Cin + BKC - 1) / BKC;
-  const int nsteps = (ABL == 5) ? 0 : nchunks * J;
+  const int nsteps = (ABL == 5 || ABL == 9) ? 0 : nchunks * J;
   const int a_off = wm * 32 + l31;
   const int x_off = wn * (NI * 32) + l31;
 
@@ -248,7 +258,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
     const bool new_chunk = has_next && jn == 0;
     if (ABL != 1 && ABL != 2 && ABL != 3) {
       if (has_next) load_A(cn, jn);
-      if (new_chunk) load_X(cn);
+      // the activation tile streams from HBM (a weight panel is an L2 hit): fetch chunk c+1 at the
+      // FIRST tap of chunk c, J steps ahead of the write that needs it
+      if (j == 0 && c + 1 < nchunks) load_X(c + 1);
     }
 
     // ---------------- MFMA: two k16 steps of tap j ----------------
@@ -315,8 +327,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   }
 
   // ABL 6: skip the epilogue but keep the accumulators live
-  if (ABL != 6 || acc[0][0][0] + acc[1][0][0] + acc[0][NI - 1][5] + acc[1][NI - 1][7] == 1.2345e30f)
-    conv_epilogue<BM, BMH, NI>(p, acc, gated, mt, wm, lhi, bcol, tcol, okc);
+  if ((ABL != 6 && ABL != 9) || acc[0][0][0] + acc[1][0][0] + acc[0][NI - 1][5] + acc[1][NI - 1][7] == 1.2345e30f)
+    conv_epilogue<BM, BMH, NI, false, ABL>(p, acc, gated, mt, wm, lhi, bcol, tcol, okc);
 }
 
 // packed fp32 [J][K][lda] -> split image [plane][j][k8][m][8]
@@ -375,6 +387,9 @@ int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
       case 4: return launch_x3_abl<4>(a, lds, st);
       case 5: return launch_x3_abl<5>(a, lds, st);
       case 6: return launch_x3_abl<6>(a, lds, st);
+      case 7: return launch_x3_abl<7>(a, lds, st);
+      case 8: return launch_x3_abl<8>(a, lds, st);
+      case 9: return launch_x3_abl<9>(a, lds, st);
     }
   }
   return a.d.xmask ? launch_x3_m<WM, WN, NI, true>(a, lds, st) : launch_x3_m<WM, WN, NI, false>(a, lds, st);
@@ -410,7 +425,7 @@ const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
 // is not eligible (caller falls back to the exact kernel), else a DV3_* code.
 int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   const bool gated = d->mode == DV3_EPI_GLU || d->mode == DV3_EPI_HIGHWAY;
-  if (d->a_bs != 0 || (d->lda & 3) || d->Tin != d->Tout || (d->Cin & 7)) return 1;
+  if (d->a_bs != 0 || (d->lda & 3) || d->Tin != d->Tout) return 1;
   if ((d->J - 1) * d->dil > HALO_MAX || d->J * 2 > 32) return 1;
   // 32-bit byte offsets inside the kernel
   if ((int64_t)d->B * d->Tout >= (1ll << 30) || (int64_t)d->B * d->x_bs >= (1ll << 30)) return 1;

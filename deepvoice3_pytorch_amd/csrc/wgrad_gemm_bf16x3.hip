@@ -14,9 +14,10 @@
 // consecutive rows of one k8 block = 512 contiguous bytes (conflict free); the k8 stride is padded
 // by 2 units so the staging writes (4 lanes = the 4 k8 blocks of a row) hit distinct banks.
 // The tap shift only moves the START of the x unit (unaligned 32-byte read from L1/L2), so no
-// shifted LDS addressing is needed.  Double-buffered LDS, next K step prefetched into registers
-// before the MFMAs of the current one, one barrier per step.
+// shifted LDS addressing is needed.  Double-buffered LDS; operands are prefetched into registers
+// TWO K steps ahead (two register sets: both operands stream from HBM), one barrier per step.
 #include "common.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -64,7 +65,7 @@ __device__ __forceinline__ void load8(const float* __restrict__ row, int t, int 
 }
 
 template <int WM, int WN, bool MASK>
-__global__ __launch_bounds__(WM* WN * 64) void wgrad_gemm_bf16x3_kernel(const WgradArgs args) {
+__global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const WgradArgs args) {
   constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
   constexpr int LDM = BM + PAD, LDN = BN + PAD;  // units per k8 block
   constexpr int GU = BM * KB / NT, XU = BN * KB / NT;
@@ -104,13 +105,16 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_gemm_bf16x3_kernel(const Wg
     xk8[u] = idx & 3;
   }
 
-  float rg[GU][8], rx[XU][8];
-  uint32_t rmask[MASK ? XU : 1];   // 8 keep-bits of the unit
+  // two register sets: the operands of step k live in set k&1 from two steps before their use
+  // (both operands stream from HBM; one step of MFMAs does not cover that latency)
+  float rg[2][GU][8], rx[2][XU][8];
+  uint32_t rmask[2][MASK ? XU : 1];   // 8 keep-bits of the unit
   const int n_tc = (T + BKT - 1) / BKT;          // time chunks per batch item
   const int n_b = (p.B - s + p.n_slabs - 1) / p.n_slabs;
   const int nsteps = n_b * n_tc;
 
-  auto load_step = [&](int step) {
+  auto load_step = [&](int step, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
     const int bi = step / n_tc, tc = step - bi * n_tc;
     const int b = s + bi * p.n_slabs;
     const int t0 = tc * BKT;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_gemm_bf16x3_kernel(const Wg
     for (int u = 0; u < GU; ++u) {
       const int m = m0 + grow[u];
       const int mc = m < M ? m : M - 1;
-      load8(gb + (int64_t)mc * p.g_rs, t0 + gk8[u] * 8, (m < M) ? T : 0, rg[u]);
+      load8(gb + (int64_t)mc * p.g_rs, t0 + gk8[u] * 8, (m < M) ? T : 0, rg[S][u]);
     }
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_gemm_bf16x3_kernel(const Wg
       const int t = t0 + xk8[u] * 8;          // g-time of the unit; x is read at t + shift
       // g is zero for g-times >= T, so x only needs its own [0, Tin) clipping
       const int tx = t + shift;
-      load8(xb + (int64_t)cc * p.x_rs, tx, (c < Cin) ? Tin : 0, rx[u]);
+      load8(xb + (int64_t)cc * p.x_rs, tx, (c < Cin) ? Tin : 0, rx[S][u]);
       if (MASK) {
         const uint32_t* __restrict__ mr = p.xmask + ((int64_t)b * Cin + cc) * p.xmask_rs;
         const int txc = max(tx, 0);
@@ -138,16 +142,17 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_gemm_bf16x3_kernel(const Wg
         const uint64_t lo = mr[min(w0, wl)], hi = mr[min(w0 + 1, wl)];
         uint32_t bits = (uint32_t)(((hi << 32) | lo) >> (txc & 31));
         if (tx < 0) bits = (-tx < 32) ? bits << (-tx) : 0u;   // bit e of `bits` <-> element e of the unit
-        rmask[u] = bits;
+        rmask[S][u] = bits;
       }
     }
   };
-  auto write_step = [&](int buf) {
+  auto write_step = [&](int buf, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
     bf16x8* dst = smem + buf * BUF;
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
       bf16x8 hi, lo;
-      split8(rg[u], hi, lo);
+      split8(rg[S][u], hi, lo);
       const int o = gk8[u] * LDM + grow[u];
       dst[o] = hi;
       dst[KB * LDM + o] = lo;
@@ -158,8 +163,8 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_gemm_bf16x3_kernel(const Wg
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        v[e] = rx[u][e];
-        if (MASK) v[e] *= ((rmask[u] >> e) & 1u) ? p.drop_scale : 0.f;
+        v[e] = rx[S][u][e];
+        if (MASK) v[e] *= ((rmask[S][u] >> e) & 1u) ? p.drop_scale : 0.f;
       }
       bf16x8 hi, lo;
       split8(v, hi, lo);
@@ -177,17 +182,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_gemm_bf16x3_kernel(const Wg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][bq][r] = 0.f;
 
-  if (nsteps > 0) {
-    load_step(0);
-    write_step(0);
-  }
-  __syncthreads();
-
-  for (int step = 0; step < nsteps; ++step) {
-    const int cur = step & 1;
-    const bool has_next = step + 1 < nsteps;
-    if (has_next) load_step(step + 1);
-
+  auto mfma_step = [&](int cur) {
     const bf16x8* GsH = smem + cur * BUF;
     const bf16x8* GsL = GsH + KB * LDM;
     const bf16x8* XsH = GsH + 2 * KB * LDM;
@@ -214,8 +209,29 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_gemm_bf16x3_kernel(const Wg
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc[1][1], 0, 0, 0);
     }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
-    if (has_next) write_step(cur ^ 1);
+  if (nsteps > 0) {
+    load_step(0, S0{});
+    write_step(0, S0{});
+  }
+  if (nsteps > 1) load_step(1, S1{});
+  __syncthreads();
+
+  // steps in pairs so the register-set index is static
+  for (int step = 0; step < nsteps; step += 2) {
+    // even step: LDS buffer 0 holds step; set 1 holds step+1; set 0 is free -> fetch step+2
+    if (step + 2 < nsteps) load_step(step + 2, S0{});
+    mfma_step(0);
+    if (step + 1 < nsteps) write_step(1, S1{});
+    __syncthreads();
+    if (step + 1 >= nsteps) break;
+    // odd step: buffer 1 holds step+1; set 0 holds step+2; set 1 is free -> fetch step+3
+    if (step + 3 < nsteps) load_step(step + 3, S1{});
+    mfma_step(1);
+    if (step + 2 < nsteps) write_step(0, S0{});
     __syncthreads();
   }
 
