@@ -1,0 +1,93 @@
+# coding: utf-8
+"""Spectrogram -> waveform on the GPU: the device-side counterpart of the reference's
+audio.inv_spectrogram (audio.py:37-43) and its helpers (audio.py:26-28,84-93).
+
+The reference hands phase reconstruction to the third-party `lws` package on the host
+(audio.py:40-42); here it is Griffin-Lim on hand-written HIP FFT kernels (csrc/audio.hip), batched
+over utterances, so synthesis never leaves the device (synthesis.py:64-71 copies the
+spectrogram to the CPU first).  STFT conventions: see include/dv3hip.h ("Audio inverse").
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _stream, _chk, _c
+
+N_FFT = 1024
+N_BIN = N_FFT // 2 + 1
+
+
+class AudioConfig(object):
+    """The hparams audio.py reads (hparams.py:38-43,124)."""
+
+    def __init__(self, fft_size=1024, hop_size=256, sample_rate=22050, preemphasis=0.97,
+                 min_level_db=-100, ref_level_db=20, power=1.4, griffin_lim_iters=60):
+        if fft_size != N_FFT:
+            raise ValueError("the HIP FFT kernels are built for fft_size=1024 (every reference preset)")
+        self.fft_size, self.hop_size, self.sample_rate = fft_size, hop_size, sample_rate
+        self.preemphasis, self.min_level_db, self.ref_level_db = preemphasis, min_level_db, ref_level_db
+        self.power, self.griffin_lim_iters = power, griffin_lim_iters
+
+
+def magnitudes(linear_outputs, cfg):
+    """(B, T, 513) normalised spectrogram (the model's linear_outputs) -> magnitudes ** power."""
+    x = _c(_chk(linear_outputs, "linear_outputs"))
+    mag = torch.empty_like(x)
+    _lib.call("dv3_gl_prepare_f32", x.data_ptr(), mag.data_ptr(), x.numel(), float(cfg.min_level_db),
+              float(cfg.ref_level_db), float(cfg.power), _stream())
+    return mag
+
+
+def istft(mag, phasor, hop):
+    """mag (B,T,513), phasor (B,T,513,2) or None -> y (B, hop*(T-1))."""
+    B, T, F = mag.shape
+    assert F == N_BIN
+    frames = torch.empty((B, T, N_FFT), dtype=torch.float32, device=mag.device)
+    _lib.call("dv3_istft_frames_f32", mag.data_ptr(), phasor.data_ptr() if phasor is not None else None,
+              frames.data_ptr(), B, T, _stream())
+    y = torch.empty((B, hop * (T - 1)), dtype=torch.float32, device=mag.device)
+    _lib.call("dv3_overlap_add_f32", frames.data_ptr(), y.data_ptr(), B, T, hop, _stream())
+    return y
+
+
+def stft(y, T, hop, want_phasor=True, want_spec=False):
+    """y (B, hop*(T-1)) -> unit phasors and/or the complex STFT, each (B,T,513,2)."""
+    y = _c(_chk(y, "y"))
+    B = y.shape[0]
+    assert y.shape[1] == hop * (T - 1)
+    ph = torch.empty((B, T, N_BIN, 2), dtype=torch.float32, device=y.device) if want_phasor else None
+    sp = torch.empty((B, T, N_BIN, 2), dtype=torch.float32, device=y.device) if want_spec else None
+    _lib.call("dv3_stft_phase_f32", y.data_ptr(), ph.data_ptr() if ph is not None else None,
+              sp.data_ptr() if sp is not None else None, B, T, hop, _stream())
+    return ph, sp
+
+
+def griffin_lim(mag, hop, n_iter, init_phasor=None):
+    """Griffin & Lim: alternate projections between the given magnitudes and consistent STFTs."""
+    ph = init_phasor
+    y = istft(mag, ph, hop)
+    T = mag.shape[1]
+    for _ in range(n_iter):
+        ph, _ = stft(y, T, hop)
+        y = istft(mag, ph, hop)
+    return y
+
+
+def inv_preemphasis_(y, coef):
+    _lib.call("dv3_deemphasis_f32", y.data_ptr(), y.shape[0], y.shape[1], float(coef), _stream())
+    return y
+
+
+def inv_spectrogram_batch(linear_outputs, cfg=None, init_phasor=None):
+    """(B, T, 513) device tensor (model linear_outputs) -> (B, hop*(T-1)) waveforms on the device."""
+    cfg = cfg or AudioConfig()
+    mag = magnitudes(linear_outputs, cfg)
+    y = griffin_lim(mag, cfg.hop_size, cfg.griffin_lim_iters, init_phasor)
+    return inv_preemphasis_(y, cfg.preemphasis)
+
+
+def inv_spectrogram(spectrogram, cfg=None, device="cuda:0"):
+    """Drop-in for audio.inv_spectrogram (audio.py:37-43): (513, T) numpy -> waveform numpy."""
+    s = torch.as_tensor(np.ascontiguousarray(np.asarray(spectrogram, dtype=np.float32).T)).unsqueeze(0)
+    y = inv_spectrogram_batch(s.to(device), cfg)
+    return y[0].cpu().numpy()

@@ -1,0 +1,232 @@
+// Audio inverse on the GPU: what synthesis.py does on the host after the model,
+// audio.inv_spectrogram (audio.py:37-43): _denormalize -> _db_to_amp (audio.py:84-93) -> magnitude
+// ** power -> phase reconstruction -> istft -> inv_preemphasis (audio.py:26-28).
+//
+// The reference delegates phase reconstruction to the third-party `lws` package (not vendored,
+// "parity unpinned"); the north-star asks for Griffin-Lim as FFT + reduction kernels.
+// These kernels implement Griffin-Lim with torch.stft / torch.istft conventions (periodic Hann
+// window of n_fft = 1024, hop 256, center=True with reflect padding, onesided 513 bins, istft
+// normalised by the overlap-added squared window) so the CPU oracle (oracle/audio_oracle.py)
+// can be an independent restatement on torch-CPU FFTs.
+//
+// One workgroup (256 threads) transforms one 1024-point frame in LDS: Stockham auto-sort radix-4,
+// five passes, one butterfly per thread per pass, twiddles from sincospif.  Frames are
+// independent, so the grid is B*T workgroups; the only cross-frame step is the overlap-add, a
+// gather over <= 4 frames per sample (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int NFFT = 1024;
+constexpr int NBIN = NFFT / 2 + 1;
+constexpr float PI_F = 3.14159265358979323846f;
+
+struct cplx {
+  float x, y;
+};
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - b.y}; }
+
+__device__ __forceinline__ float hann(int n) { return 0.5f - 0.5f * cospif(2.0f * (float)n / (float)NFFT); }
+
+// In-LDS 1024-point complex FFT (SIGN = -1 forward, +1 inverse, unnormalised).  `a` holds the
+// input in natural order; the result ends in `b` (5 passes: a->b->a->b->a->b).  256 threads.
+template <int SIGN>
+__device__ __forceinline__ void fft1024(cplx* a, cplx* b, int tid) {
+  cplx* src = a;
+  cplx* dst = b;
+#pragma unroll
+  for (int ns = 1; ns < NFFT; ns *= 4) {
+    __syncthreads();
+    const int k = tid & (ns - 1);
+    const float ang = (float)SIGN * 2.0f * (float)k / (float)(ns * 4);  // in units of pi
+    cplx v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = src[tid + r * (NFFT / 4)];
+      if (r) {
+        float s, c;
+        sincospif(ang * (float)r, &s, &c);
+        v[r] = cmul(v[r], cplx{c, s});
+      }
+    }
+    // radix-4 DFT, natural order: X[q] = sum_m v[m] * w^(q*m), w = exp(SIGN * i*pi/2)
+    const cplx s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
+    const cplx s13 = cadd(v[1], v[3]), d13 = csub(v[1], v[3]);
+    const cplx jd13 = (SIGN < 0) ? cplx{d13.y, -d13.x} : cplx{-d13.y, d13.x};  // w * d13
+    const int j0 = ((tid - k) << 2) + k;  // (tid / ns) * ns * 4 + k
+    dst[j0] = cadd(s02, s13);
+    dst[j0 + ns] = cadd(d02, jd13);
+    dst[j0 + 2 * ns] = csub(s02, s13);
+    dst[j0 + 3 * ns] = csub(d02, jd13);
+    cplx* t = src; src = dst; dst = t;
+  }
+  __syncthreads();
+}
+
+// mag[b][t][k] = (10^((clip(x,0,1)*(-min_db) + min_db + ref_db) / 20)) ^ power      audio.py:39-41,84-93
+__global__ void gl_prepare_kernel(const float* __restrict__ lin, float* __restrict__ mag, int64_t n,
+                                  float min_db, float ref_db, float power) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float x = fminf(fmaxf(lin[i], 0.f), 1.f);
+    const float db = x * (-min_db) + min_db + ref_db;
+    mag[i] = exp2f(db * 0.05f * power * 3.32192809488736234787f);  // 10^(db/20*power)
+  }
+}
+
+// frames[b][t][n] = hann[n] * irfft(mag[b][t][:] * phasor[b][t][:])[n]   (phasor NULL: zero phase)
+__global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restrict__ mag,
+                                                           const float* __restrict__ phasor,
+                                                           float* __restrict__ frames) {
+  __shared__ cplx A[NFFT], Bf[NFFT];
+  const int tid = threadIdx.x;
+  const int64_t fr = blockIdx.x;
+  const float* m = mag + fr * NBIN;
+  const float* ph = phasor ? phasor + fr * NBIN * 2 : nullptr;
+  for (int k = tid; k <= NFFT / 2; k += 256) {
+    cplx z{m[k], 0.f};
+    if (ph) z = cplx{m[k] * ph[2 * k], m[k] * ph[2 * k + 1]};
+    if (k == 0 || k == NFFT / 2) z.y = 0.f;  // c2r ignores the imaginary part of DC / Nyquist
+    A[k] = z;
+    if (k > 0 && k < NFFT / 2) A[NFFT - k] = cplx{z.x, -z.y};
+  }
+  fft1024<+1>(A, Bf, tid);
+  float* out = frames + fr * NFFT;
+  for (int n = tid; n < NFFT; n += 256) out[n] = Bf[n].x * (1.0f / NFFT) * hann(n);
+}
+
+// y[b][i] = sum_t frames[b][t][p - t*hop] / sum_t hann^2[p - t*hop],  p = i + NFFT/2, i < hop*(T-1)
+__global__ void ola_kernel(const float* __restrict__ frames, float* __restrict__ y, int T, int hop,
+                           int L) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  const int p = i + NFFT / 2;
+  int t_hi = p / hop;
+  if (t_hi > T - 1) t_hi = T - 1;
+  int t_lo = (p - NFFT + hop) / hop;  // smallest t with p - t*hop <= NFFT-1  (ceil((p-NFFT+1)/hop))
+  if (p - NFFT + 1 <= 0) t_lo = 0;
+  float acc = 0.f, wsum = 0.f;
+  const float* fb = frames + (int64_t)b * T * NFFT;
+  for (int t = t_lo; t <= t_hi; ++t) {
+    const int n = p - t * hop;
+    if (n < 0 || n >= NFFT) continue;
+    const float w = hann(n);
+    acc += fb[(int64_t)t * NFFT + n];
+    wsum += w * w;
+  }
+  y[(int64_t)b * L + i] = acc / wsum;
+}
+
+// phasor[b][t][k] = Z / max(|Z|, 1e-8), Z = rfft(hann * reflect_pad(y[b])[t*hop : t*hop + NFFT])[k]
+// (spec, optional: Z itself, for tests / spectral convergence)
+__global__ __launch_bounds__(256) void stft_phase_kernel(const float* __restrict__ y,
+                                                         float* __restrict__ phasor,
+                                                         float* __restrict__ spec, int T, int hop, int L) {
+  __shared__ cplx A[NFFT], Bf[NFFT];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / T, t = blockIdx.x - b * T;
+  const float* yb = y + (int64_t)b * L;
+  for (int n = tid; n < NFFT; n += 256) {
+    int i = t * hop + n - NFFT / 2;  // index into the un-padded signal
+    if (i < 0) i = -i;
+    if (i >= L) i = 2 * (L - 1) - i;
+    A[n] = cplx{yb[i] * hann(n), 0.f};
+  }
+  fft1024<-1>(A, Bf, tid);
+  const int64_t fr = blockIdx.x;
+  for (int k = tid; k <= NFFT / 2; k += 256) {
+    const cplx z = Bf[k];
+    if (spec) {
+      spec[(fr * NBIN + k) * 2] = z.x;
+      spec[(fr * NBIN + k) * 2 + 1] = z.y;
+    }
+    if (phasor) {
+      const float inv = 1.0f / fmaxf(sqrtf(z.x * z.x + z.y * z.y), 1e-8f);
+      phasor[(fr * NBIN + k) * 2] = z.x * inv;
+      phasor[(fr * NBIN + k) * 2 + 1] = z.y * inv;
+    }
+  }
+}
+
+// y[n] = x[n] + coef * y[n-1] per row (scipy.signal.lfilter([1], [1, -coef]); audio.py:26-28), in
+// place.  One workgroup per row: 256 contiguous segments scanned locally, carries chained in LDS.
+__global__ __launch_bounds__(256) void deemphasis_kernel(float* __restrict__ y, int L, float coef) {
+  __shared__ float seg_end[256];
+  __shared__ float carry[256];
+  const int tid = threadIdx.x;
+  float* row = y + (int64_t)blockIdx.x * L;
+  const int len = (L + 255) / 256;
+  const int lo = min(tid * len, L), hi = min(lo + len, L);
+  float v = 0.f;
+  for (int i = lo; i < hi; ++i) {
+    v = row[i] + coef * v;
+    row[i] = v;
+  }
+  seg_end[tid] = v;
+  __syncthreads();
+  if (tid == 0) {
+    float c = 0.f;  // value of y just before segment s
+    for (int s = 0; s < 256; ++s) {
+      carry[s] = c;
+      const int n = min((s + 1) * len, L) - min(s * len, L);
+      c = seg_end[s] + powf(coef, (float)n) * c;
+    }
+  }
+  __syncthreads();
+  const float c = carry[tid];
+  if (c != 0.f) {
+    float g = coef;
+    for (int i = lo; i < hi; ++i) {
+      row[i] += g * c;
+      g *= coef;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dv3_gl_prepare_f32(const float* lin, float* mag, int64_t n, float min_level_db,
+                                  float ref_level_db, float power, void* stream) {
+  DV3_REQUIRE(lin && mag && n > 0, "gl_prepare: bad arguments");
+  const int blocks = (int)(dv3_cdiv64(n, 256) < 4096 ? dv3_cdiv64(n, 256) : 4096);
+  hipLaunchKernelGGL(gl_prepare_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lin, mag, n,
+                     min_level_db, ref_level_db, power);
+  return dv3_check_launch("gl_prepare");
+}
+
+extern "C" int dv3_istft_frames_f32(const float* mag, const float* phasor, float* frames, int32_t B,
+                                    int32_t T, void* stream) {
+  DV3_REQUIRE(mag && frames && B > 0 && T > 0, "istft_frames: bad arguments");
+  hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((int64_t)B * T)), dim3(256), 0,
+                     (hipStream_t)stream, mag, phasor, frames);
+  return dv3_check_launch("istft_frames");
+}
+
+extern "C" int dv3_overlap_add_f32(const float* frames, float* y, int32_t B, int32_t T, int32_t hop,
+                                   void* stream) {
+  DV3_REQUIRE(frames && y && B > 0 && T > 1 && hop > 0 && hop <= 1024, "overlap_add: bad arguments");
+  const int L = hop * (T - 1);
+  hipLaunchKernelGGL(ola_kernel, dim3(dv3_cdiv(L, 256), B), dim3(256), 0, (hipStream_t)stream, frames, y,
+                     T, hop, L);
+  return dv3_check_launch("overlap_add");
+}
+
+extern "C" int dv3_stft_phase_f32(const float* y, float* phasor, float* spec, int32_t B, int32_t T,
+                                  int32_t hop, void* stream) {
+  DV3_REQUIRE(y && (phasor || spec) && B > 0 && T > 1 && hop > 0, "stft_phase: bad arguments");
+  const int L = hop * (T - 1);
+  DV3_REQUIRE(L > 512, "stft_phase: signal shorter than the reflect padding");
+  hipLaunchKernelGGL(stft_phase_kernel, dim3((unsigned)((int64_t)B * T)), dim3(256), 0,
+                     (hipStream_t)stream, y, phasor, spec, T, hop, L);
+  return dv3_check_launch("stft_phase");
+}
+
+extern "C" int dv3_deemphasis_f32(float* y, int32_t B, int32_t L, float coef, void* stream) {
+  DV3_REQUIRE(y && B > 0 && L > 0, "deemphasis: bad arguments");
+  hipLaunchKernelGGL(deemphasis_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, y, L, coef);
+  return dv3_check_launch("deemphasis");
+}

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 11
+#define DV3_ABI_VERSION 12
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -309,6 +309,32 @@ int dv3_clip_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
                       const float* grad_norm, float clip, const float* hyper, float beta1,
                       float beta2, float eps, float weight_decay, float grad_prescale,
                       void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Audio inverse (audio.py:37-43, synthesis.py:64-71): linear spectrogram -> waveform on the
+ * device.  The reference calls the third-party `lws` package for phase reconstruction (not
+ * vendored: parity unpinned); these entry points implement Griffin-Lim with
+ * torch.stft / torch.istft conventions: n_fft 1024 (513 bins), periodic Hann window, hop as
+ * given (preset: 256), center=True with reflect padding, istft normalised by the overlap-added
+ * squared window, signal length L = hop*(T-1).
+ *   mag     [B][T][513]      magnitudes ** power
+ *   phasor  [B][T][513][2]   unit complex phase estimate (re, im)
+ *   frames  [B][T][1024]     windowed time-domain frames
+ *   y       [B][L]
+ * One Griffin-Lim iteration = istft_frames -> overlap_add -> stft_phase.
+ * ------------------------------------------------------------------------------------ */
+/* mag = (10^((clip(x,0,1)*(-min_db) + min_db + ref_db)/20))^power   audio.py:39-41,84-93 */
+int dv3_gl_prepare_f32(const float* lin, float* mag, int64_t n, float min_level_db,
+                       float ref_level_db, float power, void* stream);
+int dv3_istft_frames_f32(const float* mag, const float* phasor /* NULL: zero phase */,
+                         float* frames, int32_t B, int32_t T, void* stream);
+int dv3_overlap_add_f32(const float* frames, float* y, int32_t B, int32_t T, int32_t hop,
+                        void* stream);
+/* phasor and/or spec ([B][T][513][2], the complex STFT itself) may be NULL */
+int dv3_stft_phase_f32(const float* y, float* phasor, float* spec, int32_t B, int32_t T,
+                       int32_t hop, void* stream);
+/* in place y[n] = x[n] + coef*y[n-1] per row: inv_preemphasis, audio.py:26-28 */
+int dv3_deemphasis_f32(float* y, int32_t B, int32_t L, float coef, void* stream);
 
 #ifdef __cplusplus
 }

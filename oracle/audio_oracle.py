@@ -1,0 +1,69 @@
+# coding: utf-8
+"""CPU restatement of the audio inverse -- TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py).
+
+PARITY UNPINNED for the phase-reconstruction part: the reference (audio.py:37-43) calls
+`lws.lws(1024, 256, mode="speech").run_lws(...)` / `.istft`, a third-party package (unpinned version,
+setup.py:87) that is not vendored and not installed; the reference has no test or golden vector
+for it (tests/test_audio.py covers _amp_to_db/_db_to_amp only).  What IS restated exactly:
+_denormalize / _db_to_amp (audio.py:84-93), magnitude ** power (audio.py:41, hparams.py:124) and
+inv_preemphasis = lfilter([1], [1, -0.97]) (audio.py:26-28, nnmnkwii).  Phase reconstruction is
+Griffin-Lim on torch-CPU FFTs (torch.stft / torch.istft, periodic Hann 1024, hop 256, center=True
+reflect) -- an independent implementation of the algorithm the HIP kernels implement.
+"""
+import numpy as np
+import torch
+
+
+def denormalize(S, min_level_db=-100):
+    """audio.py:92-93"""
+    return (np.clip(S, 0, 1) * -min_level_db) + min_level_db
+
+
+def db_to_amp(x):
+    """audio.py:84-85"""
+    return np.power(10.0, x * 0.05)
+
+
+def magnitudes(lin, min_level_db=-100, ref_level_db=20, power=1.4):
+    """audio.py:39-41: (_db_to_amp(_denormalize(S) + ref_level_db)) ** power, float64"""
+    return db_to_amp(denormalize(np.asarray(lin, dtype=np.float64), min_level_db) + ref_level_db) ** power
+
+
+def istft(spec, hop=256, n_fft=1024):
+    """spec complex (B, T, 513) -> (B, hop*(T-1))"""
+    w = torch.hann_window(n_fft, dtype=spec.real.dtype)
+    return torch.istft(spec.transpose(1, 2), n_fft, hop_length=hop, win_length=n_fft, window=w, center=True,
+                       normalized=False, onesided=True, length=hop * (spec.shape[1] - 1))
+
+
+def stft(y, hop=256, n_fft=1024):
+    """(B, L) -> complex (B, T, 513)"""
+    w = torch.hann_window(n_fft, dtype=y.dtype)
+    return torch.stft(y, n_fft, hop_length=hop, win_length=n_fft, window=w, center=True, pad_mode="reflect",
+                      normalized=False, onesided=True, return_complex=True).transpose(1, 2)
+
+
+def griffin_lim(mag, n_iter, hop=256, init_phasor=None):
+    """mag real (B, T, 513); init_phasor complex or None (zero phase)"""
+    mag = torch.as_tensor(mag)
+    cd = torch.complex128 if mag.dtype == torch.float64 else torch.complex64
+    ph = torch.ones(mag.shape, dtype=cd) if init_phasor is None else torch.as_tensor(init_phasor).to(cd)
+    y = istft(mag * ph, hop)
+    for _ in range(n_iter):
+        Z = stft(y, hop)
+        ph = Z / torch.clamp(Z.abs(), min=1e-8)
+        y = istft(mag * ph, hop)
+    return y
+
+
+def inv_preemphasis(y, coef=0.97):
+    """lfilter([1], [1, -coef], y) along the last axis"""
+    from scipy import signal
+    return signal.lfilter([1.0], [1.0, -coef], np.asarray(y, dtype=np.float64), axis=-1)
+
+
+def spectral_convergence(y, mag, hop=256):
+    """|| |STFT(y)| - mag ||_F / || mag ||_F"""
+    Z = stft(torch.as_tensor(y), hop).abs()
+    mag = torch.as_tensor(mag).to(Z.dtype)
+    return float(torch.linalg.norm(Z - mag) / torch.linalg.norm(mag))
