@@ -186,6 +186,54 @@ def cpu_baseline(B, Tt, n_frames, max_seconds=25.0):
                 host_cpus=os.cpu_count())
 
 
+def synth_bench(dev, args):
+    """BASELINE.json configs[4]: synthesis.py's path (synthesis.py:42-73) for `--batch` concurrent
+    utterances: greedy autoregressive decode (Decoder.incremental_forward) + Converter + Griffin-Lim
+    vocoder on the device.  SURVEY.md 8(d) cfg5: equal text length 100, min = max decoder steps = 200
+    -> 201 steps = 804 frames = 9.33 s of audio each; RTF = wall / audio seconds."""
+    from deepvoice3_pytorch_amd import builder, audio
+    hp = dict(DV3_LJ)
+    torch.manual_seed(0)
+    model = builder.deepvoice3(**hp).to(dev).eval()
+    model.make_generation_fast_()
+    dec = model.seq2seq.decoder
+    dec.min_decoder_steps = dec.max_decoder_steps = 200
+    B, Tt = args.batch, 100
+    rng = np.random.RandomState(0)
+    text = torch.from_numpy(rng.randint(2, hp["n_vocab"], (B, Tt))).to(dev)
+    tpos = torch.arange(1, Tt + 1).repeat(B, 1).to(dev)
+    acfg = audio.AudioConfig(griffin_lim_iters=args.gl_iters)
+
+    def run():
+        t = [time.perf_counter()]
+        with torch.no_grad():
+            mel, lin, align, done = model(text, text_positions=tpos)
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        wav = audio.inv_spectrogram_batch(lin, acfg)
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        return lin, wav, t
+    for _ in range(max(1, args.warmup // 3)):
+        run()
+    tm, tv = [], []
+    for _ in range(max(1, args.steps // 10)):
+        lin, wav, t = run()
+        tm.append(t[1] - t[0]); tv.append(t[2] - t[1])
+    assert torch.isfinite(wav).all() and lin.shape[1] == 804
+    audio_s = B * wav.shape[1] / acfg.sample_rate
+    wall = float(np.mean(tm) + np.mean(tv))
+    out = dict(metric="real-time factor (synthesis: AR decode + converter + Griffin-Lim, %d concurrent utterances)" % B,
+               value=round(wall / audio_s, 6), unit="wall seconds per audio second", n_gpus=1, steps=len(tm),
+               warmup=max(1, args.warmup // 3), ms_per_step=round(wall * 1e3, 2), higher_is_better=False,
+               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic text ids, random-init weights",
+               config=dict(workload="builder=deepvoice3 preset=deepvoice3_ljspeech synthesis, Tt=100, 201 decoder steps "
+                                    "= 804 frames per utterance", utterances=B, griffin_lim_iters=args.gl_iters,
+                           audio_seconds=round(audio_s, 1), model_ms=round(float(np.mean(tm)) * 1e3, 1),
+                           vocoder_ms=round(float(np.mean(tv)) * 1e3, 1),
+                           rtf_model_only=round(float(np.mean(tm)) / audio_s, 6),
+                           ms_per_decoder_step=round(float(np.mean(tm)) * 1e3 / 201, 3)))
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,7 +248,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--mode", default="train", choices=["train", "conv", "conv-ab"])
+    ap.add_argument("--mode", default="train", choices=["train", "conv", "conv-ab", "synth"])
+    ap.add_argument("--gl-iters", type=int, default=60, help="Griffin-Lim iterations (synth mode)")
     args = ap.parse_args()
 
     from deepvoice3_pytorch_amd import builder, train_step, ops, dist as dv3dist
@@ -211,6 +260,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.mode == "synth":
+        synth_bench(dev, args)
+        return
     if args.mode == "conv-ab":     # A/B of kernel variants / tiles at the north-star shape
         for hint in (0, 21, 22, 1, 2, 11, 12):
             for dil in (1, 27):
