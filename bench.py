@@ -129,6 +129,16 @@ def conv_roofline(dev, iters=30, tile_hint=0, dil=1, mode=None):
                traffic=None, us_per_launch=round(us, 2), alg_flops=flops, alg_bytes=byts,
                hbm_gbs=round(byts / (us * 1e-6) / 1e9, 1),
                hbm_frac=round(byts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4))
+    if x3 and tile_hint == 0 and dil == 1:
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, calibrated as
+        # MI355X_MICROARCH.md prescribes): collected offline with rocprofv3 (scripts/pmc_hbm.sh) --
+        # a counter pass can not run inside this process -- and committed under profiles/.
+        try:
+            hb = json.load(open(os.path.join(ROOT, "profiles", "r01b_conv_gemm_bf16x3_hbm.json")))
+            out["traffic"] = hb["hbm_bytes_per_launch"]
+            out["traffic_source"] = "profiles/r01b_conv_gemm_bf16x3_hbm.json (%s)" % hb["source"]
+        except (IOError, OSError, KeyError, ValueError):
+            pass
     if x3:
         out["peak_note"] = ("algorithmic fp32 FLOPs against the dense bf16 MFMA peak (2500 TF) / 3: the split-bf16 "
                             "kernel issues 3 bf16 MFMAs per product block; executed MFMA rate = 3 x achieved")
@@ -289,7 +299,10 @@ def main():
                                           bt["text_positions"], bt["frame_positions"], bt["done"],
                                           bt["target_lengths"], None, downsample_step=4, device=dev)
     trainer.check_lengths(batch)
-    use_graph = not args.no_graph
+    # one GPU: the whole step is replayed as a hipGraph.  Data parallel: eager launches -- the RCCL
+    # bucket all-reduces are issued from autograd hooks on a side stream and the step is GPU-bound at
+    # this batch size (eager 25.9 ms vs graph 24.4 ms on one GPU), so capture is not worth the risk.
+    use_graph = not args.no_graph and world == 1
     runner = None
     if use_graph:
         try:
