@@ -40,6 +40,23 @@ DV3_LJ = dict(n_vocab=149, embed_dim=256, mel_dim=80, linear_dim=513, r=1, downs
               use_decoder_state_for_postnet_input=True, max_positions=512,
               speaker_embedding_weight_std=0.01, freeze_embedding=False, window_ahead=3,
               window_backward=1, key_projection=True, value_projection=True)
+# presets/nyanko_ljspeech.json and presets/deepvoice3_vctk.json as train.build_model() forwards them
+NYANKO_LJ = dict(n_vocab=149, embed_dim=128, mel_dim=80, linear_dim=513, r=1, downsample_step=4, n_speakers=1,
+                 speaker_embed_dim=16, padding_idx=0, dropout=1 - 0.95, kernel_size=3, encoder_channels=256,
+                 decoder_channels=256, converter_channels=256, use_memory_mask=True,
+                 trainable_positional_encodings=False, force_monotonic_attention=True,
+                 use_decoder_state_for_postnet_input=True, max_positions=512, speaker_embedding_weight_std=0.01,
+                 freeze_embedding=False, window_ahead=3, window_backward=1, key_projection=False,
+                 value_projection=False)
+DV3_VCTK = dict(n_vocab=149, embed_dim=256, mel_dim=80, linear_dim=513, r=1, downsample_step=4, n_speakers=108,
+                speaker_embed_dim=16, padding_idx=0, dropout=1 - 0.95, kernel_size=3, encoder_channels=512,
+                decoder_channels=256, converter_channels=256, use_memory_mask=True,
+                trainable_positional_encodings=False, force_monotonic_attention=True,
+                use_decoder_state_for_postnet_input=True, max_positions=1024, speaker_embedding_weight_std=0.05,
+                freeze_embedding=False, window_ahead=3, window_backward=1, key_projection=True,
+                value_projection=True)
+PRESETS = {"deepvoice3_ljspeech": ("deepvoice3", DV3_LJ, 0.2), "nyanko_ljspeech": ("nyanko", NYANKO_LJ, 0.2),
+           "deepvoice3_vctk": ("deepvoice3_multispeaker", DV3_VCTK, 0.4)}
 PEAK_F32_MFMA_TF = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak (= vector peak)
 PEAK_BF16_MFMA_TF = 2500.0  # same guide: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
@@ -251,7 +268,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64,
                     help="per-GPU batch (north-star shape: 64; the preset's batch_size is 16)")
-    ap.add_argument("--gemm", default=None, choices=["bf16x3", "f32"],
+    ap.add_argument("--preset", default="deepvoice3_ljspeech", choices=sorted(PRESETS),
+                    help="BASELINE.json configs[1] (default) / [2] nyanko_ljspeech / [3] deepvoice3_vctk")
+    ap.add_argument("--gemm", default=None, choices=["bf16x3", "f32", "bf16"],
                     help="GEMM arithmetic (default: DV3_GEMM or bf16x3 = split-bf16 MFMA, fp32 accumulate)")
     ap.add_argument("--text-len", type=int, default=150)
     ap.add_argument("--frames", type=int, default=800)
@@ -288,16 +307,18 @@ def main():
                               roofline=rf)))
         return
 
-    hp = dict(DV3_LJ)
+    bname, hp0, ga_sigma = PRESETS[args.preset]
+    hp = dict(hp0)
     torch.manual_seed(0)            # identical initial weights on every rank
-    model = builder.deepvoice3(**hp).to(dev)
-    cfg = train_step.TrainConfig(max_positions=hp["max_positions"])
+    model = getattr(builder, bname)(**hp).to(dev)
+    cfg = train_step.TrainConfig(max_positions=hp["max_positions"], guided_attention_sigma=ga_sigma)
     trainer = train_step.Trainer(model, cfg, process_group=pg)
     rng = np.random.RandomState(1234 + rank)
     bt = synth_batch(rng, args.batch, args.text_len, args.frames, hp)
+    spk = torch.from_numpy(rng.randint(0, hp["n_speakers"], args.batch)) if hp["n_speakers"] > 1 else None
     batch = train_step.Batch.from_collate(bt["text"], bt["input_lengths"], bt["mel"], bt["y"],
                                           bt["text_positions"], bt["frame_positions"], bt["done"],
-                                          bt["target_lengths"], None, downsample_step=4, device=dev)
+                                          bt["target_lengths"], spk, downsample_step=4, device=dev)
     trainer.check_lengths(batch)
     # one GPU: the whole step is replayed as a hipGraph.  Data parallel: eager launches -- the RCCL
     # bucket all-reduces are issued from autograd hooks on a side stream and the step is GPU-bound at
@@ -343,26 +364,28 @@ def main():
         return
     ms = dt / args.steps * 1e3
     value = float(frames.item()) / (dt / args.steps)
-    out = dict(metric="mel-frames/sec/node (train step, deepvoice3_ljspeech)", value=round(value, 1),
+    mode_desc = {"bf16x3": "f32 (operands split hi+lo bf16 on the matrix cores, 3 MFMAs per product, fp32 accumulate; "
+                           "1e-4 rel parity with the fp32 reference)",
+                 "f32": "f32 (exact fp32 MFMA)",
+                 "bf16": "bf16 (operands rounded to bf16 at the matrix cores, fp32 accumulate, fp32 master weights)"}
+    out = dict(metric="mel-frames/sec/node (train step, %s)" % args.preset, value=round(value, 1),
                unit="mel-frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype=("f32 (operands split hi+lo bf16 on the matrix cores, 3 MFMAs per product, fp32 accumulate; "
-                      "1e-4 rel parity with the fp32 reference)" if ops.gemm_precision() == "bf16x3" else
-                      "f32 (exact fp32 MFMA)"),
+               dtype=mode_desc[ops.gemm_precision()],
                data="synthetic (fixed-shape LJSpeech-like: Tt=%d, %d frames/item; random-init weights)"
                % (args.text_len, args.frames),
-               config=dict(workload="builder=deepvoice3 preset=deepvoice3_ljspeech fp32 train step "
-                                    "(fwd+losses+bwd+clip+Adam), synthetic LJSpeech-shaped batches",
+               config=dict(workload="builder=%s preset=%s train step "
+                                    "(fwd+losses+bwd+clip+Adam), synthetic LJSpeech-shaped batches" % (bname, args.preset),
                            per_gpu_batch=args.batch, global_batch=args.batch * world, text_len=args.text_len,
                            frames_per_item=args.frames, parallelism="dp%d" % world,
                            hipgraph=bool(use_graph), gemm=ops.gemm_precision(), final_loss=round(loss, 5)))
     if not args.no_roofline:
-        out["roofline"] = conv_roofline(dev)
-        if ops.gemm_precision() == "bf16x3":      # the exact-fp32 kernel beside it, for the record
+        out["roofline"] = conv_roofline(dev, mode="bf16x3" if ops.gemm_precision() == "bf16" else None)
+        if ops.gemm_precision() != "f32":      # the exact-fp32 kernel beside it, for the record
             rf = conv_roofline(dev, mode="f32")
             out["roofline_exact_f32"] = dict(kernel=rf["kernel"], achieved=rf["achieved"], peak=rf["peak"],
                                              frac=rf["frac"], us_per_launch=rf["us_per_launch"])
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and args.preset == "deepvoice3_ljspeech":
         out["cpu_baseline"] = cpu_baseline(args.batch, args.text_len, args.frames)
     print(json.dumps(out))
 

@@ -58,8 +58,78 @@ def stft(y, T, hop, want_phasor=True, want_spec=False):
     ph = torch.empty((B, T, N_BIN, 2), dtype=torch.float32, device=y.device) if want_phasor else None
     sp = torch.empty((B, T, N_BIN, 2), dtype=torch.float32, device=y.device) if want_spec else None
     _lib.call("dv3_stft_phase_f32", y.data_ptr(), ph.data_ptr() if ph is not None else None,
-              sp.data_ptr() if sp is not None else None, B, T, hop, _stream())
+              sp.data_ptr() if sp is not None else None, None, B, T, hop, _stream())
     return ph, sp
+
+
+# ---------------------------------------------------------------------------------------------
+# forward analysis: audio.spectrogram / audio.melspectrogram (audio.py:31-35,46-51)
+# ---------------------------------------------------------------------------------------------
+def mel_basis(sample_rate=22050, n_fft=1024, n_mels=80, fmin=125.0, fmax=7600.0):
+    """The Slaney-style triangular filterbank librosa.filters.mel builds by default (htk=False,
+    norm='slaney'), restated: audio.py:70-76 with hparams.py fmin/fmax.  (num_mels, 513) float32."""
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        mel = f / (200.0 / 3)
+        lin_end = 1000.0 / (200.0 / 3)
+        logstep = np.log(6.4) / 27.0
+        return np.where(f >= 1000.0, lin_end + np.log(np.maximum(f, 1e-30) / 1000.0) / logstep, mel)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        lin_end = 1000.0 / (200.0 / 3)
+        logstep = np.log(6.4) / 27.0
+        return np.where(m >= lin_end, 1000.0 * np.exp(logstep * (m - lin_end)), m * (200.0 / 3))
+    fftfreqs = np.linspace(0, sample_rate / 2.0, n_fft // 2 + 1)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    w = np.maximum(0, np.minimum(lower, upper))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def _analysis_mag(wav, cfg):
+    """(B, L) waveform -> |STFT(preemphasis(wav))| as (B, 513, T); L must be hop*(T-1)."""
+    wav = _c(_chk(wav, "wav"))
+    B, L = wav.shape
+    hop = cfg.hop_size
+    if L % hop:
+        raise ValueError("waveform length must be a multiple of hop_size (%d)" % hop)
+    T = L // hop + 1
+    pre = torch.empty_like(wav)
+    _lib.call("dv3_preemphasis_f32", wav.data_ptr(), pre.data_ptr(), B, L, float(cfg.preemphasis), _stream())
+    mag = torch.empty((B, N_BIN, T), dtype=torch.float32, device=wav.device)
+    _lib.call("dv3_stft_phase_f32", pre.data_ptr(), None, None, mag.data_ptr(), B, T, hop, _stream())
+    return mag
+
+
+def _db_norm(x, cfg):
+    out = torch.empty_like(x)
+    _lib.call("dv3_amp_to_db_norm_f32", x.data_ptr(), out.data_ptr(), x.numel(), float(cfg.min_level_db),
+              float(cfg.ref_level_db), _stream())
+    return out
+
+
+def spectrogram_batch(wav, cfg=None):
+    """audio.spectrogram (audio.py:31-35) for a (B, L) device batch -> (B, 513, T) in [0, 1]."""
+    cfg = cfg or AudioConfig()
+    return _db_norm(_analysis_mag(wav, cfg), cfg)
+
+
+def melspectrogram_batch(wav, cfg=None, num_mels=80, fmin=125.0, fmax=7600.0):
+    """audio.melspectrogram (audio.py:46-51) for a (B, L) device batch -> (B, num_mels, T) in [0, 1]:
+    the filterbank product runs on the tap-GEMM kernel as a 1x1 convolution over the 513 bins."""
+    from . import ops
+    cfg = cfg or AudioConfig()
+    mag = _analysis_mag(wav, cfg)
+    B, F, T = mag.shape
+    basis = torch.from_numpy(mel_basis(cfg.sample_rate, cfg.fft_size, num_mels, fmin, fmax)).to(wav.device)
+    pk = ops.pack_weights(basis.unsqueeze(-1).contiguous(), None, need_bwd=False)
+    mel = ops.conv_gemm(mag, pk.fwd, pk.lda, 0, B=B, Cin=F, Tin=T, M=num_mels, Tout=T, a_split=pk.fwd_s)
+    return _db_norm(mel, cfg)
 
 
 def griffin_lim(mag, hop, n_iter, init_phasor=None):

@@ -125,7 +125,8 @@ __global__ void ola_kernel(const float* __restrict__ frames, float* __restrict__
 // (spec, optional: Z itself, for tests / spectral convergence)
 __global__ __launch_bounds__(256) void stft_phase_kernel(const float* __restrict__ y,
                                                          float* __restrict__ phasor,
-                                                         float* __restrict__ spec, int T, int hop, int L) {
+                                                         float* __restrict__ spec,
+                                                         float* __restrict__ mag_bct, int T, int hop, int L) {
   __shared__ cplx A[NFFT], Bf[NFFT];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / T, t = blockIdx.x - b * T;
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256) void stft_phase_kernel(const float* __restrict
       spec[(fr * NBIN + k) * 2] = z.x;
       spec[(fr * NBIN + k) * 2 + 1] = z.y;
     }
+    if (mag_bct) mag_bct[((int64_t)b * NBIN + k) * T + t] = sqrtf(z.x * z.x + z.y * z.y);
     if (phasor) {
       const float inv = 1.0f / fmaxf(sqrtf(z.x * z.x + z.y * z.y), 1e-8f);
       phasor[(fr * NBIN + k) * 2] = z.x * inv;
@@ -187,7 +189,45 @@ __global__ __launch_bounds__(256) void deemphasis_kernel(float* __restrict__ y, 
   }
 }
 
+// y[n] = x[n] - coef * x[n-1], y[0] = x[0]   (nnmnkwii.preprocessing.preemphasis, audio.py:21-23)
+__global__ void preemphasis_kernel(const float* __restrict__ x, float* __restrict__ y, int L, float coef) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  const float* xr = x + (int64_t)b * L;
+  y[(int64_t)b * L + i] = i ? xr[i] - coef * xr[i - 1] : xr[0];
+}
+
+// out = clip((20*log10(max(min_level, x)) - ref_db - min_db) / -min_db, 0, 1)   audio.py:34-35,79-89
+__global__ void amp_to_db_norm_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
+                                      float min_db, float ref_db) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float min_level = exp2f(min_db * 0.05f * 3.32192809488736234787f);
+  for (; i < n; i += stride) {
+    const float db = 20.0f * log10f(fmaxf(min_level, x[i])) - ref_db;
+    out[i] = fminf(fmaxf((db - min_db) / (-min_db), 0.f), 1.f);
+  }
+}
+
 }  // namespace
+
+extern "C" int dv3_preemphasis_f32(const float* x, float* y, int32_t B, int32_t L, float coef,
+                                   void* stream) {
+  DV3_REQUIRE(x && y && B > 0 && L > 0, "preemphasis: bad arguments");
+  hipLaunchKernelGGL(preemphasis_kernel, dim3(dv3_cdiv(L, 256), B), dim3(256), 0, (hipStream_t)stream, x, y,
+                     L, coef);
+  return dv3_check_launch("preemphasis");
+}
+
+extern "C" int dv3_amp_to_db_norm_f32(const float* x, float* out, int64_t n, float min_level_db,
+                                      float ref_level_db, void* stream) {
+  DV3_REQUIRE(x && out && n > 0, "amp_to_db_norm: bad arguments");
+  const int blocks = (int)(dv3_cdiv64(n, 256) < 4096 ? dv3_cdiv64(n, 256) : 4096);
+  hipLaunchKernelGGL(amp_to_db_norm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, n,
+                     min_level_db, ref_level_db);
+  return dv3_check_launch("amp_to_db_norm");
+}
 
 extern "C" int dv3_gl_prepare_f32(const float* lin, float* mag, int64_t n, float min_level_db,
                                   float ref_level_db, float power, void* stream) {
@@ -215,13 +255,13 @@ extern "C" int dv3_overlap_add_f32(const float* frames, float* y, int32_t B, int
   return dv3_check_launch("overlap_add");
 }
 
-extern "C" int dv3_stft_phase_f32(const float* y, float* phasor, float* spec, int32_t B, int32_t T,
-                                  int32_t hop, void* stream) {
-  DV3_REQUIRE(y && (phasor || spec) && B > 0 && T > 1 && hop > 0, "stft_phase: bad arguments");
+extern "C" int dv3_stft_phase_f32(const float* y, float* phasor, float* spec, float* mag_bct, int32_t B,
+                                  int32_t T, int32_t hop, void* stream) {
+  DV3_REQUIRE(y && (phasor || spec || mag_bct) && B > 0 && T > 1 && hop > 0, "stft_phase: bad arguments");
   const int L = hop * (T - 1);
   DV3_REQUIRE(L > 512, "stft_phase: signal shorter than the reflect padding");
   hipLaunchKernelGGL(stft_phase_kernel, dim3((unsigned)((int64_t)B * T)), dim3(256), 0,
-                     (hipStream_t)stream, y, phasor, spec, T, hop, L);
+                     (hipStream_t)stream, y, phasor, spec, mag_bct, T, hop, L);
   return dv3_check_launch("stft_phase");
 }
 

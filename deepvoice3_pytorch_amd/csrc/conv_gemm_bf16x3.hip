@@ -59,7 +59,7 @@ __device__ __forceinline__ T ldg_off(const void* base, uint32_t byte_off) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-template <int WM, int WN, int NI, bool MASK, int ABL = 0>
+template <int WM, int WN, int NI, bool MASK, int ABL = 0, int TERMS = 3>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const ConvArgs args) {
   constexpr int BM = WM * 64, BMH = WM * 32, BN = WN * NI * 32;
   constexpr int NT = WM * WN * 64;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
 #pragma unroll
     for (int u = 0; u < AU; ++u) {
       ra[0][u] = ldg_off<bf16x8>(srch, aoff[u]);
-      ra[1][u] = ldg_off<bf16x8>(srcl, aoff[u]);
+      if (TERMS == 3) ra[1][u] = ldg_off<bf16x8>(srcl, aoff[u]);
     }
   };
   auto write_A = [&](int buf) {
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
 #pragma unroll
     for (int u = 0; u < AU; ++u) {
       dst[tid + u * NT] = ra[0][u];
-      dst[KB * BM + tid + u * NT] = ra[1][u];
+      if (TERMS == 3) dst[KB * BM + tid + u * NT] = ra[1][u];
     }
   };
   auto load_X = [&](int chunk) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         bf16x8 hi, lo;
         split8(v, hi, lo);
         dst[idx] = hi;
-        dst[KB * BNH + idx] = lo;
+        if (TERMS == 3) dst[KB * BNH + idx] = lo;
       }
     }
   };
@@ -276,20 +276,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         const int k8 = 2 * s + lhi;
         const int ai = k8 * BM + a_off;
         const bf16x8 ah0 = AsH[ai], ah1 = AsH[ai + BMH];
-        const bf16x8 al0 = AsL[ai], al1 = AsL[ai + BMH];
+        bf16x8 al0 = ah0, al1 = ah1;
+        if (TERMS == 3) { al0 = AsL[ai]; al1 = AsL[ai + BMH]; }
         bf16x8 bh[NI], bl[NI];
         const int xi = k8 * BNH + x_off + j * dil;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           bh[ni] = XsH[xi + ni * 32];
-          bl[ni] = XsL[xi + ni * 32];
+          bl[ni] = (TERMS == 3) ? XsL[xi + ni * 32] : bh[ni];
         }
         if (fix) {
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
             const bool ok = (vbits >> (j * NI + ni)) & 1u;
             bh[ni] = ok ? bh[ni] : zero8;
-            bl[ni] = ok ? bl[ni] : zero8;
+            if (TERMS == 3) bl[ni] = ok ? bl[ni] : zero8;
           }
         }
         if (ABL == 4) {
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
           continue;
         }
         // small terms first; each accumulator is touched once per pass (no back-to-back RAW)
+        if (TERMS == 3) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[ni], acc[0][ni], 0, 0, 0);
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         for (int ni = 0; ni < NI; ++ni) {
           acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[ni], acc[0][ni], 0, 0, 0);
           acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[ni], acc[1][ni], 0, 0, 0);
+        }
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -353,11 +356,11 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
   dst[n + idx] = lo;
 }
 
-template <int WM, int WN, int NI, bool MASK>
+template <int WM, int WN, int NI, bool MASK, int TERMS>
 int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_gemm_bf16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -366,7 +369,7 @@ int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(a.n_blocks), block(WM * WN * 64);
-  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS>), grid, block, lds, st, a);
   return dv3_check_launch("conv_gemm_bf16x3");
 }
 int g_x3_ablate = 0;   // debug: dv3_debug_set(); ablation variants of the 128x128 unmasked tile
@@ -379,7 +382,7 @@ int launch_x3_abl(const ConvArgs& a, size_t lds, hipStream_t st) {
 }
 template <int WM, int WN, int NI>
 int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
-  if (g_x3_ablate && WM == 2 && WN == 2 && NI == 2 && !a.d.xmask) {
+  if (g_x3_ablate && WM == 2 && WN == 2 && NI == 2 && !a.d.xmask && a.d.split_terms != 1) {
     switch (g_x3_ablate) {
       case 1: return launch_x3_abl<1>(a, lds, st);
       case 2: return launch_x3_abl<2>(a, lds, st);
@@ -392,7 +395,9 @@ int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
       case 9: return launch_x3_abl<9>(a, lds, st);
     }
   }
-  return a.d.xmask ? launch_x3_m<WM, WN, NI, true>(a, lds, st) : launch_x3_m<WM, WN, NI, false>(a, lds, st);
+  if (a.d.split_terms == 1)
+    return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 1>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 1>(a, lds, st);
+  return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3>(a, lds, st);
 }
 
 // bf16x3 tile choice: padded work over the FLAT column axis, weight-panel traffic penalised

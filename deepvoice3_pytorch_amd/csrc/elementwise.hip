@@ -212,29 +212,70 @@ __global__ __launch_bounds__(256) void embedding_bct_kernel(const int64_t* __res
   }
 }
 
-// Dense embedding gradient, deterministic: one block per (vocab id, 64-channel tile) scans the
-// index array; dW[v][c] = sum_{(b,t): idx==v} dout[b][c][t]*keep*scale.  padding_idx row = 0.
-__global__ __launch_bounds__(64) void embedding_bct_bwd_kernel(const int64_t* __restrict__ idx,
-                                                               const float* __restrict__ dout,
-                                                               float* __restrict__ dw,
-                                                               const uint32_t* __restrict__ mask,
-                                                               int mask_rs, float dscale, int B, int T,
-                                                               int C, int padding_idx) {
+// Dense embedding gradient, deterministic: one block per vocabulary id.  The (b,t) positions that
+// hold the id are compacted IN ORDER into LDS (each thread scans a contiguous slice, counts, an
+// exclusive scan gives its write offset), then every thread owns one channel and sums dout over
+// the list:  dW[v][c] = sum_{(b,t): idx==v} dout[b][c][t]*keep*scale.  padding_idx row = 0.
+// The index array is processed in ranges of EMB_RANGE positions so the list always fits.
+constexpr int EMB_RANGE = 4096;
+__global__ __launch_bounds__(256) void embedding_bct_bwd_kernel(const int64_t* __restrict__ idx,
+                                                                const float* __restrict__ dout,
+                                                                float* __restrict__ dw,
+                                                                const uint32_t* __restrict__ mask,
+                                                                int mask_rs, float dscale, int B, int T,
+                                                                int C, int padding_idx) {
+  __shared__ int list[EMB_RANGE];
+  __shared__ int cnt[256];
+  __shared__ int total;
   const int v = blockIdx.x;
-  const int c = blockIdx.y * 64 + threadIdx.x;
-  float s = 0.f;
+  const int tid = threadIdx.x;
+  const int n = B * T;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};   // channels tid, tid+256, ... (C <= 1024)
   if (v != padding_idx) {
-    for (int64_t bt = 0; bt < (int64_t)B * T; ++bt) {
-      if (idx[bt] != v) continue;  // wave-uniform branch
-      if (c < C) {
-        const int b = (int)(bt / T), t = (int)(bt % T);
-        float g = dout[((int64_t)b * C + c) * T + t];
-        if (mask) g = dv3_keep(mask, (int64_t)b * C + c, mask_rs, t) ? g * dscale : 0.f;
-        s += g;
+    for (int r0 = 0; r0 < n; r0 += EMB_RANGE) {
+      const int rn = min(EMB_RANGE, n - r0);
+      const int len = (rn + 255) / 256;
+      const int lo = min(tid * len, rn), hi = min(lo + len, rn);
+      int c = 0;
+      for (int i = lo; i < hi; ++i) c += (idx[r0 + i] == v);
+      cnt[tid] = c;
+      __syncthreads();
+      if (tid == 0) {
+        int run = 0;
+        for (int k = 0; k < 256; ++k) {
+          const int t = cnt[k];
+          cnt[k] = run;
+          run += t;
+        }
+        total = run;
       }
+      __syncthreads();
+      int o = cnt[tid];
+      for (int i = lo; i < hi; ++i)
+        if (idx[r0 + i] == v) list[o++] = r0 + i;
+      __syncthreads();
+      const int m = total;
+      for (int q = 0; q < m; ++q) {
+        const int bt = list[q];
+        const int b = bt / T, t = bt - b * T;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int ch = tid + k * 256;
+          if (ch < C) {
+            float g = dout[((int64_t)b * C + ch) * T + t];
+            if (mask) g = dv3_keep(mask, (int64_t)b * C + ch, mask_rs, t) ? g * dscale : 0.f;
+            acc[k] += g;
+          }
+        }
+      }
+      __syncthreads();
     }
   }
-  if (c < C) dw[(int64_t)v * C + c] = s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ch = tid + k * 256;
+    if (ch < C) dw[(int64_t)v * C + ch] = acc[k];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -394,7 +435,8 @@ extern "C" int dv3_embedding_bct_bwd_f32(const int64_t* idx, const float* dout, 
                                          int32_t B, int32_t T, int32_t C, int32_t n_vocab,
                                          int32_t padding_idx, void* stream) {
   DV3_REQUIRE(idx && dout && dw && B > 0 && T > 0 && C > 0 && n_vocab > 0, "embedding_bwd: bad args");
-  hipLaunchKernelGGL(embedding_bct_bwd_kernel, dim3(n_vocab, dv3_cdiv(C, 64)), dim3(64), 0,
+  DV3_REQUIRE(C <= 1024, "embedding_bwd: C > 1024 not supported");
+  hipLaunchKernelGGL(embedding_bct_bwd_kernel, dim3(n_vocab), dim3(256), 0,
                      (hipStream_t)stream, idx, dout, dw, mask, mask_rs, drop_scale, B, T, C,
                      padding_idx);
   return dv3_check_launch("embedding_bct_bwd_f32");

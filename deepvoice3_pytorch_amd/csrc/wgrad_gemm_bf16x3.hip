@@ -64,7 +64,7 @@ __device__ __forceinline__ void load8(const float* __restrict__ row, int t, int 
   }
 }
 
-template <int WM, int WN, bool MASK>
+template <int WM, int WN, bool MASK, int TERMS>
 __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const WgradArgs args) {
   constexpr int BM = WM * 64, BN = WN * 64, NT = WM * WN * 64;
   constexpr int LDM = BM + PAD, LDN = BN + PAD;  // units per k8 block
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
       split8(rg[S][u], hi, lo);
       const int o = gk8[u] * LDM + grow[u];
       dst[o] = hi;
-      dst[KB * LDM + o] = lo;
+      if (TERMS == 3) dst[KB * LDM + o] = lo;
     }
     bf16x8* dx = dst + 2 * KB * LDM;
 #pragma unroll
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
       split8(v, hi, lo);
       const int o = xk8[u] * LDN + xrow[u];
       dx[o] = hi;
-      dx[KB * LDN + o] = lo;
+      if (TERMS == 3) dx[KB * LDN + o] = lo;
     }
   };
 
@@ -193,8 +193,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
       const int ai = k8 * LDM + wm * 64 + l31;
       const int xi = k8 * LDN + wn * 64 + l31;
       const bf16x8 ah0 = GsH[ai], ah1 = GsH[ai + 32];
-      const bf16x8 al0 = GsL[ai], al1 = GsL[ai + 32];
       const bf16x8 bh0 = XsH[xi], bh1 = XsH[xi + 32];
+      if (TERMS == 1) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh1, acc[1][1], 0, 0, 0);
+        continue;
+      }
+      const bf16x8 al0 = GsL[ai], al1 = GsL[ai + 32];
       const bf16x8 bl0 = XsL[xi], bl1 = XsL[xi + 32];
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh1, acc[0][1], 0, 0, 0);
@@ -260,10 +267,16 @@ int dv3_wgrad_gemm_bf16x3_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
   a.c_tiles = dv3_cdiv(d->Cin, 128);
   const int64_t nb = (int64_t)a.m_tiles * a.c_tiles * d->J * d->n_slabs;
   DV3_REQUIRE(nb < (1ll << 31), "wgrad_gemm: grid too large");
-  if (d->xmask) {
-    hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<2, 2, true>), dim3((unsigned)nb), dim3(256), 0, st, a);
+  if (d->split_bf16 == 2) {   // single-term bf16 (hi planes only)
+    if (d->xmask) {
+      hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<2, 2, true, 1>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<2, 2, false, 1>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    }
+  } else if (d->xmask) {
+    hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<2, 2, true, 3>), dim3((unsigned)nb), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<2, 2, false>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<2, 2, false, 3>), dim3((unsigned)nb), dim3(256), 0, st, a);
   }
   return dv3_check_launch("wgrad_gemm_bf16x3");
 }

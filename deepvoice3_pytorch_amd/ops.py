@@ -39,11 +39,14 @@ _spec_loss_desc = STRUCTS["dv3_spec_loss_desc"]
 # ----------------------------------------------------------------------------------------------
 # GEMM arithmetic: "bf16x3" = split-bf16 operands on the bf16 matrix cores with fp32 accumulate
 # (include/dv3hip.h, "Split-bf16"; ~3e-6 relative error, 16/3 x the fp32-MFMA rate) -- the
-# default; "f32" = the exact fp32 MFMA chain (v_mfma_f32_32x32x2_f32).  DV3_GEMM=f32 selects it.
+# default; "f32" = the exact fp32 MFMA chain (v_mfma_f32_32x32x2_f32); "bf16" = operands rounded to
+# bf16 at the matrix-core inputs (hi planes only, one MFMA per product, fp32 accumulate, fp32
+# master weights / activations in HBM) -- the arithmetic of BASELINE.json's bf16 configs.
+# DV3_GEMM=<mode> selects it.
 # ----------------------------------------------------------------------------------------------
 import os as _os
 
-_GEMM_MODES = ("bf16x3", "f32")
+_GEMM_MODES = ("bf16x3", "f32", "bf16")
 _gemm_mode = _os.environ.get("DV3_GEMM", "bf16x3")
 if _gemm_mode not in _GEMM_MODES:
     raise RuntimeError("DV3_GEMM must be one of %s" % (_GEMM_MODES,))
@@ -178,7 +181,7 @@ def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True):
     d.O, d.I, d.J, d.transposed, d.glu_cg = O, I, J, int(transposed), glu_cg
     _lib.call("dv3_weight_norm_pack_f32", ctypes.byref(d), _stream())
     pk.fwd_s = pk.bwd_s = None
-    if _gemm_mode == "bf16x3":
+    if _gemm_mode in ("bf16x3", "bf16"):
         # operand K/M extents of the two tap-GEMMs: fwd [J'][K=I][lda], bwd [J'][K'][ldb]
         if transposed:
             pk.fwd_s = split_pack(pk.fwd, 1, I, pk.lda)
@@ -229,6 +232,7 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
     d.B, d.Cin, d.Tin, d.M, d.Cg, d.Tout, d.J, d.dil, d.padL = B, Cin, Tin, M, Cg, Tout, J, dil, padL
     d.mode, d.residual, d.store_mode, d.tile_hint = mode, residual, store_mode, tile_hint
     d.a_split = _ptr(a_split)
+    d.split_terms = 1 if (a_split is not None and _gemm_mode == "bf16") else 0
     _lib.call("dv3_conv_gemm_f32", ctypes.byref(d), _stream())
     return y
 
@@ -249,7 +253,7 @@ def wgrad_gemm(g, x, *, B, M, Cin, T, Tin, J=1, dil=1, padL=0, n_slabs=1, xmask=
     d.xmask, d.xmask_rs, d.drop_scale = _ptr(xmask), xmask_rs, drop_scale
     d.out, d.out_ss, d.ldo = out.data_ptr(), J * M * ldo, ldo
     d.B, d.M, d.Cin, d.T, d.Tin, d.J, d.dil, d.padL, d.n_slabs = B, M, Cin, T, Tin, J, dil, padL, n_slabs
-    d.split_bf16 = int(bool(split_bf16))
+    d.split_bf16 = (2 if _gemm_mode == "bf16" else 1) if split_bf16 else 0
     _lib.call("dv3_wgrad_gemm_f32", ctypes.byref(d), _stream())
     return out
 
@@ -386,7 +390,7 @@ class ConvLayerFn(torch.autograd.Function):
                       bias=bias, spk=spk, spk_strides=spk_strides,
                       r=res_in if (mode == EPI_HIGHWAY or cfg.residual or not gated) else None,
                       r2=r2c, residual=int(cfg.residual), ab=ab, xmask=bits, xmask_rs=bits_rs,
-                      drop_scale=dscale, a_split=pk.fwd_s if _gemm_mode == "bf16x3" else None,
+                      drop_scale=dscale, a_split=pk.fwd_s if _gemm_mode != "f32" else None,
                       store_mode=STORE_INTERLEAVE2 if cfg.transposed else STORE_BCT)
         if need_grad:
             ctx.cfg, ctx.pk, ctx.dims = cfg, pk, (B, Cin, T, Tout, M, Cg, J, padL)
@@ -450,14 +454,14 @@ class ConvLayerFn(torch.autograd.Function):
             dx = conv_gemm(gmat, pk.bwd, pk.ldb, 0, B=B, Cin=Mg, Tin=Tg, M=Cin, Tout=T, J=Jd,
                            dil=cfg.dil, padL=(Jd - 1) * cfg.dil - padL, mode=EPI_DGRAD, r=dres,
                            ymask=ctx.bits, ymask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
-                           a_split=pk.bwd_s if _gemm_mode == "bf16x3" else None)
+                           a_split=pk.bwd_s if _gemm_mode != "f32" else None)
         if ctx.needs_input_grad[1]:
             Jd = 1 if cfg.transposed else J
             tiles = ((Mg + 127) // 128) * ((Cin + 127) // 128) * Jd
             S = _slab_count(B, tiles)
             slabs = wgrad_gemm(gmat, x, B=B, M=Mg, Cin=Cin, T=Tg, Tin=T, J=Jd, dil=cfg.dil, padL=padL,
                                n_slabs=S, xmask=ctx.bits, xmask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
-                               split_bf16=(_gemm_mode == "bf16x3"))
+                               split_bf16=(_gemm_mode != "f32"))
             v3 = v if v.dim() == 3 else v.unsqueeze(-1)
             dv, dg, dbias = weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None,
                                             pk.scale, part, B, pk.O, pk.I, pk.J, cfg.transposed,

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 12
+#define DV3_ABI_VERSION 14
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -101,6 +101,9 @@ typedef struct dv3_conv_desc {
   int32_t tile_hint;                         /* 0 = auto; else forces a tile config (tests) */
   const uint16_t* a_split;                   /* split-bf16 image of `a` (dv3_split_pack_bf16) or
                                                 NULL.  Non-NULL selects the bf16x3 kernel (below) */
+  int32_t split_terms;                       /* 0 or 3: hi/lo split, three MFMAs per product (fp32
+                                                class accuracy); 1: hi planes only = plain bf16 MFMA
+                                                with fp32 accumulate (BASELINE.json bf16 configs)   */
 } dv3_conv_desc;
 int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
 
@@ -139,7 +142,8 @@ typedef struct dv3_wgrad_desc {
   float* out;      int64_t out_ss;           /* [S][J][M][ldo]; slab stride                  */
   int32_t ldo;
   int32_t B, M, Cin, T, Tin, J, dil, padL, n_slabs;
-  int32_t split_bf16;                        /* 1: bf16x3 split-operand MFMA; 0: exact fp32 MFMA */
+  int32_t split_bf16;                        /* 0: exact fp32 MFMA; 1: bf16x3 split-operand MFMA;
+                                                2: single-term bf16 MFMA (hi planes only)        */
 } dv3_wgrad_desc;
 int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream);
 
@@ -330,9 +334,16 @@ int dv3_istft_frames_f32(const float* mag, const float* phasor /* NULL: zero pha
                          float* frames, int32_t B, int32_t T, void* stream);
 int dv3_overlap_add_f32(const float* frames, float* y, int32_t B, int32_t T, int32_t hop,
                         void* stream);
-/* phasor and/or spec ([B][T][513][2], the complex STFT itself) may be NULL */
-int dv3_stft_phase_f32(const float* y, float* phasor, float* spec, int32_t B, int32_t T,
-                       int32_t hop, void* stream);
+/* outputs (each may be NULL): phasor, spec = the complex STFT [B][T][513][2], mag_bct = |STFT|
+ * as [B][513][T] (the channel-major operand of the mel filterbank GEMM)                     */
+int dv3_stft_phase_f32(const float* y, float* phasor, float* spec, float* mag_bct, int32_t B,
+                       int32_t T, int32_t hop, void* stream);
+/* Forward analysis (audio.py:21-23,31-35,46-51,79-89): preemphasis, then dv3_stft_phase_f32
+ * (mag_bct), the mel filterbank as a 1x1 tap-GEMM (dv3_conv_gemm_f32, M = num_mels, Cin = 513),
+ * then amplitude -> dB -> [0,1] normalisation.                                              */
+int dv3_preemphasis_f32(const float* x, float* y, int32_t B, int32_t L, float coef, void* stream);
+int dv3_amp_to_db_norm_f32(const float* x, float* out, int64_t n, float min_level_db,
+                           float ref_level_db, void* stream);
 /* in place y[n] = x[n] + coef*y[n-1] per row: inv_preemphasis, audio.py:26-28 */
 int dv3_deemphasis_f32(float* y, int32_t B, int32_t L, float coef, void* stream);
 

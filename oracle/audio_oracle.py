@@ -67,3 +67,59 @@ def spectral_convergence(y, mag, hop=256):
     Z = stft(torch.as_tensor(y), hop).abs()
     mag = torch.as_tensor(mag).to(Z.dtype)
     return float(torch.linalg.norm(Z - mag) / torch.linalg.norm(mag))
+
+
+# ------------------------------------------------------------------------------------------------
+# forward analysis (audio.py:21-23,31-35,46-51,70-89): exact restatement of the reference's own numpy
+# helpers; the STFT is torch's (the reference's is lws.stft: unpinned) and the mel basis is an
+# independent construction of librosa.filters.mel's default (Slaney) filterbank.
+# ------------------------------------------------------------------------------------------------
+def preemphasis(x, coef=0.97):
+    x = np.asarray(x, dtype=np.float64)
+    return np.concatenate([x[..., :1], x[..., 1:] - coef * x[..., :-1]], axis=-1)
+
+
+def amp_to_db(x, min_level_db=-100):
+    """audio.py:79-81"""
+    min_level = np.exp(min_level_db / 20 * np.log(10))
+    return 20 * np.log10(np.maximum(min_level, x))
+
+
+def normalize(S, min_level_db=-100):
+    """audio.py:88-89"""
+    return np.clip((S - min_level_db) / -min_level_db, 0, 1)
+
+
+def slaney_mel_basis(sr=22050, n_fft=1024, n_mels=80, fmin=125.0, fmax=7600.0):
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+
+    def h2m(f):
+        return min_log_mel + np.log(f / min_log_hz) / logstep if f >= min_log_hz else f / f_sp
+
+    def m2h(m):
+        return min_log_hz * np.exp(logstep * (m - min_log_mel)) if m >= min_log_mel else f_sp * m
+    mels = np.linspace(h2m(fmin), h2m(fmax), n_mels + 2)
+    hz = np.array([m2h(m) for m in mels])
+    freqs = np.arange(n_fft // 2 + 1) * (sr / float(n_fft))
+    W = np.zeros((n_mels, n_fft // 2 + 1))
+    for i in range(n_mels):
+        lo, ce, hi = hz[i], hz[i + 1], hz[i + 2]
+        up = (freqs - lo) / (ce - lo)
+        down = (hi - freqs) / (hi - ce)
+        W[i] = np.maximum(0, np.minimum(up, down)) * (2.0 / (hi - lo))
+    return W
+
+
+def spectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97):
+    """(B, L) -> (B, 513, T): audio.py:31-35"""
+    D = stft(torch.from_numpy(preemphasis(wav, coef)), hop).abs().numpy().transpose(0, 2, 1)
+    return normalize(amp_to_db(D, min_level_db) - ref_level_db, min_level_db)
+
+
+def melspectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97, **mel_kw):
+    """(B, L) -> (B, 80, T): audio.py:46-51"""
+    D = stft(torch.from_numpy(preemphasis(wav, coef)), hop).abs().numpy().transpose(0, 2, 1)
+    M = np.einsum("mf,bft->bmt", slaney_mel_basis(**mel_kw), D)
+    return normalize(amp_to_db(M, min_level_db) - ref_level_db, min_level_db)

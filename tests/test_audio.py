@@ -122,3 +122,33 @@ def test_hip_deemphasis_and_inv_spectrogram(dev):
     want = A.inv_preemphasis(A.griffin_lim(torch.from_numpy(mag), 3).numpy(), 0.97)[0]
     assert wav.shape == (256 * 29,) and np.isfinite(wav).all()
     assert _rel(wav, want) < 1e-3
+
+
+def test_mel_basis_matches_independent_construction():
+    from deepvoice3_pytorch_amd import audio
+    W = audio.mel_basis()
+    assert W.shape == (80, 513) and W.dtype == np.float32
+    assert np.abs(W - A.slaney_mel_basis()).max() < 1e-6 * A.slaney_mel_basis().max()
+    assert (W.sum(axis=1) > 0).all()          # no empty filter at 22.05 kHz / 1024 / 80 mels
+
+
+@pytest.mark.gpu
+def test_hip_spectrogram_and_melspectrogram(dev):
+    """forward analysis (audio.py:31-35,46-51) on the device against the numpy/torch-FFT restatement"""
+    from deepvoice3_pytorch_amd import audio
+    rng = np.random.RandomState(8)
+    B, T, hop = 2, 33, 256
+    t = np.arange(hop * (T - 1)) / 22050.0
+    wav = (0.3 * np.sin(2 * np.pi * 440 * t)[None] + 0.05 * rng.randn(B, t.size)).astype(np.float32)
+    S = audio.spectrogram_batch(torch.from_numpy(wav).to(dev))
+    want = A.spectrogram(wav.astype(np.float64))
+    assert S.shape == (B, 513, T)
+    assert np.abs(S.cpu().numpy() - want).max() < 2e-5            # values live in [0, 1]
+    for mode in ("bf16x3", "f32"):
+        from deepvoice3_pytorch_amd import ops
+        prev = ops.set_gemm_precision(mode)
+        M = audio.melspectrogram_batch(torch.from_numpy(wav).to(dev))
+        ops.set_gemm_precision(prev)
+        wantm = A.melspectrogram(wav.astype(np.float64))
+        assert M.shape == (B, 80, T)
+        assert np.abs(M.cpu().numpy() - wantm).max() < 2e-5, mode
