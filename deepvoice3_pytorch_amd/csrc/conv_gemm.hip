@@ -313,7 +313,7 @@ int launch_cfg(const ConvArgs& a, int bkc, size_t lds, hipStream_t st) {
 int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st);  // conv_gemm_bf16x3.hip
 
 extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
-  DV3_REQUIRE(d && d->x && d->a && d->y, "conv_gemm: null pointer");
+  DV3_REQUIRE(d && d->x && (d->a || d->a_split) && d->y, "conv_gemm: null pointer");
   DV3_REQUIRE(d->B > 0 && d->Cin > 0 && d->Tin > 0 && d->M > 0 && d->Tout > 0, "conv_gemm: bad dims");
   DV3_REQUIRE(d->J >= 1 && d->J <= 16 && d->dil >= 1, "conv_gemm: bad taps J=%d dil=%d", d->J, d->dil);
   const bool a_scalar = (d->lda & 3) || (d->a_half & 3) || (d->a_bs & 3) || ((uintptr_t)d->a & 15);
@@ -340,6 +340,7 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
     if (rc != 1) return rc;
   }
   DV3_REQUIRE(d->tile_hint <= 20, "conv_gemm: tile_hint %d needs split-bf16 operands", d->tile_hint);
+  DV3_REQUIRE(d->a, "conv_gemm: shape not eligible for the split-bf16 kernel and no fp32 operand image given");
   const int rows_half = gated ? d->Cg : 0;
   // tile_hint: 0 auto (streaming kernel), 1..6 streaming kernel with that tile, 11..16 the
   // LDS-staged kernel with tile (hint-10) -- kept for A/B measurements

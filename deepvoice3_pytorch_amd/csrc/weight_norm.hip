@@ -94,6 +94,72 @@ __global__ __launch_bounds__(256) void wn_pack_transposed_kernel(const dv3_wn_de
   }
 }
 
+// Fused weight norm + split-bf16 packing of BOTH tap-GEMM operands (forward and input-gradient)
+// straight from v, g: what wn_pack_fwd + wn_pack_bwd + 2x split_pack produce, in one launch and
+// without the fp32 images.  Block = 32 output channels x 32 input channels x all taps, staged
+// through an LDS tile [32 o][32*J + 1] of scaled weights.
+//   fwd image [plane][j][k8 over i][col(o)][8 i]     bwd image [plane][J-1-j][k8 over o][i][8 o]
+typedef __bf16 wn_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void wn_split8(const float (&v)[8], wn_bf16x8& hi, wn_bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)v[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(v[i] - (float)h);
+  }
+}
+__global__ __launch_bounds__(256) void wn_split_both_kernel(const dv3_wn_desc p, wn_bf16x8* __restrict__ fs,
+                                                            wn_bf16x8* __restrict__ bs) {
+  extern __shared__ float tile[];  // [32][32*J+1]
+  const int O = p.O, I = p.I, J = p.J;
+  const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+  const int W = 32 * J, LD = W + 1;
+  for (int idx = threadIdx.x; idx < 32 * W; idx += 256) {
+    const int ol = idx / W, q = idx % W;
+    const int o = o0 + ol, i = i0 + q / J;
+    float val = 0.f;
+    if (o < O && i < I) {
+      const float sc = p.g ? p.g[o] * p.scale[o] : 1.0f;
+      val = sc * p.v[((int64_t)o * I + i0) * J + q];
+    }
+    tile[ol * LD + q] = val;
+  }
+  __syncthreads();
+  const int k8f = (I + 31) / 32 * 4, k8b = (O + 31) / 32 * 4;   // k8 blocks of the two images
+  const int64_t plane_f = (int64_t)J * k8f * p.lda, plane_b = (int64_t)J * k8b * p.ldb;
+  // forward units: (j, q in 0..3, ol): 8 consecutive i of output channel o
+  for (int u = threadIdx.x; u < J * 4 * 32; u += 256) {
+    const int ol = u & 31, q = (u >> 5) & 3, j = u >> 7;
+    const int o = o0 + ol;
+    if (o >= O) continue;
+    int col = o;
+    if (p.glu_cg > 0 && o >= p.glu_cg) col = p.a_half + (o - p.glu_cg);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[ol * LD + (q * 8 + e) * J + j];
+    wn_bf16x8 hi, lo;
+    wn_split8(v, hi, lo);
+    const int64_t g = ((int64_t)j * k8f + (i0 >> 3) + q) * p.lda + col;
+    fs[g] = hi;
+    fs[plane_f + g] = lo;
+  }
+  if (!bs) return;
+  // input-gradient units: (j, q, il): 8 consecutive o of input channel i, taps reversed
+  for (int u = threadIdx.x; u < J * 4 * 32; u += 256) {
+    const int il = u & 31, q = (u >> 5) & 3, j = u >> 7;
+    const int i = i0 + il;
+    if (i >= I) continue;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[(q * 8 + e) * LD + il * J + j];
+    wn_bf16x8 hi, lo;
+    wn_split8(v, hi, lo);
+    const int64_t g = ((int64_t)(J - 1 - j) * k8b + (o0 >> 3) + q) * p.ldb + i;
+    bs[g] = hi;
+    bs[plane_b + g] = lo;
+  }
+}
+
 __global__ void zero_kernel(float* p, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -130,6 +196,19 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const dv3_wn_bwd_desc p) {
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
   __syncthreads();
   dot = red[0] + red[1] + red[2] + red[3];
+  // bias gradient (sum of the per-batch partials) rides along: block k reduces bias channel k
+  if (p.bias_part && p.dbias) {
+    for (int o = r; o < O; o += gridDim.x) {
+      float bs = 0.f;
+      for (int k = threadIdx.x; k < p.n_part; k += 256) bs += p.bias_part[(int64_t)k * O + o];
+      bs = dv3_wave_sum(bs);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bs;
+      __syncthreads();
+      if (threadIdx.x == 0) p.dbias[o] = red[0] + red[1] + red[2] + red[3];
+      __syncthreads();
+    }
+  }
   float* dvrow = p.dv + (int64_t)r * len;
   if (p.g) {
     const float sc = p.scale[r], gg = p.g[r];
@@ -197,6 +276,23 @@ extern "C" int dv3_weight_norm_pack_f32(const dv3_wn_desc* d, void* stream) {
   return dv3_check_launch("weight_norm_pack_f32");
 }
 
+extern "C" int dv3_weight_norm_split_pack_bf16(const dv3_wn_desc* d, uint16_t* fwd_split,
+                                               uint16_t* bwd_split, void* stream) {
+  DV3_REQUIRE(d && d->v && d->scale && fwd_split, "wn_split_pack: null pointer");
+  DV3_REQUIRE(d->O > 0 && d->I > 0 && d->J > 0 && !d->transposed, "wn_split_pack: bad dims / transposed layer");
+  DV3_REQUIRE((d->lda & 3) == 0 && (!bwd_split || ((d->ldb & 3) == 0 && d->ldb >= d->I)), "wn_split_pack: bad lda/ldb");
+  DV3_REQUIRE(d->glu_cg == 0 || (2 * d->glu_cg == d->O && d->a_half >= d->glu_cg &&
+                                 d->lda >= d->a_half + d->glu_cg), "wn_split_pack: bad GLU layout");
+  DV3_REQUIRE(d->glu_cg > 0 || d->lda >= d->O, "wn_split_pack: lda < O");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wn_inv_norm_kernel, dim3(d->O), dim3(256), 0, st, d->v, d->g, d->scale, d->I * d->J);
+  const size_t lds = (size_t)32 * (32 * d->J + 1) * 4;
+  DV3_REQUIRE(lds <= 64 * 1024, "wn_split_pack: too many taps");
+  hipLaunchKernelGGL(wn_split_both_kernel, dim3(dv3_cdiv(d->O, 32), dv3_cdiv(d->I, 32)), dim3(256), lds, st,
+                     *d, reinterpret_cast<wn_bf16x8*>(fwd_split), reinterpret_cast<wn_bf16x8*>(bwd_split));
+  return dv3_check_launch("weight_norm_split_pack_bf16");
+}
+
 extern "C" int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream) {
   DV3_REQUIRE(d && d->slabs && d->v && d->dv, "wn_bwd: null pointer");
   DV3_REQUIRE(!d->g || (d->scale && d->dg), "wn_bwd: g given without scale/dg");
@@ -207,9 +303,5 @@ extern "C" int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream) {
   const size_t lds = (size_t)len * 4;
   DV3_REQUIRE(lds <= 64 * 1024, "wn_bwd: row too long (%d)", len);
   hipLaunchKernelGGL(wn_bwd_kernel, dim3(rows), dim3(256), lds, st, *d);
-  if (d->bias_part && d->dbias) {
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3(dv3_cdiv(d->O, 256)), dim3(256), 0, st, d->bias_part,
-                       d->n_part, d->O, d->dbias);
-  }
   return dv3_check_launch("weight_norm_bwd_f32");
 }

@@ -145,13 +145,35 @@ def split_pack(packed, J, K, ld):
     return out
 
 
-def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True):
-    """dv3_weight_norm_pack_f32.  v: (O,I,J) / (O,I) [Conv1d / Linear] or (I,O,J) [ConvTranspose1d]."""
+def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True, split_only=False):
+    """dv3_weight_norm_pack_f32.  v: (O,I,J) / (O,I) [Conv1d / Linear] or (I,O,J) [ConvTranspose1d].
+    split_only (split-bf16 GEMM modes, Conv1d / Linear): one fused launch writes the two split
+    images and no fp32 images (pk.fwd / pk.bwd stay None)."""
     _chk(v, "weight_v")
     v = _c(v)
     if v.dim() == 2:
         v = v.unsqueeze(-1)
     pk = Packed()
+    if split_only and not transposed and _gemm_mode != "f32":
+        O, I, J = v.shape
+        pk.O, pk.I, pk.J, pk.transposed, pk.glu_cg = O, I, J, False, glu_cg
+        if glu_cg:
+            pk.a_half = _round_up(glu_cg, 4)
+            pk.lda = 2 * pk.a_half
+        else:
+            pk.a_half, pk.lda = 0, _round_up(O, 4)
+        pk.ldb = _round_up(I, 4)
+        dev = v.device
+        pk.fwd = pk.bwd = None
+        pk.scale = torch.empty(O, dtype=torch.float32, device=dev)
+        pk.fwd_s = torch.empty(2 * J * _round_up(I, 32) * pk.lda, dtype=torch.int16, device=dev)
+        pk.bwd_s = torch.empty(2 * J * _round_up(O, 32) * pk.ldb, dtype=torch.int16, device=dev) if need_bwd else None
+        d = _wn_desc()
+        d.v, d.g, d.scale = v.data_ptr(), _ptr(_c(g) if g is not None else None), pk.scale.data_ptr()
+        d.lda, d.a_half, d.ldb = pk.lda, pk.a_half, pk.ldb
+        d.O, d.I, d.J, d.transposed, d.glu_cg = O, I, J, 0, glu_cg
+        _lib.call("dv3_weight_norm_split_pack_bf16", ctypes.byref(d), pk.fwd_s.data_ptr(), _ptr(pk.bwd_s), _stream())
+        return pk
     if transposed:
         I, O, J = v.shape
     else:
@@ -214,9 +236,10 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
         y_bs = y.stride(0)
     d = _conv_desc()
     d.x = x.data_ptr()
+    d.a = _ptr(a)
     d.x_bs = x_bs if x_bs is not None else x.stride(0)
     d.x_rs = x_rs if x_rs is not None else x.stride(1)
-    d.a, d.a_bs, d.lda, d.a_half = a.data_ptr(), a_bs, lda, a_half
+    d.a_bs, d.lda, d.a_half = a_bs, lda, a_half
     d.bias = _ptr(bias)
     d.spk = _ptr(spk)
     d.spk_bs, d.spk_rs, d.spk_ts = spk_strides
@@ -363,8 +386,11 @@ class ConvLayerFn(torch.autograd.Function):
             M, Cg = O, (O // 2 if gated else 0)
         if packed is not None and need_grad and packed.bwd is None:
             packed = None
+        # the fused split-only packing when the split-bf16 tap-GEMM is sure to take the shape
+        J_ = 1 if cfg.transposed else J
+        split_only = (cfg.t_out is None or cfg.t_out == T) and (J_ - 1) * cfg.dil <= 64 and J_ <= 16
         pk = packed if packed is not None else pack_weights(v, g, glu_cg=Cg, transposed=cfg.transposed,
-                                                            need_bwd=need_grad)
+                                                            need_bwd=need_grad, split_only=split_only)
         bits, bits_rs, dscale = None, 0, 1.0
         if cfg.training and cfg.p > 0:
             bits, bits_rs = dropout_bits(B * Cin, T, cfg.p, x.device, cfg.site)
@@ -478,6 +504,12 @@ def conv_layer(x, v, g, bias, cfg, spk=None, r=None, r2=None, packed=None):
 # attention core (deepvoice3.py:143-171): S = q^T k -> mask/softmax/dropout -> ctx = v Pd^T sqrt(Tk)
 # q (B,E,Tq), k (B,E,Tk), v (B,E,Tk) all BCT; returns ctx (B,E,Tq) BCT and P (B,Tq,Tk).
 # ----------------------------------------------------------------------------------------------
+def _attn_split():
+    """the batched attention products (torch.bmm, deepvoice3.py:143,167) follow the GEMM mode; the
+    incremental decode (Tq == 1) keeps the exact kernel (a 1-row product is not MFMA work)"""
+    return _gemm_mode != "f32"
+
+
 class AttnCoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, key_len, last_attended, cfg):
@@ -501,7 +533,7 @@ class AttnCoreFn(torch.autograd.Function):
         _lib.call("dv3_attn_softmax_f32", ctypes.byref(d), _stream())
         P = S
         # context: out[b][e][t] = sum_n v[b][e][n] * pd[b][t][n]
-        ctxv = wgrad_gemm(v, pd, B=B, M=E, Cin=Tq, T=Tk, Tin=Tk, n_slabs=B).view(B, E, Tq)
+        ctxv = wgrad_gemm(v, pd, B=B, M=E, Cin=Tq, T=Tk, Tin=Tk, n_slabs=B, split_bf16=_attn_split()).view(B, E, Tq)
         if any(ctx.needs_input_grad[:3]):
             ctx.save_for_backward(q, k, v, P, pd)
             ctx.bits, ctx.bits_rs, ctx.dscale, ctx.pd_scale = bits, bits_rs, dscale, d.pd_scale
@@ -515,7 +547,7 @@ class AttnCoreFn(torch.autograd.Function):
         dctx = _c(dctx)
         # dv[b][e][n] = sum_t dctx[b][e][t] * pd[b][t][n]  -> needs pd^T (B,Tk,Tq)
         pdT = transpose(pd)
-        dv = wgrad_gemm(dctx, pdT, B=B, M=E, Cin=Tk, T=Tq, Tin=Tq, n_slabs=B).view(B, E, Tk)
+        dv = wgrad_gemm(dctx, pdT, B=B, M=E, Cin=Tk, T=Tq, Tin=Tq, n_slabs=B, split_bf16=_attn_split()).view(B, E, Tk)
         # dpd[b][t][n] = sum_e dctx[b][e][t] * v[b][e][n]   (per-batch operand A = dctx[b])
         dpd = conv_gemm(v, dctx, Tq, 0, B=B, Cin=E, Tin=Tk, M=Tq, Tout=Tk, a_bs=E * Tq)
         dS = torch.empty_like(P)
@@ -526,10 +558,10 @@ class AttnCoreFn(torch.autograd.Function):
         d.B, d.Tq, d.Tk = B, Tq, Tk
         _lib.call("dv3_attn_softmax_bwd_f32", ctypes.byref(d), _stream())
         # dq[b][e][t] = sum_n k[b][e][n] * dS[b][t][n]
-        dq = wgrad_gemm(k, dS, B=B, M=E, Cin=Tq, T=Tk, Tin=Tk, n_slabs=B).view(B, E, Tq)
+        dq = wgrad_gemm(k, dS, B=B, M=E, Cin=Tq, T=Tk, Tin=Tk, n_slabs=B, split_bf16=_attn_split()).view(B, E, Tq)
         # dk[b][e][n] = sum_t q[b][e][t] * dS[b][t][n]  -> needs dS^T
         dST = transpose(dS)
-        dk = wgrad_gemm(q, dST, B=B, M=E, Cin=Tk, T=Tq, Tin=Tq, n_slabs=B).view(B, E, Tk)
+        dk = wgrad_gemm(q, dST, B=B, M=E, Cin=Tk, T=Tq, Tin=Tq, n_slabs=B, split_bf16=_attn_split()).view(B, E, Tk)
         return dq, dk, dv, None, None, None
 
 

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 14
+#define DV3_ABI_VERSION 15
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -165,6 +165,14 @@ typedef struct dv3_wn_desc {
   int32_t O, I, J, transposed, glu_cg;
 } dv3_wn_desc;
 int dv3_weight_norm_pack_f32(const dv3_wn_desc* d, void* stream);
+
+/* Fused form for the split-bf16 GEMM modes (Conv1d / Linear layers): scale + BOTH split images
+ * (dv3_split_pack_bf16 layout; fwd over K = I with lda columns, bwd over K = O with ldb columns,
+ * taps reversed) straight from v, g -- no fp32 images.  d->fwd_pack / d->bwd_pack are ignored;
+ * bwd_split may be NULL.  K pad rows are written as zeros; pad COLUMNS are left untouched (they
+ * only feed output rows the GEMM epilogue drops).                                          */
+int dv3_weight_norm_split_pack_bf16(const dv3_wn_desc* d, uint16_t* fwd_split, uint16_t* bwd_split,
+                                    void* stream);
 
 /*
  * Backward of weight norm from wgrad slabs: dW = sum_s slab[s]; dg, dv.
