@@ -124,7 +124,10 @@ extern "C" int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream) {
   a.d = *d;
   hipStream_t st = (hipStream_t)stream;
   const bool small = (d->M <= 64 && d->Cin <= 64);
-  if (d->split_bf16 && !small) return dv3_wgrad_gemm_bf16x3_dispatch(d, st);
+  if (d->split_bf16 && !small) {
+    const int rc = dv3_wgrad_gemm_bf16x3_dispatch(d, st);
+    if (rc != 1) return rc;
+  }
   if (small) {
     a.m_tiles = dv3_cdiv(d->M, 64);
     a.c_tiles = dv3_cdiv(d->Cin, 64);

@@ -47,21 +47,37 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
   }
 }
 
-// 8 consecutive floats row[t..t+8), zero outside [0, len); `row` may be any valid pointer when
-// nothing is in range.
-__device__ __forceinline__ void load8(const float* __restrict__ row, int t, int len, float (&v)[8]) {
-  if (t >= 0 && t + 8 <= len) {
-    const f32x4u a = *reinterpret_cast<const f32x4u*>(row + t);
-    const f32x4u b = *reinterpret_cast<const f32x4u*>(row + t + 4);
+template <typename T>
+__device__ __forceinline__ T ldg_off(const void* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+// 8 consecutive floats at element offset `off` of a tensor with `total` elements, RAW (the
+// caller masks elements outside its row: a unit that merely crosses a row end reads the
+// neighbouring row's finite values, which are then zeroed).  Uniform base + 32-bit offsets; the
+// whole wave takes the two-dwordx4 path unless one of its units touches the tensor's two ends.
+__device__ __forceinline__ void load8_raw(const float* __restrict__ base, int off, int total,
+                                          float (&v)[8]) {
+  const bool inside = (unsigned)off <= (unsigned)(total - 8);
+  if (__all(inside)) {
+    const f32x4u a = ldg_off<f32x4u>(base, (uint32_t)off * 4u);
+    const f32x4u b = ldg_off<f32x4u>(base, (uint32_t)off * 4u + 16u);
     v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
     v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int tt = t + e;
-      v[e] = (tt >= 0 && tt < len) ? row[tt] : 0.f;
-    }
+    for (int e = 0; e < 8; ++e) v[e] = ldg_off<float>(base, (uint32_t)min(max(off + e, 0), total - 1) * 4u);
   }
+}
+// bit e set <=> 0 <= t + e < len
+__device__ __forceinline__ uint32_t valid8(int t, int len) {
+  const int elo = max(0, -t), ehi = min(8, len - t);
+  return ehi > elo ? (((1u << ehi) - 1u) & ~((1u << elo) - 1u)) : 0u;
+}
+// v[e] = bit e of m ? v[e] : 0
+__device__ __forceinline__ void mask8(float (&v)[8], uint32_t m) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    v[e] = __uint_as_float(__float_as_uint(v[e]) & (uint32_t)__builtin_amdgcn_sbfe((int)m, e, 1));
 }
 
 template <int WM, int WN, bool MASK, int TERMS>
@@ -108,42 +124,64 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
   // two register sets: the operands of step k live in set k&1 from two steps before their use
   // (both operands stream from HBM; one step of MFMAs does not cover that latency)
   float rg[2][GU][8], rx[2][XU][8];
-  uint32_t rmask[2][MASK ? XU : 1];   // 8 keep-bits of the unit
+  uint32_t gval[2][GU], xval[2][XU];   // per-unit element masks: validity (& dropout keep-bits for x)
   const int n_tc = (T + BKT - 1) / BKT;          // time chunks per batch item
   const int n_b = (p.B - s + p.n_slabs - 1) / p.n_slabs;
   const int nsteps = n_b * n_tc;
+  const int g_total = (p.B - 1) * (int)p.g_bs + (M - 1) * (int)p.g_rs + T;      // < 2^31 (host-checked)
+  const int x_total = (p.B - 1) * (int)p.x_bs + (Cin - 1) * (int)p.x_rs + Tin;
+  const int wl = (Tin + 31) / 32 - 1;
+  // per-unit row offsets (elements) and mask-row offsets (words), fixed over the K loop
+  int grow_off[GU], xrow_off[XU], xm_off[MASK ? XU : 1];
+  bool grow_ok[GU], xrow_ok[XU];
+#pragma unroll
+  for (int u = 0; u < GU; ++u) {
+    const int m = m0 + grow[u];
+    grow_ok[u] = m < M;
+    grow_off[u] = (m < M ? m : M - 1) * (int)p.g_rs + gk8[u] * 8;
+  }
+#pragma unroll
+  for (int u = 0; u < XU; ++u) {
+    const int c = c0 + xrow[u];
+    xrow_ok[u] = c < Cin;
+    const int cc = c < Cin ? c : Cin - 1;
+    xrow_off[u] = cc * (int)p.x_rs + xk8[u] * 8 + shift;
+    if (MASK) xm_off[u] = cc * p.xmask_rs;
+  }
 
   auto load_step = [&](int step, auto set_c) {
     constexpr int S = decltype(set_c)::value;
     const int bi = step / n_tc, tc = step - bi * n_tc;
     const int b = s + bi * p.n_slabs;
     const int t0 = tc * BKT;
-    const float* __restrict__ gb = p.g + (int64_t)b * p.g_bs;
-    const float* __restrict__ xb = p.x + (int64_t)b * p.x_bs;
+    const int gb = b * (int)p.g_bs + t0, xb = b * (int)p.x_bs + t0;
+    const bool g_edge = t0 + BKT > T;                      // uniform: the chunk holds the row tail
+    const bool x_edge = t0 + shift < 0 || t0 + BKT + shift > Tin;
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
-      const int m = m0 + grow[u];
-      const int mc = m < M ? m : M - 1;
-      load8(gb + (int64_t)mc * p.g_rs, t0 + gk8[u] * 8, (m < M) ? T : 0, rg[S][u]);
+      load8_raw(p.g, gb + grow_off[u], g_total, rg[S][u]);
+      uint32_t vm = 0xffu;
+      if (g_edge) vm = valid8(t0 + gk8[u] * 8, T);
+      gval[S][u] = grow_ok[u] ? vm : 0u;
     }
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
-      const int c = c0 + xrow[u];
-      const int cc = c < Cin ? c : Cin - 1;
-      const int t = t0 + xk8[u] * 8;          // g-time of the unit; x is read at t + shift
-      // g is zero for g-times >= T, so x only needs its own [0, Tin) clipping
-      const int tx = t + shift;
-      load8(xb + (int64_t)cc * p.x_rs, tx, (c < Cin) ? Tin : 0, rx[S][u]);
+      load8_raw(p.x, xb + xrow_off[u], x_total, rx[S][u]);
+      const int tx = t0 + xk8[u] * 8 + shift;   // g is zero for g-times >= T: x needs only its own clipping
+      uint32_t vm = 0xffu;
+      if (x_edge) vm = valid8(tx, Tin);
+      if (!xrow_ok[u]) vm = 0u;
       if (MASK) {
-        const uint32_t* __restrict__ mr = p.xmask + ((int64_t)b * Cin + cc) * p.xmask_rs;
+        const uint32_t mo = (uint32_t)(b * Cin * p.xmask_rs + xm_off[u]);
         const int txc = max(tx, 0);
-        const int w0 = txc >> 5;
-        const int wl = (Tin + 31) / 32 - 1;
-        const uint64_t lo = mr[min(w0, wl)], hi = mr[min(w0 + 1, wl)];
-        uint32_t bits = (uint32_t)(((hi << 32) | lo) >> (txc & 31));
-        if (tx < 0) bits = (-tx < 32) ? bits << (-tx) : 0u;   // bit e of `bits` <-> element e of the unit
-        rmask[S][u] = bits;
+        const int w0 = min(txc >> 5, wl);
+        const uint32_t lo = ldg_off<uint32_t>(p.xmask, (mo + (uint32_t)w0) * 4u);
+        const uint32_t hi = ldg_off<uint32_t>(p.xmask, (mo + (uint32_t)min(w0 + 1, wl)) * 4u);
+        uint32_t bits = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(txc & 31));
+        if (x_edge && tx < 0) bits = (-tx < 32) ? bits << (-tx) : 0u;   // bit e <-> element e of the unit
+        vm &= bits;
       }
+      xval[S][u] = vm;
     }
   };
   auto write_step = [&](int buf, auto set_c) {
@@ -151,6 +189,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
     bf16x8* dst = smem + buf * BUF;
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
+      if (__any((gval[S][u] & 0xffu) != 0xffu)) mask8(rg[S][u], gval[S][u]);   // rare: row tails
       bf16x8 hi, lo;
       split8(rg[S][u], hi, lo);
       const int o = gk8[u] * LDM + grow[u];
@@ -160,14 +199,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
     bf16x8* dx = dst + 2 * KB * LDM;
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = rx[S][u][e];
-        if (MASK) v[e] *= ((rmask[S][u] >> e) & 1u) ? p.drop_scale : 0.f;
-      }
+      // dropout: keep-bits select here, the 1/(1-p) scale is applied once to the accumulators
+      if (MASK || __any((xval[S][u] & 0xffu) != 0xffu)) mask8(rx[S][u], xval[S][u]);
       bf16x8 hi, lo;
-      split8(v, hi, lo);
+      split8(rx[S][u], hi, lo);
       const int o = xk8[u] * LDN + xrow[u];
       dx[o] = hi;
       if (TERMS == 3) dx[KB * LDN + o] = lo;
@@ -243,6 +278,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
   }
 
   float* __restrict__ ob = p.out + (int64_t)s * p.out_ss + (int64_t)j * M * p.ldo;
+  const float oscale = MASK ? p.drop_scale : 1.0f;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -252,7 +288,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (m < M) ob[(int64_t)m * p.ldo + c] = acc[mi][ni][r];
+        if (m < M) ob[(int64_t)m * p.ldo + c] = acc[mi][ni][r] * oscale;
       }
     }
 }
@@ -267,6 +303,11 @@ int dv3_wgrad_gemm_bf16x3_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
   a.c_tiles = dv3_cdiv(d->Cin, 128);
   const int64_t nb = (int64_t)a.m_tiles * a.c_tiles * d->J * d->n_slabs;
   DV3_REQUIRE(nb < (1ll << 31), "wgrad_gemm: grid too large");
+  // 32-bit element offsets inside the kernel
+  if ((int64_t)d->B * d->g_bs + (int64_t)d->M * d->g_rs >= (1ll << 30) ||
+      (int64_t)d->B * d->x_bs + (int64_t)d->Cin * d->x_rs >= (1ll << 30) ||
+      (d->xmask && (int64_t)d->B * d->Cin * d->xmask_rs >= (1ll << 30)))
+    return 1;   // caller falls back to the exact kernel
   if (d->split_bf16 == 2) {   // single-term bf16 (hi planes only)
     if (d->xmask) {
       hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<2, 2, true, 1>), dim3((unsigned)nb), dim3(256), 0, st, a);
