@@ -117,13 +117,15 @@ int dv3_wgrad_gemm_bf16x3_dispatch(const dv3_wgrad_desc* d, hipStream_t st);  //
 extern "C" int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream) {
   DV3_REQUIRE(d && d->g && d->x && d->out, "wgrad_gemm: null pointer");
   DV3_REQUIRE(d->B > 0 && d->M > 0 && d->Cin > 0 && d->T > 0 && d->Tin > 0, "wgrad_gemm: bad dims");
-  DV3_REQUIRE(d->J >= 1 && d->dil >= 1 && d->n_slabs >= 1 && d->n_slabs <= d->B, "wgrad_gemm: bad J/dil/slabs");
+  DV3_REQUIRE(d->J >= 1 && d->dil >= 1 && d->n_slabs >= 1 && (d->k_split || d->n_slabs <= d->B),
+              "wgrad_gemm: bad J/dil/slabs");
   DV3_REQUIRE(d->ldo >= d->Cin, "wgrad_gemm: ldo < Cin");
   if (d->xmask) DV3_REQUIRE(d->xmask_rs * 32 >= d->Tin, "wgrad_gemm: xmask row stride too small");
   WgradArgs a;
   a.d = *d;
   hipStream_t st = (hipStream_t)stream;
   const bool small = (d->M <= 64 && d->Cin <= 64);
+  DV3_REQUIRE(!d->k_split || (d->split_bf16 && !small), "wgrad_gemm: k_split needs the split-bf16 kernel");
   if (d->split_bf16 && !small) {
     const int rc = dv3_wgrad_gemm_bf16x3_dispatch(d, st);
     if (rc != 1) return rc;

@@ -126,8 +126,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
   float rg[2][GU][8], rx[2][XU][8];
   uint32_t gval[2][GU], xval[2][XU];   // per-unit element masks: validity (& dropout keep-bits for x)
   const int n_tc = (T + BKT - 1) / BKT;          // time chunks per batch item
-  const int n_b = (p.B - s + p.n_slabs - 1) / p.n_slabs;
-  const int nsteps = n_b * n_tc;
+  // K partition: k_split 0 = slab s owns batch items s, s+S, ...; 1 = slab s owns the s-th contiguous
+  // range of the flattened (batch item, chunk) sequence (any S: the grid can be sized to the chip)
+  int nsteps, step0 = 0;
+  if (p.k_split) {
+    const int total = p.B * n_tc, q = (total + p.n_slabs - 1) / p.n_slabs;
+    step0 = s * q;
+    nsteps = max(0, min(q, total - step0));
+  } else {
+    nsteps = ((p.B - s + p.n_slabs - 1) / p.n_slabs) * n_tc;
+  }
   const int g_total = (p.B - 1) * (int)p.g_bs + (M - 1) * (int)p.g_rs + T;      // < 2^31 (host-checked)
   const int x_total = (p.B - 1) * (int)p.x_bs + (Cin - 1) * (int)p.x_rs + Tin;
   const int wl = (Tin + 31) / 32 - 1;
@@ -151,8 +159,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
 
   auto load_step = [&](int step, auto set_c) {
     constexpr int S = decltype(set_c)::value;
-    const int bi = step / n_tc, tc = step - bi * n_tc;
-    const int b = s + bi * p.n_slabs;
+    const int gs = step0 + step;
+    const int bi = gs / n_tc, tc = gs - bi * n_tc;
+    const int b = p.k_split ? bi : s + bi * p.n_slabs;
     const int t0 = tc * BKT;
     const int gb = b * (int)p.g_bs + t0, xb = b * (int)p.x_bs + t0;
     const bool g_edge = t0 + BKT > T;                      // uniform: the chunk holds the row tail

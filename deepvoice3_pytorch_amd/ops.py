@@ -262,7 +262,7 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
 
 def wgrad_gemm(g, x, *, B, M, Cin, T, Tin, J=1, dil=1, padL=0, n_slabs=1, xmask=None, xmask_rs=0,
                drop_scale=1.0, out=None, ldo=None, g_bs=None, g_rs=None, x_bs=None, x_rs=None,
-               split_bf16=False):
+               split_bf16=False, k_split=False):
     """dv3_wgrad_gemm_f32 -> out [S][J][M][ldo]."""
     if ldo is None:
         ldo = Cin
@@ -277,6 +277,7 @@ def wgrad_gemm(g, x, *, B, M, Cin, T, Tin, J=1, dil=1, padL=0, n_slabs=1, xmask=
     d.out, d.out_ss, d.ldo = out.data_ptr(), J * M * ldo, ldo
     d.B, d.M, d.Cin, d.T, d.Tin, d.J, d.dil, d.padL, d.n_slabs = B, M, Cin, T, Tin, J, dil, padL, n_slabs
     d.split_bf16 = (2 if _gemm_mode == "bf16" else 1) if split_bf16 else 0
+    d.k_split = int(bool(k_split))
     _lib.call("dv3_wgrad_gemm_f32", ctypes.byref(d), _stream())
     return out
 
@@ -332,6 +333,23 @@ def axpby(a, b, alpha):
     _lib.call("dv3_axpby_f32", a.data_ptr(), _ptr(_c(b) if b is not None else None), out.data_ptr(),
               a.numel(), float(alpha), _stream())
     return out
+
+
+def _ksplit_count(total_steps, tiles, slots=512, min_steps=8):
+    """Split-K factor for the bf16x3 wgrad: the grid (tiles x S workgroups) should fill the chip's
+    2 x 256 workgroup slots a whole number of times, with at least `min_steps` K steps each."""
+    s_max = max(1, total_steps // min_steps)
+    if tiles >= slots:
+        return 1
+    best, best_eff = 1, 0.0
+    for s in range(1, min(s_max, slots) + 1):
+        blocks = tiles * s
+        rounds = -(-blocks // slots)
+        eff = blocks / float(rounds * slots)          # occupancy of the last round included
+        eff *= 1.0 - 0.008 * s                         # fewer slabs: less partial-sum traffic
+        if eff > best_eff:
+            best, best_eff = s, eff
+    return best
 
 
 def _slab_count(B, tiles):
@@ -484,10 +502,14 @@ class ConvLayerFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             Jd = 1 if cfg.transposed else J
             tiles = ((Mg + 127) // 128) * ((Cin + 127) // 128) * Jd
-            S = _slab_count(B, tiles)
+            x3 = _gemm_mode != "f32" and not (Mg <= 64 and Cin <= 64)
+            if x3:   # split-K over contiguous (batch, chunk) ranges: size the grid to 2 workgroups per CU
+                S = _ksplit_count(B * ((Tg + 31) // 32), tiles)
+            else:
+                S = _slab_count(B, tiles)
             slabs = wgrad_gemm(gmat, x, B=B, M=Mg, Cin=Cin, T=Tg, Tin=T, J=Jd, dil=cfg.dil, padL=padL,
                                n_slabs=S, xmask=ctx.bits, xmask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
-                               split_bf16=(_gemm_mode != "f32"))
+                               split_bf16=x3, k_split=x3)
             v3 = v if v.dim() == 3 else v.unsqueeze(-1)
             dv, dg, dbias = weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None,
                                             pk.scale, part, B, pk.O, pk.I, pk.J, cfg.transposed,

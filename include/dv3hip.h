@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 15
+#define DV3_ABI_VERSION 16
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -144,6 +144,10 @@ typedef struct dv3_wgrad_desc {
   int32_t B, M, Cin, T, Tin, J, dil, padL, n_slabs;
   int32_t split_bf16;                        /* 0: exact fp32 MFMA; 1: bf16x3 split-operand MFMA;
                                                 2: single-term bf16 MFMA (hi planes only)        */
+  int32_t k_split;                           /* 0: slab s = batch items s, s+S, ... (S == B: a per-batch
+                                                result); 1 (split-bf16 kernels): slab s = the s-th
+                                                contiguous range of the (batch item, 32-step chunk)
+                                                sequence -- any S, so the grid can match the chip  */
 } dv3_wgrad_desc;
 int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream);
 

@@ -91,12 +91,12 @@ def time_wgrad(B, M, Cin, T, J=3, dil=3, split=True, masked=True, iters=10):
     g = torch.randn(B, M, T, device=dev)
     x = torch.randn(B, Cin, T, device=dev)
     tiles = ((M + 127) // 128) * ((Cin + 127) // 128) * J
-    S = ops._slab_count(B, tiles)
+    S = ops._ksplit_count(B * ((T + 31) // 32), tiles) if split else ops._slab_count(B, tiles)
     bits, rs = (ops.dropout_bits(B * Cin, T, 0.05, dev) if masked else (None, 0))
     out = torch.empty(S, J, M, Cin, device=dev)
     def launch():
         ops.wgrad_gemm(g, x, B=B, M=M, Cin=Cin, T=T, Tin=T, J=J, dil=dil, padL=dil, n_slabs=S, xmask=bits,
-                       xmask_rs=rs, drop_scale=1 / 0.95, out=out, split_bf16=split)
+                       xmask_rs=rs, drop_scale=1 / 0.95, out=out, split_bf16=split, k_split=split)
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
@@ -112,9 +112,10 @@ def time_wgrad(B, M, Cin, T, J=3, dil=3, split=True, masked=True, iters=10):
 
 
 if __name__ == "__main__":
-    for sp in (True, False):
+    for sp in (True,):
         time_wgrad(64, 512, 256, 800, split=sp)
         time_wgrad(64, 1024, 512, 150, split=sp)
+        time_wgrad(64, 1024, 512, 800, split=sp)
         time_wgrad(16, 512, 256, 800, split=sp)
     mask_check()
     for shape in [(3, 64, 200, 3, 1, False), (3, 96, 150, 3, 27, True), (3, 20, 37, 5, 3, False), (3, 128, 513, 3, 9, True),
