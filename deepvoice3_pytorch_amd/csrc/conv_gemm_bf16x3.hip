@@ -28,6 +28,7 @@
 //   * wave tile 64(M: the `a` rows + their gate rows) x NI*32(N), same accumulator layout as the
 //     fp32 kernel, so the epilogue (conv_common.h) is shared verbatim.
 #include "conv_common.h"
+#include <math.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -411,11 +412,16 @@ const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
     const int BM = c.wm * 64, BMH = c.wm * 32, BN = c.wn * c.ni * 32;
     const int64_t mt = gated ? dv3_cdiv(d->Cg, BMH) : dv3_cdiv(d->M, BM);
     const int64_t ntl = dv3_cdiv64(ntot, BN);
-    const double work = (double)mt * BM * (double)ntl * BN;
-    double pen = 1.0 + 24.0 / BN + 8.0 / BM;   // operand traffic per MFMA ~ 1/BN (weights) + 1/BM
+    // time ~ (rounds of the chip's 2 x 256 resident workgroups) x (tile work) x (operand traffic
+    // per MFMA ~ 1/BN for the weight panel + 1/BM for the activation tile).  A last round with at
+    // most one workgroup per CU runs those workgroups unshared, i.e. faster.
     const double blocks = (double)mt * ntl;
-    if (blocks < 512) pen *= 1.0 + 0.25 * (512 - blocks) / 512;
-    const double cost = work * pen;
+    const double full = floor(blocks / 512.0), rem = blocks - 512.0 * full;
+    const double rounds = full + (rem == 0 ? 0.0 : (rem <= 256 ? 0.6 : 1.0));
+    // measured time per unit of tile work relative to the 128x128 tile (north-star shape, d = 1..27):
+    // the 2-wave 64-row tiles and the 32-column tiles stage far more per MFMA
+    static const double kRel[7] = {0, 1.0, 1.12, 2.0, 2.2, 1.8, 2.0};
+    const double cost = rounds * BM * BN * kRel[c.id];
     if (!best || cost < best_cost) {
       best = &c;
       best_cost = cost;
