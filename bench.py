@@ -275,6 +275,7 @@ def main():
     ap.add_argument("--text-len", type=int, default=150)
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="force the whole-step hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "conv", "conv-ab", "synth"])
@@ -320,10 +321,11 @@ def main():
                                           bt["text_positions"], bt["frame_positions"], bt["done"],
                                           bt["target_lengths"], spk, downsample_step=4, device=dev)
     trainer.check_lengths(batch)
-    # one GPU: the whole step is replayed as a hipGraph.  Data parallel: eager launches -- the RCCL
-    # bucket all-reduces are issued from autograd hooks on a side stream and the step is GPU-bound at
-    # this batch size (eager 25.9 ms vs graph 24.4 ms on one GPU), so capture is not worth the risk.
-    use_graph = not args.no_graph and world == 1
+    # Launch mode.  The step is ~1.9k kernel launches; at the north-star batch (64) the GPU stays ahead of
+    # the host, eager launches are GPU-bound (measured 18.25 ms/step eager vs 18.71 ms replayed) and the
+    # RCCL bucket all-reduces can be issued from autograd hooks on a side stream.  A whole-step hipGraph
+    # pays only when the step is launch-bound: small per-GPU batches on one GPU (B=16: 9.5 ms replayed).
+    use_graph = (args.graph or args.batch < 32) and not args.no_graph and world == 1
     runner = None
     if use_graph:
         try:
