@@ -205,7 +205,10 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const dv3_wn_bwd_desc p) {
       __syncthreads();
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bs;
       __syncthreads();
-      if (threadIdx.x == 0) p.dbias[o] = red[0] + red[1] + red[2] + red[3];
+      if (threadIdx.x == 0) {
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        p.dbias[o] = p.accumulate ? p.dbias[o] + tot : tot;
+      }
       __syncthreads();
     }
   }
@@ -213,11 +216,14 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const dv3_wn_bwd_desc p) {
   if (p.g) {
     const float sc = p.scale[r], gg = p.g[r];
     const float dg = dot * sc;
-    if (threadIdx.x == 0) p.dg[r] = dg;
+    if (threadIdx.x == 0) p.dg[r] = p.accumulate ? p.dg[r] + dg : dg;
     const float c1 = gg * sc, c2 = gg * sc * sc * dg;
-    for (int idx = threadIdx.x; idx < len; idx += 256) dvrow[idx] = c1 * dw[idx] - c2 * vrow[idx];
+    for (int idx = threadIdx.x; idx < len; idx += 256) {
+      const float val = c1 * dw[idx] - c2 * vrow[idx];
+      dvrow[idx] = p.accumulate ? dvrow[idx] + val : val;
+    }
   } else {
-    for (int idx = threadIdx.x; idx < len; idx += 256) dvrow[idx] = dw[idx];
+    for (int idx = threadIdx.x; idx < len; idx += 256) dvrow[idx] = p.accumulate ? dvrow[idx] + dw[idx] : dw[idx];
   }
 }
 

@@ -43,8 +43,13 @@ class BucketedAllReduce(object):
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self._armed = False
+        # a parameter reports its gradient final either through autograd (AccumulateGrad hook) or, for
+        # the conv-layer parameters whose gradient is accumulated in place, through ops.grad_ready_hooks
+        self._index_of = {id(p): i for i, p in enumerate(arena.params)}
         for i, p in enumerate(arena.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
+        from . import ops as _ops
+        _ops.grad_ready_hooks.append(self._on_inplace_grad)
 
     def _make_hook(self, i):
         def hook(param):
@@ -55,6 +60,11 @@ class BucketedAllReduce(object):
             if self.pending[b] == 0:
                 self._launch(b)
         return hook
+
+    def _on_inplace_grad(self, param):
+        i = self._index_of.get(id(param))
+        if i is not None:
+            self._make_hook(i)(param)
 
     def arm(self):
         """Call right before backward."""

@@ -301,11 +301,16 @@ def gate_bwd(dy, ab_or_y, x, *, B, C, T, mode, residual=0, alpha=1.0, want_dres=
 
 
 def weight_norm_bwd(slabs, n_slabs, ldo, v, g, scale, bias_part, n_part, O, I, J, transposed=False,
-                    want_bias=True):
+                    want_bias=True, into=None):
+    """into = (dv, dg, dbias) gradient buffers to ACCUMULATE into (the parameters' own .grad views in
+    the trainer's flat arena) instead of fresh tensors."""
     dev = v.device
-    dv = torch.empty_like(v)
-    dg = torch.empty_like(g) if g is not None else None
-    dbias = torch.empty(O, dtype=torch.float32, device=dev) if (want_bias and bias_part is not None) else None
+    if into is not None:
+        dv, dg, dbias = into
+    else:
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(g) if g is not None else None
+        dbias = torch.empty(O, dtype=torch.float32, device=dev) if (want_bias and bias_part is not None) else None
     d = _wn_bwd_desc()
     M = J * O if transposed else O
     Jk = 1 if transposed else J
@@ -314,6 +319,7 @@ def weight_norm_bwd(slabs, n_slabs, ldo, v, g, scale, bias_part, n_part, O, I, J
     d.dv, d.dg = dv.data_ptr(), _ptr(dg)
     d.bias_part, d.n_part, d.dbias = _ptr(bias_part) if dbias is not None else None, n_part, _ptr(dbias)
     d.O, d.I, d.J, d.transposed = O, I, J, int(transposed)
+    d.accumulate = int(into is not None)
     _lib.call("dv3_weight_norm_bwd_f32", ctypes.byref(d), _stream())
     return dv, dg, dbias
 
@@ -382,6 +388,10 @@ def _pad_left(k, dil, causal):
     return (k - 1) * dil if causal else (k - 1) // 2 * dil
 
 
+# called with a Parameter once its in-place gradient (see ConvLayerFn.backward) is final for this step
+grad_ready_hooks = []
+
+
 class ConvLayerFn(torch.autograd.Function):
     """y = layer(x; v, g, bias[, spk][, r][, r2]).  See LayerCfg.  `packed` may carry a cached
     Packed (eval mode); spk is the additive per-(b,channel[,t]) term on the `a` half (already
@@ -437,6 +447,15 @@ class ConvLayerFn(torch.autograd.Function):
                       drop_scale=dscale, a_split=pk.fwd_s if _gemm_mode != "f32" else None,
                       store_mode=STORE_INTERLEAVE2 if cfg.transposed else STORE_BCT)
         if need_grad:
+            # parameters whose .grad lives in the trainer's flat arena take their gradient in place
+            # (no AccumulateGrad add kernel per parameter); count the uses so the "gradient final"
+            # notification fires once, after the last of them
+            leaves = [t for t in (v, g, bias) if t is not None]
+            ctx.inplace = bool(leaves) and all(getattr(t, "_dv3_grad_inplace", False) and t.grad is not None and
+                                               t.requires_grad for t in leaves)
+            ctx.leaves = (v, g, bias) if ctx.inplace else None
+            if ctx.inplace:
+                v._dv3_pending = getattr(v, "_dv3_pending", 0) + 1
             ctx.cfg, ctx.pk, ctx.dims = cfg, pk, (B, Cin, T, Tout, M, Cg, J, padL)
             ctx.bits, ctx.bits_rs, ctx.dscale = bits, bits_rs, dscale
             ctx.spk_dim = spk.dim() if spk is not None else 0
@@ -511,10 +530,24 @@ class ConvLayerFn(torch.autograd.Function):
                                n_slabs=S, xmask=ctx.bits, xmask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
                                split_bf16=x3, k_split=x3)
             v3 = v if v.dim() == 3 else v.unsqueeze(-1)
-            dv, dg, dbias = weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None,
-                                            pk.scale, part, B, pk.O, pk.I, pk.J, cfg.transposed,
-                                            want_bias=ctx.has_bias)
-            dv = dv.view_as(v)
+            if ctx.inplace:
+                pv, pg, pb = ctx.leaves
+                weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None, pk.scale, part, B,
+                                pk.O, pk.I, pk.J, cfg.transposed, want_bias=ctx.has_bias,
+                                into=(pv.grad, pg.grad if pg is not None else None,
+                                      pb.grad if pb is not None else None))
+                pv._dv3_pending -= 1
+                if pv._dv3_pending == 0:
+                    for hook in grad_ready_hooks:
+                        for t in (pv, pg, pb):
+                            if t is not None:
+                                hook(t)
+                dv = dg = dbias = None
+            else:
+                dv, dg, dbias = weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None,
+                                                pk.scale, part, B, pk.O, pk.I, pk.J, cfg.transposed,
+                                                want_bias=ctx.has_bias)
+                dv = dv.view_as(v)
         return dx, dv, dg, dbias, dspk, dr, dr2, None, None
 
 

@@ -123,6 +123,7 @@ class FlatArena(object):
             self.flat[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
+            p._dv3_grad_inplace = True     # ops.ConvLayerFn accumulates straight into p.grad
 
 
 class Trainer(object):
@@ -176,6 +177,8 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         """model forward + losses + backward.  Returns the scalars as device tensors."""
         c = self.cfg
         r = c.outputs_per_step
+        for p in self.arena.params:      # in-place gradient bookkeeping of ops.ConvLayerFn (uses this step)
+            p._dv3_pending = 0
         self.model.train()
         mel_out, lin_out, attn, done_hat = self.model(
             batch.text, batch.mel, speaker_ids=batch.speaker_ids, text_positions=batch.text_positions,

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 16
+#define DV3_ABI_VERSION 17
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -190,6 +190,9 @@ typedef struct dv3_wn_bwd_desc {
   float* dv; float* dg;                      /* dg NULL when g NULL (plain weight: dv = dW) */
   const float* bias_part; int32_t n_part; float* dbias;
   int32_t O, I, J, transposed;
+  int32_t accumulate;                        /* 1: dv, dg, dbias += (gradient buffers that are zeroed once
+                                                per step and shared by every use of the parameter);
+                                                0: overwrite                                          */
 } dv3_wn_bwd_desc;
 int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream);
 
