@@ -132,6 +132,24 @@ def _ddp_worker(rank, world, port, q):
         for i, p in enumerate(params):
             want = 0.0 if i == 3 else (i + 1) * sum(rr + 1 + step for rr in range(world))
             assert torch.allclose(p.grad, torch.full_like(p.grad, want)), (rank, i)
+    # in-place path (ops.ConvLayerFn writes conv-layer gradients straight into p.grad and reports
+    # them through ops.grad_ready_hooks): params 0, 2, 4 in place, 1 through autograd, 3 untouched
+    from deepvoice3_pytorch_amd import ops
+    assert comm._on_inplace_grad in ops.grad_ready_hooks
+    arena.grad.zero_()
+    comm.arm()
+    (2.0 * (rank + 1) * params[1].sum()).backward()
+    for i in (4, 0, 2):
+        params[i].grad.add_(float((i + 1) * (rank + 1)))
+        for hook in ops.grad_ready_hooks:
+            hook(params[i])
+    assert all(comm.launched[comm.bucket_of[i]] for i in (0, 1, 2, 4) if
+               all(j in (0, 1, 2, 4) for j in comm.buckets[comm.bucket_of[i]][2]))
+    comm.finish()
+    tot = sum(rr + 1 for rr in range(world))
+    for i, p in enumerate(params):
+        want = 0.0 if i == 3 else (2.0 if i == 1 else float(i + 1)) * tot
+        assert torch.allclose(p.grad, torch.full_like(p.grad, want)), (rank, i)
     q.put((rank, float(arena.grad.sum())))
     dist.destroy_process_group()
 
