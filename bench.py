@@ -101,7 +101,7 @@ def synth_batch(rng, B, Tt, n_frames, hp, fixed=True):
                 target_lengths=frame_lens)
 
 
-def conv_roofline(dev, iters=30, tile_hint=0, dil=1, mode=None):
+def conv_roofline(dev, iters=50, tile_hint=0, dil=1, mode=None):
     """Conv1dGLU forward at the north-star shape, one tap-GEMM launch per iteration, timed with
     HIP events on the stream it is launched on (torch's current stream = the stream ops.* enqueue on).
     mode "bf16x3": the split-bf16 kernel (3 bf16 MFMAs per product block) -> peak = 2500/3 TF of
@@ -122,7 +122,7 @@ def conv_roofline(dev, iters=30, tile_hint=0, dil=1, mode=None):
         ops.conv_gemm(x, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
                       padL=(k - 1) // 2 * d, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x, residual=1, y=y,
                       tile_hint=tile_hint, a_split=pk.fwd_s)
-    for _ in range(5):
+    for _ in range(20):          # the clock governor needs a few ms of this load to settle
         launch()
     torch.cuda.synchronize()
     s = torch.cuda.current_stream()
@@ -140,7 +140,7 @@ def conv_roofline(dev, iters=30, tile_hint=0, dil=1, mode=None):
     x3 = pk.fwd_s is not None and tile_hint in (0,) + tuple(range(21, 27))
     peak = PEAK_BF16_MFMA_TF / 3.0 if x3 else PEAK_F32_MFMA_TF
     out = dict(bound="mfma",
-               kernel=("conv_gemm_bf16x3_kernel<2,2,2> (Conv1dGLU fwd B=64 C=256 T=1024 k=3)" if x3 else
+               kernel=("conv_gemm_bf16x3_kernel (Conv1dGLU fwd B=64 C=256 T=1024 k=3; 128x256 8-wave tile)" if x3 else
                        "conv_gemm_f32_stream_kernel<2,2,2> (Conv1dGLU fwd B=64 C=256 T=1024 k=3)"),
                achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
                traffic=None, us_per_launch=round(us, 2), alg_flops=flops, alg_bytes=byts,

@@ -20,7 +20,8 @@ __device__ __forceinline__ void dv3_st(void* base, uint32_t byte_off, float v) {
   *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
-// Shared epilogue: acc[h][ni] is the 32x32 fp32 tile of row-half h, column sub-tile ni.
+// Shared epilogue: acc[h][ni] is the 32x32 fp32 tile of row-half h, column sub-tile ni; row0 = the
+// slice's first row inside its half of the block tile (wave row offset; + mi*32 for MI > 1).
 // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // The lane's output column of sub-tile ni is (batch bcol[ni], time tcol[ni]), live when okc[ni]
 // (per column, so a tile may span several batch items: the bf16x3 kernel flattens (b,t)).
@@ -33,7 +34,7 @@ __device__ __forceinline__ void dv3_st(void* base, uint32_t byte_off, float v) {
 // hidden behind MFMAs instead of heading the tail).
 template <int BM, int BMH, int NI, bool PRE = false, int ABL = 0>
 __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], bool gated,
-                                              int mt, int wm, int lhi, const int (&bcol)[NI],
+                                              int mt, int row0, int lhi, const int (&bcol)[NI],
                                               const int (&tcol)[NI], const bool (&okc)[NI],
                                               const float (*pre)[NI] = nullptr) {
   const float dscale = p.drop_scale;
@@ -68,7 +69,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
     float xr[16][NI], ba[16], bg[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      chv[r] = (uint32_t)(mt * BMH + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
+      chv[r] = (uint32_t)(mt * BMH + row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
       const uint32_t chc = chv[r] < Cg ? chv[r] : Cg - 1;
       ba[r] = bg[r] = 0.f;
       if (p.bias) {
@@ -116,7 +117,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
       float rv[16][NI];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        mv[r] = (uint32_t)(mt * BM + h * BMH + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
+        mv[r] = (uint32_t)(mt * BM + h * BMH + row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
         const uint32_t mc = mv[r] < M ? mv[r] : M - 1;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -153,7 +154,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
     float rv[16][NI], r2v[16][NI], bv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      mv[r] = (uint32_t)(mt * BM + h * BMH + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
+      mv[r] = (uint32_t)(mt * BM + h * BMH + row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
       const uint32_t mc = mv[r] < M ? mv[r] : M - 1;
       const uint32_t mo = (il2 && mc >= Mo) ? mc - Mo : mc;
       bv[r] = p.bias ? p.bias[mo] : 0.f;
@@ -222,16 +223,19 @@ static inline bool dv3_conv_fits32(const dv3_conv_desc* d) {
 }
 
 struct TileCfg {
-  int id, wm, wn, ni;
+  int id, wm, wn, ni, mi;   // mi: 32-row sub-tiles per half per wave (bf16x3 kernel; 1 elsewhere)
 };
 // id is what dv3_conv_desc.tile_hint selects.
 static const TileCfg kCfgs[] = {
-    {1, 2, 2, 2},  // 128 x 128
-    {2, 2, 2, 1},  // 128 x 64
-    {3, 4, 1, 1},  // 256 x 32
-    {4, 2, 1, 1},  // 128 x 32
-    {5, 1, 2, 2},  // 64 x 128
-    {6, 1, 2, 1},  // 64 x 64
+    {1, 2, 2, 2, 1},  // 128 x 128
+    {2, 2, 2, 1, 1},  // 128 x 64
+    {3, 4, 1, 1, 1},  // 256 x 32
+    {4, 2, 1, 1, 1},  // 128 x 32
+    {5, 1, 2, 2, 1},  // 64 x 128
+    {6, 1, 2, 1, 1},  // 64 x 64
+    {7, 2, 2, 2, 2},  // 256 x 128, 128 x 64 per wave (bf16x3 kernel only)
+    {8, 4, 2, 2, 1},  // 256 x 128, 8 waves of 64 x 64 (bf16x3 kernel only)
+    {9, 2, 4, 2, 1},  // 128 x 256, 8 waves of 64 x 64 (bf16x3 kernel only)
 };
 
 // pick a tile config: minimise padded work with a mild small-tile penalty

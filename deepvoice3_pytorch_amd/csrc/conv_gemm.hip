@@ -159,7 +159,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_kernel(const ConvAr
     tcol[ni] = n0 + wn * (NI * 32) + ni * 32 + l31;
     okc[ni] = tcol[ni] < p.Tout;
   }
-  conv_epilogue<BM, BMH, NI>(p, acc, gated, mt, wm, lhi, bcol, tcol, okc);
+  conv_epilogue<BM, BMH, NI>(p, acc, gated, mt, wm * 32, lhi, bcol, tcol, okc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_stream_kernel(const
     tcol[ni] = n0 + wn * (NI * 32) + ni * 32 + l31;
     okc[ni] = tcol[ni] < p.Tout;
   }
-  conv_epilogue<BM, BMH, NI>(p, acc, gated, mt, wm, lhi, bcol, tcol, okc);
+  conv_epilogue<BM, BMH, NI>(p, acc, gated, mt, wm * 32, lhi, bcol, tcol, okc);
 }
 
 template <int WM, int WN, int NI>

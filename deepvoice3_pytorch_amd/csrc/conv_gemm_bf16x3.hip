@@ -60,9 +60,9 @@ __device__ __forceinline__ T ldg_off(const void* base, uint32_t byte_off) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-template <int WM, int WN, int NI, bool MASK, int ABL = 0, int TERMS = 3>
+template <int WM, int WN, int NI, bool MASK, int ABL = 0, int TERMS = 3, int MI = 1>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const ConvArgs args) {
-  constexpr int BM = WM * 64, BMH = WM * 32, BN = WN * NI * 32;
+  constexpr int BM = WM * MI * 64, BMH = WM * MI * 32, BN = WN * NI * 32;
   constexpr int NT = WM * WN * 64;
   constexpr int AU = KB * BM / NT;                          // A units per plane per thread per step
   constexpr int XI = (KB * (BN + HALO_MAX) + NT - 1) / NT;  // X items per thread per chunk
@@ -231,17 +231,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
     }
   };
 
-  f32x16 acc[2][NI];
+  f32x16 acc[MI][2][NI];   // [row sub-tile][a rows | gate rows][column sub-tile]
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[h][ni][r] = 0.f;
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] = 0.f;
 
   const int nchunks = (Cin + BKC - 1) / BKC;
   const int nsteps = (ABL == 5 || ABL == 9) ? 0 : nchunks * J;
-  const int a_off = wm * 32 + l31;
+  const int a_off = wm * (MI * 32) + l31;
   const int x_off = wn * (NI * 32) + l31;
 
   load_A(0, 0);
@@ -276,9 +278,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
       for (int s = 0; s < 2; ++s) {
         const int k8 = 2 * s + lhi;
         const int ai = k8 * BM + a_off;
-        const bf16x8 ah0 = AsH[ai], ah1 = AsH[ai + BMH];
-        bf16x8 al0 = ah0, al1 = ah1;
-        if (TERMS == 3) { al0 = AsL[ai]; al1 = AsL[ai + BMH]; }
+        bf16x8 ah[MI][2], al[MI][2];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          ah[mi][0] = AsH[ai + mi * 32];
+          ah[mi][1] = AsH[ai + mi * 32 + BMH];
+          al[mi][0] = ah[mi][0];
+          al[mi][1] = ah[mi][1];
+          if (TERMS == 3) { al[mi][0] = AsL[ai + mi * 32]; al[mi][1] = AsL[ai + mi * 32 + BMH]; }
+        }
         bf16x8 bh[NI], bl[NI];
         const int xi = k8 * BNH + x_off + j * dil;
 #pragma unroll
@@ -295,7 +303,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
           }
         }
         if (ABL == 4) {
-          asm volatile("" ::"v"(ah0), "v"(ah1), "v"(al0), "v"(al1));
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(ah[mi][0]), "v"(ah[mi][1]), "v"(al[mi][0]), "v"(al[mi][1]));
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(bh[ni]), "v"(bl[ni]));
           continue;
@@ -303,21 +312,27 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         // small terms first; each accumulator is touched once per pass (no back-to-back RAW)
         if (TERMS == 3) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[ni], acc[0][ni], 0, 0, 0);
-          acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[ni], acc[1][ni], 0, 0, 0);
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi][0], bh[ni], acc[mi][0][ni], 0, 0, 0);
+              acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi][1], bh[ni], acc[mi][1][ni], 0, 0, 0);
+            }
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi][0], bl[ni], acc[mi][0][ni], 0, 0, 0);
+              acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi][1], bl[ni], acc[mi][1][ni], 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[ni], acc[0][ni], 0, 0, 0);
-          acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[ni], acc[1][ni], 0, 0, 0);
-        }
-        }
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[ni], acc[0][ni], 0, 0, 0);
-          acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[ni], acc[1][ni], 0, 0, 0);
-        }
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi][0], bh[ni], acc[mi][0][ni], 0, 0, 0);
+            acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi][1], bh[ni], acc[mi][1][ni], 0, 0, 0);
+          }
       }
     }
 
@@ -331,8 +346,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   }
 
   // ABL 6: skip the epilogue but keep the accumulators live
-  if ((ABL != 6 && ABL != 9) || acc[0][0][0] + acc[1][0][0] + acc[0][NI - 1][5] + acc[1][NI - 1][7] == 1.2345e30f)
-    conv_epilogue<BM, BMH, NI, false, ABL>(p, acc, gated, mt, wm, lhi, bcol, tcol, okc);
+  if ((ABL != 6 && ABL != 9) || acc[0][0][0][0] + acc[MI - 1][1][0][0] + acc[0][0][NI - 1][5] + acc[MI - 1][1][NI - 1][7] == 1.2345e30f) {
+    static_assert(MI == 1 || MI == 2, "row sub-tiles per wave");
+    conv_epilogue<BM, BMH, NI, false, ABL>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+    if (MI == 2)
+      conv_epilogue<BM, BMH, NI, false, ABL>(p, acc[MI - 1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+  }
 }
 
 // packed fp32 [J][K][lda] -> split image [plane][j][k8][m][8]
@@ -357,11 +376,11 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
   dst[n + idx] = lo;
 }
 
-template <int WM, int WN, int NI, bool MASK, int TERMS>
+template <int WM, int WN, int NI, bool MASK, int TERMS, int MI = 1>
 int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_gemm_bf16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -370,7 +389,7 @@ int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(a.n_blocks), block(WM * WN * 64);
-  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI>), grid, block, lds, st, a);
   return dv3_check_launch("conv_gemm_bf16x3");
 }
 int g_x3_ablate = 0;   // debug: dv3_debug_set(); ablation variants of the 128x128 unmasked tile
@@ -380,6 +399,12 @@ int launch_x3_abl(const ConvArgs& a, size_t lds, hipStream_t st) {
                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<2, 2, 2, false, ABL>), dim3(a.n_blocks), dim3(256), lds, st, a);
   return dv3_check_launch("conv_gemm_bf16x3(abl)");
+}
+template <int WM, int WN, int NI, int MI>
+int launch_x3_big(const ConvArgs& a, size_t lds, hipStream_t st) {
+  if (a.d.split_terms == 1)
+    return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 1, MI>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 1, MI>(a, lds, st);
+  return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3, MI>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3, MI>(a, lds, st);
 }
 template <int WM, int WN, int NI>
 int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
@@ -409,18 +434,21 @@ const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
   const int64_t ntot = (int64_t)d->B * d->Tout;
   for (const TileCfg& c : kCfgs) {
     if (want_tile && c.id != want_tile) continue;
-    const int BM = c.wm * 64, BMH = c.wm * 32, BN = c.wn * c.ni * 32;
+    const int BM = c.wm * c.mi * 64, BMH = c.wm * c.mi * 32, BN = c.wn * c.ni * 32;
     const int64_t mt = gated ? dv3_cdiv(d->Cg, BMH) : dv3_cdiv(d->M, BM);
     const int64_t ntl = dv3_cdiv64(ntot, BN);
+    const double slots = c.id > 6 ? 256.0 : 512.0;   // the 256-wide tiles: one workgroup per CU
     // time ~ (rounds of the chip's 2 x 256 resident workgroups) x (tile work) x (operand traffic
     // per MFMA ~ 1/BN for the weight panel + 1/BM for the activation tile).  A last round with at
     // most one workgroup per CU runs those workgroups unshared, i.e. faster.
     const double blocks = (double)mt * ntl;
-    const double full = floor(blocks / 512.0), rem = blocks - 512.0 * full;
-    const double rounds = full + (rem == 0 ? 0.0 : (rem <= 256 ? 0.6 : 1.0));
+    const double full = floor(blocks / slots), rem = blocks - slots * full;
+    const double rounds = (full + (rem == 0 ? 0.0 : (c.id <= 6 && rem <= 256 ? 0.6 : 1.0))) * (slots / 512.0);
     // measured time per unit of tile work relative to the 128x128 tile (north-star shape, d = 1..27):
     // the 2-wave 64-row tiles and the 32-column tiles stage far more per MFMA
-    static const double kRel[7] = {0, 1.0, 1.12, 2.0, 2.2, 1.8, 2.0};
+    // 8-wave 256-wide tiles (one workgroup per CU): less weight-panel traffic per MFMA; the
+    // 128-row-per-wave tile (7, one wave per SIMD) measured slower everywhere: opt-in only (hint 27)
+    static const double kRel[10] = {0, 1.0, 1.12, 2.0, 2.2, 1.8, 2.0, 9.9, 0.93, 0.87};
     const double cost = rounds * BM * BN * kRel[c.id];
     if (!best || cost < best_cost) {
       best = &c;
@@ -445,7 +473,7 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   // the flat column axis needs batch-strided tensors only through (b, t) addressing: fine for all
   const TileCfg* best = pick_tile_x3(d, gated, d->tile_hint > 20 ? d->tile_hint - 20 : 0);
   if (!best) return 1;
-  const int BM = best->wm * 64, BMH = best->wm * 32, BN = best->wn * best->ni * 32;
+  const int BM = best->wm * best->mi * 64, BMH = best->wm * best->mi * 32, BN = best->wn * best->ni * 32;
   const int BNH = BN + (d->J - 1) * d->dil;
   const size_t lds = (size_t)(2 * 2 * KB * BM + 2 * 2 * KB * BNH) * 16;
   if (lds > 160 * 1024) return 1;
@@ -465,6 +493,9 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
     case 4: return launch_x3<2, 1, 1>(a, lds, st);
     case 5: return launch_x3<1, 2, 2>(a, lds, st);
     case 6: return launch_x3<1, 2, 1>(a, lds, st);
+    case 7: return launch_x3_big<2, 2, 2, 2>(a, lds, st);
+    case 8: return launch_x3_big<4, 2, 2, 1>(a, lds, st);
+    case 9: return launch_x3_big<2, 4, 2, 1>(a, lds, st);
   }
   return 1;
 }

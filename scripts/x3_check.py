@@ -112,31 +112,26 @@ def time_wgrad(B, M, Cin, T, J=3, dil=3, split=True, masked=True, iters=10):
 
 
 if __name__ == "__main__":
-    for sp in (True,):
-        time_wgrad(64, 512, 256, 800, split=sp)
-        time_wgrad(64, 1024, 512, 150, split=sp)
-        time_wgrad(64, 1024, 512, 800, split=sp)
-        time_wgrad(16, 512, 256, 800, split=sp)
     mask_check()
     for shape in [(3, 64, 200, 3, 1, False), (3, 96, 150, 3, 27, True), (3, 20, 37, 5, 3, False), (3, 128, 513, 3, 9, True),
                   (2, 256, 1024, 3, 1, False), (2, 512, 150, 3, 27, False)]:
-        for hint in (0, 21, 22, 23, 24, 25, 26):
+        for hint in ():
             try:
                 run(*shape, hint)
             except RuntimeError as e:
                 print('skip', shape, hint, str(e)[-60:])
     from deepvoice3_pytorch_amd import _lib
-    for abl in (0, 5, 6, 0):
+    for abl in ():
         _lib.call("dv3_debug_set", 1, abl)
         print("ablation", abl, end=": ")
         timeit(21, 1)
     _lib.call("dv3_debug_set", 1, 0)
-    for hint in (0, 21, 22, 1):
-        for dil in (1, 27):
+    for hint in (0, 21, 29, 0):
+        for dil in (1,):
             timeit(hint, dil)
-    timeit(1, 1, B=16, C=512, T=150)
-    timeit(0, 1, B=16, C=512, T=150)
-    timeit(0, 27, B=16, C=512, T=150)
-    timeit(0, 3, B=16, C=256, T=200)
+    for h in ():
+        timeit(h, 3, B=64, C=512, T=150)
+        timeit(h, 3, B=64, C=512, T=800)
+        timeit(h, 3, B=64, C=256, T=800)
     timeit(0, 3, B=16, C=256, T=800)
     timeit(0, 3, B=64, C=512, T=150)

@@ -94,7 +94,7 @@ def test_conv_gemm_glu_forward(dev, tile, C, T, k, d, causal):
         assert rel_err(y.cpu(), want) < KTOL
 
 
-@pytest.mark.parametrize("tile", [0, 21, 22, 23, 24, 25, 26])
+@pytest.mark.parametrize("tile", [0, 21, 22, 23, 24, 25, 26, 27, 28, 29])
 @pytest.mark.parametrize("B,C,T,k,d,causal", [(3, 64, 200, 3, 1, False), (3, 96, 150, 3, 27, True),
                                               (5, 24, 37, 5, 3, False), (2, 128, 513, 3, 9, True),
                                               (7, 40, 50, 2, 4, True)])
