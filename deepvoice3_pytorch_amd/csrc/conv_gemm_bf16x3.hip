@@ -500,8 +500,10 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   return 1;
 }
 
+extern int g_wgrad_tile;   // wgrad_gemm_bf16x3.hip
 extern "C" int dv3_debug_set(int what, int value) {
   if (what == 1) g_x3_ablate = value;
+  if (what == 2) g_wgrad_tile = value;
   return DV3_OK;
 }
 

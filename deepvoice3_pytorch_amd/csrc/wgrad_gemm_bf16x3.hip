@@ -304,29 +304,42 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
 
 }  // namespace
 
+int g_wgrad_tile = 0;   // debug (dv3_debug_set(2, v)): 0 auto, 1 force 128x128, 2 force 256x128
+
+template <int WM, int WN>
+static int launch_wgrad_x3(const WgradArgs& a, int64_t nb, hipStream_t st) {
+  const dv3_wgrad_desc* d = &a.d;
+  dim3 grid((unsigned)nb), block(WM * WN * 64);
+  if (d->split_bf16 == 2) {   // single-term bf16 (hi planes only)
+    if (d->xmask) {
+      hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<WM, WN, true, 1>), grid, block, 0, st, a);
+    } else {
+      hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<WM, WN, false, 1>), grid, block, 0, st, a);
+    }
+  } else if (d->xmask) {
+    hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<WM, WN, true, 3>), grid, block, 0, st, a);
+  } else {
+    hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<WM, WN, false, 3>), grid, block, 0, st, a);
+  }
+  return dv3_check_launch("wgrad_gemm_bf16x3");
+}
+
 // called by dv3_wgrad_gemm_f32 (wgrad_gemm.hip) when d->split_bf16 is set
 int dv3_wgrad_gemm_bf16x3_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
-  WgradArgs a;
-  a.d = *d;
-  a.m_tiles = dv3_cdiv(d->M, 128);
-  a.c_tiles = dv3_cdiv(d->Cin, 128);
-  const int64_t nb = (int64_t)a.m_tiles * a.c_tiles * d->J * d->n_slabs;
-  DV3_REQUIRE(nb < (1ll << 31), "wgrad_gemm: grid too large");
   // 32-bit element offsets inside the kernel
   if ((int64_t)d->B * d->g_bs + (int64_t)d->M * d->g_rs >= (1ll << 30) ||
       (int64_t)d->B * d->x_bs + (int64_t)d->Cin * d->x_rs >= (1ll << 30) ||
       (d->xmask && (int64_t)d->B * d->Cin * d->xmask_rs >= (1ll << 30)))
     return 1;   // caller falls back to the exact kernel
-  if (d->split_bf16 == 2) {   // single-term bf16 (hi planes only)
-    if (d->xmask) {
-      hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<2, 2, true, 1>), dim3((unsigned)nb), dim3(256), 0, st, a);
-    } else {
-      hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<2, 2, false, 1>), dim3((unsigned)nb), dim3(256), 0, st, a);
-    }
-  } else if (d->xmask) {
-    hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<2, 2, true, 3>), dim3((unsigned)nb), dim3(256), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((wgrad_gemm_bf16x3_kernel<2, 2, false, 3>), dim3((unsigned)nb), dim3(256), 0, st, a);
-  }
-  return dv3_check_launch("wgrad_gemm_bf16x3");
+  WgradArgs a;
+  a.d = *d;
+  // 128 x 128 (4 waves, two workgroups per CU).  The 256 x 128 8-wave variant (one workgroup per CU)
+  // measured within run-to-run noise of it (+-5 %, scripts/x3_check.py): kept behind the debug knob.
+  const bool big = g_wgrad_tile == 2;
+  const int bm = big ? 256 : 128;
+  a.m_tiles = dv3_cdiv(d->M, bm);
+  a.c_tiles = dv3_cdiv(d->Cin, 128);
+  const int64_t nb = (int64_t)a.m_tiles * a.c_tiles * d->J * d->n_slabs;
+  DV3_REQUIRE(nb < (1ll << 31), "wgrad_gemm: grid too large");
+  return big ? launch_wgrad_x3<4, 2>(a, nb, st) : launch_wgrad_x3<2, 2>(a, nb, st);
 }

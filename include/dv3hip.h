@@ -37,7 +37,8 @@ const char* dv3_last_error(void);
 int dv3_device_info(int dev, char* name, int name_len, int* n_cu);
 /* sizeof(struct <name>) or -1: lets a foreign-language mirror of the descriptors self-check */
 int dv3_sizeof(const char* name);
-/* Developer knobs for measurements (what = 1: ablation variant of the bf16x3 tap-GEMM; 0 = off). */
+/* Developer knobs for measurements (what = 1: ablation variant of the bf16x3 tap-GEMM, 0 = off;
+ * what = 2: bf16x3 wgrad tile, 0 auto / 1 = 128x128 / 2 = 256x128). */
 int dv3_debug_set(int what, int value);
 
 /* ------------------------------------------------------------------------------------

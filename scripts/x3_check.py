@@ -87,11 +87,14 @@ def mask_check(B=3, C=96, T=150, k=3, d=9):
     print("masked x3 vs f32: max rel %.2e" % float((ys[0] - ys[1]).abs().max() / ys[0].abs().max()))
 
 
-def time_wgrad(B, M, Cin, T, J=3, dil=3, split=True, masked=True, iters=10):
+def time_wgrad(B, M, Cin, T, J=3, dil=3, split=True, masked=True, iters=10, big=0):
+    from deepvoice3_pytorch_amd import _lib
+    _lib.call("dv3_debug_set", 2, 2 if big else 1)
     g = torch.randn(B, M, T, device=dev)
     x = torch.randn(B, Cin, T, device=dev)
-    tiles = ((M + 127) // 128) * ((Cin + 127) // 128) * J
-    S = ops._ksplit_count(B * ((T + 31) // 32), tiles) if split else ops._slab_count(B, tiles)
+    bm = 256 if big else 128
+    tiles = ((M + bm - 1) // bm) * ((Cin + 127) // 128) * J
+    S = ops._ksplit_count(B * ((T + 31) // 32), tiles, slots=256 if big else 512) if split else ops._slab_count(B, tiles)
     bits, rs = (ops.dropout_bits(B * Cin, T, 0.05, dev) if masked else (None, 0))
     out = torch.empty(S, J, M, Cin, device=dev)
     def launch():
@@ -108,14 +111,19 @@ def time_wgrad(B, M, Cin, T, J=3, dil=3, split=True, masked=True, iters=10):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     fl = 2.0 * B * T * M * Cin * J
-    print("wgrad split=%d B=%d M=%d Cin=%d T=%d S=%d: %8.1f us  %7.1f TFLOP/s" % (split, B, M, Cin, T, S, us, fl / us / 1e6))
+    print("wgrad split=%d big=%d B=%d M=%d Cin=%d T=%d S=%d: %8.1f us  %7.1f TFLOP/s" % (split, big, B, M, Cin, T, S, us, fl / us / 1e6))
+    _lib.call("dv3_debug_set", 2, 0)
 
 
 if __name__ == "__main__":
+    for rep in range(2):      # interleaved A/B: the first seconds of a process run at lower clocks
+        for big in (0, 1):
+            time_wgrad(64, 512, 256, 800, big=big)
+            time_wgrad(64, 1024, 512, 150, big=big)
     mask_check()
     for shape in [(3, 64, 200, 3, 1, False), (3, 96, 150, 3, 27, True), (3, 20, 37, 5, 3, False), (3, 128, 513, 3, 9, True),
                   (2, 256, 1024, 3, 1, False), (2, 512, 150, 3, 27, False)]:
-        for hint in ():
+        for hint in (0, 21, 22, 28, 29):
             try:
                 run(*shape, hint)
             except RuntimeError as e:
@@ -126,8 +134,8 @@ if __name__ == "__main__":
         print("ablation", abl, end=": ")
         timeit(21, 1)
     _lib.call("dv3_debug_set", 1, 0)
-    for hint in (0, 21, 29, 0):
-        for dil in (1,):
+    for hint in (0, 21, 29, 21, 29):
+        for dil in (1, 27):
             timeit(hint, dil)
     for h in ():
         timeit(h, 3, B=64, C=512, T=150)
