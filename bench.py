@@ -225,6 +225,7 @@ def synth_bench(dev, args):
     model.make_generation_fast_()
     dec = model.seq2seq.decoder
     dec.min_decoder_steps = dec.max_decoder_steps = 200
+    dec.use_step_graph = not args.no_graph       # replay one hipGraph per decoder step
     B, Tt = args.batch, 100
     rng = np.random.RandomState(0)
     text = torch.from_numpy(rng.randint(2, hp["n_vocab"], (B, Tt))).to(dev)
@@ -253,7 +254,7 @@ def synth_bench(dev, args):
                warmup=max(1, args.warmup // 3), ms_per_step=round(wall * 1e3, 2), higher_is_better=False,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic text ids, random-init weights",
                config=dict(workload="builder=deepvoice3 preset=deepvoice3_ljspeech synthesis, Tt=100, 201 decoder steps "
-                                    "= 804 frames per utterance", utterances=B, griffin_lim_iters=args.gl_iters,
+                                    "= 804 frames per utterance", utterances=B, griffin_lim_iters=args.gl_iters, step_hipgraph=bool(dec.use_step_graph),
                            audio_seconds=round(audio_s, 1), model_ms=round(float(np.mean(tm)) * 1e3, 1),
                            vocoder_ms=round(float(np.mean(tv)) * 1e3, 1),
                            rtf_model_only=round(float(np.mean(tm)) / audio_s, 6),
@@ -381,6 +382,20 @@ def main():
                            per_gpu_batch=args.batch, global_batch=args.batch * world, text_len=args.text_len,
                            frames_per_item=args.frames, parallelism="dp%d" % world,
                            hipgraph=bool(use_graph), gemm=ops.gemm_precision(), final_loss=round(loss, 5)))
+    # the boundary can also be handed host buffers (train.py:655-663 copies 8 tensors per step): time the
+    # H2D of one pinned batch and report the rate with that copy serialised in front of every step
+    pinned = {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in bt.items()}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        train_step.Batch.from_collate(pinned["text"], pinned["input_lengths"], pinned["mel"], pinned["y"],
+                                      pinned["text_positions"], pinned["frame_positions"], pinned["done"],
+                                      pinned["target_lengths"], spk, downsample_step=4, device=dev)
+        torch.cuda.synchronize()
+    h2d_ms = (time.perf_counter() - t0) / 3 * 1e3
+    out["host_buffers"] = dict(h2d_ms_per_batch=round(h2d_ms, 3),
+                               value_with_serial_h2d=round(float(frames.item()) / ((ms + h2d_ms) * 1e-3), 1),
+                               note="pinned host batch -> HBM copied synchronously before each step; never `value`")
     if not args.no_roofline:
         out["roofline"] = conv_roofline(dev, mode="bf16x3" if ops.gemm_precision() == "bf16" else None)
         if ops.gemm_precision() != "f32":      # the exact-fp32 kernel beside it, for the record

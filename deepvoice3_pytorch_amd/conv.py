@@ -121,20 +121,15 @@ class Conv1d(_WNLayer):
             xb = x_t.reshape(B, self.in_channels, 1)
             lbuf = 1
         else:
+            # the last k + (k-1)(d-1) frames, newest last; shifted in place by one HIP launch per step
+            # (static addresses: the whole decode step can be captured as a hipGraph)
             lbuf = k + (k - 1) * (d - 1)
             if self.input_buffer is None or self.input_buffer.size(0) != B:
-                self._buf_cap = lbuf + 1024
-                self.input_buffer = x_t.new_zeros(B, self.in_channels, self._buf_cap)
-                self._buf_pos = lbuf - 1            # index of the newest frame
-            else:
-                self._buf_pos += 1
-                if self._buf_pos >= self._buf_cap:   # wrap: move the live window to the front
-                    live = self.input_buffer[:, :, self._buf_pos - lbuf + 1:self._buf_pos].clone()
-                    self.input_buffer.zero_()
-                    self.input_buffer[:, :, :lbuf - 1] = live
-                    self._buf_pos = lbuf - 1
-            self.input_buffer[:, :, self._buf_pos] = x_t
-            xb = self.input_buffer[:, :, self._buf_pos - lbuf + 1:self._buf_pos + 1]
+                self.input_buffer = x_t.new_zeros(B, self.in_channels, lbuf)
+            xc = x_t if x_t.stride(-1) == 1 and x_t.stride(0) == self.in_channels else x_t.contiguous()
+            ops._lib.call("dv3_shift_append_f32", self.input_buffer.data_ptr(), xc.data_ptr(),
+                          B * self.in_channels, lbuf, 1, ops._stream())
+            xb = self.input_buffer
         with torch.no_grad():
             gate = _gate or {}
             mode = gate.get("mode", ops.EPI_LINEAR)
@@ -151,9 +146,13 @@ class Conv1d(_WNLayer):
         return y.transpose(1, 2)                    # (B, 1, out) view of (B, out, 1)
 
     def clear_buffer(self):
-        self.input_buffer = None
-        self._buf_pos = 0
-        self._buf_cap = 0
+        """forget the window (reference conv.py:48-49).  An existing buffer is zeroed in place rather
+        than dropped, so a captured decode-step graph keeps pointing at live memory."""
+        buf = self.__dict__.get("input_buffer")
+        if buf is not None:
+            buf.zero_()
+        else:
+            self.input_buffer = None
 
 
 class Linear(_WNLayer):

@@ -212,6 +212,30 @@ __global__ __launch_bounds__(256) void embedding_bct_kernel(const int64_t* __res
   }
 }
 
+// Incremental-conv window (conv.py:34-46: `input_buffer[:, :-1] = input_buffer[:, 1:]; buffer[:, -1] = x`):
+// buf [rows][L] shifts left by one frame and takes x[row] as its newest frame.  One wave per row: all
+// lanes load (l+1) before any lane stores (l), so the in-place shift is race free; static addresses keep
+// the decode step hipGraph-capturable.
+__global__ __launch_bounds__(256) void shift_append_kernel(float* __restrict__ buf,
+                                                           const float* __restrict__ x, int64_t rows,
+                                                           int L, int64_t x_stride) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float* b = buf + row * L;
+  const float newest = x[row * x_stride];
+  for (int l0 = 0; l0 < L; l0 += 64) {       // L <= 64 for every reference layer; loop kept for generality
+    const int l = l0 + lane;
+    float v = 0.f;
+    if (l < L) v = (l + 1 < L) ? b[l + 1] : newest;
+    __builtin_amdgcn_s_waitcnt(0);           // every load of this pass has landed
+    __builtin_amdgcn_wave_barrier();
+    if (l < L) b[l] = v;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Dense embedding gradient, deterministic: one block per vocabulary id.  The (b,t) positions that
 // hold the id are compacted IN ORDER into LDS (each thread scans a contiguous slice, counts, an
 // exclusive scan gives its write offset), then every thread owns one channel and sums dout over
@@ -440,6 +464,14 @@ extern "C" int dv3_embedding_bct_bwd_f32(const int64_t* idx, const float* dout, 
                      (hipStream_t)stream, idx, dout, dw, mask, mask_rs, drop_scale, B, T, C,
                      padding_idx);
   return dv3_check_launch("embedding_bct_bwd_f32");
+}
+
+extern "C" int dv3_shift_append_f32(float* buf, const float* x, int64_t rows, int32_t L, int64_t x_stride,
+                                    void* stream) {
+  DV3_REQUIRE(buf && x && rows > 0 && L > 0, "shift_append: bad args");
+  hipLaunchKernelGGL(shift_append_kernel, dim3((unsigned)dv3_cdiv64(rows, 4)), dim3(256), 0,
+                     (hipStream_t)stream, buf, x, rows, L, x_stride);
+  return dv3_check_launch("shift_append_f32");
 }
 
 extern "C" int dv3_sincos_pos_bct_f32(const int64_t* pos, const float* table, const float* w,

@@ -260,6 +260,7 @@ class Decoder(nn.Module):
 
         self.max_decoder_steps = 200
         self.min_decoder_steps = 10
+        self.use_step_graph = False     # free-running decode: replay one hipGraph per step
         self.use_memory_mask = use_memory_mask
         if isinstance(force_monotonic_attention, bool):
             self.force_monotonic_attention = [force_monotonic_attention] * len(convolutions)
@@ -360,24 +361,13 @@ class Decoder(nn.Module):
                          for v in self.force_monotonic_attention]
         num_attention_layers = sum([layer is not None for layer in self.attention])
         wq = self._rate(self.query_position_rate, self.speaker_proj2, speaker_embed)
-        t = 0
         if initial_input is None:
             initial_input = keys.new_zeros(B, 1, self.in_dim * self.r)
-        current_input = initial_input
-        while True:
-            frame_pos = torch.full((B, 1), t + 1, dtype=torch.long, device=dev)
+
+        def step(x, frame_pos):
+            """one decoder step (deepvoice3.py:397-461): x (B,1,in_dim*r), frame_pos (B,1) long"""
             frame_pos_embed = self.embed_query_positions.forward_bct(frame_pos, wq)   # (B, C, 1)
-
-            if test_inputs is not None:
-                if t >= test_inputs.size(1):
-                    break
-                current_input = test_inputs[:, t, :].unsqueeze(1)
-            else:
-                if t > 0:
-                    current_input = outputs[-1]
-            x = current_input
             x = self._incremental_stack(self.preattention, x, speaker_embed)
-
             ave_alignment = None
             for idx, (f, attention) in enumerate(zip(self.convolutions, self.attention)):
                 residual = x
@@ -398,12 +388,46 @@ class Decoder(nn.Module):
                     else:
                         ave_alignment = ave_alignment + ave_alignment
                 x = (x + residual) * math.sqrt(0.5)
-
             decoder_state = x
             x = self.last_conv.incremental_forward(x)
             ave_alignment = ave_alignment / num_attention_layers
-            output = torch.sigmoid(x)
-            done = torch.sigmoid(self.fc(x))
+            return torch.sigmoid(x), torch.sigmoid(self.fc(x)), decoder_state, ave_alignment
+
+        # Free-running decode can replay ONE captured hipGraph per step (~100 launches): every address in
+        # the step is static (in-place conv windows, device-side last_attended and position counter).
+        graphed = bool(getattr(self, "use_step_graph", False)) and test_inputs is None and keys.is_cuda
+        t = 0
+        if graphed:
+            step_in = initial_input.clone()
+            step_pos = torch.ones((B, 1), dtype=torch.long, device=dev)
+            graph, gout = None, None
+        current_input = initial_input
+        while True:
+            if test_inputs is not None:
+                if t >= test_inputs.size(1):
+                    break
+                current_input = test_inputs[:, t, :].unsqueeze(1)
+            elif t > 0 and not graphed:
+                current_input = outputs[-1]
+
+            if not graphed:
+                frame_pos = torch.full((B, 1), t + 1, dtype=torch.long, device=dev)
+                output, done, decoder_state, ave_alignment = step(current_input, frame_pos)
+            else:
+                if t == 0:        # eager: also fills the packed-weight caches the graph will reuse
+                    res = step(step_in, step_pos)
+                    step_in.copy_(res[0])
+                    step_pos.add_(1)
+                else:
+                    if graph is None:
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph):
+                            gout = step(step_in, step_pos)
+                            step_in.copy_(gout[0])
+                            step_pos.add_(1)
+                    graph.replay()
+                    res = gout
+                output, done, decoder_state, ave_alignment = [r.clone() for r in res]
 
             decoder_states += [decoder_state]
             outputs += [output]

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 17
+#define DV3_ABI_VERSION 18
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -285,6 +285,10 @@ int dv3_sincos_pos_bct_f32(const int64_t* pos, const float* table, const float* 
 int dv3_sincos_pos_bwd_f32(const int64_t* pos, const float* table, const float* w,
                            int32_t w_per_batch, const float* dout, float* dw, int32_t B, int32_t T,
                            int32_t C, int32_t n_pos, void* stream);
+/* Incremental-conv window (conv.py:34-46): buf [rows][L] shifts left one frame and takes
+ * x[row * x_stride] as its newest; in place, static addresses (hipGraph-capturable decode step) */
+int dv3_shift_append_f32(float* buf, const float* x, int64_t rows, int32_t L, int64_t x_stride,
+                         void* stream);
 /* dy [B][O][2T] -> out[b][j*O+o][t] = dy[b][o][2t+j]: operand of the ConvTranspose1d(k2,s2)
  * backward GEMMs (deepvoice3.py:519-520,527-528)                                          */
 int dv3_deinterleave2_f32(const float* dy, float* out, int32_t B, int32_t O, int32_t T,

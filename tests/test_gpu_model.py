@@ -348,3 +348,25 @@ def test_bf16_mode_forward_and_gradients(dev, name, gemm_mode):
         assert cos > 0.999, cos
     finally:
         ops.set_gemm_precision(prev)
+
+
+def test_graphed_decode_equals_eager_decode(dev, gemm_mode):
+    """free-running decode with one captured hipGraph per step (decoder.use_step_graph, what
+    bench.py --mode synth times) must reproduce the eager step-by-step decode"""
+    fx, b, hp, sd, x, model = _build("dv3_tiny", dev)
+    model.eval()
+    model.make_generation_fast_()
+    dec = model.seq2seq.decoder
+    dec.min_decoder_steps = dec.max_decoder_steps = 12
+    xg = _to(x, dev)
+    outs = {}
+    for graphed in (False, True, True):
+        dec.use_step_graph = graphed
+        with torch.no_grad():
+            outs[graphed] = model(xg["text"], text_positions=xg["text_positions"])
+    dec.use_step_graph = False
+    for a, bb, n in zip(outs[False], outs[True], ("mel", "linear", "alignments", "done")):
+        a = torch.stack(a) if isinstance(a, (list, tuple)) else a
+        bb = torch.stack(bb) if isinstance(bb, (list, tuple)) else bb
+        assert a.shape == bb.shape, n
+        assert rel_err(bb.cpu(), a.cpu()) < 1e-6, n
