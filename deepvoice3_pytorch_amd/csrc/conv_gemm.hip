@@ -168,7 +168,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_f32_kernel(const ConvAr
 // fragments coalesced from L1/L2 (128-B row segments per half-wave) through a PF-deep software
 // prefetch ring and never synchronises with its neighbours.  rocprofv3 on the LDS-staged kernel
 // showed the matrix pipe 52% busy with waves parked 34% of their life at s_waitcnt/s_barrier
-// (profiles/r01_conv_gemm_pmc.md); this removes every such wait.
+// (profiles/r01_conv_gemm_f32_pmc.md); this removes every such wait.
 // K order: channel pairs outer, taps inner, so the J shifted re-reads of an x row hit L1.
 // ------------------------------------------------------------------------------------------
 template <int WM, int WN, int NI, bool MASK>
