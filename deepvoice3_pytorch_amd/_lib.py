@@ -147,6 +147,10 @@ def lib():
         if n != ctypes.sizeof(cls):
             raise Dv3LibraryError("struct %s: C sizeof %d != ctypes %d" % (name, n, ctypes.sizeof(cls)))
     _lib = h
+    # developer knobs (include/dv3hip.h: dv3_debug_set) from the environment, for A/B runs
+    for what, var in ((1, "DV3_X3_ABLATE"), (2, "DV3_WGRAD_TILE")):
+        if os.environ.get(var):
+            h.dv3_debug_set(what, int(os.environ[var]))
     return h
 
 
