@@ -1,0 +1,55 @@
+# coding: utf-8
+"""Batch assembly in the conventions of the reference's train.collate_fn (train.py:293-360), so a
+training loop can feed train_step.Trainer from the reference's own datasets: ragged (text ids, mel,
+linear[, speaker id]) items -> padded tensors + position tensors + done flags.
+
+Host-side (numpy) like the reference; the masks and guided-attention weights that the reference
+builds on the host afterwards (train.py:261-271,594-601) are computed on the device by the loss
+kernels from the length vectors this function returns.
+"""
+import numpy as np
+import torch
+
+from .train_step import Batch
+
+
+def collate_fn(batch, outputs_per_step=1, downsample_step=4):
+    """-> (x, input_lengths, mel, y, (text_positions, frame_positions), done, target_lengths,
+    speaker_ids), exactly the reference's tuple (train.py:359-360)."""
+    r, ds = int(outputs_per_step), int(downsample_step)
+    n = len(batch)
+    multi_speaker = len(batch[0]) == 4
+    in_len = np.array([len(item[0]) for item in batch], dtype=np.int64)
+    tgt_len = np.array([len(item[1]) for item in batch], dtype=np.int64)
+    # frames: round the longest target up to r and to downsample_step, then b_pad = r leading
+    # zero frames per decoder stride ("imitates initial decoder states", train.py:313-316)
+    T = int(tgt_len.max())
+    T += (-T) % r
+    T += (-T) % ds
+    b_pad = r
+    T += b_pad * ds
+    Tt = int(in_len.max())
+    x = np.zeros((n, Tt), dtype=np.int64)
+    tpos = np.zeros((n, Tt), dtype=np.int64)
+    mel = np.zeros((n, T, batch[0][1].shape[1]), dtype=np.float32)
+    y = np.zeros((n, T, batch[0][2].shape[1]), dtype=np.float32)
+    Td = T // r // ds
+    done = np.ones((n, Td, 1), dtype=np.float32)
+    for i, item in enumerate(batch):
+        L, F = int(in_len[i]), int(tgt_len[i])
+        x[i, :L] = item[0]
+        tpos[i, :L] = np.arange(1, L + 1)
+        mel[i, b_pad:b_pad + F] = item[1]
+        y[i, b_pad:b_pad + F] = item[2]
+        done[i, :max(F // r // ds - 1, 0)] = 0.0
+    fpos = np.tile(np.arange(1, Td + 1, dtype=np.int64)[None], (n, 1))
+    spk = torch.from_numpy(np.array([item[3] for item in batch], dtype=np.int64)) if multi_speaker else None
+    return (torch.from_numpy(x), torch.from_numpy(in_len), torch.from_numpy(mel), torch.from_numpy(y),
+            (torch.from_numpy(tpos), torch.from_numpy(fpos)), torch.from_numpy(done), torch.from_numpy(tgt_len), spk)
+
+
+def to_device_batch(collated, device, outputs_per_step=1, downsample_step=4):
+    """collate_fn's tuple -> train_step.Batch on `device` (mel time-downsampled as train.py:639-640)."""
+    x, in_len, mel, y, (tpos, fpos), done, tgt_len, spk = collated
+    return Batch.from_collate(x, in_len, mel, y, tpos, fpos, done, tgt_len, spk, downsample_step, device,
+                              r=outputs_per_step)

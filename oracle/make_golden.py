@@ -263,6 +263,34 @@ def gen_misc():
     print("wrote misc.npz")
 
 
+def gen_collate():
+    """The reference's own train.collate_fn on ragged items, single- and multi-speaker, r in {1, 2}."""
+    train, hparams, _ = refimport.load_train_module()
+    out = {}
+    rng = np.random.RandomState(21)
+    for case, (r, ds, spk) in enumerate([(1, 4, False), (2, 4, True), (1, 1, False), (4, 1, True)]):
+        hparams.outputs_per_step, hparams.downsample_step = r, ds
+        items = []
+        for n_frames, n_text in [(37, 9), (52, 13), (8, 2), (44, 11)]:
+            it = (np.concatenate([rng.randint(2, 149, size=n_text - 1), [1]]).astype(np.int64),
+                  rng.rand(n_frames, 5).astype(np.float32), rng.rand(n_frames, 7).astype(np.float32))
+            items.append(it + ((int(rng.randint(0, 10)),) if spk else ()))
+        x, in_len, mel, y, (tp, fp), done, tgt_len, sid = train.collate_fn(items)
+        pre = "c%d/" % case
+        out[pre + "r_ds"] = np.array([r, ds], dtype=np.int64)
+        for i, it in enumerate(items):
+            out[pre + "item%d/text" % i], out[pre + "item%d/mel" % i], out[pre + "item%d/y" % i] = it[0], it[1], it[2]
+            if spk:
+                out[pre + "item%d/spk" % i] = np.int64(it[3])
+        for k, v in dict(x=x, input_lengths=in_len, mel=mel, y=y, text_positions=tp, frame_positions=fp,
+                         done=done, target_lengths=tgt_len).items():
+            out[pre + "out/" + k] = _np(v)
+        if spk:
+            out[pre + "out/speaker_ids"] = _np(sid)
+    np.savez_compressed(os.path.join(OUT, "collate.npz"), **out)
+    print("wrote collate.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, b, hp in MODELS:
@@ -270,6 +298,7 @@ def main():
     gen_losses()
     gen_misc()
     gen_trainstep()
+    gen_collate()
 
 
 if __name__ == "__main__":

@@ -111,6 +111,36 @@ def test_lr_schedule_and_batch_rules():
     assert float(bt["done"][0, : 203 // 4 - 1].sum()) == 0.0 and float(bt["done"][0, 203 // 4 - 1:].min()) == 1.0
 
 
+def test_collate_fn_matches_reference():
+    """deepvoice3_pytorch_amd.data.collate_fn against the reference's own train.collate_fn
+    (tests/golden/collate.npz, generated by oracle/make_golden.py from the unmodified reference):
+    ragged items, r in {1, 2, 4}, downsample_step in {1, 4}, with and without speaker ids -- bit exact."""
+    from deepvoice3_pytorch_amd import data
+    fx = load_golden("collate")
+    cases = sorted({k.split("/")[0] for k in fx})
+    assert len(cases) == 4
+    for c in cases:
+        r, ds = [int(v) for v in fx[c + "/r_ds"]]
+        items, i = [], 0
+        while "%s/item%d/text" % (c, i) in fx:
+            it = (fx["%s/item%d/text" % (c, i)], fx["%s/item%d/mel" % (c, i)], fx["%s/item%d/y" % (c, i)])
+            if "%s/item%d/spk" % (c, i) in fx:
+                it = it + (int(fx["%s/item%d/spk" % (c, i)]),)
+            items.append(it)
+            i += 1
+        x, in_len, mel, y, (tp, fp), done, tgt_len, sid = data.collate_fn(items, outputs_per_step=r, downsample_step=ds)
+        got = dict(x=x, input_lengths=in_len, mel=mel, y=y, text_positions=tp, frame_positions=fp, done=done,
+                   target_lengths=tgt_len)
+        for k, v in got.items():
+            want = fx["%s/out/%s" % (c, k)]
+            assert v.shape == want.shape, (c, k, v.shape, want.shape)
+            assert np.array_equal(v.numpy(), want), (c, k)
+        if sid is not None:
+            assert np.array_equal(sid.numpy(), fx[c + "/out/speaker_ids"])
+        else:
+            assert c + "/out/speaker_ids" not in fx
+
+
 def _ddp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist

@@ -97,7 +97,11 @@ def test_conv_gemm_glu_forward(dev, tile, C, T, k, d, causal):
 @pytest.mark.parametrize("tile", [0, 21, 22, 23, 24, 25, 26, 27, 28, 29])
 @pytest.mark.parametrize("B,C,T,k,d,causal", [(3, 64, 200, 3, 1, False), (3, 96, 150, 3, 27, True),
                                               (5, 24, 37, 5, 3, False), (2, 128, 513, 3, 9, True),
-                                              (7, 40, 50, 2, 4, True)])
+                                              (7, 40, 50, 2, 4, True),
+                                              # degenerate sizes: one frame, sequences shorter than the
+                                              # receptive field, a 1x1 conv
+                                              (1, 8, 1, 3, 1, True), (1, 16, 3, 3, 2, False),
+                                              (2, 8, 33, 1, 1, False)])
 def test_conv_gemm_bf16x3_forward(dev, gemm_mode, tile, B, C, T, k, d, causal):
     """the split-bf16 tap-GEMM, every tile: column tiles span several batch items here (B*T is
     flattened), so the per-fragment sequence-edge zeroing is exercised for every tap"""
