@@ -263,3 +263,68 @@ class GraphedTrainer(object):
         self.graph.replay()
         self.t.global_step += 1
         return self.scal
+
+
+# ------------------------------------------------------------------------------------------------
+# checkpoint interop with the reference (train.py:788-867): same file name, same dict
+#   {"state_dict", "optimizer" (torch.optim.Adam.state_dict() layout), "global_step", "global_epoch"}
+# so a run can move between the reference trainer and this one in either direction.
+# ------------------------------------------------------------------------------------------------
+def checkpoint_dict(trainer, global_epoch=0, save_optimizer_state=True):
+    """The dict train.save_checkpoint writes (train.py:800-807), from the flat arena."""
+    a, c = trainer.arena, trainer.cfg
+    opt = None
+    if save_optimizer_state:
+        state = {}
+        if trainer.adam_step > 0:
+            for i, (o, n, p) in enumerate(zip(a.offsets, a.sizes, a.params)):
+                state[i] = dict(step=torch.tensor(float(trainer.adam_step)),
+                                exp_avg=a.exp_avg[o:o + n].view(p.shape).clone(),
+                                exp_avg_sq=a.exp_avg_sq[o:o + n].view(p.shape).clone())
+        group = dict(lr=float(trainer.current_lr()), betas=(c.adam_beta1, c.adam_beta2), eps=c.adam_eps,
+                     weight_decay=c.weight_decay, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                     differentiable=False, fused=None, params=list(range(len(a.params))))
+        opt = dict(state=state, param_groups=[group])
+    return {"state_dict": {k: v.detach().clone() for k, v in trainer.model.state_dict().items()},
+            "optimizer": opt, "global_step": trainer.global_step, "global_epoch": global_epoch}
+
+
+def save_checkpoint(trainer, checkpoint_dir, global_epoch=0, save_optimizer_state=True):
+    """train.save_checkpoint (train.py:788-809): checkpoint_step{:09d}.pth in `checkpoint_dir`."""
+    import os
+    path = os.path.join(checkpoint_dir, "checkpoint_step{:09d}.pth".format(trainer.global_step))
+    torch.save(checkpoint_dict(trainer, global_epoch, save_optimizer_state), path)
+    return path
+
+
+def load_checkpoint(path_or_dict, trainer, reset_optimizer=False):
+    """train.load_checkpoint (train.py:852-867): model weights, (unless reset_optimizer) the Adam
+    moments, and the two counters.  Returns global_epoch.  Accepts files written by the reference:
+    its optimizer enumerates get_trainable_parameters() in the same order the arena does."""
+    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu")
+    a = trainer.arena
+    with torch.no_grad():     # copy INTO the arena views (load_state_dict would keep them too; be explicit)
+        own = trainer.model.state_dict()
+        missing = [k for k in own if k not in ck["state_dict"]]
+        unexpected = [k for k in ck["state_dict"] if k not in own]
+        if missing or unexpected:
+            raise RuntimeError("state_dict mismatch: missing %s unexpected %s" % (missing, unexpected))
+        for k, v in ck["state_dict"].items():
+            own[k].copy_(v)
+    opt = ck.get("optimizer")
+    if opt is not None and not reset_optimizer:
+        if len(opt["param_groups"]) != 1 or len(opt["param_groups"][0]["params"]) != len(a.params):
+            raise RuntimeError("optimizer state does not match get_trainable_parameters()")
+        steps = set()
+        for i, (o, n) in enumerate(zip(a.offsets, a.sizes)):
+            st = opt["state"].get(i)
+            if st is None:
+                continue
+            a.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            a.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise RuntimeError("per-parameter Adam step counts differ: %s" % sorted(steps))
+        trainer.adam_step = steps.pop() if steps else 0
+    trainer.global_step = int(ck["global_step"])
+    return int(ck.get("global_epoch", 0))

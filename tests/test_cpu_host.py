@@ -111,6 +111,45 @@ def test_lr_schedule_and_batch_rules():
     assert float(bt["done"][0, : 203 // 4 - 1].sum()) == 0.0 and float(bt["done"][0, 203 // 4 - 1:].min()) == 1.0
 
 
+def test_checkpoint_interop_with_torch_adam_layout(tmp_path):
+    """train_step.save/load_checkpoint speak the reference's checkpoint format (train.py:788-867):
+    the optimizer entry loads into a torch.optim.Adam over get_trainable_parameters() and back."""
+    from deepvoice3_pytorch_amd import builder, train_step
+    hp = dict(n_vocab=20, embed_dim=16, mel_dim=8, linear_dim=9, r=1, downsample_step=4, padding_idx=0, dropout=0.0,
+              kernel_size=3, encoder_channels=16, decoder_channels=16, converter_channels=16, max_positions=32)
+    torch.manual_seed(0)
+    model = builder.deepvoice3(**hp)
+    tr = train_step.Trainer(model, train_step.TrainConfig(max_positions=32), global_step=41)
+    tr.adam_step = 7
+    tr.arena.exp_avg.copy_(torch.randn_like(tr.arena.exp_avg))
+    tr.arena.exp_avg_sq.copy_(torch.rand_like(tr.arena.exp_avg_sq))
+    path = train_step.save_checkpoint(tr, str(tmp_path), global_epoch=3)
+    assert os.path.basename(path) == "checkpoint_step000000041.pth"
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert sorted(ck) == ["global_epoch", "global_step", "optimizer", "state_dict"]
+    # the reference side: a fresh model + torch Adam over get_trainable_parameters() takes it as is
+    torch.manual_seed(1)
+    model2 = builder.deepvoice3(**hp)
+    model2.load_state_dict(ck["state_dict"])
+    opt = torch.optim.Adam(model2.get_trainable_parameters(), lr=5e-4, betas=(0.5, 0.9), eps=1e-6)
+    opt.load_state_dict(ck["optimizer"])
+    p0 = next(iter(model2.get_trainable_parameters()))
+    assert torch.equal(opt.state[p0]["exp_avg"], tr.arena.exp_avg[:p0.numel()].view(p0.shape))
+    assert float(opt.state[p0]["step"]) == 7.0
+    # ... and a checkpoint written by that optimizer comes back into a fresh trainer
+    ref_ck = {"state_dict": model2.state_dict(), "optimizer": opt.state_dict(), "global_step": 1234, "global_epoch": 5}
+    torch.manual_seed(2)
+    tr3 = train_step.Trainer(builder.deepvoice3(**hp), train_step.TrainConfig(max_positions=32))
+    assert train_step.load_checkpoint(ref_ck, tr3) == 5
+    assert tr3.global_step == 1234 and tr3.adam_step == 7
+    for o, n in zip(tr.arena.offsets, tr.arena.sizes):           # (the 4-element alignment pads are not state)
+        assert torch.equal(tr3.arena.exp_avg[o:o + n], tr.arena.exp_avg[o:o + n])
+        assert torch.equal(tr3.arena.exp_avg_sq[o:o + n], tr.arena.exp_avg_sq[o:o + n])
+        assert torch.equal(tr3.arena.flat[o:o + n], tr.arena.flat[o:o + n])     # parameters live in the arena
+    for (k, v), (k2, v2) in zip(tr3.model.state_dict().items(), model.state_dict().items()):
+        assert k == k2 and torch.equal(v, v2)
+
+
 def test_collate_fn_matches_reference():
     """deepvoice3_pytorch_amd.data.collate_fn against the reference's own train.collate_fn
     (tests/golden/collate.npz, generated by oracle/make_golden.py from the unmodified reference):
