@@ -40,6 +40,7 @@ class BucketedAllReduce(object):
         for b, (_, _, plist) in enumerate(self.buckets):
             for i in plist:
                 self.bucket_of[i] = b
+        self.notified = [False] * len(arena.params)
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self._armed = False
@@ -53,8 +54,12 @@ class BucketedAllReduce(object):
 
     def _make_hook(self, i):
         def hook(param):
-            if not self._armed:
+            # idempotent per step: a conv-layer parameter reports through ops.grad_ready_hooks when its
+            # in-place gradient is final, and autograd's AccumulateGrad hook may fire for it as well
+            # (measured on torch 2.10: it does, even though the Function returns no gradient for it)
+            if not self._armed or self.notified[i]:
                 return
+            self.notified[i] = True
             b = self.bucket_of[i]
             self.pending[b] -= 1
             if self.pending[b] == 0:
@@ -71,6 +76,7 @@ class BucketedAllReduce(object):
         for b, (_, _, plist) in enumerate(self.buckets):
             self.pending[b] = len(plist)
             self.launched[b] = False
+        self.notified = [False] * len(self.arena.params)
         self._armed = True
 
     def _launch(self, b):

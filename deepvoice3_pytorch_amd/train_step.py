@@ -13,6 +13,7 @@ sequence masks, ~12 .item() syncs, per-tensor Adam -- is done here on the device
 Scalars stay on the device; nothing in step() synchronises with the host.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -123,7 +124,7 @@ class FlatArena(object):
             self.flat[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat[o:o + n].view(p.shape)
             p.grad = self.grad[o:o + n].view(p.shape)
-            p._dv3_grad_inplace = True     # ops.ConvLayerFn accumulates straight into p.grad
+            p._dv3_grad_inplace = not os.environ.get("DV3_NO_INPLACE_GRAD")   # ops.ConvLayerFn accumulates straight into p.grad
 
 
 class Trainer(object):

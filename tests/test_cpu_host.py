@@ -212,6 +212,9 @@ def _ddp_worker(rank, world, port, q):
         params[i].grad.add_(float((i + 1) * (rank + 1)))
         for hook in ops.grad_ready_hooks:
             hook(params[i])
+        # autograd's AccumulateGrad hook fires for such a parameter as well (torch 2.10): a second
+        # report must not count twice, or buckets launch before their other gradients exist
+        comm._make_hook(i)(params[i])
     assert all(comm.launched[comm.bucket_of[i]] for i in (0, 1, 2, 4) if
                all(j in (0, 1, 2, 4) for j in comm.buckets[comm.bucket_of[i]][2]))
     comm.finish()
