@@ -53,3 +53,41 @@ def to_device_batch(collated, device, outputs_per_step=1, downsample_step=4):
     x, in_len, mel, y, (tpos, fpos), done, tgt_len, spk = collated
     return Batch.from_collate(x, in_len, mel, y, tpos, fpos, done, tgt_len, spk, downsample_step, device,
                               r=outputs_per_step)
+
+
+class PreprocessedDataset(torch.utils.data.Dataset):
+    """A directory written by the reference's preprocess.py (preprocess.py:27-31): `train.txt` with one
+    `spec.npy|mel.npy|n_frames|text[|speaker_id]` line per utterance.  Items are the tuples collate_fn
+    takes: (text ids, mel (n_frames, num_mels), linear (n_frames, fft/2+1)[, speaker id]) -- what the
+    reference assembles from TextDataSource / MelSpecDataSource / LinearSpecDataSource
+    (train.py:96-192) through nnmnkwii.  `text_to_sequence` is the text frontend (the reference's
+    `frontend.en.text_to_sequence`, out of scope here); `speaker_id` filters a multi-speaker set down
+    to one speaker exactly as the reference does (train.py:113-119,163-171)."""
+
+    def __init__(self, data_root, text_to_sequence, speaker_id=None):
+        import os
+        self.data_root = data_root
+        self.text_to_sequence = text_to_sequence
+        with open(os.path.join(data_root, "train.txt"), "rb") as f:
+            rows = [ln.decode("utf-8").rstrip("\n").split("|") for ln in f if ln.strip()]
+        if not rows or len(rows[0]) not in (4, 5):
+            raise ValueError("train.txt: expected 4 or 5 '|'-separated columns")
+        self.multi_speaker = len(rows[0]) == 5
+        if self.multi_speaker and speaker_id is not None:
+            rows = [r for r in rows if int(r[-1]) == speaker_id]
+            self.multi_speaker = False
+        self.rows = rows
+        self.frame_lengths = [int(r[2]) for r in rows]      # what the length-bucketing sampler sorts by
+
+    def __len__(self):
+        return len(self.rows)
+
+    def __getitem__(self, i):
+        import os
+        r = self.rows[i]
+        text = np.asarray(self.text_to_sequence(r[3]), dtype=np.int32)
+        mel = np.load(os.path.join(self.data_root, r[1]))
+        spec = np.load(os.path.join(self.data_root, r[0]))
+        if self.multi_speaker:
+            return text, mel, spec, int(r[4])
+        return text, mel, spec

@@ -180,6 +180,27 @@ def test_collate_fn_matches_reference():
             assert c + "/out/speaker_ids" not in fx
 
 
+def test_preprocessed_dataset_reads_reference_layout(tmp_path):
+    """train.txt + .npy files as preprocess.py writes them (preprocess.py:27-31) -> collate_fn items"""
+    from deepvoice3_pytorch_amd import data
+    rng = np.random.RandomState(3)
+    lines = []
+    for i, (n, spk) in enumerate([(12, 0), (20, 1), (9, 0)]):
+        np.save(str(tmp_path / ("spec-%05d.npy" % i)), rng.rand(n, 7).astype(np.float32))
+        np.save(str(tmp_path / ("mel-%05d.npy" % i)), rng.rand(n, 5).astype(np.float32))
+        lines.append("spec-%05d.npy|mel-%05d.npy|%d|text number %d|%d" % (i, i, n, i, spk))
+    (tmp_path / "train.txt").write_text("\n".join(lines) + "\n", encoding="utf-8")
+    t2s = lambda t: [ord(c) % 20 + 2 for c in t] + [1]
+    ds = data.PreprocessedDataset(str(tmp_path), t2s)
+    assert len(ds) == 3 and ds.multi_speaker and ds.frame_lengths == [12, 20, 9]
+    text, mel, spec, spk = ds[1]
+    assert mel.shape == (20, 5) and spec.shape == (20, 7) and spk == 1 and text[-1] == 1
+    one = data.PreprocessedDataset(str(tmp_path), t2s, speaker_id=0)      # train.py:113-119
+    assert len(one) == 2 and not one.multi_speaker and len(one[0]) == 3
+    x, in_len, m, y, (tp, fp), done, tgt, sid = data.collate_fn([ds[i] for i in range(3)])
+    assert m.shape == (3, 24, 5) and y.shape == (3, 24, 7) and list(tgt) == [12, 20, 9] and list(sid) == [0, 1, 0]
+
+
 def _ddp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
