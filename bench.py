@@ -101,7 +101,7 @@ def synth_batch(rng, B, Tt, n_frames, hp, fixed=True):
                 target_lengths=frame_lens)
 
 
-def conv_roofline(dev, iters=50, tile_hint=0, dil=1, mode=None):
+def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None):
     """Conv1dGLU forward at the north-star shape, one tap-GEMM launch per iteration, timed with
     HIP events on the stream it is launched on (torch's current stream = the stream ops.* enqueue on).
     mode "bf16x3": the split-bf16 kernel (3 bf16 MFMAs per product block) -> peak = 2500/3 TF of
@@ -122,7 +122,7 @@ def conv_roofline(dev, iters=50, tile_hint=0, dil=1, mode=None):
         ops.conv_gemm(x, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
                       padL=(k - 1) // 2 * d, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x, residual=1, y=y,
                       tile_hint=tile_hint, a_split=pk.fwd_s)
-    for _ in range(20):          # the clock governor needs a few ms of this load to settle
+    for _ in range(100):         # the clock governor needs ~20 ms of this load to settle (first launches run ~20 % slower)
         launch()
     torch.cuda.synchronize()
     s = torch.cuda.current_stream()
