@@ -265,8 +265,9 @@ def synth_bench(dev, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed steps (the GPU clocks need ~1 s of this load to settle)")
     ap.add_argument("--batch", type=int, default=64,
                     help="per-GPU batch (north-star shape: 64; the preset's batch_size is 16)")
     ap.add_argument("--preset", default="deepvoice3_ljspeech", choices=sorted(PRESETS),
