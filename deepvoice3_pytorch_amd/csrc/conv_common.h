@@ -28,15 +28,11 @@ __device__ __forceinline__ void dv3_st(void* base, uint32_t byte_off, float v) {
 // All addressing is uniform base + 32-bit byte offset (the host checks every tensor < 4 GB):
 // the straightforward 64-bit form made this fully unrolled tail ~10k instructions -- more than
 // the instruction cache, i.e. a fixed ~40 us of fetch stalls per launch at the north-star shape.
-//
-// PRE (gated modes): the residual / highway input `r` was prefetched into pre[r][ni] by
-// conv_prefetch_residual (issued a K step before the end of the main loop, so its HBM latency is
-// hidden behind MFMAs instead of heading the tail).
-template <int BM, int BMH, int NI, bool PRE = false, int ABL = 0>
+// ABL: measurement variants (dv3_debug_set): 7 = no residual load, 8 = no store.
+template <int BM, int BMH, int NI, int ABL = 0>
 __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], bool gated,
                                               int mt, int row0, int lhi, const int (&bcol)[NI],
-                                              const int (&tcol)[NI], const bool (&okc)[NI],
-                                              const float (*pre)[NI] = nullptr) {
+                                              const int (&tcol)[NI], const bool (&okc)[NI]) {
   const float dscale = p.drop_scale;
   const uint32_t Tout = (uint32_t)p.Tout, M = (uint32_t)p.M, Cg = (uint32_t)p.Cg;
   const float rs2 = 0.70710678118654752440f;
@@ -78,7 +74,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        xr[r][ni] = (has_r && ABL != 7) ? (PRE ? pre[r][ni] : dv3_ld<float>(p.r, rbc[ni] + chc * r_rs)) : 0.f;
+        xr[r][ni] = (has_r && ABL != 7) ? dv3_ld<float>(p.r, rbc[ni] + chc * r_rs) : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -182,29 +178,6 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
         dv3_st(p.y, yb[ni] + mo * y_rs + odd, v);
       }
     }
-  }
-}
-
-// Issue the loads of the gated epilogue's `r` operand (residual / highway input) early.
-// Rows / columns that the epilogue drops are clamped to a valid address and never used.
-template <int BM, int BMH, int NI>
-__device__ __forceinline__ void conv_prefetch_residual(const dv3_conv_desc& p, bool gated, int mt, int wm,
-                                                       int lhi, const int (&bcol)[NI],
-                                                       const int (&tcol)[NI], const bool (&okc)[NI],
-                                                       float (*pre)[NI]) {
-  if (!gated || !(p.mode == DV3_EPI_HIGHWAY || p.residual)) return;
-  const uint32_t r_rs = (uint32_t)p.r_rs * 4u;
-  const uint32_t rows = (uint32_t)p.Cg;
-  uint32_t rb[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
-    rb[ni] = okc[ni] ? ((uint32_t)bcol[ni] * (uint32_t)p.r_bs + (uint32_t)tcol[ni]) * 4u : 0u;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    uint32_t m = (uint32_t)(mt * BMH + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
-    m = m < rows ? m : rows - 1;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) pre[r][ni] = dv3_ld<float>(p.r, rb[ni] + m * r_rs);
   }
 }
 

@@ -348,9 +348,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   // ABL 6: skip the epilogue but keep the accumulators live
   if ((ABL != 6 && ABL != 9) || acc[0][0][0][0] + acc[MI - 1][1][0][0] + acc[0][0][NI - 1][5] + acc[MI - 1][1][NI - 1][7] == 1.2345e30f) {
     static_assert(MI == 1 || MI == 2, "row sub-tiles per wave");
-    conv_epilogue<BM, BMH, NI, false, ABL>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+    conv_epilogue<BM, BMH, NI, ABL>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
     if (MI == 2)
-      conv_epilogue<BM, BMH, NI, false, ABL>(p, acc[MI - 1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+      conv_epilogue<BM, BMH, NI, ABL>(p, acc[MI - 1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
   }
 }
 
