@@ -148,8 +148,8 @@ def lib():
             raise Dv3LibraryError("struct %s: C sizeof %d != ctypes %d" % (name, n, ctypes.sizeof(cls)))
     _lib = h
     # developer knobs (include/dv3hip.h: dv3_debug_set) from the environment, for A/B runs
-    for what, var in ((1, "DV3_X3_ABLATE"), (2, "DV3_WGRAD_TILE")):
-        if os.environ.get(var):
+    for what, var in ((1, "DV3_X3_ABLATE"), (2, "DV3_WGRAD_TILE"), (3, "DV3_X3_PINGPONG")):
+        if os.environ.get(var) is not None and os.environ[var] != "":
             h.dv3_debug_set(what, int(os.environ[var]))
     return h
 

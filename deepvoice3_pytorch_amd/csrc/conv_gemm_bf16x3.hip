@@ -60,8 +60,14 @@ __device__ __forceinline__ T ldg_off(const void* base, uint32_t byte_off) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-template <int WM, int WN, int NI, bool MASK, int ABL = 0, int TERMS = 3, int MI = 1>
+// ABL 10 (dv3_debug_set(1, 10), 128x256 ping-pong tile): per-wave phase timestamps of ONE workgroup,
+// [wave][slot][0 = s_memrealtime (100 MHz), 1 = s_memtime]; read back with dv3_debug_read(1, ...)
+constexpr int STAMP_SLOTS = 192;
+__device__ unsigned long long g_x3_stamps[8 * STAMP_SLOTS * 2];
+
+template <int WM, int WN, int NI, bool MASK, int ABL = 0, int TERMS = 3, int MI = 1, bool PP = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const ConvArgs args) {
+  static_assert(!PP || (WM * WN == 8 && MI == 1 && (ABL == 0 || ABL >= 10)), "ping-pong: 8 waves, one row sub-tile per wave");
   constexpr int BM = WM * MI * 64, BMH = WM * MI * 32, BN = WN * NI * 32;
   constexpr int NT = WM * WN * 64;
   constexpr int AU = KB * BM / NT;                          // A units per plane per thread per step
@@ -105,18 +111,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   const float dscale = p.drop_scale;
 
   // ---- this lane's output columns: (batch, time) and per-tap validity of the shifted read ----
-  int bcol[NI], tcol[NI];
-  bool okc[NI];
   uint32_t vbits = 0;  // bit j*NI+ni: the tap-j input of column ni lies inside its batch item
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
-    okc[ni] = n < Ntot;
-    bcol[ni] = n / T;
-    tcol[ni] = n - bcol[ni] * T;
+    const int bc = n / T, tc = n - bc * T;
     for (int j = 0; j < J; ++j) {
-      const int ts = tcol[ni] + j * dil - p.padL;
-      if (okc[ni] && ts >= 0 && ts < T) vbits |= 1u << (j * NI + ni);
+      const int ts = tc + j * dil - p.padL;
+      if (n < Ntot && ts >= 0 && ts < T) vbits |= 1u << (j * NI + ni);
     }
   }
   uint32_t need = 0;  // wave-uniform: taps for which some lane of this wave must zero its fragment
@@ -130,8 +132,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   // Nothing staged needs zeroing: columns outside the tensor or outside an output column's own
   // batch item are zeroed per fragment (vbits), channels >= Cin (clamped reads) meet zero weight
   // rows, and weight rows beyond the tile's valid range only feed output rows the epilogue drops.
-  uint32_t xoff[XI];                // byte offset of (b, 0, t) from p.x  (< 2^32, host-checked)
-  uint32_t xmo[MASK ? XI : 1];      // byte offset of word (b*Cin, t>>5) in xmask
+  uint32_t xoff[XI];                // byte offset of (b, k8*8, t) from p.x  (< 2^32, host-checked)
+  uint32_t xmo[MASK ? XI : 1];      // byte offset of word (b*Cin + k8*8, t>>5) in xmask
   int xsh[MASK ? XI : 1];           // bit position t & 31
   int xk8[XI];
   const int n_items = KB * BNH;
@@ -147,9 +149,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
       tf = f - bf * T;
     }
     xk8[i] = k8 < KB ? k8 * 8 : 0;
-    xoff[i] = ((uint32_t)bf * (uint32_t)p.x_bs + (uint32_t)tf) * 4u;
+    xoff[i] = ((uint32_t)bf * (uint32_t)p.x_bs + (uint32_t)tf) * 4u + (uint32_t)xk8[i] * x_rsb;
     if (MASK) {
-      xmo[i] = ((uint32_t)(bf * Cin) * (uint32_t)p.xmask_rs + (uint32_t)(tf >> 5)) * 4u;
+      xmo[i] = ((uint32_t)(bf * Cin) * (uint32_t)p.xmask_rs + (uint32_t)(tf >> 5)) * 4u + (uint32_t)xk8[i] * m_rsb;
       xsh[i] = tf & 31;
     }
   }
@@ -188,25 +190,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   };
   auto load_X = [&](int chunk) {
     const int c0 = chunk * BKC;
+    if (c0 + BKC <= Cin) {
+      // whole chunk in range (uniform): 8 uniform row bases + one loop-invariant per-thread offset
+      // per item -> every load is the SGPR-base form with no address arithmetic
+      const char* xb = reinterpret_cast<const char*>(p.x) + (int64_t)c0 * x_rsb;
+      const char* mb = reinterpret_cast<const char*>(xmask) + (int64_t)c0 * m_rsb;
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      // channels >= Cin are clamped to the last real row: they meet zero weight rows
-      const int cbi = c0 + xk8[i];
-      if (cbi + 8 <= Cin) {
-        const uint32_t o = xoff[i] + (uint32_t)cbi * x_rsb;
+      for (int e = 0; e < 8; ++e) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rx[i][e] = ldg_off<float>(p.x, o + e * x_rsb);
-        if (MASK) {
-          const uint32_t mo = xmo[i] + (uint32_t)cbi * m_rsb;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) rm[i][e] = ldg_off<uint32_t>(xmask, mo + e * m_rsb);
+        for (int i = 0; i < XI; ++i) {
+          rx[i][e] = ldg_off<float>(xb + (int64_t)e * x_rsb, xoff[i]);
+          if (MASK) rm[i][e] = ldg_off<uint32_t>(mb + (int64_t)e * m_rsb, xmo[i]);
         }
-      } else {
+      }
+    } else {
+      // last, partial chunk: channels >= Cin are clamped to the last real row (they meet zero
+      // weight rows)
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const uint32_t c = (uint32_t)min(cbi + e, Cin - 1);
-          rx[i][e] = ldg_off<float>(p.x, xoff[i] + c * x_rsb);
-          if (MASK) rm[i][e] = ldg_off<uint32_t>(xmask, xmo[i] + c * m_rsb);
+          // row relative to this item's k8 block (mod 2^32: may be "negative" when Cin < k8*8)
+          const uint32_t dc = (uint32_t)(min(c0 + xk8[i] + e, Cin - 1) - xk8[i]);
+          rx[i][e] = ldg_off<float>(p.x, xoff[i] + dc * x_rsb);
+          if (MASK) rm[i][e] = ldg_off<uint32_t>(xmask, xmo[MASK ? i : 0] + dc * m_rsb);
         }
       }
     }
@@ -252,7 +259,134 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   write_X(0);
   __syncthreads();
 
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if constexpr (ABL == 10) {
+      if (blockIdx.x == gridDim.x / 2 && n_stamp < STAMP_SLOTS) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), t1 = __builtin_readcyclecounter();
+        if (lane == 0) {
+          g_x3_stamps[(wave * STAMP_SLOTS + n_stamp) * 2] = t0;
+          g_x3_stamps[(wave * STAMP_SLOTS + n_stamp) * 2 + 1] = t1;
+        }
+      }
+      ++n_stamp;
+    }
+  };
   int c = 0, j = 0;
+  if constexpr (PP) {
+    // ---- ping-pong main loop (8-wave tiles, one workgroup per CU) ----
+    // Waves w and w+4 of a workgroup share a SIMD (MI355X_MICROARCH.md, "Two waves per SIMD"): its
+    // matrix pipe serves one MFMA stream at a time, so the two run the SAME step sequence half a
+    // step apart -- while one issues its 24 back-to-back MFMAs from registers (COMPUTE) the other
+    // fetches its 16 fragments of the next step from LDS, zeroes sequence-edge columns and stores
+    // its share of the following tiles (LOAD).  One barrier per phase; the late half enters the
+    // loop one barrier later and skips the last one, so both execute 2*nsteps barriers.
+    //   interval:   I0      I1      I2      I3
+    //   waves 0-3:  L(0)    C(0)    L(1)    C(1) ...
+    //   waves 4-7:  -       L(0)    C(0)    L(1) ...
+    // LDS hazards: the tile of step s+1 is stored during L(s) by each half (intervals 2s, 2s+1)
+    // into the buffer last read for step s-1 (intervals 2s-2, 2s-1) and first read in interval
+    // 2s+2; the activation tile of chunk c+1 likewise during the L of chunk c's last tap.  Global
+    // fetches run a full step ahead of their store: right after L(s) has stored the panel of step
+    // s+1 it fetches that of step s+2 into the same registers, and the activation tile of chunk
+    // c+2 right after chunk c+1's was stored.
+    const int late = wave >> 2;
+    load_A((1 < nsteps && J == 1) ? 1 : 0, (1 < nsteps && J > 1) ? 1 : 0);
+    if (1 < nchunks) load_X(1);
+    stamp();                       // slot 0: prologue done
+    if (late) __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+      const int cur = step & 1;
+      int jn = j + 1, cn = c;
+      if (jn == J) { jn = 0; cn = c + 1; }
+      const bool has_next = step + 1 < nsteps;
+      const bool new_chunk = has_next && jn == 0;
+      stamp();                     // slot 1 + 6*step: LOAD begins
+      // ---------------- LOAD ----------------
+      bf16x8 ah[2][2], al[2][2], bh[2][NI], bl[2][NI];
+      {
+        const bf16x8* AsH = As + cur * (2 * KB * BM);
+        const bf16x8* AsL = AsH + KB * BM;
+        const bf16x8* XsH = Xs + (c & 1) * xbuf;
+        const bf16x8* XsL = XsH + KB * BNH;
+        const bool fix = (need >> j) & 1u;
+        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int k8 = 2 * s + lhi;
+          const int ai = k8 * BM + a_off;
+          ah[s][0] = AsH[ai];
+          ah[s][1] = AsH[ai + BMH];
+          al[s][0] = (TERMS == 3) ? AsL[ai] : ah[s][0];
+          al[s][1] = (TERMS == 3) ? AsL[ai + BMH] : ah[s][1];
+          const int xi = k8 * BNH + x_off + j * dil;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            bh[s][ni] = XsH[xi + ni * 32];
+            bl[s][ni] = (TERMS == 3) ? XsL[xi + ni * 32] : bh[s][ni];
+          }
+        }
+        if (fix) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              const bool ok = (vbits >> (j * NI + ni)) & 1u;
+              bh[s][ni] = ok ? bh[s][ni] : zero8;
+              if (TERMS == 3) bl[s][ni] = ok ? bl[s][ni] : zero8;
+            }
+        }
+      }
+      // stores of the next tiles, then the fetches that refill their registers: every vmcnt wait
+      // of this phase precedes its fetches, so it only covers loads issued a full step ago, and
+      // the COMPUTE phase is MFMAs only.  The panel store / fetch pair is unconditional (the last
+      // steps re-fetch the current panel and store into the buffer nobody reads any more): a
+      // conditional pair makes the compiler guard the fetch's registers with a vmcnt(0) that
+      // would then sit behind the activation fetch issued just above.
+      stamp();                     // fragments in registers
+      write_A(cur ^ 1);
+      stamp();                     // panel stored
+      if (new_chunk) {
+        write_X((c + 1) & 1);
+        if (cn + 1 < nchunks) load_X(cn + 1);
+      }
+      {
+        int j2 = jn + 1, c2 = cn;
+        if (j2 == J) { j2 = 0; c2 = cn + 1; }
+        const bool more = step + 2 < nsteps;
+        load_A(more ? c2 : c, more ? j2 : j);
+      }
+      stamp();                     // LOAD issued (the SMEM read waits for the LDS queue)
+      __syncthreads();
+      stamp();                     // COMPUTE begins
+      // ---------------- COMPUTE ----------------
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (TERMS == 3) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[0][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][0], bh[s][ni], acc[0][0][ni], 0, 0, 0);
+            acc[0][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][1], bh[s][ni], acc[0][1][ni], 0, 0, 0);
+          }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[0][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][0], bl[s][ni], acc[0][0][ni], 0, 0, 0);
+            acc[0][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][1], bl[s][ni], acc[0][1][ni], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[0][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][0], bh[s][ni], acc[0][0][ni], 0, 0, 0);
+          acc[0][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][1], bh[s][ni], acc[0][1][ni], 0, 0, 0);
+        }
+      }
+      stamp();                     // MFMAs issued
+      if (has_next || !late) __syncthreads();
+      j = jn;
+      c = cn;
+    }
+    stamp();                       // slot 1 + 6*nsteps: main loop left
+  } else
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
     int jn = j + 1, cn = c;
@@ -348,10 +482,24 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   // ABL 6: skip the epilogue but keep the accumulators live
   if ((ABL != 6 && ABL != 9) || acc[0][0][0][0] + acc[MI - 1][1][0][0] + acc[0][0][NI - 1][5] + acc[MI - 1][1][NI - 1][7] == 1.2345e30f) {
     static_assert(MI == 1 || MI == 2, "row sub-tiles per wave");
+    // (batch, time) of this lane's output columns, recomputed from an opaque copy of the tile origin
+    // instead of being carried through the main loop in registers
+    int n0e = n0;
+    asm volatile("" : "+s"(n0e));
+    int bcol[NI], tcol[NI];
+    bool okc[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0e + wn * (NI * 32) + ni * 32 + l31;
+      okc[ni] = n < Ntot;
+      bcol[ni] = n / T;
+      tcol[ni] = n - bcol[ni] * T;
+    }
     conv_epilogue<BM, BMH, NI, ABL>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
     if (MI == 2)
       conv_epilogue<BM, BMH, NI, ABL>(p, acc[MI - 1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
   }
+  stamp();                         // last slot: epilogue stores issued
 }
 
 // packed fp32 [J][K][lda] -> split image [plane][j][k8][m][8]
@@ -376,11 +524,11 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
   dst[n + idx] = lo;
 }
 
-template <int WM, int WN, int NI, bool MASK, int TERMS, int MI = 1>
+template <int WM, int WN, int NI, bool MASK, int TERMS, int MI = 1, bool PP = false>
 int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_gemm_bf16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -389,7 +537,7 @@ int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(a.n_blocks), block(WM * WN * 64);
-  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP>), grid, block, lds, st, a);
   return dv3_check_launch("conv_gemm_bf16x3");
 }
 int g_x3_ablate = 0;   // debug: dv3_debug_set(); ablation variants of the 128x128 unmasked tile
@@ -400,11 +548,27 @@ int launch_x3_abl(const ConvArgs& a, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<2, 2, 2, false, ABL>), dim3(a.n_blocks), dim3(256), lds, st, a);
   return dv3_check_launch("conv_gemm_bf16x3(abl)");
 }
+int g_x3_pingpong = 1;  // debug: dv3_debug_set(3, 0) runs the 8-wave tiles on the in-phase main loop
+template <int WM, int WN, int NI, int MI, bool PP>
+int launch_x3_big_pp(const ConvArgs& a, size_t lds, hipStream_t st) {
+  if (a.d.split_terms == 1)
+    return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 1, MI, PP>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 1, MI, PP>(a, lds, st);
+  return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3, MI, PP>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3, MI, PP>(a, lds, st);
+}
 template <int WM, int WN, int NI, int MI>
 int launch_x3_big(const ConvArgs& a, size_t lds, hipStream_t st) {
-  if (a.d.split_terms == 1)
-    return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 1, MI>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 1, MI>(a, lds, st);
-  return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3, MI>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3, MI>(a, lds, st);
+  if constexpr (WM == 2 && WN == 4 && MI == 1) {
+    if (g_x3_ablate == 10 && !a.d.xmask && a.d.split_terms != 1) {
+      (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<2, 4, 2, false, 10, 3, 1, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<2, 4, 2, false, 10, 3, 1, true>), dim3(a.n_blocks), dim3(512), lds, st, a);
+      return dv3_check_launch("conv_gemm_bf16x3(stamps)");
+    }
+  }
+  if constexpr (WM * WN == 8 && MI == 1) {
+    if (g_x3_pingpong) return launch_x3_big_pp<WM, WN, NI, MI, true>(a, lds, st);
+  }
+  return launch_x3_big_pp<WM, WN, NI, MI, false>(a, lds, st);
 }
 template <int WM, int WN, int NI>
 int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
@@ -504,6 +668,18 @@ extern int g_wgrad_tile;   // wgrad_gemm_bf16x3.hip
 extern "C" int dv3_debug_set(int what, int value) {
   if (what == 1) g_x3_ablate = value;
   if (what == 2) g_wgrad_tile = value;
+  if (what == 3) g_x3_pingpong = value;
+  return DV3_OK;
+}
+
+extern "C" int dv3_debug_read(int what, void* dst, int64_t bytes) {
+  DV3_REQUIRE(what == 1 && dst && bytes > 0 && bytes <= (int64_t)sizeof(unsigned long long) * 8 * STAMP_SLOTS * 2,
+              "debug_read: bad arguments");
+  hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_x3_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) {
+    dv3_set_error("debug_read: %s", hipGetErrorString(e));
+    return DV3_ELAUNCH;
+  }
   return DV3_OK;
 }
 

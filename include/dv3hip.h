@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 18
+#define DV3_ABI_VERSION 19
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -38,8 +38,12 @@ int dv3_device_info(int dev, char* name, int name_len, int* n_cu);
 /* sizeof(struct <name>) or -1: lets a foreign-language mirror of the descriptors self-check */
 int dv3_sizeof(const char* name);
 /* Developer knobs for measurements (what = 1: ablation variant of the bf16x3 tap-GEMM, 0 = off;
- * what = 2: bf16x3 wgrad tile, 0 auto / 1 = 128x128 / 2 = 256x128). */
+ * what = 2: bf16x3 wgrad tile, 0 auto / 1 = 128x128 / 2 = 256x128; what = 3: 8-wave bf16x3
+ * tap-GEMM tiles on the ping-pong main loop (1, default) or the in-phase one (0)). */
 int dv3_debug_set(int what, int value);
+/* what = 1: phase timestamps left by the last dv3_debug_set(1, 10) launch of the 128x256 bf16x3 tile
+ * ([8 waves][192 slots][2] uint64, host pointer). */
+int dv3_debug_read(int what, void* dst, int64_t bytes);
 
 /* ------------------------------------------------------------------------------------
  * Epilogue modes of the tap-GEMM (dv3_conv_gemm_f32).
