@@ -352,6 +352,7 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
   ConvArgs a;
   a.d = *d;
   a.a_scalar = a_scalar ? 1 : 0;
+  a.kp = 0;
   const int BM = best->wm * 64, BMH = best->wm * 32, BN = best->wn * best->ni * 32;
   a.m_tiles = gated ? dv3_cdiv(rows_half, BMH) : dv3_cdiv(d->M, BM);
   a.n_tiles = dv3_cdiv(d->Tout, BN);

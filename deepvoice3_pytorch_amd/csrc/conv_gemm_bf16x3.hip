@@ -172,6 +172,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   float rx[XI][8];
   uint32_t rm[MASK ? XI : 1][8];
 
+  const int nchunks = (Cin + BKC - 1) / BKC;
+
   auto load_A = [&](int chunk, int j) {
     const bf16x8* srch = Wh + (int64_t)(j * k8_total + chunk * KB) * lda;  // uniform
     const bf16x8* srcl = srch + plane;
@@ -249,7 +251,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] = 0.f;
 
-  const int nchunks = (Cin + BKC - 1) / BKC;
   const int nsteps = (ABL == 5 || ABL == 9) ? 0 : nchunks * J;
   const int a_off = wm * (MI * 32) + l31;
   const int x_off = wn * (NI * 32) + l31;
@@ -503,383 +504,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   stamp();                         // last slot: epilogue stores issued
 }
 
-// ---------------------------------------------------------------------------------------------
-// Producer / consumer form of the 128 x 256 tile ("ws", dv3_debug_set(3, 2)).
-// The phase timestamps of the ping-pong loop (scripts/pp_stamps.py) show its LOAD phase -- 16
-// fragment reads, the wave's share of the weight-panel and activation-tile staging -- costs ~1200
-// cycles per step against 800 for the 24 MFMAs, so the matrix pipe waits on staging.  Here the
-// staging leaves the MFMA waves altogether:
-//   * waves 0-3 (one per SIMD) are CONSUMERS: each owns 128 rows x 64 columns (MI = 2 row
-//     sub-tiles per half, 8 accumulators = 128 VGPRs); per step it reads 24 fragments (0.5 LDS reads
-//     per MFMA instead of 0.67) and issues 48 MFMAs; it never touches global memory in the loop.
-//   * waves 4-7 (their SIMD partners) are PRODUCERS: 256 threads stage every weight panel and
-//     activation tile (fetch a step / a chunk ahead into registers, split, store to LDS) with the
-//     VALU, VMEM and LDS-store slots the consumers leave idle; the items of an activation tile
-//     are spread over the taps of the previous chunk so no step carries a burst.
-//   * ONE barrier per step: after barrier(s) the consumers read tile s while the producers
-//     overwrite the buffer of tile s-1 with tile s+1.
-//   * the epilogue is shared again: each consumer hands its second row sub-tile (64 VGPRs) to
-//     its producer partner through the (now idle) LDS, and all 8 waves run the fused tail on
-//     64 x 64 outputs as before.
-// Accumulation order per accumulator is that of the other bf16x3 loops: results are bit-identical.
-template <bool MASK, int TERMS, int ABL = 0>
-__global__ __launch_bounds__(512) void conv_gemm_bf16x3_ws_kernel(const ConvArgs args) {
-  constexpr int BM = 128, BMH = 64, BN = 256, NI = 2, MI = 2;
-  constexpr int NP = 256;                                   // producer threads
-  constexpr int AU = KB * BM / NP;                          // A units per plane per producer thread per step
-  constexpr int XI = (KB * (BN + HALO_MAX) + NP - 1) / NP;  // X items per producer thread per chunk
-  const dv3_conv_desc& p = args.d;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int J = p.J, dil = p.dil;
-  const int BNH = BN + (J - 1) * dil;
-  bf16x8* const As = reinterpret_cast<bf16x8*>(smem_raw);
-  bf16x8* const Xs = As + 2 * 2 * KB * BM;
-  const int xbuf = 2 * KB * BNH;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave >= 4;
-  const int cw = wave & 3;            // consumer index = column quarter; producer cw+4 is its SIMD partner
-  const int l31 = lane & 31, lhi = lane >> 5;
-
-  const int pid = dv3_xcd_remap(blockIdx.x, args.n_blocks);
-  const int mt = pid % args.m_tiles;
-  const int nt = pid / args.m_tiles;
-  const int n0 = nt * BN;
-
-  const bool gated = (p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY);
-  int h0b, h1b;
-  if (gated) {
-    h0b = mt * BMH; h1b = p.a_half + mt * BMH;
-  } else {
-    h0b = mt * BM; h1b = mt * BM + BMH;
-  }
-  const int Cin = p.Cin, T = p.Tout, lda = p.lda, B = p.B;
-  const int Ntot = B * T;
-  const int k8_total = args.kp >> 3;
-  const int nchunks = (Cin + BKC - 1) / BKC;
-  const int nsteps = nchunks * J;
-
-  f32x16 eacc[2][NI];   // what this wave's epilogue works on
-  int erow0;
-  int n_stamp = 0;      // ABL 10: phase timestamps of one workgroup (see g_x3_stamps)
-  auto stamp = [&]() {
-    if constexpr (ABL == 10) {
-      if (blockIdx.x == gridDim.x / 2 && n_stamp < STAMP_SLOTS) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), t1 = __builtin_readcyclecounter();
-        if (lane == 0) {
-          g_x3_stamps[(wave * STAMP_SLOTS + n_stamp) * 2] = t0;
-          g_x3_stamps[(wave * STAMP_SLOTS + n_stamp) * 2 + 1] = t1;
-        }
-      }
-      ++n_stamp;
-    }
-  };
-
-  if (producer) {
-    // ======================= PRODUCER =======================
-    const int ptid = tid - NP;
-    const bf16x8* __restrict__ Wh = reinterpret_cast<const bf16x8*>(p.a_split);
-    const int64_t plane = (int64_t)J * k8_total * lda;
-    const uint32_t* __restrict__ xmask = p.xmask;
-    const float dscale = p.drop_scale;
-    uint32_t xoff[XI];
-    uint32_t xmo[MASK ? XI : 1];
-    int xsh[MASK ? XI : 1];
-    int xk8[XI];
-    const int n_items = KB * BNH;
-    const uint32_t x_rsb = (uint32_t)p.x_rs * 4u, m_rsb = (uint32_t)p.xmask_rs * 4u;
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int idx = ptid + i * NP;
-      const int k8 = idx / BNH, q = idx - k8 * BNH;
-      const int f = n0 - p.padL + q;
-      int bf = 0, tf = 0;
-      if (idx < n_items && f >= 0 && f < Ntot) {
-        bf = f / T;
-        tf = f - bf * T;
-      }
-      xk8[i] = k8 < KB ? k8 * 8 : 0;
-      xoff[i] = ((uint32_t)bf * (uint32_t)p.x_bs + (uint32_t)tf) * 4u + (uint32_t)xk8[i] * x_rsb;
-      if (MASK) {
-        xmo[i] = ((uint32_t)(bf * Cin) * (uint32_t)p.xmask_rs + (uint32_t)(tf >> 5)) * 4u + (uint32_t)xk8[i] * m_rsb;
-        xsh[i] = tf & 31;
-      }
-    }
-    uint32_t aoff[AU];
-#pragma unroll
-    for (int u = 0; u < AU; ++u) {
-      const int idx = ptid + u * NP;  // k8 * BM + col
-      const int col = idx % BM, k8 = idx / BM;
-      const bool hi_half = col >= BMH;
-      const int gcol = (hi_half ? h1b : h0b) + (col - (hi_half ? BMH : 0));
-      aoff[u] = (uint32_t)(k8 * lda + (gcol < lda ? gcol : 0)) * 16u;
-    }
-    bf16x8 ra[2][AU];
-    float rx[XI][8];
-    uint32_t rm[MASK ? XI : 1][8];
-
-    auto load_A = [&](int chunk, int j) {
-      const bf16x8* srch = Wh + (int64_t)(j * k8_total + chunk * KB) * lda;  // uniform
-      const bf16x8* srcl = srch + plane;
-#pragma unroll
-      for (int u = 0; u < AU; ++u) {
-        ra[0][u] = ldg_off<bf16x8>(srch, aoff[u]);
-        if (TERMS == 3) ra[1][u] = ldg_off<bf16x8>(srcl, aoff[u]);
-      }
-    };
-    auto write_A = [&](int buf) {
-      bf16x8* dst = As + buf * (2 * KB * BM);
-#pragma unroll
-      for (int u = 0; u < AU; ++u) {
-        dst[ptid + u * NP] = ra[0][u];
-        if (TERMS == 3) dst[KB * BM + ptid + u * NP] = ra[1][u];
-      }
-    };
-    // item i of the activation tile of `chunk`: 8 channels of one flat column
-    auto load_X_item = [&](int chunk, auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const int c0 = chunk * BKC;
-      if (c0 + BKC <= Cin) {
-        const char* xb = reinterpret_cast<const char*>(p.x) + (int64_t)c0 * x_rsb;
-        const char* mb = reinterpret_cast<const char*>(xmask) + (int64_t)c0 * m_rsb;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          rx[i][e] = ldg_off<float>(xb + (int64_t)e * x_rsb, xoff[i]);
-          if (MASK) rm[MASK ? i : 0][e] = ldg_off<uint32_t>(mb + (int64_t)e * m_rsb, xmo[MASK ? i : 0]);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const uint32_t dc = (uint32_t)(min(c0 + xk8[i] + e, Cin - 1) - xk8[i]);
-          rx[i][e] = ldg_off<float>(p.x, xoff[i] + dc * x_rsb);
-          if (MASK) rm[MASK ? i : 0][e] = ldg_off<uint32_t>(xmask, xmo[MASK ? i : 0] + dc * m_rsb);
-        }
-      }
-    };
-    auto write_X_item = [&](int buf, auto ic) {
-      constexpr int i = decltype(ic)::value;
-      bf16x8* dst = Xs + buf * xbuf;
-      const int idx = ptid + i * NP;
-      if (idx < n_items) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] = rx[i][e];
-          if (MASK) v[e] *= ((rm[MASK ? i : 0][e] >> xsh[MASK ? i : 0]) & 1u) ? dscale : 0.f;
-        }
-        bf16x8 hi, lo;
-        split8(v, hi, lo);
-        dst[idx] = hi;
-        if (TERMS == 3) dst[KB * BNH + idx] = lo;
-      }
-    };
-    auto for_items = [&](auto&& fn) {   // fn(integral_constant<int, i>) for i in 0..XI-1, unrolled
-      fn(std::integral_constant<int, 0>{});
-      if constexpr (XI > 1) fn(std::integral_constant<int, 1>{});
-      if constexpr (XI > 2) fn(std::integral_constant<int, 2>{});
-      if constexpr (XI > 3) fn(std::integral_constant<int, 3>{});
-      if constexpr (XI > 4) fn(std::integral_constant<int, 4>{});
-      static_assert(XI <= 5, "for_items covers 5 items");
-    };
-
-    // prologue: tile 0 into buffer 0, then the fetches of step 1 / chunk 1
-    load_A(0, 0);
-    for_items([&](auto ic) { load_X_item(0, ic); });
-    write_A(0);
-    for_items([&](auto ic) { write_X_item(0, ic); });
-    load_A((1 < nsteps && J == 1) ? 1 : 0, (1 < nsteps && J > 1) ? 1 : 0);
-    if (1 < nchunks) for_items([&](auto ic) { load_X_item(1, ic); });
-    stamp();             // slot 0: prologue issued
-
-    int c = 0, j = 0;
-    for (int step = 0; step < nsteps; ++step) {
-      int jn = j + 1, cn = c;
-      if (jn == J) { jn = 0; cn = c + 1; }
-      __syncthreads();   // barrier(step): tile `step` complete; the buffers of tile step-1 are free
-      stamp();           // slot 1 + 4*step
-      // weight panel of step+1 (unconditional pair, see the ping-pong loop), then its refill
-      write_A((step + 1) & 1);
-      stamp();           // slot 2 + 4*step: panel stored
-      {
-        int j2 = jn + 1, c2 = cn;
-        if (j2 == J) { j2 = 0; c2 = cn + 1; }
-        const bool more = step + 2 < nsteps;
-        load_A(more ? c2 : c, more ? j2 : j);
-      }
-      stamp();           // slot 3 + 4*step: panel fetch issued
-      // activation tile of chunk c+1: the items whose turn is tap j (item i at tap i mod J), each
-      // followed by the fetch of the same item of chunk c+2
-      if (c + 1 < nchunks) {
-        for_items([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if (i % J == j) {
-            write_X_item((c + 1) & 1, ic);
-            if (c + 2 < nchunks) load_X_item(c + 2, ic);
-          }
-        });
-      }
-      stamp();           // slot 4 + 4*step: activation items stored / fetched
-      j = jn;
-      c = cn;
-    }
-    stamp();             // slot 1 + 4*nsteps
-    __syncthreads();     // E1: every consumer has left the main loop, LDS is free
-    __syncthreads();     // E2: hand-off written
-    {
-      const f32x4* hs = reinterpret_cast<const f32x4*>(smem_raw) + cw * (16 * 64) + lane;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 v = hs[((h * NI + ni) * 4 + q) * 64];
-            eacc[h][ni][4 * q] = v[0]; eacc[h][ni][4 * q + 1] = v[1];
-            eacc[h][ni][4 * q + 2] = v[2]; eacc[h][ni][4 * q + 3] = v[3];
-          }
-    }
-    erow0 = 32;
-  } else {
-    // ======================= CONSUMER =======================
-    uint32_t vbits = 0;  // bit j*NI+ni: the tap-j input of column ni lies inside its batch item
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int n = n0 + cw * (NI * 32) + ni * 32 + l31;
-      const int bc = n / T, tc = n - bc * T;
-      for (int j = 0; j < J; ++j) {
-        const int ts = tc + j * dil - p.padL;
-        if (n < Ntot && ts >= 0 && ts < T) vbits |= 1u << (j * NI + ni);
-      }
-    }
-    uint32_t need = 0;
-    for (int j = 0; j < J; ++j) {
-      const uint32_t all = ((1u << NI) - 1u) << (j * NI);
-      if (!__all((vbits & all) == all)) need |= 1u << j;
-    }
-    need = __builtin_amdgcn_readfirstlane(need);
-
-    f32x16 acc[MI][2][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] = 0.f;
-    const int x_off = cw * (NI * 32) + l31;
-    stamp();             // slot 0
-
-    int c = 0, j = 0;
-    for (int step = 0; step < nsteps; ++step) {
-      const int cur = step & 1;
-      __syncthreads();   // barrier(step)
-      stamp();           // slot 1 + 4*step
-      const bf16x8* AsH = As + cur * (2 * KB * BM);
-      const bf16x8* AsL = AsH + KB * BM;
-      const bf16x8* XsH = Xs + (c & 1) * xbuf;
-      const bf16x8* XsL = XsH + KB * BNH;
-      const bool fix = (need >> j) & 1u;
-      const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-      bf16x8 ah[2][MI][2], al[2][MI][2], bh[2][NI], bl[2][NI];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int k8 = 2 * s + lhi;
-        const int ai = k8 * BM + l31;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            ah[s][mi][h] = AsH[ai + h * BMH + mi * 32];
-            al[s][mi][h] = (TERMS == 3) ? AsL[ai + h * BMH + mi * 32] : ah[s][mi][h];
-          }
-        const int xi = k8 * BNH + x_off + j * dil;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          bh[s][ni] = XsH[xi + ni * 32];
-          bl[s][ni] = (TERMS == 3) ? XsL[xi + ni * 32] : bh[s][ni];
-        }
-      }
-      if (fix) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            const bool ok = (vbits >> (j * NI + ni)) & 1u;
-            bh[s][ni] = ok ? bh[s][ni] : zero8;
-            if (TERMS == 3) bl[s][ni] = ok ? bl[s][ni] : zero8;
-          }
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (TERMS == 3) {
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mi][0], bh[s][ni], acc[mi][0][ni], 0, 0, 0);
-              acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mi][1], bh[s][ni], acc[mi][1][ni], 0, 0, 0);
-            }
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mi][0], bl[s][ni], acc[mi][0][ni], 0, 0, 0);
-              acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mi][1], bl[s][ni], acc[mi][1][ni], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mi][0], bh[s][ni], acc[mi][0][ni], 0, 0, 0);
-            acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mi][1], bh[s][ni], acc[mi][1][ni], 0, 0, 0);
-          }
-      }
-      stamp();           // slots 2..4 + 4*step: MFMAs issued
-      stamp();
-      stamp();
-      if (++j == J) { j = 0; ++c; }
-    }
-    stamp();             // slot 1 + 4*nsteps
-    __syncthreads();     // E1
-    {
-      f32x4* hs = reinterpret_cast<f32x4*>(smem_raw) + cw * (16 * 64) + lane;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 v = {acc[1][h][ni][4 * q], acc[1][h][ni][4 * q + 1], acc[1][h][ni][4 * q + 2], acc[1][h][ni][4 * q + 3]};
-            hs[((h * NI + ni) * 4 + q) * 64] = v;
-          }
-    }
-    __syncthreads();     // E2
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) eacc[h][ni] = acc[0][h][ni];
-    erow0 = 0;
-  }
-
-  // ---- shared fused tail: 64 x 64 outputs per wave ----
-  int bcol[NI], tcol[NI];
-  bool okc[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = n0 + cw * (NI * 32) + ni * 32 + l31;
-    okc[ni] = n < Ntot;
-    bcol[ni] = n / T;
-    tcol[ni] = n - bcol[ni] * T;
-  }
-  conv_epilogue<BM, BMH, NI, ABL>(p, eacc, gated, mt, erow0, lhi, bcol, tcol, okc);
-  stamp();               // last slot: epilogue stores issued
-}
-
 // packed fp32 [J][K][lda] -> split image [plane][j][k8][m][8]
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ src,
                                                          bf16x8* __restrict__ dst, int J, int K,
@@ -926,24 +550,8 @@ int launch_x3_abl(const ConvArgs& a, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<2, 2, 2, false, ABL>), dim3(a.n_blocks), dim3(256), lds, st, a);
   return dv3_check_launch("conv_gemm_bf16x3(abl)");
 }
-// main loop of the 8-wave tiles, dv3_debug_set(3, v): 0 = in-phase, 1 = ping-pong, 2 = producer/consumer
-// (128 x 256 tile only; the 256 x 128 tile then runs ping-pong)
+// main loop of the 8-wave tiles, dv3_debug_set(3, v): 0 = in-phase, 1 = ping-pong (default)
 int g_x3_pingpong = 1;
-template <bool MASK, int TERMS>
-int launch_x3_ws(const ConvArgs& a, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_ws_kernel<MASK, TERMS>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      dv3_set_error("conv_gemm_bf16x3(ws): hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return DV3_ELAUNCH;
-    }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv_gemm_bf16x3_ws_kernel<MASK, TERMS>), dim3(a.n_blocks), dim3(512), lds, st, a);
-  return dv3_check_launch("conv_gemm_bf16x3(ws)");
-}
 template <int WM, int WN, int NI, int MI, bool PP>
 int launch_x3_big_pp(const ConvArgs& a, size_t lds, hipStream_t st) {
   if (a.d.split_terms == 1)
@@ -953,24 +561,11 @@ int launch_x3_big_pp(const ConvArgs& a, size_t lds, hipStream_t st) {
 template <int WM, int WN, int NI, int MI>
 int launch_x3_big(const ConvArgs& a, size_t lds, hipStream_t st) {
   if constexpr (WM == 2 && WN == 4 && MI == 1) {
-    if (g_x3_ablate == 10 && !a.d.xmask && a.d.split_terms != 1) {
+    if (g_x3_ablate == 10 && g_x3_pingpong && !a.d.xmask && a.d.split_terms != 1) {
       (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<2, 4, 2, false, 10, 3, 1, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<2, 4, 2, false, 10, 3, 1, true>), dim3(a.n_blocks), dim3(512), lds, st, a);
       return dv3_check_launch("conv_gemm_bf16x3(stamps)");
-    }
-  }
-  if constexpr (WM == 2 && WN == 4 && MI == 1) {
-    if (g_x3_pingpong == 2) {
-      if (g_x3_ablate == 10 && !a.d.xmask && a.d.split_terms != 1) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_ws_kernel<false, 3, 10>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((conv_gemm_bf16x3_ws_kernel<false, 3, 10>), dim3(a.n_blocks), dim3(512), lds, st, a);
-        return dv3_check_launch("conv_gemm_bf16x3(ws stamps)");
-      }
-      if (a.d.split_terms == 1)
-        return a.d.xmask ? launch_x3_ws<true, 1>(a, lds, st) : launch_x3_ws<false, 1>(a, lds, st);
-      return a.d.xmask ? launch_x3_ws<true, 3>(a, lds, st) : launch_x3_ws<false, 3>(a, lds, st);
     }
   }
   if constexpr (WM * WN == 8 && MI == 1) {

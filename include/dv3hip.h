@@ -39,7 +39,7 @@ int dv3_device_info(int dev, char* name, int name_len, int* n_cu);
 int dv3_sizeof(const char* name);
 /* Developer knobs for measurements (what = 1: ablation variant of the bf16x3 tap-GEMM, 0 = off;
  * what = 2: bf16x3 wgrad tile, 0 auto / 1 = 128x128 / 2 = 256x128; what = 3: 8-wave bf16x3
- * tap-GEMM tiles on the in-phase (0), ping-pong (1, default) or producer/consumer (2) main loop). */
+ * tap-GEMM tiles on the in-phase (0) or ping-pong (1, default) main loop). */
 int dv3_debug_set(int what, int value);
 /* what = 1: phase timestamps left by the last dv3_debug_set(1, 10) launch of the 128x256 bf16x3 tile
  * ([8 waves][192 slots][2] uint64, host pointer). */

@@ -11,7 +11,7 @@ from x3_check import ref_glu, dev
 
 
 def pp(mode):
-    """0 = in-phase, 1 = ping-pong, 2 = producer/consumer (128x256 tile only)"""
+    """0 = in-phase, 1 = ping-pong main loop of the 8-wave tiles"""
     _lib.call("dv3_debug_set", 3, int(mode))
 
 
@@ -32,20 +32,20 @@ def parity(B, C, T, k, d, causal, hint, masked, terms=3):
         bits, rs = ops.dropout_bits(B * C, T, 0.3, dev)
         kw = dict(xmask=bits, xmask_rs=rs, drop_scale=1 / 0.7)
     ys = []
-    for on in (0, 1, 2):
+    for on in (0, 1):
         pp(on)
         ys.append(ops.conv_gemm(xg, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
                                 padL=padL, mode=ops.EPI_GLU, Cg=C, bias=bias.to(dev), r=xg, residual=1,
                                 a_split=pk.fwd_s, tile_hint=hint, **kw))
-    same = bool(torch.equal(ys[0], ys[1])) and bool(torch.equal(ys[0], ys[2]))
-    msg = "B=%d C=%d T=%d k=%d d=%d causal=%d hint=%d masked=%d terms=%d: pp == ws == in-phase bitwise %s" % (
+    same = all(bool(torch.equal(ys[0], y)) for y in ys[1:])
+    msg = "B=%d C=%d T=%d k=%d d=%d causal=%d hint=%d masked=%d terms=%d: pp == in-phase bitwise %s" % (
         B, C, T, k, d, causal, hint, masked, terms, same)
     if not masked:
         want = ref_glu(x, w, bias, k, d, causal, True)
         e = (ys[1].cpu().double() - want).abs()
         msg += "  | vs fp64 max %.2e" % float(e.max() / want.abs().max())
     if not same:
-        msg += "  MAXDIFF pp %.3e ws %.3e" % (float((ys[0] - ys[1]).abs().max()), float((ys[0] - ys[2]).abs().max()))
+        msg += "  MAXDIFF %.3e" % float((ys[0] - ys[1]).abs().max())
     print(msg)
     return same
 
@@ -95,14 +95,11 @@ if __name__ == "__main__":
         ok &= parity(*shape, 29, 1, terms=1)
     print("PARITY", "OK" if ok else "FAILED")
     for rep in range(3):      # interleaved A/B: the first seconds of a process run at lower clocks
-        for mode in (0, 1, 2):
-            timeit(29, mode, 1)
-    for mode in (1, 2, 1, 2):
+        for hint in (29, 28):
+            for mode in (0, 1):
+                timeit(hint, mode, 1)
+    for mode in (0, 1, 0, 1):
         timeit(29, mode, 27)
-    for mode in (1, 2, 1, 2):
+    for mode in (0, 1, 0, 1):
         timeit(29, mode, 1, masked=True)
-    for mode in (1, 2):
-        timeit(29, mode, 1, k=1)
-        timeit(29, mode, 1, C=512, T=150, B=64)
-        timeit(29, mode, 3, k=5, C=128)
     pp(1)

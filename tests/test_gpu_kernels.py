@@ -127,6 +127,47 @@ def test_conv_gemm_bf16x3_forward(dev, gemm_mode, tile, B, C, T, k, d, causal):
         assert rel_err(y.cpu(), want) < KTOL
 
 
+@pytest.mark.parametrize("tile", [28, 29])
+@pytest.mark.parametrize("B,C,T,k,d,causal", [(3, 96, 150, 3, 27, True), (2, 256, 600, 3, 1, False),
+                                              (5, 24, 37, 5, 3, False), (4, 160, 300, 1, 1, False)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_conv_gemm_bf16x3_pingpong_equals_inphase(dev, gemm_mode, tile, B, C, T, k, d, causal, masked):
+    """the 8-wave tiles run a ping-pong main loop (SIMD partners half a step apart); it accumulates
+    in the order of the in-phase loop, so the two must agree bit for bit -- with the oracle as the
+    anchor of one of them.  Covers several chunks (C > 32), partial chunks, 1x1 and 5 taps, the
+    dropout keep-bits path."""
+    if gemm_mode != "bf16x3":
+        pytest.skip("bf16x3 kernel test")
+    ops = _ops()
+    from deepvoice3_pytorch_amd import _lib
+    rng = np.random.RandomState(C + T + k + d)
+    sd = _glu_sd(C, k, rng)
+    x = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
+    pk = ops.pack_weights(sd["l.conv.weight_v"].to(dev), sd["l.conv.weight_g"].to(dev), glu_cg=C, need_bwd=False)
+    padL = (k - 1) * d if causal else (k - 1) // 2 * d
+    xg = x.to(dev)
+    kw = {}
+    if masked:
+        ops.dropout_state.manual_seed(11)
+        bits, rs = ops.dropout_bits(B * C, T, 0.25, dev)
+        kw = dict(xmask=bits, xmask_rs=rs, drop_scale=1 / 0.75)
+    ys = []
+    try:
+        for mode in (0, 1):
+            _lib.call("dv3_debug_set", 3, mode)
+            ys.append(ops.conv_gemm(xg, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
+                                    padL=padL, mode=ops.EPI_GLU, Cg=C, bias=sd["l.conv.bias"].to(dev), r=xg,
+                                    residual=1, tile_hint=tile, a_split=pk.fwd_s, **kw))
+    except RuntimeError as e:
+        assert "needs split-bf16" in str(e)
+        pytest.skip("tile %d not eligible for this shape" % tile)
+    finally:
+        _lib.call("dv3_debug_set", 3, 1)
+    assert torch.equal(ys[0], ys[1])
+    if not masked:
+        assert rel_err(ys[1].cpu(), O.conv1d_glu(sd, "l", x, k, d, causal, True)) < KTOL
+
+
 def test_conv_gemm_highway_and_activations(dev):
     ops = _ops()
     rng = np.random.RandomState(5)
