@@ -370,6 +370,22 @@ __global__ __launch_bounds__(256) void sincos_pos_bwd_kernel(const int64_t* __re
   if (threadIdx.x == 0) dw[b] = red[0] + red[1] + red[2] + red[3];
 }
 
+// Ragged -> padded rows of 32-bit words (the padding half of train.collate_fn, train.py:293-360, on the
+// device): one workgroup per output row.  HBM-bound byte mover: each output word is written once, each
+// source word read at most once, both coalesced along the row.
+__global__ __launch_bounds__(256) void ragged_pad_rows_kernel(const uint32_t* __restrict__ src,
+                                                              const int32_t* __restrict__ row_off,
+                                                              uint32_t* __restrict__ out, int T_out, int D,
+                                                              int lead, int t_stride) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int r0 = row_off[b], n = row_off[b + 1] - r0;
+  const int s = t * t_stride - lead;
+  const bool inside = s >= 0 && s < n;                      // uniform per workgroup
+  const uint32_t* in = src + (int64_t)(r0 + (inside ? s : 0)) * D;
+  uint32_t* o = out + ((int64_t)b * T_out + t) * D;
+  for (int d = threadIdx.x; d < D; d += 256) o[d] = inside ? in[d] : 0u;
+}
+
 }  // namespace
 
 extern "C" int dv3_sincos_pos_bwd_f32(const int64_t* pos, const float* table, const float* w,
@@ -464,6 +480,15 @@ extern "C" int dv3_embedding_bct_bwd_f32(const int64_t* idx, const float* dout, 
                      (hipStream_t)stream, idx, dout, dw, mask, mask_rs, drop_scale, B, T, C,
                      padding_idx);
   return dv3_check_launch("embedding_bct_bwd_f32");
+}
+
+extern "C" int dv3_ragged_pad_rows_b32(const uint32_t* src, const int32_t* row_off, uint32_t* out, int32_t B,
+                                       int32_t T_out, int32_t D, int32_t lead, int32_t t_stride, void* stream) {
+  DV3_REQUIRE(src && row_off && out, "ragged_pad_rows: null pointer");
+  DV3_REQUIRE(B > 0 && T_out > 0 && D > 0 && t_stride > 0 && lead >= 0 && B <= 65535, "ragged_pad_rows: bad arguments");
+  hipLaunchKernelGGL(ragged_pad_rows_kernel, dim3((unsigned)T_out, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     src, row_off, out, T_out, D, lead, t_stride);
+  return dv3_check_launch("ragged_pad_rows_b32");
 }
 
 extern "C" int dv3_shift_append_f32(float* buf, const float* x, int64_t rows, int32_t L, int64_t x_stride,

@@ -3,9 +3,15 @@
 training loop can feed train_step.Trainer from the reference's own datasets: ragged (text ids, mel,
 linear[, speaker id]) items -> padded tensors + position tensors + done flags.
 
-Host-side (numpy) like the reference; the masks and guided-attention weights that the reference
-builds on the host afterwards (train.py:261-271,594-601) are computed on the device by the loss
-kernels from the length vectors this function returns.
+`collate_fn` is host-side (numpy) like the reference; the masks and guided-attention weights that the
+reference builds on the host afterwards (train.py:261-271,594-601) are computed on the device by the
+loss kernels from the length vectors this function returns.
+
+`pack_batch` + `device_collate` are the device-side form of the same assembly (SURVEY section 8f, rank
+1): the host only concatenates the ragged items (no padding loops, no padded bytes over PCIe: three
+flat buffers + two offset vectors instead of nine padded tensors) and the HIP path pads, down-samples
+the mel and derives the position tensors and done flags from the lengths.  Bit-identical to
+`to_device_batch(collate_fn(batch))` (tests/test_gpu_model.py).
 """
 import numpy as np
 import torch
@@ -53,6 +59,72 @@ def to_device_batch(collated, device, outputs_per_step=1, downsample_step=4):
     x, in_len, mel, y, (tpos, fpos), done, tgt_len, spk = collated
     return Batch.from_collate(x, in_len, mel, y, tpos, fpos, done, tgt_len, spk, downsample_step, device,
                               r=outputs_per_step)
+
+
+class PackedBatch(object):
+    """Ragged items of one batch, concatenated on the host (pinned when CUDA is present)."""
+
+    def __init__(self, text, mel, lin, in_len, tgt_len, speaker_ids):
+        self.text, self.mel, self.lin = text, mel, lin
+        self.in_len, self.tgt_len, self.speaker_ids = in_len, tgt_len, speaker_ids
+
+
+def pack_batch(batch, pin=None):
+    """[(text ids, mel (n, num_mels), linear (n, fft/2+1)[, speaker id])] -> PackedBatch: the items
+    back to back in three flat buffers, no padding."""
+    in_len = np.array([len(item[0]) for item in batch], dtype=np.int64)
+    tgt_len = np.array([len(item[1]) for item in batch], dtype=np.int64)
+    for item in batch:
+        if len(item[2]) != len(item[1]):
+            raise ValueError("mel and linear spectrogram of an item differ in frame count")
+    text = torch.from_numpy(np.concatenate([np.asarray(item[0], dtype=np.int64) for item in batch]))
+    mel = torch.from_numpy(np.ascontiguousarray(np.concatenate([item[1] for item in batch], 0), dtype=np.float32))
+    lin = torch.from_numpy(np.ascontiguousarray(np.concatenate([item[2] for item in batch], 0), dtype=np.float32))
+    if pin is None:
+        pin = torch.cuda.is_available()
+    if pin:
+        text, mel, lin = text.pin_memory(), mel.pin_memory(), lin.pin_memory()
+    spk = np.array([item[3] for item in batch], dtype=np.int64) if len(batch[0]) == 4 else None
+    return PackedBatch(text, mel, lin, in_len, tgt_len, spk)
+
+
+def padded_frames(tgt_len, outputs_per_step=1, downsample_step=4):
+    """(T, b_pad): frame count of the padded batch and its leading zero frames (train.py:307-316)."""
+    r, ds = int(outputs_per_step), int(downsample_step)
+    T = int(np.max(tgt_len))
+    T += (-T) % r
+    T += (-T) % ds
+    b_pad = r
+    return T + b_pad * ds, b_pad
+
+
+def device_collate(packed, device, outputs_per_step=1, downsample_step=4):
+    """PackedBatch -> train_step.Batch on `device`, equal bit for bit to
+    `to_device_batch(collate_fn(batch), device, ...)`; the padding runs on the GPU
+    (dv3_ragged_pad_rows_b32), positions and done flags come from the length vectors."""
+    from . import ops
+    r, ds = int(outputs_per_step), int(downsample_step)
+    n = len(packed.in_len)
+    T, b_pad = padded_frames(packed.tgt_len, r, ds)
+    Tt = int(packed.in_len.max())
+    Td = T // r // ds
+    dev = torch.device(device)
+    f = lambda t: t.to(dev, non_blocking=True)
+    text, mel, lin = f(packed.text), f(packed.mel), f(packed.lin)
+    off = lambda lens: f(torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)))
+    toff, foff = off(packed.in_len), off(packed.tgt_len)
+    x = ops.ragged_pad_rows(text, toff, n, Tt, lead=0, t_stride=1)
+    y = ops.ragged_pad_rows(lin, foff, n, T, lead=b_pad, t_stride=1)
+    # the reference down-samples the padded mel in time (train.py:639-640): same rows, picked while padding
+    mel_ds = ops.ragged_pad_rows(mel, foff, n, (T + ds - 1) // ds if ds > 1 else T, lead=b_pad, t_stride=ds)
+    in_len_d = f(torch.from_numpy(packed.in_len))
+    ar = torch.arange(1, Tt + 1, device=dev, dtype=torch.int64)[None]
+    tpos = ar * (ar <= in_len_d[:, None])
+    fpos = torch.arange(1, Td + 1, device=dev, dtype=torch.int64)[None].repeat(n, 1)
+    first_done = f(torch.from_numpy(np.maximum(packed.tgt_len // r // ds - 1, 0)))
+    done = (torch.arange(Td, device=dev)[None] >= first_done[:, None]).float()[:, :, None]
+    spk = f(torch.from_numpy(packed.speaker_ids)) if packed.speaker_ids is not None else None
+    return Batch(x, tpos, fpos, mel_ds, y, done, packed.in_len, packed.tgt_len, spk, r, ds, dev)
 
 
 class PreprocessedDataset(torch.utils.data.Dataset):

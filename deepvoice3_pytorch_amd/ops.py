@@ -857,3 +857,21 @@ def clip_adam(p, g, m, v, grad_norm, clip, hyper, beta1, beta2, eps, weight_deca
     _lib.call("dv3_clip_adam_f32", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
               _ptr(grad_norm), float(clip), hyper.data_ptr(), float(beta1), float(beta2), float(eps),
               float(weight_decay), float(grad_prescale), _stream())
+
+
+def ragged_pad_rows(src, row_off, B, T_out, lead=0, t_stride=1):
+    """Items packed back to back as rows (`src` [rows] or [rows][D], f32 or int64; item b = rows
+    row_off[b]..row_off[b+1], int32 on the device) -> zero-padded [B][T_out][D] ([B][T_out] for 1-D
+    input): out[b][t] = row t*t_stride - lead of item b, or 0 outside it.  The `_pad` / `_pad_2d` loops of
+    the reference's collate_fn (train.py:293-360) and its mel time down-sampling (train.py:639-640)."""
+    _chk(src, "src", src.dtype)
+    _chk(row_off, "row_off", torch.int32)
+    if src.dtype not in (torch.float32, torch.int64, torch.int32):
+        raise RuntimeError("ragged_pad_rows: f32 / int32 / int64 rows only")
+    src = src.contiguous()
+    D = 1 if src.dim() == 1 else int(src.shape[1])
+    words = D * (src.element_size() // 4)
+    out = torch.empty((B, T_out) if src.dim() == 1 else (B, T_out, D), dtype=src.dtype, device=src.device)
+    _lib.call("dv3_ragged_pad_rows_b32", src.data_ptr(), row_off.data_ptr(), out.data_ptr(), B, T_out, words,
+              lead, t_stride, _stream())
+    return out

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 19
+#define DV3_ABI_VERSION 20
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -293,6 +293,14 @@ int dv3_sincos_pos_bwd_f32(const int64_t* pos, const float* table, const float* 
  * x[row * x_stride] as its newest; in place, static addresses (hipGraph-capturable decode step) */
 int dv3_shift_append_f32(float* buf, const float* x, int64_t rows, int32_t L, int64_t x_stride,
                          void* stream);
+/* Device-side batch padding (the `_pad` / `_pad_2d` loops of train.collate_fn, train.py:293-360, and the
+ * mel time down-sampling of train.py:639-640 in the same pass): items are packed back to back as rows of
+ * D 32-bit words (f32 features; int64 text ids as D = 2), item b owning rows [row_off[b], row_off[b+1]).
+ *   out[b][t][0..D) = src[row_off[b] + s][0..D),  s = t * t_stride - lead,   if 0 <= s < rows of item b
+ *                   = 0                                                      otherwise
+ * out is [B][T_out][D].  lead = the b_pad leading zero frames, t_stride = downsample_step for the mel. */
+int dv3_ragged_pad_rows_b32(const uint32_t* src, const int32_t* row_off, uint32_t* out, int32_t B,
+                            int32_t T_out, int32_t D, int32_t lead, int32_t t_stride, void* stream);
 /* dy [B][O][2T] -> out[b][j*O+o][t] = dy[b][o][2t+j]: operand of the ConvTranspose1d(k2,s2)
  * backward GEMMs (deepvoice3.py:519-520,527-528)                                          */
 int dv3_deinterleave2_f32(const float* dy, float* out, int32_t B, int32_t O, int32_t T,

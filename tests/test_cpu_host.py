@@ -260,3 +260,23 @@ def test_bucketed_allreduce_gloo_world2():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(2))
     assert res[0][1] == res[1][1]      # both ranks hold the same reduced gradient arena
+
+
+def test_pack_batch_layout():
+    """data.pack_batch: items back to back, no padding; padded_frames restates the frame arithmetic of
+    train.collate_fn (train.py:307-316) that collate_fn itself is pinned on"""
+    from deepvoice3_pytorch_amd import data
+    rng = np.random.RandomState(4)
+    items = [(rng.randint(1, 20, L).astype(np.int32), rng.rand(F, 6).astype(np.float32), rng.rand(F, 9).astype(np.float32), k)
+             for k, (L, F) in enumerate([(5, 11), (9, 30), (2, 17)])]
+    pb = data.pack_batch(items, pin=False)
+    assert pb.text.dtype == torch.int64 and pb.text.shape == (16,) and pb.mel.shape == (58, 6) and pb.lin.shape == (58, 9)
+    assert np.array_equal(pb.in_len, [5, 9, 2]) and np.array_equal(pb.tgt_len, [11, 30, 17])
+    assert np.array_equal(pb.mel[11:41].numpy(), items[1][1]) and np.array_equal(pb.text[5:14].numpy(), items[1][0])
+    assert np.array_equal(pb.speaker_ids, [0, 1, 2])
+    for r, ds in ((1, 4), (2, 1), (4, 4), (1, 1)):
+        T, b_pad = data.padded_frames(pb.tgt_len, r, ds)
+        col = data.collate_fn(items, outputs_per_step=r, downsample_step=ds)
+        assert col[2].shape[1] == T and b_pad == r
+    with pytest.raises(ValueError):
+        data.pack_batch([(items[0][0], items[0][1], items[1][2])], pin=False)

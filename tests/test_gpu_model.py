@@ -370,3 +370,63 @@ def test_graphed_decode_equals_eager_decode(dev, gemm_mode):
         bb = torch.stack(bb) if isinstance(bb, (list, tuple)) else bb
         assert a.shape == bb.shape, n
         assert rel_err(bb.cpu(), a.cpu()) < 1e-6, n
+
+
+@pytest.mark.gpu
+def test_device_collate_matches_reference_golden(dev):
+    """data.pack_batch + data.device_collate (padding, mel down-sampling, positions, done flags on the
+    GPU) against the reference's own train.collate_fn outputs (tests/golden/collate.npz, written by
+    oracle/make_golden.py from the unmodified reference) and against the host path
+    to_device_batch(collate_fn(...)): bit exact, r in {1, 2, 4}, downsample_step in {1, 4}, with and
+    without speaker ids, ragged lengths."""
+    from deepvoice3_pytorch_amd import data
+    fx = load_golden("collate")
+    cases = sorted({k.split("/")[0] for k in fx})
+    assert len(cases) == 4
+    for c in cases:
+        r, ds = [int(v) for v in fx[c + "/r_ds"]]
+        items, i = [], 0
+        while "%s/item%d/text" % (c, i) in fx:
+            it = (fx["%s/item%d/text" % (c, i)], fx["%s/item%d/mel" % (c, i)], fx["%s/item%d/y" % (c, i)])
+            if "%s/item%d/spk" % (c, i) in fx:
+                it = it + (int(fx["%s/item%d/spk" % (c, i)]),)
+            items.append(it)
+            i += 1
+        got = data.device_collate(data.pack_batch(items), dev, outputs_per_step=r, downsample_step=ds)
+        host = data.to_device_batch(data.collate_fn(items, outputs_per_step=r, downsample_step=ds), dev,
+                                    outputs_per_step=r, downsample_step=ds)
+        want_mel = fx[c + "/out/mel"][:, 0::ds, :] if ds > 1 else fx[c + "/out/mel"]
+        for name, ref in (("text", fx[c + "/out/x"]), ("text_positions", fx[c + "/out/text_positions"]),
+                          ("frame_positions", fx[c + "/out/frame_positions"]), ("mel", want_mel),
+                          ("y", fx[c + "/out/y"]), ("done", fx[c + "/out/done"])):
+            g = getattr(got, name)
+            assert tuple(g.shape) == ref.shape, (c, name, tuple(g.shape), ref.shape)
+            assert np.array_equal(g.cpu().numpy(), ref), (c, name)
+            assert g.dtype == getattr(host, name).dtype and torch.equal(g, getattr(host, name)), (c, name)
+        for name in ("input_lengths", "target_lengths", "decoder_lengths"):
+            assert torch.equal(getattr(got, name), getattr(host, name)), (c, name)
+        assert got.n_frames == host.n_frames
+        if host.speaker_ids is None:
+            assert got.speaker_ids is None
+        else:
+            assert torch.equal(got.speaker_ids, host.speaker_ids)
+
+
+@pytest.mark.gpu
+def test_ragged_pad_rows_edges(dev):
+    """single-frame items, an item as long as the padded batch, stride > 1 landing past an item's end"""
+    from deepvoice3_pytorch_amd import ops
+    rng = np.random.RandomState(0)
+    lens = [1, 7, 3, 12]
+    rows = rng.randn(sum(lens), 5).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    for T_out, lead, stride in ((12, 0, 1), (5, 2, 3), (1, 0, 1), (20, 4, 1)):
+        want = np.zeros((len(lens), T_out, 5), np.float32)
+        for b, n in enumerate(lens):
+            for t in range(T_out):
+                s = t * stride - lead
+                if 0 <= s < n:
+                    want[b, t] = rows[off[b] + s]
+        got = ops.ragged_pad_rows(torch.from_numpy(rows).to(dev), torch.from_numpy(off).to(dev), len(lens), T_out,
+                                  lead=lead, t_stride=stride)
+        assert np.array_equal(got.cpu().numpy(), want), (T_out, lead, stride)
