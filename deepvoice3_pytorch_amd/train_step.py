@@ -329,3 +329,58 @@ def load_checkpoint(path_or_dict, trainer, reset_optimizer=False):
         trainer.adam_step = steps.pop() if steps else 0
     trainer.global_step = int(ck["global_step"])
     return int(ck.get("global_epoch", 0))
+
+
+def _state_dict_of(path_or_dict):
+    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu")
+    return ck["state_dict"] if "state_dict" in ck else ck
+
+
+def restore_parts(path_or_dict, model):
+    """train.restore_parts (train.py:878-897): take from a checkpoint every entry whose name the model
+    has and whose shape fits, leave the rest of the model as it is (transfer between presets, e.g. a
+    single-speaker seq2seq into a multi-speaker model).  Entries with a different shape are skipped with
+    a warning, as the reference does after its per-parameter retry.  Copies INTO the existing tensors,
+    so a Trainer's flat parameter arena stays the storage.  -> (restored names, skipped names)"""
+    import warnings
+    state = _state_dict_of(path_or_dict)
+    own = model.state_dict()
+    restored, skipped = [], []
+    with torch.no_grad():
+        for k, v in state.items():
+            if k not in own:
+                continue
+            if tuple(own[k].shape) != tuple(v.shape):
+                warnings.warn("%s: may contain invalid size of weight. skipping..." % k)
+                skipped.append(k)
+                continue
+            own[k].copy_(v)
+            restored.append(k)
+    return restored, skipped
+
+
+def load_embedding(path_or_dict, model):
+    """train._load_embedding (train.py:870-873): the text embedding table of a checkpoint into
+    model.seq2seq.encoder.embed_tokens (same KeyError when the checkpoint has none)."""
+    state = _state_dict_of(path_or_dict)
+    w = state["seq2seq.encoder.embed_tokens.weight"]
+    dst = model.seq2seq.encoder.embed_tokens.weight
+    if tuple(dst.shape) != tuple(w.shape):
+        raise RuntimeError("embedding table %s does not fit %s" % (tuple(w.shape), tuple(dst.shape)))
+    with torch.no_grad():
+        dst.copy_(w)
+
+
+def load_submodule_checkpoint(path_or_dict, module):
+    """`--checkpoint-seq2seq` / `--checkpoint-postnet` of the reference (train.py:985-989): a checkpoint
+    written for model.seq2seq or model.postnet alone goes into that sub-module (strict names, weights
+    only -- the reference passes the full model's optimizer there, whose state can not match)."""
+    state = _state_dict_of(path_or_dict)
+    own = module.state_dict()
+    missing = [k for k in own if k not in state]
+    unexpected = [k for k in state if k not in own]
+    if missing or unexpected:
+        raise RuntimeError("state_dict mismatch: missing %s unexpected %s" % (missing, unexpected))
+    with torch.no_grad():
+        for k, v in state.items():
+            own[k].copy_(v)

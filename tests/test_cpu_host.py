@@ -280,3 +280,43 @@ def test_pack_batch_layout():
         assert col[2].shape[1] == T and b_pad == r
     with pytest.raises(ValueError):
         data.pack_batch([(items[0][0], items[0][1], items[1][2])], pin=False)
+
+
+def test_restore_parts_and_load_embedding():
+    """train.restore_parts / train._load_embedding (train.py:870-897): partial restore by name, entries
+    of another shape skipped with the reference's warning, the rest of the model untouched"""
+    from deepvoice3_pytorch_amd import builder, train_step
+    hp = dict(n_vocab=20, embed_dim=16, mel_dim=8, linear_dim=9, r=1, downsample_step=4, padding_idx=0, dropout=0.0,
+              kernel_size=3, encoder_channels=16, decoder_channels=16, converter_channels=16, max_positions=32)
+    torch.manual_seed(0)
+    src = builder.deepvoice3(**hp)
+    torch.manual_seed(1)
+    dst = builder.deepvoice3(**dict(hp, n_vocab=24))          # another vocabulary: the embedding table differs
+    before = {k: v.clone() for k, v in dst.state_dict().items()}
+    ck = {"state_dict": dict(src.state_dict(), **{"not.in.the.model": torch.zeros(3)})}
+    with pytest.warns(UserWarning, match="invalid size of weight"):
+        restored, skipped = train_step.restore_parts(ck, dst)
+    assert skipped == ["seq2seq.encoder.embed_tokens.weight"] and "not.in.the.model" not in restored
+    after = dst.state_dict()
+    for k in restored:
+        assert torch.equal(after[k], ck["state_dict"][k])
+    assert torch.equal(after[skipped[0]], before[skipped[0]])
+    assert len(restored) == len(before) - 1
+    # the embedding alone, same vocabulary
+    torch.manual_seed(2)
+    dst2 = builder.deepvoice3(**hp)
+    train_step.load_embedding(ck, dst2)
+    assert torch.equal(dst2.seq2seq.encoder.embed_tokens.weight, src.seq2seq.encoder.embed_tokens.weight)
+    with pytest.raises(RuntimeError):
+        train_step.load_embedding(ck, dst)
+    with pytest.raises(KeyError):
+        train_step.load_embedding({"state_dict": {}}, dst2)
+    # a seq2seq-only / postnet-only checkpoint into the sub-module (train.py:985-989)
+    torch.manual_seed(3)
+    dst3 = builder.deepvoice3(**hp)
+    train_step.load_submodule_checkpoint({"state_dict": src.seq2seq.state_dict()}, dst3.seq2seq)
+    train_step.load_submodule_checkpoint({"state_dict": src.postnet.state_dict()}, dst3.postnet)
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst3.state_dict()[k], v), k
+    with pytest.raises(RuntimeError):
+        train_step.load_submodule_checkpoint({"state_dict": src.postnet.state_dict()}, dst3.seq2seq)
