@@ -4,7 +4,9 @@
 PARITY UNPINNED for the phase-reconstruction part: the reference (audio.py:37-43) calls
 `lws.lws(1024, 256, mode="speech").run_lws(...)` / `.istft`, a third-party package (unpinned version,
 setup.py:87) that is not vendored and not installed; the reference has no test or golden vector
-for it (tests/test_audio.py covers _amp_to_db/_db_to_amp only).  What IS restated exactly:
+for it (tests/test_audio.py covers _amp_to_db/_db_to_amp only).  What IS restated exactly, and pinned bit
+for bit against the reference's own functions run unmodified (tests/golden/audio_helpers.npz,
+oracle/make_golden.py:gen_audio_helpers):
 _denormalize / _db_to_amp (audio.py:84-93), magnitude ** power (audio.py:41, hparams.py:124) and
 inv_preemphasis = lfilter([1], [1, -0.97]) (audio.py:26-28, nnmnkwii).  Phase reconstruction is
 Griffin-Lim on torch-CPU FFTs (torch.stft / torch.istft, periodic Hann 1024, hop 256, center=True
@@ -25,8 +27,11 @@ def db_to_amp(x):
 
 
 def magnitudes(lin, min_level_db=-100, ref_level_db=20, power=1.4):
-    """audio.py:39-41: (_db_to_amp(_denormalize(S) + ref_level_db)) ** power, float64"""
-    return db_to_amp(denormalize(np.asarray(lin, dtype=np.float64), min_level_db) + ref_level_db) ** power
+    """audio.py:39-41: _db_to_amp(_denormalize(S) + ref_level_db) in the dtype of S (float32 for model
+    outputs), then .astype(float64) ** power -- the dtype flow is part of the restatement
+    (tests/golden/audio_helpers.npz pins it bit for bit)"""
+    S = db_to_amp(denormalize(np.asarray(lin), min_level_db) + ref_level_db)
+    return S.astype(np.float64) ** power
 
 
 def istft(spec, hop=256, n_fft=1024):

@@ -291,6 +291,32 @@ def gen_collate():
     print("wrote collate.npz")
 
 
+def gen_audio_helpers():
+    """The reference's own amplitude / dB / normalisation helpers (audio.py:75-93), run unmodified with the
+    ljspeech preset's hparams: the part of the audio path that does not need the third-party lws / librosa /
+    nnmnkwii packages (those are stubbed by refimport, so spectrogram / inv_spectrogram themselves cannot run)."""
+    train, hparams, _ = refimport.load_train_module()
+    hparams.parse_json(open(os.path.join(refimport.REF_ROOT, "presets", "deepvoice3_ljspeech.json")).read())
+    import audio                                   # the reference audio.py, unmodified
+    rng = np.random.RandomState(11)
+    amp = np.concatenate([np.abs(rng.randn(64)) * 3.0, [0.0, 1e-7, 1e-5, 1.0, 37.5]]).astype(np.float64)
+    amp32 = amp.astype(np.float32)
+    db = np.concatenate([rng.uniform(-130, 30, 64), [-100.0, 0.0, -99.999, 20.0]]).astype(np.float64)
+    norm = np.concatenate([rng.uniform(-0.3, 1.3, 64), [0.0, 1.0, 0.5]]).astype(np.float32)
+    out = {"hp/min_level_db": np.float64(hparams.min_level_db), "hp/ref_level_db": np.float64(hparams.ref_level_db),
+           "hp/power": np.float64(hparams.power), "hp/preemphasis": np.float64(hparams.preemphasis),
+           "in/amp": amp, "in/amp32": amp32, "in/db": db, "in/norm": norm,
+           "out/amp_to_db": audio._amp_to_db(amp), "out/amp_to_db32": audio._amp_to_db(amp32),
+           "out/db_to_amp": audio._db_to_amp(db), "out/normalize": audio._normalize(db),
+           "out/denormalize": audio._denormalize(norm),
+           # the magnitude chain of inv_spectrogram up to the lws call (audio.py:39-41)
+           "out/inv_mag": audio._db_to_amp(audio._denormalize(norm) + hparams.ref_level_db).astype(np.float64) ** hparams.power,
+           # and of spectrogram after the STFT (audio.py:33-34)
+           "out/spec_norm": audio._normalize(audio._amp_to_db(amp) - hparams.ref_level_db)}
+    np.savez_compressed(os.path.join(OUT, "audio_helpers.npz"), **out)
+    print("audio_helpers", len(out))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, b, hp in MODELS:
@@ -299,6 +325,7 @@ def main():
     gen_misc()
     gen_trainstep()
     gen_collate()
+    gen_audio_helpers()
 
 
 if __name__ == "__main__":

@@ -22,6 +22,25 @@ def test_oracle_amp_db_and_denormalize_known_answers():
     assert np.allclose(A.magnitudes(np.array([1.0])), 10.0 ** 1.4)
 
 
+def test_oracle_helpers_match_reference_golden():
+    """oracle/audio_oracle.py against the reference's own audio._amp_to_db / _db_to_amp / _normalize /
+    _denormalize run unmodified under the ljspeech preset (tests/golden/audio_helpers.npz, written by
+    oracle/make_golden.py:gen_audio_helpers): bit exact, including values below min_level and outside
+    the clipping range, and the two composite chains inv_spectrogram / spectrogram apply around lws."""
+    from tests.util import load_golden
+    fx = load_golden("audio_helpers")
+    mn, ref, power = float(fx["hp/min_level_db"]), float(fx["hp/ref_level_db"]), float(fx["hp/power"])
+    assert (mn, ref, power, float(fx["hp/preemphasis"])) == (-100.0, 20.0, 1.4, 0.97)   # the defaults the oracle carries
+    assert np.array_equal(A.amp_to_db(fx["in/amp"], mn), fx["out/amp_to_db"])
+    assert np.array_equal(A.amp_to_db(fx["in/amp32"], mn), fx["out/amp_to_db32"])
+    assert np.array_equal(A.db_to_amp(fx["in/db"]), fx["out/db_to_amp"])
+    assert np.array_equal(A.normalize(fx["in/db"], mn), fx["out/normalize"])
+    d = A.denormalize(fx["in/norm"], mn)
+    assert d.dtype == fx["out/denormalize"].dtype and np.array_equal(d, fx["out/denormalize"])
+    assert np.array_equal(A.magnitudes(fx["in/norm"], mn, ref, power), fx["out/inv_mag"])
+    assert np.array_equal(A.normalize(A.amp_to_db(fx["in/amp"], mn) - ref, mn), fx["out/spec_norm"])
+
+
 def test_oracle_stft_istft_roundtrip_and_griffin_lim_converges():
     rng = np.random.RandomState(1)
     T, hop = 40, 256
