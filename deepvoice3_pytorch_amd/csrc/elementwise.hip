@@ -10,6 +10,7 @@ namespace {
 // pre-activation gradients are written per (b, row) for the deterministic bias / speaker-bias
 // reduction.  Autograd of modules.py:157-164 (GLU) and :224-226 (highway).
 // ------------------------------------------------------------------------------------------
+template <bool VEC4>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // b*C + ch
@@ -26,23 +27,56 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
     const float k = (p.mode == DV3_EPI_GLU && p.residual) ? 0.70710678118654752440f : 1.0f;
     const float* x = p.x ? p.x + row * T : nullptr;
     float* dres = p.dres ? p.dres + row * T : nullptr;
-    for (int t = lane; t < T; t += 64) {
-      const float d = dy[t] * k;
-      const float s = 1.0f / (1.0f + expf(-g[t]));
-      float va, vg;
-      if (p.mode == DV3_EPI_GLU) {
-        va = d * s;
-        vg = d * a[t] * s * (1.0f - s);
-        if (dres) dres[t] = d;
+    const bool glu = p.mode == DV3_EPI_GLU;
+    // one element: (dy, a, g, x) -> (da, dg, dres)
+    auto elem = [&](float dyv, float av, float gv, float xv, float& va, float& vg, float& vr) {
+      const float d = dyv * k;
+      const float s = 1.0f / (1.0f + expf(-gv));
+      va = d * s;
+      if (glu) {
+        vg = d * av * s * (1.0f - s);
+        vr = d;
       } else {
-        va = d * s;
-        vg = d * (a[t] - x[t]) * s * (1.0f - s);
-        if (dres) dres[t] = d * (1.0f - s);
+        vg = d * (av - xv) * s * (1.0f - s);
+        vr = d * (1.0f - s);
       }
-      da[t] = va;
-      dg[t] = vg;
-      sa += va;
-      sg += vg;
+    };
+    if (VEC4) {
+      // rows are 16-byte aligned and T % 4 == 0 (checked by the launcher): 16 bytes per lane and access
+      const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+      const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+      const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+      f32x4* da4 = reinterpret_cast<f32x4*>(da);
+      f32x4* dg4 = reinterpret_cast<f32x4*>(dg);
+      f32x4* dres4 = reinterpret_cast<f32x4*>(dres);
+      for (int q = lane; q < (T >> 2); q += 64) {
+        const f32x4 dv = dy4[q], av = a4[q], gv = g4[q];
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+        if (!glu) xv = x4[q];
+        f32x4 oa, og, orr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float va, vg, vr;
+          elem(dv[e], av[e], gv[e], xv[e], va, vg, vr);
+          oa[e] = va; og[e] = vg; orr[e] = vr;
+          sa += va;
+          sg += vg;
+        }
+        da4[q] = oa;
+        dg4[q] = og;
+        if (dres) dres4[q] = orr;
+      }
+    } else {
+      for (int t = lane; t < T; t += 64) {
+        float va, vg, vr;
+        elem(dy[t], a[t], g[t], glu ? 0.f : x[t], va, vg, vr);
+        if (dres) dres[t] = vr;
+        da[t] = va;
+        dg[t] = vg;
+        sa += va;
+        sg += vg;
+      }
     }
     sa = dv3_wave_sum(sa);
     sg = dv3_wave_sum(sg);
@@ -409,8 +443,14 @@ extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
     DV3_REQUIRE(d->mode != DV3_EPI_DGRAD, "gate_bwd: bad mode");
   }
   const int64_t rows = (int64_t)d->B * d->C;
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)dv3_cdiv64(rows, 4)), dim3(256), 0,
-                     (hipStream_t)stream, *d);
+  // 16 bytes per lane when every row starts 16-byte aligned (gated modes; the others are small)
+  const uintptr_t ptrs = (uintptr_t)d->dy | (uintptr_t)d->ab_or_y | (uintptr_t)d->dab | (uintptr_t)d->x | (uintptr_t)d->dres;
+  if (gated && (d->T & 3) == 0 && (ptrs & 15) == 0)
+    hipLaunchKernelGGL(gate_bwd_kernel<true>, dim3((unsigned)dv3_cdiv64(rows, 4)), dim3(256), 0,
+                       (hipStream_t)stream, *d);
+  else
+    hipLaunchKernelGGL(gate_bwd_kernel<false>, dim3((unsigned)dv3_cdiv64(rows, 4)), dim3(256), 0,
+                       (hipStream_t)stream, *d);
   return dv3_check_launch("gate_bwd_f32");
 }
 
