@@ -320,3 +320,50 @@ def test_restore_parts_and_load_embedding():
         assert torch.equal(dst3.state_dict()[k], v), k
     with pytest.raises(RuntimeError):
         train_step.load_submodule_checkpoint({"state_dict": src.postnet.state_dict()}, dst3.seq2seq)
+
+
+def _ragged_pad_rows_numpy(src, row_off, B, T_out, lead=0, t_stride=1):
+    """what dv3_ragged_pad_rows_b32 computes (include/dv3hip.h), in numpy: lets the host half of
+    data.device_collate run on CPU"""
+    one = src.dim() == 1
+    out = torch.zeros((B, T_out) if one else (B, T_out, src.shape[1]), dtype=src.dtype)
+    ro = row_off.numpy()
+    for b in range(B):
+        n = int(ro[b + 1] - ro[b])
+        t = np.arange(T_out)
+        s_ = t * t_stride - lead
+        ok = (s_ >= 0) & (s_ < n)
+        out[b, torch.from_numpy(t[ok])] = src[torch.from_numpy(ro[b] + s_[ok])]
+    return out
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_device_collate_host_logic_equals_collate_fn(monkeypatch, seed):
+    """data.device_collate with the padding kernel emulated in numpy == to_device_batch(collate_fn(...))
+    for random ragged batches: lengths of 1, r in {1, 2, 4}, downsample_step in {1, 2, 4}, frame counts
+    that are and are not multiples of r * downsample_step, with and without speaker ids.  (The kernel
+    itself is pinned against the reference golden on the GPU: tests/test_gpu_model.py.)"""
+    from deepvoice3_pytorch_amd import data, ops
+    monkeypatch.setattr(ops, "ragged_pad_rows", _ragged_pad_rows_numpy)
+    rng = np.random.RandomState(100 + seed)
+    r = int(rng.choice([1, 2, 4]))
+    ds = int(rng.choice([1, 2, 4]))
+    n = int(rng.randint(1, 7))
+    multi = bool(rng.randint(2))
+    items = []
+    for i in range(n):
+        L = int(rng.randint(1, 30))
+        F = int(rng.randint(1, 70)) if rng.rand() < 0.8 else int(rng.randint(1, 6)) * r * ds
+        it = (rng.randint(1, 40, L).astype(np.int32), rng.rand(F, 5).astype(np.float32), rng.rand(F, 7).astype(np.float32))
+        items.append(it + (int(rng.randint(3)),) if multi else it)
+    got = data.device_collate(data.pack_batch(items, pin=False), "cpu", outputs_per_step=r, downsample_step=ds)
+    host = data.to_device_batch(data.collate_fn(items, outputs_per_step=r, downsample_step=ds), "cpu",
+                                outputs_per_step=r, downsample_step=ds)
+    for name in ("text", "text_positions", "frame_positions", "mel", "y", "done", "input_lengths", "target_lengths",
+                 "decoder_lengths", "linear_mask_lengths"):
+        g, h = getattr(got, name), getattr(host, name)
+        assert g.dtype == h.dtype and g.shape == h.shape and torch.equal(g, h), (name, r, ds)
+    assert got.n_frames == host.n_frames
+    assert (got.speaker_ids is None) == (host.speaker_ids is None)
+    if multi:
+        assert torch.equal(got.speaker_ids, host.speaker_ids)
