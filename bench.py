@@ -6,16 +6,20 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one full optimisation step (forward + losses + backward + [all-reduce] + clip + Adam,
-train.py:604-785) of builder=deepvoice3 preset=deepvoice3_ljspeech, fp32, on a synthetic
-LJSpeech-shaped batch resident in HBM.  value = sum over ranks of un-padded target frames per
-step / wall time per step (max over ranks).  Prints ONE JSON line on rank 0 with two extra
-objects:
-  roofline      the dominant kernel (conv_gemm_f32, Conv1dGLU forward at the north-star shape
+train.py:604-785) of builder=deepvoice3 preset=deepvoice3_ljspeech on a synthetic LJSpeech-shaped
+batch resident in HBM.  value = sum over ranks of un-padded target frames per step / wall time per
+step (max over ranks).  GEMM arithmetic: --gemm bf16x3 (default: fp32 operands split into hi+lo bf16
+on the matrix cores, fp32 accumulate, 1e-4 parity with the fp32 reference), f32 (exact fp32 MFMA) or
+bf16.  Prints ONE JSON line on rank 0 with these extra objects:
+  roofline      the dominant kernel (the tap-GEMM, Conv1dGLU forward at the north-star shape
                 B=64 x 256ch x 1024T, k=3) timed with HIP events on its launch stream;
-                bound "mfma": algorithmic FLOPs / time vs the fp32 matrix peak (157.3 TF);
-                hbm_frac reports the same launch against the 8 TB/s HBM roof for the record.
+                bound "mfma": algorithmic FLOPs / time vs the MFMA roof of the mode (bf16x3:
+                2500/3 TF; f32: 157.3 TF); hbm_frac is the same launch against the 8 TB/s HBM roof;
+                traffic = HBM bytes per launch from the PMC passes recorded under profiles/
+  roofline_exact_f32   the exact-fp32 kernel on the same launch, for the record
   cpu_baseline  the CPU oracle port of the same train step (oracle/dv3_oracle.py: the reference's
-                own torch-CPU ops) on this host's cores, a bounded sample of the same workload.
+                own torch-CPU ops) on this host's cores, a bounded sample of the same workload
+  host_buffers  the step rate if the boundary is handed pinned host tensors instead (never `value`)
 """
 import argparse
 import json
@@ -375,7 +379,8 @@ def main():
     out = dict(metric="mel-frames/sec/node (train step, %s)" % args.preset, value=round(value, 1),
                unit="mel-frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype=mode_desc[ops.gemm_precision()],
+               dtype={"bf16x3": "f32", "f32": "f32", "bf16": "bf16"}[ops.gemm_precision()],
+               dtype_note=mode_desc[ops.gemm_precision()],
                data="synthetic (fixed-shape LJSpeech-like: Tt=%d, %d frames/item; random-init weights)"
                % (args.text_len, args.frames),
                config=dict(workload="builder=%s preset=%s train step "
