@@ -1,0 +1,161 @@
+// Primitive costs inside one 512-thread workgroup per CU on MI355X (gfx950): what a LOAD / COMPUTE phase of the
+// bf16x3 tap-GEMM is made of, measured in isolation and next to a partner wave on the same SIMD.
+// Developer micro-benchmark, not part of the product or its tests.
+//   hipcc --offload-arch=gfx950 -O3 -o cu_phases cu_phases.hip && ./cu_phases
+// Each test (template <role of waves 0-3, role of waves 4-7, barrier per iteration>: the timed loops are
+// straight-line) runs ITER iterations per wave on 256 workgroups x 8 waves; waves 0-3 ("early", one per SIMD)
+// and waves 4-7 ("late", their SIMD partners) may do different things.  s_memtime around the loop, per-iteration
+// cycles of wave 0 and wave 4 of workgroup 0 are reported (plus the max over a few workgroups).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ITER = 256;
+enum Role { IDLE = 0, MFMA24, LDSR16, GLD2, DSW2, VALU96, BARRIER, STAMP, PHASE_L, PHASE_C };
+
+struct Args {
+  const f32x4* gsrc;          // >= 256 * 16 KB, L2-resident after the first touch
+  float* sink;                // 256 * 512 floats
+  unsigned long long* cyc;    // [blocks][8]
+};
+
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int RE, int RL, int SYNC>
+__global__ __launch_bounds__(512) void k(const Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // explicit LDS address space: a volatile generic pointer would compile to flat_load / flat_store
+  typedef __attribute__((address_space(3))) volatile bf16x8 lds_unit;
+  lds_unit* lds = (lds_unit*)smem_raw;   // 96 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int late = wave >> 2;
+
+  // operands / accumulators
+  bf16x8 fa[4], fb[4];
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i) {
+    for (int e = 0; e < 8; ++e) { fa[i][e] = (__bf16)(0.001f * (lane + i + e)); fb[i][e] = (__bf16)(0.002f * (lane - i + e)); }
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  }
+  for (int i = tid; i < 96 * 1024 / 16; i += 512) lds[i] = fa[i & 3];
+  __syncthreads();
+  f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
+  float vacc = (float)lane;
+  unsigned long long t0 = 0, t1 = 0, st = 0;
+
+  auto mfma24 = [&]() {
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(i + q) & 3], fb[i], acc[i], 0, 0, 0);
+  };
+  auto ldsr16 = [&](int it) {
+    // 16 fragment reads: lanes 0-31 / 32-63 read 512 contiguous bytes each (the kernel's conflict-free pattern)
+    const int base = ((it & 1) * 2048 + wave * 256 + (lane >> 5) * 128 + (lane & 31));
+    bf16x8 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = lds[base + (r * 64) % 1536 + (r >> 2) * 16];
+    wait_lgkm0();
+#pragma unroll
+    for (int r = 0; r < 16; r += 4) fa[r >> 2] = v[r];           // consume (keeps the reads)
+  };
+  auto gld2 = [&](int it) {
+    // two 16-byte loads per lane inside the workgroup's own 16 KB (L2 hits after the first pass)
+    const f32x4* g0 = a.gsrc + (size_t)blockIdx.x * 1024;
+    const f32x4 x0 = g0[(tid + it * 64) & 1023];
+    const f32x4 x1 = g0[(tid + 512 + it * 64) & 1023];
+    wait_vm0();
+    gacc += x0 + x1;
+  };
+  auto dsw2 = [&](int it) {
+    lds[4096 + (it & 1) * 1024 + tid] = fa[0];
+    lds[4096 + 2048 + (it & 1) * 1024 + tid] = fb[0];
+    wait_lgkm0();
+  };
+  auto valu96 = [&]() {
+#pragma unroll
+    for (int q = 0; q < 96; ++q) vacc = vacc * 1.0001f + 0.5f;
+  };
+  auto body = [&](auto role_c, int it) {          // straight-line per role: no dispatch inside the timed loop
+    constexpr int ROLE = decltype(role_c)::value;
+    if constexpr (ROLE == MFMA24 || ROLE == PHASE_C) mfma24();
+    if constexpr (ROLE == LDSR16) ldsr16(it);
+    if constexpr (ROLE == GLD2) gld2(it);
+    if constexpr (ROLE == DSW2) dsw2(it);
+    if constexpr (ROLE == VALU96) valu96();
+    if constexpr (ROLE == STAMP) st += __builtin_readcyclecounter() & 1;
+    if constexpr (ROLE == PHASE_L) { ldsr16(it); dsw2(it); gld2(it); }   // a LOAD phase minus the activation tile
+    if constexpr (SYNC) { wait_lgkm0(); __builtin_amdgcn_s_barrier(); }
+  };
+
+  __syncthreads();
+  t0 = __builtin_readcyclecounter();
+  if (late) {
+    for (int it = 0; it < ITER; ++it) body(std::integral_constant<int, RL>{}, it);
+  } else {
+    for (int it = 0; it < ITER; ++it) body(std::integral_constant<int, RE>{}, it);
+  }
+  t1 = __builtin_readcyclecounter();
+  if (lane == 0) a.cyc[blockIdx.x * 8 + wave] = t1 - t0;
+  float s = vacc + gacc[0] + gacc[1] + gacc[2] + gacc[3] + (float)(st & 1);
+  for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][7] + (float)fa[i][0];
+  a.sink[blockIdx.x * 512 + tid] = s;
+}
+
+static const char* kName[] = {"idle", "mfma24", "ldsr16", "gld2", "dsw2", "valu96", "barrier", "stamp", "phaseL", "phaseC"};
+
+template <int RE, int RL, int SYNC>
+static void run(const Args& a, std::vector<unsigned long long>& h, int blocks) {
+  (void)hipFuncSetAttribute((const void*)k<RE, RL, SYNC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<RE, RL, SYNC>), dim3(blocks), dim3(512), 96 * 1024, 0, a);
+  if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); exit(2); }
+  (void)hipMemcpy(h.data(), a.cyc, h.size() * 8, hipMemcpyDeviceToHost);
+  unsigned long long me = 0, ml = 0;
+  for (int b = 0; b < blocks; ++b) { if (h[b * 8] > me) me = h[b * 8]; if (h[b * 8 + 4] > ml) ml = h[b * 8 + 4]; }
+  printf("%-8s %-8s %d    | %9.1f %9.1f | %9.1f %9.1f\n", kName[RE], kName[RL], SYNC, h[0] / (double)ITER,
+         h[4] / (double)ITER, me / (double)ITER, ml / (double)ITER);
+}
+
+int main() {
+  const int blocks = 256;
+  f32x4* gsrc; float* sink; unsigned long long* cyc;
+  if (hipMalloc(&gsrc, (size_t)blocks * 16384) != hipSuccess) { printf("no GPU\n"); return 1; }
+  (void)hipMemset(gsrc, 0, (size_t)blocks * 16384);
+  (void)hipMalloc(&sink, (size_t)blocks * 512 * 4);
+  (void)hipMalloc(&cyc, (size_t)blocks * 8 * 8);
+  Args a{gsrc, sink, cyc};
+  std::vector<unsigned long long> h(blocks * 8);
+  (void)hipFuncSetAttribute((const void*)k<MFMA24, MFMA24, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  for (int warm = 0; warm < 400; ++warm)          // ~50 ms of matrix load: let the clock governor settle
+    hipLaunchKernelGGL((k<MFMA24, MFMA24, 0>), dim3(blocks), dim3(512), 96 * 1024, 0, a);
+  (void)hipDeviceSynchronize();
+  printf("%-8s %-8s sync | cycles/iter: early(w0)  late(w4) | max over workgroups: early late\n", "early", "late");
+  run<IDLE, IDLE, 0>(a, h, blocks);               // loop overhead
+  run<STAMP, IDLE, 0>(a, h, blocks);
+  run<BARRIER, BARRIER, 1>(a, h, blocks);
+  run<MFMA24, IDLE, 0>(a, h, blocks);
+  run<MFMA24, MFMA24, 0>(a, h, blocks);
+  run<MFMA24, MFMA24, 1>(a, h, blocks);           // in-phase: both waves of a SIMD compute between barriers
+  run<LDSR16, IDLE, 0>(a, h, blocks);
+  run<LDSR16, LDSR16, 0>(a, h, blocks);
+  run<LDSR16, MFMA24, 0>(a, h, blocks);
+  run<GLD2, IDLE, 0>(a, h, blocks);
+  run<GLD2, MFMA24, 0>(a, h, blocks);
+  run<DSW2, IDLE, 0>(a, h, blocks);
+  run<DSW2, MFMA24, 0>(a, h, blocks);
+  run<VALU96, IDLE, 0>(a, h, blocks);
+  run<VALU96, MFMA24, 0>(a, h, blocks);
+  run<PHASE_L, IDLE, 0>(a, h, blocks);
+  run<PHASE_L, PHASE_C, 0>(a, h, blocks);
+  run<PHASE_L, PHASE_C, 1>(a, h, blocks);         // ping-pong: LOAD beside COMPUTE, one barrier per phase
+  return 0;
+}
