@@ -64,7 +64,8 @@ class _WNLayer(nn.Module):
         v, g = self.wn_params()
         if torch.is_grad_enabled() and (v.requires_grad or (g is not None and g.requires_grad)):
             return None
-        key = (v.data_ptr(), v._version, None if g is None else (g.data_ptr(), g._version), glu_cg)
+        key = (v.data_ptr(), v._version, None if g is None else (g.data_ptr(), g._version), glu_cg,
+               ops.param_epoch, ops.gemm_precision())
         if self._pack_cache is None or self._pack_cache[0] != key:
             pk = ops.pack_weights(v.detach(), None if g is None else g.detach(), glu_cg=glu_cg,
                                   transposed=self.transposed, need_bwd=False)

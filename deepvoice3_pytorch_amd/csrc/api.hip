@@ -11,6 +11,13 @@ void dv3_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int g_dv3_last_conv = 0, g_dv3_last_wgrad = 0;
+extern "C" int dv3_debug_get(int what) {
+  if (what == 10) return g_dv3_last_conv;
+  if (what == 11) return g_dv3_last_wgrad;
+  return 0;
+}
+
 extern "C" const char* dv3_last_error(void) { return g_err; }
 extern "C" int dv3_abi_version(void) { return DV3_ABI_VERSION; }
 

@@ -31,6 +31,9 @@ static inline int dv3_check_launch(const char* what) {
   return DV3_OK;
 }
 
+// dv3_debug_get(10 / 11): which kernel variant the last tap-GEMM / wgrad call launched (api.hip)
+extern int g_dv3_last_conv, g_dv3_last_wgrad;
+
 static inline int dv3_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t dv3_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -370,6 +370,7 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
   if (use_lds) DV3_REQUIRE(lds <= 64 * 1024, "conv_gemm: LDS tile %zu B too large (J=%d dil=%d)", lds, d->J, d->dil);
 
   hipStream_t st = (hipStream_t)stream;
+  g_dv3_last_conv = (use_lds ? 2000 : 1000) + best->id * 10;
   if (!use_lds) {
     switch (best->id) {
       case 1: return launch_stream<2, 2, 2>(a, st);

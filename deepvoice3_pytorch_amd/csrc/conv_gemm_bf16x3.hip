@@ -653,6 +653,8 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   const int64_t nb = (int64_t)a.m_tiles * a.n_tiles;
   DV3_REQUIRE(nb < (1ll << 31), "conv_gemm: grid too large");
   a.n_blocks = (int)nb;
+  g_dv3_last_conv = (d->split_terms == 1 ? 4000 : 3000) + best->id * 10 +
+                    ((best->id >= 8 && g_x3_pingpong) ? 1 : 0);
   switch (best->id) {
     case 1: return launch_x3<2, 2, 2>(a, lds, st);
     case 2: return launch_x3<2, 2, 1>(a, lds, st);

@@ -341,5 +341,6 @@ int dv3_wgrad_gemm_bf16x3_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
   a.c_tiles = dv3_cdiv(d->Cin, 128);
   const int64_t nb = (int64_t)a.m_tiles * a.c_tiles * d->J * d->n_slabs;
   DV3_REQUIRE(nb < (1ll << 31), "wgrad_gemm: grid too large");
+  g_dv3_last_wgrad = (d->split_bf16 == 2 ? 4000 : 3000) + (big ? 20 : 10);
   return big ? launch_wgrad_x3<4, 2>(a, nb, st) : launch_wgrad_x3<2, 2>(a, nb, st);
 }

@@ -47,10 +47,22 @@ class BucketedAllReduce(object):
         # a parameter reports its gradient final either through autograd (AccumulateGrad hook) or, for
         # the conv-layer parameters whose gradient is accumulated in place, through ops.grad_ready_hooks
         self._index_of = {id(p): i for i, p in enumerate(arena.params)}
-        for i, p in enumerate(arena.params):
-            p.register_post_accumulate_grad_hook(self._make_hook(i))
+        self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i))
+                         for i, p in enumerate(arena.params)]
         from . import ops as _ops
-        _ops.grad_ready_hooks.append(self._on_inplace_grad)
+        self._ops_hook = self._on_inplace_grad
+        _ops.grad_ready_hooks.append(self._ops_hook)
+
+    def close(self):
+        """Detach from the parameters and from ops.grad_ready_hooks (a second Trainer in the same process
+        must not leave this one's hooks -- and through them its arena -- alive)."""
+        from . import ops as _ops
+        if self._ops_hook in _ops.grad_ready_hooks:
+            _ops.grad_ready_hooks.remove(self._ops_hook)
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        self._armed = False
 
     def _make_hook(self, i):
         def hook(param):

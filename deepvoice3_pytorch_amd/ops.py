@@ -853,7 +853,20 @@ def grad_sqnorm(flat_grad, partial, out2):
               partial.numel(), out2.data_ptr(), _stream())
 
 
+# Raw-pointer writes (dv3_clip_adam_f32 on the flat arena, a replayed step graph) do not bump
+# tensor._version, so everything that caches a function of the parameters (conv._WNLayer.packed: the
+# eval-mode packed weights, hence incremental decode and the decode-step graph) also keys on this
+# counter; whoever writes parameters behind autograd's back bumps it.
+param_epoch = 0
+
+
+def bump_param_epoch():
+    global param_epoch
+    param_epoch += 1
+
+
 def clip_adam(p, g, m, v, grad_norm, clip, hyper, beta1, beta2, eps, weight_decay=0.0, grad_prescale=1.0):
+    bump_param_epoch()
     _lib.call("dv3_clip_adam_f32", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
               _ptr(grad_norm), float(clip), hyper.data_ptr(), float(beta1), float(beta2), float(eps),
               float(weight_decay), float(grad_prescale), _stream())

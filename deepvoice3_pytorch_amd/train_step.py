@@ -126,18 +126,47 @@ class FlatArena(object):
             p.grad = self.grad[o:o + n].view(p.shape)
             p._dv3_grad_inplace = not os.environ.get("DV3_NO_INPLACE_GRAD")   # ops.ConvLayerFn accumulates straight into p.grad
 
+    def rebind(self):
+        """Every parameter's .grad must BE its slice of the gradient arena (clip/Adam and the all-reduce
+        read the arena, nothing else).  model.zero_grad() / optimizer.zero_grad() default to
+        set_to_none=True and autograd would then allocate fresh .grad tensors outside it: put the views
+        back (the arena itself is zeroed by the caller).  A .grad that points elsewhere is an error."""
+        for p, o, n in zip(self.params, self.offsets, self.sizes):
+            g = p.grad
+            if g is None:
+                p.grad = self.grad[o:o + n].view(p.shape)
+            elif g.data_ptr() != self.grad.data_ptr() + 4 * o:
+                raise RuntimeError("a parameter's .grad no longer aliases the flat gradient arena "
+                                   "(was it replaced by an optimizer or a manual assignment?)")
+
 
 class Trainer(object):
+    HYPER_SLOTS = 8
+
     def __init__(self, model, cfg, global_step=0, process_group=None, bucket_mb=25.0):
         self.model, self.cfg = model, cfg
         self.global_step = global_step
         self.adam_step = 0
         params = list(model.get_trainable_parameters())
         self.arena = FlatArena(params)
+        # parameters the optimizer does not own (the frozen position tables, the text embedding under
+        # freeze_embedding; reference __init__.py:48-63) take no gradient at all: a .grad outside the arena
+        # would never be zeroed and only cost backward work
+        owned = set(id(p) for p in params)
+        for p in model.parameters():
+            if id(p) not in owned:
+                p.requires_grad_(False)
         dev = self.arena.flat.device
         self.device = dev
         self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(3)
+        # (lr, 1-b1^t, sqrt(1-b2^t)) travel through a RING of pinned host slots: step() never waits for the
+        # GPU, so the host may run steps ahead of it; a single staging buffer would be overwritten by step
+        # N+1 before step N's queued copy has executed.  A slot is reused only after the copy that read it
+        # has completed (its event), i.e. the host can lead by at most HYPER_SLOTS - 1 steps.
+        self._hyper_ring = [(torch.zeros(3, dtype=torch.float32).pin_memory() if dev.type == "cuda"
+                             else torch.zeros(3)) for _ in range(self.HYPER_SLOTS)]
+        self._hyper_events = [None] * self.HYPER_SLOTS
+        self._hyper_slot = 0
         self.norm_partial = torch.empty(1024, dtype=torch.float32, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
         self.pg = process_group
@@ -147,6 +176,12 @@ class Trainer(object):
             from . import dist as _dist
             self.world = torch.distributed.get_world_size(process_group)
             self.comm = _dist.BucketedAllReduce(self.arena, process_group, bucket_mb)
+
+    def close(self):
+        """Detach the gradient-exchange hooks (call before building another Trainer on the same model)."""
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
     # ------------------------------------------------------------------------------------
     def current_lr(self):
@@ -159,10 +194,19 @@ class Trainer(object):
         c = self.cfg
         self.adam_step += 1
         t = self.adam_step
-        self._hyper_host[0] = float(self.current_lr())
-        self._hyper_host[1] = 1.0 - c.adam_beta1 ** t
-        self._hyper_host[2] = math.sqrt(1.0 - c.adam_beta2 ** t)
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        i = self._hyper_slot
+        self._hyper_slot = (i + 1) % self.HYPER_SLOTS
+        if self._hyper_events[i] is not None:
+            self._hyper_events[i].synchronize()       # the copy that read this slot has run
+        h = self._hyper_ring[i]
+        h[0] = float(self.current_lr())
+        h[1] = 1.0 - c.adam_beta1 ** t
+        h[2] = math.sqrt(1.0 - c.adam_beta2 ** t)
+        self.hyper.copy_(h, non_blocking=True)
+        if self.device.type == "cuda":
+            ev = self._hyper_events[i] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._hyper_events[i] = ev
 
     def check_lengths(self, batch):
         """train.py:646-652."""
@@ -178,6 +222,7 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         """model forward + losses + backward.  Returns the scalars as device tensors."""
         c = self.cfg
         r = c.outputs_per_step
+        self.arena.rebind()
         for p in self.arena.params:      # in-place gradient bookkeeping of ops.ConvLayerFn (uses this step)
             p._dv3_pending = 0
         self.model.train()
@@ -215,6 +260,7 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
 
     def step(self, batch):
         """One full optimisation step; returns device scalars (loss terms, grad_norm, lr)."""
+        self.check_lengths(batch)        # host-side numpy on the batch's length vectors: no device sync
         self._set_hyper()
         self.arena.grad.zero_()
         scal = self.forward_backward(batch)
@@ -233,6 +279,7 @@ class GraphedTrainer(object):
     def __init__(self, trainer, static_batch, warmup=3):
         self.t = trainer
         self.batch = static_batch
+        trainer.check_lengths(static_batch)
         dev = trainer.device
         self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
         ops.dropout_state.dev_offset = self.seed_offset
@@ -262,6 +309,7 @@ class GraphedTrainer(object):
     def step(self):
         self.t._set_hyper()
         self.graph.replay()
+        ops.bump_param_epoch()           # the replayed clip/Adam wrote the parameters
         self.t.global_step += 1
         return self.scal
 

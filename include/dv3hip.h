@@ -44,6 +44,13 @@ int dv3_debug_set(int what, int value);
 /* what = 1: phase timestamps left by the last dv3_debug_set(1, 10) launch of the 128x256 bf16x3 tile
  * ([8 waves][192 slots][2] uint64, host pointer). */
 int dv3_debug_read(int what, void* dst, int64_t bytes);
+/* what = 10: which kernel the LAST dv3_conv_gemm_f32 call of this process launched, encoded
+ * family * 1000 + tile_id * 10 + pingpong; family 1 = exact-fp32 streaming kernel, 2 = exact-fp32
+ * LDS-staged kernel, 3 = split-bf16 (3 MFMAs per product), 4 = bf16 (1 MFMA per product); tile ids as
+ * dv3_conv_desc.tile_hint (9 = the 8-wave 128x256 tile).  what = 11: same for dv3_wgrad_gemm_f32
+ * (family 1 = exact fp32, 3 = split-bf16, 4 = bf16; tile 1 = 128x128, 2 = 256x128).  Tests use it to
+ * assert that a shape was served by the kernel the benchmark times.  Returns the value (>= 0). */
+int dv3_debug_get(int what);
 
 /* ------------------------------------------------------------------------------------
  * Epilogue modes of the tap-GEMM (dv3_conv_gemm_f32).

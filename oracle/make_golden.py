@@ -317,8 +317,54 @@ def gen_audio_helpers():
     print("audio_helpers", len(out))
 
 
+def gen_presets():
+    """Preset-size outputs of the unmodified reference (BASELINE.json configs 2-4 at their real channel
+    counts, bench-shaped batch B=2, Tt=150, 800 frames).  The 100 MB state_dicts are not stored: the
+    weights are regenerated on both sides from (seed, per-tensor mean/std) by tests/util.synth_state_dict;
+    the statistics are those of the reference's own initialisation."""
+    import bench
+    from tests.util import synth_state_dict
+    from tests.test_gpu_preset_scale import _batch
+    refimport.load_model_package()
+    from deepvoice3_pytorch import builder
+    for preset, (bname, hp, _) in sorted(bench.PRESETS.items()):
+        hp = dict(hp)
+        torch.manual_seed(99)
+        model = getattr(builder, bname)(**hp)
+        sd0 = model.state_dict()
+        stats = {}
+        for k, v in sd0.items():
+            if k.endswith("positions.weight"):
+                continue                      # frozen tables: deterministic, kept as built
+            v = v.double()
+            std = float(v.std()) if v.numel() > 1 else 0.0
+            if k.endswith(".bias") and std == 0.0:
+                std = 0.05                    # the reference zero-initialises biases: make them matter
+            stats[k] = [float(v.mean()), std]
+        seed, batch_seed = 20260922, 5
+        sd = synth_state_dict({k: tuple(v.shape) for k, v in sd0.items()}, stats, seed, keep=sd0)
+        model.load_state_dict(sd)
+        model.eval()
+        bt, spk = _batch(hp, seed=batch_seed)
+        mel_ds = bt["mel"][:, 0::4, :].contiguous()
+        with torch.no_grad():
+            mo, lo, al, dn = ref_forward(model, bt["text"], mel_ds, speaker_ids=spk,
+                                         text_positions=bt["text_positions"],
+                                         frame_positions=bt["frame_positions"],
+                                         input_lengths=bt["input_lengths"])
+        out = {"sd_stats": json.dumps(stats), "seed": np.int64(seed), "batch_seed": np.int64(batch_seed),
+               "out/mel": _np(mo), "out/linear_8": _np(lo[:, ::8].contiguous()), "out/alignments": _np(al),
+               "out/done": _np(dn)}
+        np.savez_compressed(os.path.join(OUT, "preset_%s.npz" % preset), **out)
+        print("wrote preset_%s.npz: mel %s linear %s align %s" % (preset, tuple(mo.shape), tuple(lo.shape),
+                                                                   tuple(al.shape)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "presets":
+        gen_presets()
+        return
     for name, b, hp in MODELS:
         gen_model(name, b, hp)
     gen_losses()
@@ -326,6 +372,7 @@ def main():
     gen_trainstep()
     gen_collate()
     gen_audio_helpers()
+    gen_presets()
 
 
 if __name__ == "__main__":

@@ -430,3 +430,41 @@ def test_ragged_pad_rows_edges(dev):
         got = ops.ragged_pad_rows(torch.from_numpy(rows).to(dev), torch.from_numpy(off).to(dev), len(lens), T_out,
                                   lead=lead, t_stride=stride)
         assert np.array_equal(got.cpu().numpy(), want), (T_out, lead, stride)
+
+
+@pytest.mark.gpu
+def test_eval_after_training_uses_current_weights(dev, gemm_mode):
+    """train.py's normal flow: eval -> train N steps -> eval.  The optimiser writes the parameters through
+    raw pointers (dv3_clip_adam_f32 on the flat arena), which does not bump tensor._version; the
+    eval-mode packed-weight cache must still notice (ops.param_epoch).  Also: model.zero_grad() (grads set
+    to None) between steps must not detach the gradients from the arena."""
+    from deepvoice3_pytorch_amd import builder, train_step
+    fx, b, hp, sd, x, model = _build("dv3_preset_like", dev)
+    xg = _to(x, dev)
+
+    def ev(m):
+        m.eval()
+        with torch.no_grad():
+            return m(xg["text"], xg["mel"], None, xg["text_positions"], xg["frame_positions"],
+                     x["input_lengths"].numpy())[1].clone()
+    trainer = train_step.Trainer(model, train_step.TrainConfig(max_positions=hp.get("max_positions", 512),
+                                                               initial_learning_rate=5e-3, lr_schedule=None))
+    y0 = ev(model)                       # packs cached against the arena views
+    B, Td = x["mel"].shape[0], x["mel"].shape[1]
+    rng = np.random.RandomState(0)
+    batch = train_step.Batch(xg["text"], xg["text_positions"], xg["frame_positions"], xg["mel"],
+                             torch.from_numpy(rng.rand(B, Td * 4, hp["linear_dim"]).astype(np.float32)).to(dev),
+                             torch.zeros(B, Td, 1, device=dev), x["input_lengths"].numpy(),
+                             np.full(B, Td * 4 - 4), None, 1, 4, dev)
+    for i in range(3):
+        if i == 1:
+            model.zero_grad()            # set_to_none=True: Trainer must put the arena views back
+        trainer.step(batch)
+    gn = float(trainer.norm_out[0])
+    assert np.isfinite(gn) and gn > 0    # an all-zero arena (detached grads) would give exactly 0
+    y1 = ev(model)
+    fresh = getattr(builder, b)(**hp).to(dev)
+    fresh.load_state_dict(model.state_dict())
+    y2 = ev(fresh)
+    assert rel_err(y1.cpu(), y2.cpu()) < 1e-6
+    assert rel_err(y1.cpu(), y0.cpu()) > 1e-4   # the weights did move

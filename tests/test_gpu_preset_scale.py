@@ -1,0 +1,341 @@
+# coding: utf-8
+"""-m gpu: parity AT THE SIZES THAT ARE BENCHMARKED.
+
+  * the three BASELINE.json model configurations at their preset channel counts
+    (presets/deepvoice3_ljspeech.json, nyanko_ljspeech.json, deepvoice3_vctk.json as
+    train.build_model() forwards them, train.py:812-840), Tt = 150, 800 target frames (the bench
+    batch shape, B = 2 so the CPU oracle finishes in seconds): eval forward and ONE training
+    forward + losses + backward (train.py:685-759) with the HIP path's own dropout keep-bits
+    replayed into oracle/dv3_oracle.py -- outputs, loss terms, gradient norm and every parameter
+    gradient;
+  * the north-star kernel shape (Conv1dGLU, B=64 x 256 ch x 1024 T, k=3; modules.py:145-164):
+    the FULL output tensor against the oracle for d in {1,3,9,27}, causal and not, eval and
+    dropout-masked, asserting the tile picker served it with the kernel bench.py times
+    (8-wave 128x256 ping-pong tile); input and weight gradients at the same size;
+  * preset-size outputs of the UNMODIFIED reference (tests/golden/preset_*.npz written by
+    oracle/make_golden.py: weights regenerated from a seed, see tests/util.synth_state_dict).
+
+Tolerances (stated, BASELINE.json north_star: 1e-4 rel fp32): model outputs and loss terms 1e-4 in
+the `f32` and `bf16x3` GEMM modes; parameter gradients 5e-4 of each tensor's max (they pass through
+~40 layers of backward GEMMs); `bf16` mode (BASELINE configs 3/4): 3e-2 on outputs, 2e-2 on loss
+terms, gradient cosine > 0.995 per the bf16 arithmetic (8 significand bits).
+Every measured error is appended to gpurun_out/parity_scale.jsonl for profiles/.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dv3_oracle as O
+from tests.util import ROOT, rel_err, load_golden, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+TOL_OUT = 1e-4
+TOL_GRAD = 5e-4
+BF16_OUT, BF16_LOSS, BF16_COS = 3e-2, 2e-2, 0.995
+
+
+def _record(**kw):
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "parity_scale.jsonl"), "a") as f:
+        f.write(json.dumps(kw) + "\n")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["bf16x3", "f32", "bf16"])
+def gemm_mode(request):
+    from deepvoice3_pytorch_amd import ops
+    prev = ops.set_gemm_precision(request.param)
+    yield request.param
+    ops.set_gemm_precision(prev)
+
+
+def _preset(name):
+    import bench
+    bname, hp, sigma = bench.PRESETS[name]
+    return bname, dict(hp), sigma
+
+
+def _batch(hp, B=2, Tt=150, n_frames=800, seed=5):
+    """bench.synth_batch conventions (train.collate_fn padding), ragged: item 0 full length"""
+    import bench
+    rng = np.random.RandomState(seed)
+    bt = bench.synth_batch(rng, B, Tt, n_frames, hp, fixed=True)
+    # make the second item shorter so the masks (memory mask, loss masks, guided attention) matter
+    il = np.array(bt["input_lengths"]).copy()
+    tl = np.array(bt["target_lengths"]).copy()
+    for b in range(1, B):
+        il[b] = Tt - 33 * b
+        tl[b] = n_frames - 4 * 37 * b
+        bt["text"][b, il[b] - 1] = 1
+        bt["text"][b, il[b]:] = 0
+        bt["text_positions"][b, il[b]:] = 0
+        bt["mel"][b, 1 + tl[b]:] = 0
+        bt["y"][b, 1 + tl[b]:] = 0
+        bt["done"][b] = 1
+        bt["done"][b, :tl[b] // 4 - 1] = 0
+    bt["input_lengths"], bt["target_lengths"] = il, tl
+    spk = torch.from_numpy(rng.randint(0, hp["n_speakers"], B)) if hp["n_speakers"] > 1 else None
+    return bt, spk
+
+
+def _drop_replay(ops):
+    rec = ops.dropout_state.record
+
+    def drop(site, t, p, layout):
+        bits, rows, T = rec["model." + site]
+        keep = torch.from_numpy(O.unpack_keep_bits(bits.cpu().numpy().view(np.uint32), rows,
+                                                   (T + 31) // 32, T)).float()
+        if layout == "btc":
+            m = keep.view(t.size(0), t.size(2), t.size(1)).transpose(1, 2)
+        else:
+            m = keep.view(t.shape)
+        return t * m / (1 - p)
+    return drop
+
+
+PRESET_NAMES = ["deepvoice3_ljspeech", "nyanko_ljspeech", "deepvoice3_vctk"]
+
+
+@pytest.mark.parametrize("preset", PRESET_NAMES)
+def test_preset_eval_forward_matches_oracle(dev, preset, gemm_mode):
+    from deepvoice3_pytorch_amd import builder
+    bname, hp, _ = _preset(preset)
+    torch.manual_seed(11)
+    model = getattr(builder, bname)(**hp).to(dev).eval()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    spec = O.build_spec(bname, **hp)
+    bt, spk = _batch(hp)
+    mel_ds = bt["mel"][:, 0::4, :].contiguous()
+    with torch.no_grad():
+        got = model(bt["text"].to(dev), mel_ds.to(dev), spk.to(dev) if spk is not None else None,
+                    bt["text_positions"].to(dev), bt["frame_positions"].to(dev), bt["input_lengths"])
+        want = O.model_forward(sd, spec, bt["text"], mel_ds, spk, bt["text_positions"], bt["frame_positions"],
+                               bt["input_lengths"])
+    tol = BF16_OUT if gemm_mode == "bf16" else TOL_OUT
+    errs = {}
+    for g, w, n in zip(got, want, ("mel", "linear", "alignments", "done")):
+        assert tuple(g.shape) == tuple(w.shape), n
+        errs[n] = rel_err(g.cpu(), w)
+    _record(test="eval_forward", preset=preset, gemm=gemm_mode, **errs)
+    for n, e in errs.items():
+        assert e < tol, (n, e)
+
+
+@pytest.mark.parametrize("preset", PRESET_NAMES)
+def test_preset_train_step_matches_oracle(dev, preset, gemm_mode):
+    """forward (dropout on) + the four fused losses + backward through train_step.Trainer, against
+    the oracle's model_forward + train_losses + autograd with the same keep-bits"""
+    from deepvoice3_pytorch_amd import builder, ops, train_step
+    bname, hp, sigma = _preset(preset)
+    torch.manual_seed(12)
+    model = getattr(builder, bname)(**hp).to(dev)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    spec = O.build_spec(bname, **hp)
+    bt, spk = _batch(hp)
+    cfg = train_step.TrainConfig(max_positions=hp["max_positions"], guided_attention_sigma=sigma)
+    trainer = train_step.Trainer(model, cfg)
+    batch = train_step.Batch.from_collate(bt["text"], bt["input_lengths"], bt["mel"], bt["y"],
+                                          bt["text_positions"], bt["frame_positions"], bt["done"],
+                                          bt["target_lengths"], spk, downsample_step=4, device=dev)
+    ops.dropout_state.manual_seed(777)
+    ops.dropout_state.record = {}
+    try:
+        trainer.arena.grad.zero_()
+        scal = trainer.forward_backward(batch)
+        ops.grad_sqnorm(trainer.arena.grad, trainer.norm_partial, trainer.norm_out)
+        gnorm = float(trainer.norm_out[0])
+        scal = {k: float(v) for k, v in scal.items()}
+        drop = _drop_replay(ops)
+        sdc = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+        mel_ds = bt["mel"][:, 0::4, :].contiguous()
+        out = O.model_forward(sdc, spec, bt["text"], mel_ds, spk, bt["text_positions"], bt["frame_positions"],
+                              bt["input_lengths"], drop=drop)
+    finally:
+        ops.dropout_state.record = None
+    lhp = dict(outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5, binary_divergence_weight=0.1,
+               use_guided_attention=True, guided_attention_sigma=sigma)
+    loss, parts = O.train_losses(spec, lhp, out, mel_ds, bt["y"], bt["done"], bt["input_lengths"],
+                                 bt["target_lengths"])
+    loss.backward()
+    bf = gemm_mode == "bf16"
+    names = dict(loss="loss", mel_l1_loss="mel_l1", mel_binary_div_loss="mel_bd", linear_l1_loss="lin_l1",
+                 linear_binary_div_loss="lin_bd", done_loss="done_loss", attn_loss="attn_loss")
+    lerr = {}
+    for k, ko in names.items():
+        w = float(parts[ko])
+        lerr[k] = abs(scal[k] - w) / max(abs(w), 1e-12)
+    frozen = ("embed_query_positions.weight", "embed_keys_positions.weight")
+    gl, gw = [], []
+    worst, n_par = ("", 0.0), 0
+    scale = max(float(v.grad.abs().max()) for v in sdc.values() if v.grad is not None)
+    for k, p in model.named_parameters():
+        if k.endswith(frozen):
+            continue
+        gc = sdc[k].grad
+        assert p.grad is not None and gc is not None, k
+        gl.append(p.grad.detach().cpu().reshape(-1).double())
+        gw.append(gc.reshape(-1).double())
+        gmax = float(gc.abs().max())
+        if gmax < 1e-5 * scale:       # mathematically-zero gradients: round-off only
+            assert float(p.grad.abs().max()) < 1e-4 * scale, k
+            continue
+        e = rel_err(p.grad.cpu(), gc)
+        n_par += 1
+        if e > worst[1]:
+            worst = (k, e)
+    gl, gw = torch.cat(gl), torch.cat(gw)
+    cos = float((gl * gw).sum() / (gl.norm() * gw.norm()))
+    gn_want = float(gw.norm())
+    gn_err = abs(gnorm - gn_want) / gn_want
+    _record(test="train_step", preset=preset, gemm=gemm_mode, losses=lerr, grad_norm_err=gn_err,
+            grad_cos=cos, worst_param=worst[0], worst_param_err=worst[1], params_compared=n_par,
+            loss=scal["loss"], grad_norm=gnorm)
+    for k, e in lerr.items():
+        assert e < (BF16_LOSS if bf else TOL_OUT), (k, e)
+    if bf:
+        assert cos > BF16_COS, cos
+        assert gn_err < 5e-2, gn_err
+    else:
+        assert gn_err < TOL_OUT, gn_err
+        assert worst[1] < TOL_GRAD, worst
+        assert cos > 1 - 1e-6, cos
+
+
+# ---------------------------------------------------------------------------------------------
+# the north-star kernel shape, full tensors
+# ---------------------------------------------------------------------------------------------
+def _ns_layer(dev, d, causal, seed=0):
+    from deepvoice3_pytorch_amd import modules
+    C, k = 256, 3
+    torch.manual_seed(seed)
+    layer = modules.Conv1dGLU(1, 16, C, C, k, dropout=0.05, dilation=d, causal=causal, residual=True).to(dev)
+    with torch.no_grad():
+        layer.conv.bias.uniform_(-0.1, 0.1)
+    layer._dv3_site = "site"       # names the dropout site so the keep-bits are recorded
+    return layer
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("d", [1, 3, 9, 27])
+def test_north_star_conv1dglu_full_tensor(dev, d, causal, gemm_mode):
+    """Conv1dGLU forward at B=64 x 256 x 1024 (BASELINE north_star; the shape bench.py's roofline
+    times): every output element against the oracle, eval and dropout-masked, and the picker must have
+    chosen the 8-wave 128x256 ping-pong tile (family 3/4, tile 9, pp 1) in the split-bf16 modes."""
+    from deepvoice3_pytorch_amd import ops, _lib
+    B, C, T, k = 64, 256, 1024, 3
+    layer = _ns_layer(dev, d, causal)
+    sd = {"l." + n: v.detach().cpu() for n, v in layer.state_dict().items()}
+    torch.manual_seed(1)
+    x = torch.randn(B, C, T)
+    tol = BF16_OUT if gemm_mode == "bf16" else 5e-5
+    for training in (False, True):
+        layer.train(training)
+        ops.dropout_state.manual_seed(99)
+        ops.dropout_state.record = {}
+        try:
+            with torch.no_grad():
+                y = layer(x.to(dev))
+            variant = _lib.lib().dv3_debug_get(10)
+            drop = None
+            if training:
+                (site, (bits, rows, Tm)), = ops.dropout_state.record.items()
+                keep = torch.from_numpy(O.unpack_keep_bits(bits.cpu().numpy().view(np.uint32), rows,
+                                                           (Tm + 31) // 32, Tm)).float().view(B, C, T)
+                drop = lambda s, t, p, layout: t * keep / (1 - p)
+        finally:
+            ops.dropout_state.record = None
+        want = O.conv1d_glu(sd, "l", x, k, d, causal, True, p=0.05, drop=drop)
+        e = rel_err(y.cpu(), want)
+        _record(test="north_star_fwd", d=d, causal=causal, training=training, gemm=gemm_mode, err=e,
+                variant=variant)
+        assert e < tol, (d, causal, training, e)
+        if gemm_mode == "bf16x3":
+            assert variant == 3091, variant
+        elif gemm_mode == "bf16":
+            assert variant == 4091, variant
+        else:
+            assert variant // 1000 == 1, variant
+
+
+@pytest.mark.parametrize("d,causal", [(1, False), (27, True)])
+def test_north_star_conv1dglu_gradients_full_tensor(dev, d, causal, gemm_mode):
+    """input, weight_v, weight_g and bias gradients of the same launch shape (dropout-masked), full
+    tensors against autograd through the oracle"""
+    from deepvoice3_pytorch_amd import ops, _lib
+    B, C, T, k = 64, 256, 1024, 3
+    layer = _ns_layer(dev, d, causal, seed=3).train()
+    sd = {"l." + n: v.detach().cpu().clone().requires_grad_(True) for n, v in layer.state_dict().items()}
+    torch.manual_seed(2)
+    x = torch.randn(B, C, T)
+    w = torch.randn(B, C, T) / (B * T) ** 0.5
+    xg = x.to(dev).requires_grad_(True)
+    ops.dropout_state.manual_seed(5)
+    ops.dropout_state.record = {}
+    try:
+        y = layer(xg)
+        (y * w.to(dev)).sum().backward()
+        wv = _lib.lib().dv3_debug_get(11)
+        (site, (bits, rows, Tm)), = ops.dropout_state.record.items()
+        keep = torch.from_numpy(O.unpack_keep_bits(bits.cpu().numpy().view(np.uint32), rows,
+                                                   (Tm + 31) // 32, Tm)).float().view(B, C, T)
+    finally:
+        ops.dropout_state.record = None
+    xc = x.clone().requires_grad_(True)
+    want = O.conv1d_glu(sd, "l", xc, k, d, causal, True, p=0.05, drop=lambda s, t, p, layout: t * keep / (1 - p))
+    (want * w).sum().backward()
+    bf = gemm_mode == "bf16"
+    errs = dict(dx=rel_err(xg.grad.cpu(), xc.grad))
+    for n, p in layer.named_parameters():
+        errs[n] = rel_err(p.grad.cpu(), sd["l." + n].grad)
+    _record(test="north_star_bwd", d=d, causal=causal, gemm=gemm_mode, wgrad_variant=wv, **errs)
+    for n, e in errs.items():
+        assert e < (BF16_OUT if bf else 1e-4), (n, e)
+    if gemm_mode != "f32":
+        assert wv // 1000 == (4 if bf else 3), wv
+
+
+# ---------------------------------------------------------------------------------------------
+# preset-size outputs of the unmodified reference
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("preset", PRESET_NAMES)
+def test_preset_forward_matches_reference_golden(dev, preset, gemm_mode):
+    """tests/golden/preset_<name>.npz: oracle/make_golden.py built the REFERENCE model at the preset's
+    sizes, loaded weights regenerated from a seed (tests/util.synth_state_dict: the file stores the
+    per-tensor statistics, not 100 MB of weights), ran its forward on the seeded bench-shaped batch and
+    stored the outputs (the linear output every 8th frame).  The HIP model rebuilds the same weights."""
+    from deepvoice3_pytorch_amd import builder
+    try:
+        fx = load_golden("preset_" + preset)
+    except (IOError, OSError):
+        pytest.skip("golden not generated")
+    bname, hp, _ = _preset(preset)
+    model = getattr(builder, bname)(**hp)
+    stats = json.loads(str(fx["sd_stats"]))
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, stats, int(fx["seed"]),
+                          keep=model.state_dict())
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    bt, spk = _batch(hp, seed=int(fx["batch_seed"]))
+    mel_ds = bt["mel"][:, 0::4, :].contiguous()
+    with torch.no_grad():
+        mel, lin, align, done = model(bt["text"].to(dev), mel_ds.to(dev),
+                                      spk.to(dev) if spk is not None else None,
+                                      bt["text_positions"].to(dev), bt["frame_positions"].to(dev),
+                                      bt["input_lengths"])
+    tol = BF16_OUT if gemm_mode == "bf16" else TOL_OUT
+    errs = dict(mel=rel_err(mel.cpu(), fx["out/mel"]), linear=rel_err(lin.cpu()[:, ::8], fx["out/linear_8"]),
+                alignments=rel_err(align.cpu(), fx["out/alignments"]), done=rel_err(done.cpu(), fx["out/done"]))
+    _record(test="reference_golden_preset", preset=preset, gemm=gemm_mode, **errs)
+    for n, e in errs.items():
+        assert e < tol, (n, e)

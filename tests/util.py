@@ -29,3 +29,20 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def synth_state_dict(shapes, stats, seed, keep=None):
+    """Deterministic weights for the preset-size goldens: tensor i (keys in sorted order) =
+    mean_i + std_i * RandomState(seed + i).standard_normal(shape), float32 -- numpy's legacy generator is
+    stable across versions, so oracle/make_golden.py (reference side) and the GPU test (HIP side) rebuild
+    identical bits from the few statistics stored in the golden file.  Keys absent from `stats` (the frozen
+    position tables, deterministic functions of the hyper-parameters) are taken from `keep`."""
+    out = {}
+    for i, k in enumerate(sorted(shapes)):
+        if k not in stats:
+            out[k] = keep[k].detach().clone()
+            continue
+        mean, std = stats[k]
+        rs = np.random.RandomState(seed + i)
+        out[k] = torch.from_numpy((rs.standard_normal(tuple(shapes[k])) * std + mean).astype(np.float32))
+    return out
