@@ -6,20 +6,30 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one full optimisation step (forward + losses + backward + [all-reduce] + clip + Adam,
-train.py:604-785) of builder=deepvoice3 preset=deepvoice3_ljspeech on a synthetic LJSpeech-shaped
-batch resident in HBM.  value = sum over ranks of un-padded target frames per step / wall time per
-step (max over ranks).  GEMM arithmetic: --gemm bf16x3 (default: fp32 operands split into hi+lo bf16
-on the matrix cores, fp32 accumulate, 1e-4 parity with the fp32 reference), f32 (exact fp32 MFMA) or
-bf16.  Prints ONE JSON line on rank 0 with these extra objects:
-  roofline      the dominant kernel (the tap-GEMM, Conv1dGLU forward at the north-star shape
-                B=64 x 256ch x 1024T, k=3) timed with HIP events on its launch stream;
-                bound "mfma": algorithmic FLOPs / time vs the MFMA roof of the mode (bf16x3:
-                2500/3 TF; f32: 157.3 TF); hbm_frac is the same launch against the 8 TB/s HBM roof;
-                traffic = HBM bytes per launch from the PMC passes recorded under profiles/
-  roofline_exact_f32   the exact-fp32 kernel on the same launch, for the record
-  cpu_baseline  the CPU oracle port of the same train step (oracle/dv3_oracle.py: the reference's
-                own torch-CPU ops) on this host's cores, a bounded sample of the same workload
-  host_buffers  the step rate if the boundary is handed pinned host tensors instead (never `value`)
+train.py:604-785) of builder=deepvoice3 preset=deepvoice3_ljspeech (BASELINE.json configs[1]) on a synthetic
+LJSpeech-shaped batch resident in HBM.  value = sum over ranks of un-padded target frames per step / wall
+time per step (max over ranks).  GEMM arithmetic --gemm: f16x3 (default: fp32 operands split into scaled fp16
+hi+lo for the forward GEMMs and bf16 hi+lo for the gradient GEMMs, three 16-bit MFMAs per product, fp32
+accumulate; 1e-4 parity with the fp32 reference at the preset sizes), bf16x3, f32 (exact fp32 MFMA), bf16.
+`dtype` names that arithmetic.  Rank 0 prints ONE JSON line; beside the contract's fields it carries
+
+  roofline            the dominant kernel (forward tap-GEMM, Conv1dGLU at the north-star shape B=64 x 256ch x
+                      1024T, k=3) timed with HIP events on its launch stream; bound "mfma": algorithmic FLOPs /
+                      time vs the MFMA roof of the mode (three 16-bit MFMAs per product: 2500/3 TF; f32: 157.3
+                      TF); traffic = HBM bytes per launch from the PMC passes under profiles/ (null until the
+                      pass for THIS kernel has been collected)
+  roofline_wgrad      the weight-gradient GEMM of the same layer, same way
+  roofline_exact_f32  the exact-fp32 forward kernel on the same launch, for the record
+  step_flop_frac      whole step: algorithmic FLOPs per mel-frame x frames / step time vs the
+                      same MFMA roof
+  value_exact_f32     the same step with every GEMM on the exact fp32 MFMA chain (5 steps)
+  configs             BASELINE.json configs[2..4] from the same process: nyanko_ljspeech bf16,
+                      deepvoice3_vctk bf16 (n_gpus = this run's), synthesis RTF (64 utterances)
+  input_pipeline      the same step fed by data.Prefetcher (rank-sharded length-bucketed sampler, pinned
+                      staging, H2D + device-side collate on a side stream) instead of a resident batch
+  host_buffers        the step rate if the boundary is handed pinned host tensors synchronously (never `value`)
+  cpu_baseline        the reference's own train.train() on the host cores when the reference tree is present
+                      (kind "reference"), else the CPU oracle port of the same step (kind "port"); bounded sample
 """
 import argparse
 import json
@@ -61,9 +71,22 @@ DV3_VCTK = dict(n_vocab=149, embed_dim=256, mel_dim=80, linear_dim=513, r=1, dow
                 value_projection=True)
 PRESETS = {"deepvoice3_ljspeech": ("deepvoice3", DV3_LJ, 0.2), "nyanko_ljspeech": ("nyanko", NYANKO_LJ, 0.2),
            "deepvoice3_vctk": ("deepvoice3_multispeaker", DV3_VCTK, 0.4)}
+# algorithmic forward+backward FLOPs per un-padded mel-frame at the bench shapes (FlopCounterMode)
+MFLOP_PER_FRAME = {"deepvoice3_ljspeech": 57.1, "nyanko_ljspeech": 64.8, "deepvoice3_vctk": 52.9}
 PEAK_F32_MFMA_TF = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak (= vector peak)
-PEAK_BF16_MFMA_TF = 2500.0  # same guide: dense bf16 MFMA peak
+PEAK_16BIT_MFMA_TF = 2500.0  # same guide: dense bf16 / fp16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+
+DTYPE_NOTE = {
+    "f16x3": "fp32 operands as scaled fp16 hi+lo (forward GEMMs) / bf16 hi+lo (gradient GEMMs) on the matrix cores, "
+             "3 MFMAs per product, fp32 accumulate, fp32 storage; 1e-4 rel parity with the fp32 reference at preset sizes",
+    "bf16x3": "fp32 operands as bf16 hi+lo on the matrix cores, 3 MFMAs per product, fp32 accumulate, fp32 storage",
+    "f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+    "bf16": "operands rounded to bf16 at the matrix cores, 1 MFMA per product, fp32 accumulate, fp32 master weights"}
+
+
+def mfma_peak_tf(mode):
+    return {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_16BIT_MFMA_TF}.get(mode, PEAK_16BIT_MFMA_TF / 3.0)
 
 
 def synth_batch(rng, B, Tt, n_frames, hp, fixed=True):
@@ -105,12 +128,38 @@ def synth_batch(rng, B, Tt, n_frames, hp, fixed=True):
                 target_lengths=frame_lens)
 
 
+# -------------------------------------------------------------------------------------------------
+# kernel rooflines (HIP events on the launch stream)
+# -------------------------------------------------------------------------------------------------
+def _time_launches(launch, iters, settle=100):
+    for _ in range(settle):      # the clock governor needs ~20 ms of this load to settle (first launches run ~20 % slower)
+        launch()
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream()      # the stream ops.* enqueue on
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(iters):
+        launch()
+    e1.record(s)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def _traffic(kernel_key):
+    """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, calibrated as MI355X_MICROARCH.md
+    prescribes), collected offline with rocprofv3 (scripts/pmc_hbm.sh; a counter pass can not run inside this
+    process) and committed under profiles/ -- used only when the file was collected for THIS kernel."""
+    try:
+        hb = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
+        ent = hb[kernel_key]
+        return ent["hbm_bytes_per_launch"], "profiles/r02_hbm_traffic.json (%s)" % ent["source"]
+    except (IOError, OSError, KeyError, ValueError):
+        return None, None
+
+
 def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None):
-    """Conv1dGLU forward at the north-star shape, one tap-GEMM launch per iteration, timed with
-    HIP events on the stream it is launched on (torch's current stream = the stream ops.* enqueue on).
-    mode "bf16x3": the split-bf16 kernel (3 bf16 MFMAs per product block) -> peak = 2500/3 TF of
-    fp32-equivalent work; mode "f32": the exact fp32-MFMA kernel -> peak 157.3 TF."""
-    from deepvoice3_pytorch_amd import ops
+    """Conv1dGLU forward at the north-star shape, one tap-GEMM launch per iteration."""
+    from deepvoice3_pytorch_amd import ops, _lib
     mode = mode or ops.gemm_precision()
     prev = ops.set_gemm_precision(mode)
     B, C, T, k, d = 64, 256, 1024, 3, dil
@@ -126,50 +175,119 @@ def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None):
         ops.conv_gemm(x, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
                       padL=(k - 1) // 2 * d, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x, residual=1, y=y,
                       tile_hint=tile_hint, a_split=pk.fwd_s)
-    for _ in range(100):         # the clock governor needs ~20 ms of this load to settle (first launches run ~20 % slower)
-        launch()
-    torch.cuda.synchronize()
-    s = torch.cuda.current_stream()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(s)
-    for _ in range(iters):
-        launch()
-    e1.record(s)
-    torch.cuda.synchronize()
+    us = _time_launches(launch, iters)
+    variant = _lib.lib().dv3_debug_get(10)
     ops.set_gemm_precision(prev)
-    us = e0.elapsed_time(e1) * 1e3 / iters
     flops = 2.0 * B * T * (2 * C) * (k * C)                     # 51.54 GFLOP
     byts = 4.0 * (B * C * T * 2 + 2 * C * C * k + 2 * C)         # x + y + weights + bias: 135.8 MB
     tf = flops / (us * 1e-6) / 1e12
-    x3 = pk.fwd_s is not None and tile_hint in (0,) + tuple(range(21, 27))
-    peak = PEAK_BF16_MFMA_TF / 3.0 if x3 else PEAK_F32_MFMA_TF
-    out = dict(bound="mfma",
-               kernel=("conv_gemm_bf16x3_kernel (Conv1dGLU fwd B=64 C=256 T=1024 k=3; 128x256 8-wave tile)" if x3 else
-                       "conv_gemm_f32_stream_kernel<2,2,2> (Conv1dGLU fwd B=64 C=256 T=1024 k=3)"),
+    fam = variant // 1000
+    peak = {1: PEAK_F32_MFMA_TF, 2: PEAK_F32_MFMA_TF, 4: PEAK_16BIT_MFMA_TF}.get(fam, PEAK_16BIT_MFMA_TF / 3.0)
+    kname = {1: "conv_gemm_f32_stream_kernel", 2: "conv_gemm_f32_kernel", 3: "conv_gemm_bf16x3_kernel<bf16 hi/lo>",
+             4: "conv_gemm_bf16x3_kernel<bf16 x1>", 5: "conv_gemm_bf16x3_kernel<fp16 hi/lo>",
+             6: "conv_planes_kernel<fp16 hi/lo>", 7: "conv_planes_kernel<bf16>"}.get(fam, "?")
+    key = "conv_fwd:%d" % variant
+    out = dict(bound="mfma", kernel="%s variant %d (Conv1dGLU fwd B=64 C=256 T=1024 k=3)" % (kname, variant),
                achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
                traffic=None, us_per_launch=round(us, 2), alg_flops=flops, alg_bytes=byts,
                hbm_gbs=round(byts / (us * 1e-6) / 1e9, 1),
-               hbm_frac=round(byts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4))
-    if x3 and tile_hint == 0 and dil == 1:
-        # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, calibrated as
-        # MI355X_MICROARCH.md prescribes): collected offline with rocprofv3 (scripts/pmc_hbm.sh) --
-        # a counter pass can not run inside this process -- and committed under profiles/.
-        try:
-            hb = json.load(open(os.path.join(ROOT, "profiles", "r01b_conv_gemm_bf16x3_hbm.json")))
-            out["traffic"] = hb["hbm_bytes_per_launch"]
-            out["traffic_source"] = "profiles/r01b_conv_gemm_bf16x3_hbm.json (%s)" % hb["source"]
-        except (IOError, OSError, KeyError, ValueError):
-            pass
-    if x3:
-        out["peak_note"] = ("algorithmic fp32 FLOPs against the dense bf16 MFMA peak (2500 TF) / 3: the split-bf16 "
-                            "kernel issues 3 bf16 MFMAs per product block; executed MFMA rate = 3 x achieved")
+               hbm_frac=round(byts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4), variant=variant)
+    if dil == 1 and tile_hint == 0:
+        out["traffic"], src = _traffic(key)
+        if src:
+            out["traffic_source"] = src
+    if fam in (3, 5, 6):
+        out["peak_note"] = ("algorithmic fp32 FLOPs against the dense 16-bit MFMA peak (2500 TF) / 3: the split "
+                            "kernels issue 3 MFMAs per product block; executed MFMA rate = 3 x achieved")
         out["mfma_executed_tflops"] = round(3 * tf, 1)
-        out["frac_of_bf16_mfma_peak"] = round(3 * tf / PEAK_BF16_MFMA_TF, 4)
         out["x_fp32_matrix_peak"] = round(tf / PEAK_F32_MFMA_TF, 3)
     return out
 
 
-def cpu_baseline(B, Tt, n_frames, max_seconds=25.0):
+def wgrad_roofline(dev, iters=50, mode=None):
+    """Weight gradient of the same Conv1dGLU layer (B=64, M=512 gradient rows, Cin=256, T=1024, k=3,
+    dropout-masked input as in training): out[j][m][c] = sum_{b,t} g[b][m][t] x[b][c][t+j-1]."""
+    from deepvoice3_pytorch_amd import ops, _lib
+    mode = mode or ops.gemm_precision()
+    prev = ops.set_gemm_precision(mode)
+    B, C, T, k = 64, 256, 1024, 3
+    torch.manual_seed(0)
+    x = torch.randn(B, C, T, device=dev)
+    gm = torch.randn(B, 2 * C, T, device=dev)
+    bits, rs = ops.dropout_bits(B * C, T, 0.05, dev)
+    x3 = mode != "f32"
+    tiles = ((2 * C + 127) // 128) * ((C + 127) // 128) * k
+    S = ops._ksplit_count(B * ((T + 31) // 32), tiles) if x3 else ops._slab_count(B, tiles)
+    out_t = torch.empty((S, k, 2 * C, C), dtype=torch.float32, device=dev)
+
+    def launch():
+        ops.wgrad_gemm(gm, x, B=B, M=2 * C, Cin=C, T=T, Tin=T, J=k, dil=1, padL=1, n_slabs=S, xmask=bits,
+                       xmask_rs=rs, drop_scale=1.0 / 0.95, split_bf16=x3, k_split=x3, out=out_t)
+    us = _time_launches(launch, iters, settle=50)
+    variant = _lib.lib().dv3_debug_get(11)
+    ops.set_gemm_precision(prev)
+    flops = 2.0 * B * T * (2 * C) * (k * C)
+    byts = 4.0 * (B * 2 * C * T + B * C * T + S * k * 2 * C * C)     # g + x + slabs
+    tf = flops / (us * 1e-6) / 1e12
+    fam = variant // 1000
+    peak = {1: PEAK_F32_MFMA_TF, 4: PEAK_16BIT_MFMA_TF}.get(fam, PEAK_16BIT_MFMA_TF / 3.0)
+    out = dict(bound="mfma", kernel="wgrad variant %d (Conv1dGLU wgrad B=64 M=512 Cin=256 T=1024 k=3, %d K-slabs)" % (variant, S),
+               achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
+               traffic=None, us_per_launch=round(us, 2), alg_flops=flops, alg_bytes=byts,
+               hbm_gbs=round(byts / (us * 1e-6) / 1e9, 1), variant=variant)
+    out["traffic"], src = _traffic("wgrad:%d" % variant)
+    if src:
+        out["traffic_source"] = src
+    return out
+
+
+# -------------------------------------------------------------------------------------------------
+# CPU baseline
+# -------------------------------------------------------------------------------------------------
+def _bench_items(rng, B, Tt, n_frames, hp):
+    """ragged items (text ids, mel, linear) of the fixed bench shape, as the reference's datasets yield them"""
+    items = []
+    for _ in range(B):
+        text = np.concatenate([rng.randint(2, hp["n_vocab"], Tt - 1), [1]]).astype(np.int64)
+        items.append((text, rng.rand(n_frames, hp["mel_dim"]).astype(np.float32),
+                      rng.rand(n_frames, hp["linear_dim"]).astype(np.float32)))
+    return items
+
+
+def cpu_baseline_reference(B, Tt, n_frames, max_seconds=25.0):
+    """The UNMODIFIED reference's train.train() (train.py:604-785) on the host cores, imported through
+    oracle/refimport.py (stubs for absent non-arithmetic imports; numba.jit = identity, so guided_attention
+    runs as plain Python like any install without numba).  Only possible where the reference tree exists."""
+    from oracle import refimport
+    train, hparams, Writer = refimport.load_train_module()
+    import deepvoice3_pytorch.frontend as fe
+    hparams.parse_json(open(os.path.join(refimport.REF_ROOT, "presets", "deepvoice3_ljspeech.json")).read())
+    train._frontend = fe.en
+    torch.manual_seed(0)
+    model = train.build_model()
+    rng = np.random.RandomState(1234)
+    items = [(t.astype(np.int32), m, y) for t, m, y in _bench_items(rng, B, Tt, n_frames, DV3_LJ)]
+    batch = train.collate_fn(items)
+    opt = torch.optim.Adam(model.get_trainable_parameters(), lr=hparams.initial_learning_rate,
+                           betas=(hparams.adam_beta1, hparams.adam_beta2), eps=hparams.adam_eps,
+                           weight_decay=hparams.weight_decay, amsgrad=hparams.amsgrad)
+
+    def run(n):
+        train.global_step, train.global_epoch = 0, 0
+        t0 = time.time()
+        train.train(torch.device("cpu"), model, [batch] * n, opt, Writer(), init_lr=hparams.initial_learning_rate,
+                    checkpoint_dir="/tmp", checkpoint_interval=10 ** 9, nepochs=1, clip_thresh=hparams.clip_thresh)
+        return time.time() - t0
+    t1 = run(1)                                   # warm-up step (allocator, thread pool)
+    n = int(max(1, min(20, max_seconds // max(t1, 1e-3))))
+    dt = run(n) / n
+    frames = float(B * n_frames)
+    return dict(value=round(frames / dt, 1), unit="mel-frames/s", cores=torch.get_num_threads(), kind="reference",
+                sample="%d steps of the reference's own train.train() on the same workload (B=%d, Tt=%d, %d "
+                       "frames/item), %.2f s/step" % (n, B, Tt, n_frames, dt), host_cpus=os.cpu_count())
+
+
+def cpu_baseline_port(B, Tt, n_frames, max_seconds=25.0):
     """The oracle port of the reference train step on the host cores (bounded sample)."""
     from oracle import dv3_oracle as O
     hp = dict(DV3_LJ)
@@ -188,7 +306,6 @@ def cpu_baseline(B, Tt, n_frames, max_seconds=25.0):
     mel = bt["mel"][:, 0::4, :].contiguous()
     lhp = dict(outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5, binary_divergence_weight=0.1,
                use_guided_attention=True, guided_attention_sigma=0.2)
-    g = torch.Generator().manual_seed(0)
 
     def drop(site, t, p, layout):     # F.dropout stand-in with the same cost profile (bernoulli_ + mul)
         return torch.nn.functional.dropout(t, p, True)
@@ -211,30 +328,50 @@ def cpu_baseline(B, Tt, n_frames, max_seconds=25.0):
         n += 1
     dt = (time.time() - t0) / n
     frames = float(bt["target_lengths"].sum())
-    return dict(value=round(frames / dt, 1), unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d train steps of the same workload (B=%d, Tt=%d, %d frames/item) through "
-                       "oracle/dv3_oracle.py on the host, %.2f s/step" % (n, B, Tt, n_frames, dt),
-                host_cpus=os.cpu_count())
+    out = dict(value=round(frames / dt, 1), unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
+               sample="%d train steps of the same workload (B=%d, Tt=%d, %d frames/item) through "
+                      "oracle/dv3_oracle.py on the host, %.2f s/step" % (n, B, Tt, n_frames, dt),
+               host_cpus=os.cpu_count())
+    try:      # port / reference time ratio recorded once in the build container (scripts/cpu_baseline_calibration.py)
+        cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_port_vs_reference.json")))
+        out["port_over_reference_time"] = cal["port_over_reference_time"]
+        out["calibration"] = "profiles/r02_cpu_port_vs_reference.json"
+    except (IOError, OSError, KeyError, ValueError):
+        pass
+    return out
 
 
-def synth_bench(dev, args):
-    """BASELINE.json configs[4]: synthesis.py's path (synthesis.py:42-73) for `--batch` concurrent
-    utterances: greedy autoregressive decode (Decoder.incremental_forward) + Converter + Griffin-Lim
-    vocoder on the device.  SURVEY.md 8(d) cfg5: equal text length 100, min = max decoder steps = 200
-    -> 201 steps = 804 frames = 9.33 s of audio each; RTF = wall / audio seconds."""
-    from deepvoice3_pytorch_amd import builder, audio
+def cpu_baseline(B, Tt, n_frames, max_seconds=25.0):
+    from oracle import refimport
+    if refimport.available():
+        try:
+            return cpu_baseline_reference(B, Tt, n_frames, max_seconds)
+        except Exception as e:      # the reference tree is there but does not import here: say so, use the port
+            sys.stderr.write("reference cpu baseline failed (%s: %s); using the oracle port\n" % (type(e).__name__, e))
+    return cpu_baseline_port(B, Tt, n_frames, max_seconds)
+
+
+# -------------------------------------------------------------------------------------------------
+# synthesis (BASELINE.json configs[4])
+# -------------------------------------------------------------------------------------------------
+def synth_run(dev, batch=64, reps=3, warm=1, gl_iters=60, step_graph=True):
+    """synthesis.py's path (synthesis.py:42-73) for `batch` concurrent utterances: greedy autoregressive decode
+    (Decoder.incremental_forward) + Converter + Griffin-Lim vocoder on the device.  SURVEY.md 8(d) cfg5: equal
+    text length 100, min = max decoder steps = 200 -> 201 steps = 804 frames = 9.33 s of audio each;
+    RTF = wall / audio seconds."""
+    from deepvoice3_pytorch_amd import builder, audio, ops
     hp = dict(DV3_LJ)
     torch.manual_seed(0)
     model = builder.deepvoice3(**hp).to(dev).eval()
     model.make_generation_fast_()
     dec = model.seq2seq.decoder
     dec.min_decoder_steps = dec.max_decoder_steps = 200
-    dec.use_step_graph = not args.no_graph       # replay one hipGraph per decoder step
-    B, Tt = args.batch, 100
+    dec.use_step_graph = step_graph       # replay one hipGraph per decoder step
+    B, Tt = batch, 100
     rng = np.random.RandomState(0)
     text = torch.from_numpy(rng.randint(2, hp["n_vocab"], (B, Tt))).to(dev)
     tpos = torch.arange(1, Tt + 1).repeat(B, 1).to(dev)
-    acfg = audio.AudioConfig(griffin_lim_iters=args.gl_iters)
+    acfg = audio.AudioConfig(griffin_lim_iters=gl_iters)
 
     def run():
         t = [time.perf_counter()]
@@ -244,26 +381,128 @@ def synth_bench(dev, args):
         wav = audio.inv_spectrogram_batch(lin, acfg)
         torch.cuda.synchronize(); t.append(time.perf_counter())
         return lin, wav, t
-    for _ in range(max(1, args.warmup // 3)):
+    for _ in range(warm):
         run()
     tm, tv = [], []
-    for _ in range(max(1, args.steps // 10)):
+    for _ in range(reps):
         lin, wav, t = run()
         tm.append(t[1] - t[0]); tv.append(t[2] - t[1])
     assert torch.isfinite(wav).all() and lin.shape[1] == 804
     audio_s = B * wav.shape[1] / acfg.sample_rate
     wall = float(np.mean(tm) + np.mean(tv))
-    out = dict(metric="real-time factor (synthesis: AR decode + converter + Griffin-Lim, %d concurrent utterances)" % B,
-               value=round(wall / audio_s, 6), unit="wall seconds per audio second", n_gpus=1, steps=len(tm),
-               warmup=max(1, args.warmup // 3), ms_per_step=round(wall * 1e3, 2), higher_is_better=False,
-               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic text ids, random-init weights",
-               config=dict(workload="builder=deepvoice3 preset=deepvoice3_ljspeech synthesis, Tt=100, 201 decoder steps "
-                                    "= 804 frames per utterance", utterances=B, griffin_lim_iters=args.gl_iters, step_hipgraph=bool(dec.use_step_graph),
-                           audio_seconds=round(audio_s, 1), model_ms=round(float(np.mean(tm)) * 1e3, 1),
-                           vocoder_ms=round(float(np.mean(tv)) * 1e3, 1),
-                           rtf_model_only=round(float(np.mean(tm)) / audio_s, 6),
-                           ms_per_decoder_step=round(float(np.mean(tm)) * 1e3 / 201, 3)))
-    print(json.dumps(out))
+    return dict(value=round(wall / audio_s, 6), unit="wall seconds per audio second", higher_is_better=False,
+                ms_per_step=round(wall * 1e3, 2), reps=reps, dtype=ops.gemm_precision(),
+                config=dict(workload="builder=deepvoice3 preset=deepvoice3_ljspeech synthesis, Tt=100, 201 decoder steps "
+                                     "= 804 frames per utterance", utterances=B, griffin_lim_iters=gl_iters,
+                            step_hipgraph=bool(dec.use_step_graph), audio_seconds=round(audio_s, 1),
+                            model_ms=round(float(np.mean(tm)) * 1e3, 1), vocoder_ms=round(float(np.mean(tv)) * 1e3, 1),
+                            rtf_model_only=round(float(np.mean(tm)) / audio_s, 6),
+                            ms_per_decoder_step=round(float(np.mean(tm)) * 1e3 / 201, 3)))
+
+
+# -------------------------------------------------------------------------------------------------
+# the train step
+# -------------------------------------------------------------------------------------------------
+class TrainRun(object):
+    """model + trainer + resident batch of one (preset, gemm mode); .measure() = the contract's timed loop"""
+
+    def __init__(self, dev, pg, rank, world, preset, gemm, batch, text_len, frames, graph):
+        from deepvoice3_pytorch_amd import builder, train_step, ops
+        self.ops, self.train_step = ops, train_step
+        self.prev_mode = ops.set_gemm_precision(gemm)
+        self.dev, self.pg, self.rank, self.world = dev, pg, rank, world
+        self.preset, self.gemm = preset, gemm
+        bname, hp0, ga_sigma = PRESETS[preset]
+        self.bname, self.hp = bname, dict(hp0)
+        torch.manual_seed(0)            # identical initial weights on every rank
+        self.model = getattr(builder, bname)(**self.hp).to(dev)
+        cfg = train_step.TrainConfig(max_positions=self.hp["max_positions"], guided_attention_sigma=ga_sigma)
+        self.trainer = train_step.Trainer(self.model, cfg, process_group=pg)
+        rng = np.random.RandomState(1234 + rank)
+        self.bt = synth_batch(rng, batch, text_len, frames, self.hp)
+        self.spk = torch.from_numpy(rng.randint(0, self.hp["n_speakers"], batch)) if self.hp["n_speakers"] > 1 else None
+        bt = self.bt
+        self.batch = train_step.Batch.from_collate(bt["text"], bt["input_lengths"], bt["mel"], bt["y"],
+                                                   bt["text_positions"], bt["frame_positions"], bt["done"],
+                                                   bt["target_lengths"], self.spk, downsample_step=4, device=dev)
+        self.trainer.check_lengths(self.batch)
+        # Launch mode.  At the north-star batch (64) the GPU stays ahead of the host, eager launches are
+        # GPU-bound and the RCCL bucket all-reduces can be issued from autograd hooks on a side stream.  A
+        # whole-step hipGraph pays when the step is launch-bound: small per-GPU batches on one GPU.
+        self.use_graph = graph and world == 1
+        self.runner = None
+        if self.use_graph:
+            try:
+                self.runner = train_step.GraphedTrainer(self.trainer, self.batch, warmup=2)
+            except Exception as e:      # capture not possible: say so, go eager
+                if rank == 0:
+                    import traceback
+                    traceback.print_exc()
+                    print("hipGraph capture failed (%s); running eager" % type(e).__name__, file=sys.stderr)
+                self.use_graph = False
+                torch.cuda.synchronize()
+
+    def step(self, batch=None):
+        if self.use_graph:
+            return self.runner.step()
+        return self.trainer.step(batch if batch is not None else self.batch)
+
+    def measure(self, steps, warmup, feed=None):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks.
+        feed: an iterator of device batches (data.Prefetcher) used instead of the resident batch."""
+        pg, dev = self.pg, self.dev
+        nxt = (lambda: next(feed)) if feed is not None else (lambda: None)
+        for _ in range(warmup):
+            scal = self.step(nxt())
+        if pg is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            scal = self.step(nxt())
+        torch.cuda.synchronize()
+        if pg is not None:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        frames = torch.tensor([float(self.batch.n_frames)], dtype=torch.float64, device=dev)
+        if pg is not None:
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            torch.distributed.all_reduce(frames, op=torch.distributed.ReduceOp.SUM)
+        dt = float(tmax.item())
+        loss = float(scal["loss"])
+        if not math.isfinite(loss):
+            raise RuntimeError("non-finite training loss (%r): the measurement is void" % loss)
+        ms = dt / steps * 1e3
+        value = float(frames.item()) / (dt / steps)
+        tf = MFLOP_PER_FRAME[self.preset] * 1e6 * value / 1e12
+        return dict(value=round(value, 1), ms_per_step=round(ms, 3), steps=steps, warmup=warmup,
+                    final_loss=round(loss, 5), frames_per_step=float(frames.item()),
+                    step_flop_frac=dict(alg_mflop_per_frame=MFLOP_PER_FRAME[self.preset], achieved_tflops=round(tf, 1),
+                                        peak=round(mfma_peak_tf(self.gemm), 1),
+                                        frac=round(tf / mfma_peak_tf(self.gemm), 4)))
+
+    def close(self):
+        self.trainer.close()
+        self.ops.dropout_state.dev_offset = None
+        self.ops.set_gemm_precision(self.prev_mode)
+        self.runner = self.trainer = self.model = self.batch = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
+def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup):
+    run = TrainRun(dev, pg, rank, world, preset, gemm, args.batch, args.text_len, args.frames,
+                   graph=(args.graph or args.batch < 32) and not args.no_graph)
+    try:
+        m = run.measure(steps, warmup)
+    finally:
+        run.close()
+    return dict(metric="mel-frames/sec/node (train step, %s)" % preset, value=m["value"], unit="mel-frames/s",
+                n_gpus=world, steps=steps, warmup=warmup, ms_per_step=m["ms_per_step"], dtype=gemm,
+                dtype_note=DTYPE_NOTE[gemm], step_flop_frac=m["step_flop_frac"],
+                config=dict(workload="builder=%s preset=%s train step" % (PRESETS[preset][0], preset),
+                            per_gpu_batch=args.batch, global_batch=args.batch * world, final_loss=m["final_loss"]))
 
 
 def main():
@@ -276,136 +515,139 @@ def main():
                     help="per-GPU batch (north-star shape: 64; the preset's batch_size is 16)")
     ap.add_argument("--preset", default="deepvoice3_ljspeech", choices=sorted(PRESETS),
                     help="BASELINE.json configs[1] (default) / [2] nyanko_ljspeech / [3] deepvoice3_vctk")
-    ap.add_argument("--gemm", default=None, choices=["bf16x3", "f32", "bf16"],
-                    help="GEMM arithmetic (default: DV3_GEMM or bf16x3 = split-bf16 MFMA, fp32 accumulate)")
+    ap.add_argument("--gemm", default=None, choices=["f16x3", "bf16x3", "f32", "bf16"],
+                    help="GEMM arithmetic (default: DV3_GEMM or f16x3)")
     ap.add_argument("--text-len", type=int, default=150)
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph replay")
     ap.add_argument("--graph", action="store_true", help="force the whole-step hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip value_exact_f32 / configs / input_pipeline (headline + rooflines only)")
     ap.add_argument("--mode", default="train", choices=["train", "conv", "conv-ab", "synth"])
     ap.add_argument("--gl-iters", type=int, default=60, help="Griffin-Lim iterations (synth mode)")
     args = ap.parse_args()
 
-    from deepvoice3_pytorch_amd import builder, train_step, ops, dist as dv3dist
+    from deepvoice3_pytorch_amd import ops, dist as dv3dist
     if args.gemm:
         ops.set_gemm_precision(args.gemm)
+    gemm = ops.gemm_precision()
     pg, rank, world, local_rank = dv3dist.init_from_env()
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torchrun for --gpus > 1"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
     if args.mode == "synth":
-        synth_bench(dev, args)
+        s = synth_run(dev, args.batch, reps=max(1, args.steps // 10), warm=max(1, args.warmup // 3),
+                      gl_iters=args.gl_iters, step_graph=not args.no_graph)
+        s.update(metric="real-time factor (synthesis: AR decode + converter + Griffin-Lim, %d concurrent utterances)"
+                 % args.batch, n_gpus=1, steps=s["reps"], warmup=max(1, args.warmup // 3), scaling="weak",
+                 vs_baseline=None, data="synthetic text ids, random-init weights")
+        print(json.dumps(s))
         return
     if args.mode == "conv-ab":     # A/B of kernel variants / tiles at the north-star shape
         for hint in (0, 21, 22, 1, 2, 11, 12):
             for dil in (1, 27):
-                rf = conv_roofline(dev, iters=10, tile_hint=hint, dil=dil, mode="bf16x3")
+                rf = conv_roofline(dev, iters=10, tile_hint=hint, dil=dil)
                 print("tile_hint=%2d dil=%2d  %8.1f us  %6.1f TFLOP/s  frac %.3f" % (hint, dil, rf["us_per_launch"], rf["achieved"], rf["frac"]))
         return
     if args.mode == "conv":
         rf = conv_roofline(dev, iters=max(args.steps, 10))
         print(json.dumps(dict(metric="conv1dglu_fwd_tflops", value=rf["achieved"], unit="TFLOP/s", n_gpus=1,
                               steps=args.steps, warmup=5, ms_per_step=rf["us_per_launch"] / 1e3,
-                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                              higher_is_better=True, scaling="weak", vs_baseline=None, dtype=gemm,
                               data="synthetic", config=dict(workload="Conv1dGLU fwd B=64 C=256 T=1024 k=3"),
-                              roofline=rf)))
+                              roofline=rf, roofline_wgrad=wgrad_roofline(dev))))
         return
 
-    bname, hp0, ga_sigma = PRESETS[args.preset]
-    hp = dict(hp0)
-    torch.manual_seed(0)            # identical initial weights on every rank
-    model = getattr(builder, bname)(**hp).to(dev)
-    cfg = train_step.TrainConfig(max_positions=hp["max_positions"], guided_attention_sigma=ga_sigma)
-    trainer = train_step.Trainer(model, cfg, process_group=pg)
-    rng = np.random.RandomState(1234 + rank)
-    bt = synth_batch(rng, args.batch, args.text_len, args.frames, hp)
-    spk = torch.from_numpy(rng.randint(0, hp["n_speakers"], args.batch)) if hp["n_speakers"] > 1 else None
-    batch = train_step.Batch.from_collate(bt["text"], bt["input_lengths"], bt["mel"], bt["y"],
-                                          bt["text_positions"], bt["frame_positions"], bt["done"],
-                                          bt["target_lengths"], spk, downsample_step=4, device=dev)
-    trainer.check_lengths(batch)
-    # Launch mode.  The step is ~1.9k kernel launches; at the north-star batch (64) the GPU stays ahead of
-    # the host, eager launches are GPU-bound (measured 18.25 ms/step eager vs 18.71 ms replayed) and the
-    # RCCL bucket all-reduces can be issued from autograd hooks on a side stream.  A whole-step hipGraph
-    # pays only when the step is launch-bound: small per-GPU batches on one GPU (B=16: 9.5 ms replayed).
-    use_graph = (args.graph or args.batch < 32) and not args.no_graph and world == 1
-    runner = None
-    if use_graph:
+    graph = (args.graph or args.batch < 32) and not args.no_graph
+    run = TrainRun(dev, pg, rank, world, args.preset, gemm, args.batch, args.text_len, args.frames, graph)
+    m = run.measure(args.steps, args.warmup)
+    out = None
+    if rank == 0:
+        out = dict(metric="mel-frames/sec/node (train step, %s)" % args.preset, value=m["value"],
+                   unit="mel-frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=m["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype=gemm, dtype_note=DTYPE_NOTE[gemm],
+                   data="synthetic (fixed-shape LJSpeech-like: Tt=%d, %d frames/item; random-init weights)"
+                   % (args.text_len, args.frames),
+                   config=dict(workload="builder=%s preset=%s train step "
+                                        "(fwd+losses+bwd+clip+Adam), synthetic LJSpeech-shaped batches" % (run.bname, args.preset),
+                               per_gpu_batch=args.batch, global_batch=args.batch * world, text_len=args.text_len,
+                               frames_per_item=args.frames, parallelism="dp%d" % world,
+                               hipgraph=bool(run.use_graph), gemm=gemm, final_loss=m["final_loss"]),
+                   step_flop_frac=m["step_flop_frac"])
+    extras = not args.no_extras
+    # ---- the same step fed through the input pipeline (sampler -> pinned staging -> side-stream H2D + device collate)
+    if extras and not run.use_graph:
         try:
-            runner = train_step.GraphedTrainer(trainer, batch, warmup=max(1, min(args.warmup, 3)))
-        except Exception as e:      # capture not possible (e.g. collective not capturable): say so, go eager
+            from deepvoice3_pytorch_amd import data as dv3data
+            rng = np.random.RandomState(99 + rank)
+            n_items = args.batch * world * 4
+            ds = dv3data.ListDataset(_bench_items(rng, min(n_items, 4 * args.batch), args.text_len, args.frames, run.hp),
+                                     repeat=world)
+            sampler = dv3data.LengthBucketedSampler(ds.frame_lengths, args.batch, rank=rank, world=world, seed=0)
+            feed = dv3data.Prefetcher(ds, sampler, dev, outputs_per_step=1, downsample_step=4, depth=2, workers=4,
+                                      loop=True)
+            try:
+                mf = run.measure(max(10, args.steps // 2), 5, feed=iter(feed))
+            finally:
+                feed.close()
             if rank == 0:
-                import traceback
-                traceback.print_exc()
-                print("hipGraph capture failed (%s); running eager" % type(e).__name__, file=sys.stderr)
-            use_graph = False
+                out["input_pipeline"] = dict(value=mf["value"], ms_per_step=mf["ms_per_step"], steps=mf["steps"],
+                                             note="every step consumes a fresh batch from data.Prefetcher: rank-sharded "
+                                                  "length-bucketed sampler, ragged items copied into pinned staging by "
+                                                  "worker threads, H2D + dv3_ragged_pad_rows on a side stream, double buffered")
+        except Exception as e:
+            if rank == 0:
+                out["input_pipeline"] = dict(error="%s: %s" % (type(e).__name__, e))
+    if rank == 0:
+        # the boundary can also be handed host buffers (train.py:655-663 copies 8 tensors per step): time the
+        # H2D of one pinned batch and report the rate with that copy serialised in front of every step
+        bt, spk = run.bt, run.spk
+        pinned = {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in bt.items()}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            run.train_step.Batch.from_collate(pinned["text"], pinned["input_lengths"], pinned["mel"], pinned["y"],
+                                              pinned["text_positions"], pinned["frame_positions"], pinned["done"],
+                                              pinned["target_lengths"], spk, downsample_step=4, device=dev)
             torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - t0) / 3 * 1e3
+        out["host_buffers"] = dict(h2d_ms_per_batch=round(h2d_ms, 3),
+                                   value_with_serial_h2d=round(m["frames_per_step"] / world / ((m["ms_per_step"] + h2d_ms) * 1e-3) * world, 1),
+                                   note="pinned host batch -> HBM copied synchronously before each step; never `value`")
+    run.close()
+    del run
 
-    def do_step():
-        return runner.step() if use_graph else trainer.step(batch)
-
-    for _ in range(args.warmup):
-        scal = do_step()
-    if pg is not None:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        scal = do_step()
-    torch.cuda.synchronize()
-    if pg is not None:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    frames = torch.tensor([float(batch.n_frames)], dtype=torch.float64, device=dev)
-    if pg is not None:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        torch.distributed.all_reduce(frames, op=torch.distributed.ReduceOp.SUM)
-    dt = float(tmax.item())
-    loss = float(scal["loss"])
-    if not math.isfinite(loss):
-        raise RuntimeError("non-finite training loss (%r): the measurement is void" % loss)
+    if extras and args.preset == "deepvoice3_ljspeech":
+        if gemm != "f32":
+            e = side_config(dev, pg, rank, world, args.preset, "f32", args, 5, 2)
+            if rank == 0:
+                out["value_exact_f32"] = dict(value=e["value"], ms_per_step=e["ms_per_step"], steps=5, dtype="f32",
+                                              dtype_note=DTYPE_NOTE["f32"], step_flop_frac=e["step_flop_frac"])
+        cfgs = {}
+        cfgs["nyanko_bf16"] = side_config(dev, pg, rank, world, "nyanko_ljspeech", "bf16", args, 20, 8)
+        cfgs["vctk_bf16"] = side_config(dev, pg, rank, world, "deepvoice3_vctk", "bf16", args, 20, 8)
+        if world == 1:
+            cfgs["nyanko_" + gemm] = side_config(dev, pg, rank, world, "nyanko_ljspeech", gemm, args, 20, 8)
+            try:
+                s = synth_run(dev, 64, reps=2, warm=1, gl_iters=args.gl_iters)
+                s["metric"] = "real-time factor (synthesis: AR decode + converter + Griffin-Lim, 64 concurrent utterances)"
+                cfgs["synth_rtf"] = s
+            except Exception as e:
+                cfgs["synth_rtf"] = dict(error="%s: %s" % (type(e).__name__, e))
+        if rank == 0:
+            out["configs"] = cfgs
     if rank != 0:
         return
-    ms = dt / args.steps * 1e3
-    value = float(frames.item()) / (dt / args.steps)
-    mode_desc = {"bf16x3": "f32 (operands split hi+lo bf16 on the matrix cores, 3 MFMAs per product, fp32 accumulate; "
-                           "1e-4 rel parity with the fp32 reference)",
-                 "f32": "f32 (exact fp32 MFMA)",
-                 "bf16": "bf16 (operands rounded to bf16 at the matrix cores, fp32 accumulate, fp32 master weights)"}
-    out = dict(metric="mel-frames/sec/node (train step, %s)" % args.preset, value=round(value, 1),
-               unit="mel-frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype={"bf16x3": "f32", "f32": "f32", "bf16": "bf16"}[ops.gemm_precision()],
-               dtype_note=mode_desc[ops.gemm_precision()],
-               data="synthetic (fixed-shape LJSpeech-like: Tt=%d, %d frames/item; random-init weights)"
-               % (args.text_len, args.frames),
-               config=dict(workload="builder=%s preset=%s train step "
-                                    "(fwd+losses+bwd+clip+Adam), synthetic LJSpeech-shaped batches" % (bname, args.preset),
-                           per_gpu_batch=args.batch, global_batch=args.batch * world, text_len=args.text_len,
-                           frames_per_item=args.frames, parallelism="dp%d" % world,
-                           hipgraph=bool(use_graph), gemm=ops.gemm_precision(), final_loss=round(loss, 5)))
-    # the boundary can also be handed host buffers (train.py:655-663 copies 8 tensors per step): time the
-    # H2D of one pinned batch and report the rate with that copy serialised in front of every step
-    pinned = {k: (v.pin_memory() if torch.is_tensor(v) else v) for k, v in bt.items()}
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        train_step.Batch.from_collate(pinned["text"], pinned["input_lengths"], pinned["mel"], pinned["y"],
-                                      pinned["text_positions"], pinned["frame_positions"], pinned["done"],
-                                      pinned["target_lengths"], spk, downsample_step=4, device=dev)
-        torch.cuda.synchronize()
-    h2d_ms = (time.perf_counter() - t0) / 3 * 1e3
-    out["host_buffers"] = dict(h2d_ms_per_batch=round(h2d_ms, 3),
-                               value_with_serial_h2d=round(float(frames.item()) / ((ms + h2d_ms) * 1e-3), 1),
-                               note="pinned host batch -> HBM copied synchronously before each step; never `value`")
     if not args.no_roofline:
-        out["roofline"] = conv_roofline(dev, mode="bf16x3" if ops.gemm_precision() == "bf16" else None)
-        if ops.gemm_precision() != "f32":      # the exact-fp32 kernel beside it, for the record
-            rf = conv_roofline(dev, mode="f32")
+        rmode = "f16x3" if gemm == "bf16" else gemm
+        out["roofline"] = conv_roofline(dev, mode=rmode)
+        out["roofline_wgrad"] = wgrad_roofline(dev, mode=rmode)
+        if gemm != "f32":      # the exact-fp32 kernel beside it, for the record
+            rf = conv_roofline(dev, mode="f32", iters=30)
             out["roofline_exact_f32"] = dict(kernel=rf["kernel"], achieved=rf["achieved"], peak=rf["peak"],
                                              frac=rf["frac"], us_per_launch=rf["us_per_launch"])
     if not args.no_cpu_baseline and world == 1 and args.preset == "deepvoice3_ljspeech":

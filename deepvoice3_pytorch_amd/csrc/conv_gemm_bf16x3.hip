@@ -33,6 +33,8 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
@@ -54,6 +56,32 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
   }
 }
 
+// Scaled fp16 split (include/dv3hip.h, "f16x3"): v arrives already multiplied by its power-of-two scale;
+// clamp to the fp16 range, hi = fp16_rn(a), lo = fp16_rn(a - hi).  The 16-byte units travel through the same
+// LDS images as the bf16 ones (raw bits in a bf16x8).
+__device__ __forceinline__ void split8_f16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  f16x8 h8, l8;
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const f32x2 f = {__builtin_amdgcn_fmed3f(v[i], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[i + 1], -65504.f, 65504.f)};
+    const f16x2 h = __builtin_convertvector(f, f16x2);
+    const f32x2 r = f - __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    h8[i] = h[0]; h8[i + 1] = h[1];
+    l8[i] = l[0]; l8[i + 1] = l[1];
+  }
+  hi = __builtin_bit_cast(bf16x8, h8);
+  lo = __builtin_bit_cast(bf16x8, l8);
+}
+// one 32x32x16 MFMA on raw 16-byte operand units, bf16 or fp16
+template <bool F16>
+__device__ __forceinline__ f32x16 mma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // uniform base + zero-extended 32-bit byte offset: selects the SGPR-base global_load form (one
 // VALU add per load instead of a 64-bit address build)
 template <typename T>
@@ -66,8 +94,9 @@ __device__ __forceinline__ T ldg_off(const void* base, uint32_t byte_off) {
 constexpr int STAMP_SLOTS = 192;
 __device__ unsigned long long g_x3_stamps[8 * STAMP_SLOTS * 2];
 
-template <int WM, int WN, int NI, bool MASK, int ABL = 0, int TERMS = 3, int MI = 1, bool PP = false>
+template <int WM, int WN, int NI, bool MASK, int ABL = 0, int TERMS = 3, int MI = 1, bool PP = false, bool F16 = false>
 __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const ConvArgs args) {
+  static_assert(!F16 || TERMS == 3, "the fp16 form is the three-term split");
   static_assert(!PP || (WM * WN == 8 && MI == 1 && (ABL == 0 || ABL >= 10)), "ping-pong: 8 waves, one row sub-tile per wave");
   constexpr int BM = WM * MI * 64, BMH = WM * MI * 32, BN = WN * NI * 32;
   constexpr int NT = WM * WN * 64;
@@ -109,7 +138,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   const bf16x8* __restrict__ Wh = reinterpret_cast<const bf16x8*>(p.a_split);
   const int64_t plane = (int64_t)J * k8_total * lda;  // 16-byte units per plane
   const uint32_t* __restrict__ xmask = p.xmask;
-  const float dscale = p.drop_scale;
+  // fp16 form: the activation scale 2^DV3_F16_ACT_SHIFT rides on the dropout scale (or is applied alone)
+  const float xscale = F16 ? (float)(1 << DV3_F16_ACT_SHIFT) : 1.0f;
+  const float dscale = p.drop_scale * xscale;
 
   // ---- this lane's output columns: (batch, time) and per-tap validity of the shifted read ----
   uint32_t vbits = 0;  // bit j*NI+ni: the tap-j input of column ni lies inside its batch item
@@ -232,9 +263,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         for (int e = 0; e < 8; ++e) {
           v[e] = rx[i][e];
           if (MASK) v[e] *= ((rm[i][e] >> xsh[i]) & 1u) ? dscale : 0.f;
+          else if (F16) v[e] *= xscale;
         }
         bf16x8 hi, lo;
-        split8(v, hi, lo);
+        if constexpr (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
         dst[idx] = hi;
         if (TERMS == 3) dst[KB * BNH + idx] = lo;
       }
@@ -367,19 +399,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         if (TERMS == 3) {
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
-            acc[0][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][0], bh[s][ni], acc[0][0][ni], 0, 0, 0);
-            acc[0][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][1], bh[s][ni], acc[0][1][ni], 0, 0, 0);
+            acc[0][0][ni] = mma16<F16>(al[s][0], bh[s][ni], acc[0][0][ni]);
+            acc[0][1][ni] = mma16<F16>(al[s][1], bh[s][ni], acc[0][1][ni]);
           }
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
-            acc[0][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][0], bl[s][ni], acc[0][0][ni], 0, 0, 0);
-            acc[0][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][1], bl[s][ni], acc[0][1][ni], 0, 0, 0);
+            acc[0][0][ni] = mma16<F16>(ah[s][0], bl[s][ni], acc[0][0][ni]);
+            acc[0][1][ni] = mma16<F16>(ah[s][1], bl[s][ni], acc[0][1][ni]);
           }
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          acc[0][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][0], bh[s][ni], acc[0][0][ni], 0, 0, 0);
-          acc[0][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][1], bh[s][ni], acc[0][1][ni], 0, 0, 0);
+          acc[0][0][ni] = mma16<F16>(ah[s][0], bh[s][ni], acc[0][0][ni]);
+          acc[0][1][ni] = mma16<F16>(ah[s][1], bh[s][ni], acc[0][1][ni]);
         }
       }
       stamp();                     // MFMAs issued
@@ -451,23 +483,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-              acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi][0], bh[ni], acc[mi][0][ni], 0, 0, 0);
-              acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi][1], bh[ni], acc[mi][1][ni], 0, 0, 0);
+              acc[mi][0][ni] = mma16<F16>(al[mi][0], bh[ni], acc[mi][0][ni]);
+              acc[mi][1][ni] = mma16<F16>(al[mi][1], bh[ni], acc[mi][1][ni]);
             }
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-              acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi][0], bl[ni], acc[mi][0][ni], 0, 0, 0);
-              acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi][1], bl[ni], acc[mi][1][ni], 0, 0, 0);
+              acc[mi][0][ni] = mma16<F16>(ah[mi][0], bl[ni], acc[mi][0][ni]);
+              acc[mi][1][ni] = mma16<F16>(ah[mi][1], bl[ni], acc[mi][1][ni]);
             }
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
-            acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi][0], bh[ni], acc[mi][0][ni], 0, 0, 0);
-            acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi][1], bh[ni], acc[mi][1][ni], 0, 0, 0);
+            acc[mi][0][ni] = mma16<F16>(ah[mi][0], bh[ni], acc[mi][0][ni]);
+            acc[mi][1][ni] = mma16<F16>(ah[mi][1], bh[ni], acc[mi][1][ni]);
           }
       }
     }
@@ -484,6 +516,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   // ABL 6: skip the epilogue but keep the accumulators live
   if ((ABL != 6 && ABL != 9) || acc[0][0][0][0] + acc[MI - 1][1][0][0] + acc[0][0][NI - 1][5] + acc[MI - 1][1][NI - 1][7] == 1.2345e30f) {
     static_assert(MI == 1 || MI == 2, "row sub-tiles per wave");
+    if constexpr (F16) {   // the accumulators carry 2^(weight shift + activation shift) x the result
+      constexpr float kInv = 1.0f / (float)(1 << (DV3_F16_WEIGHT_SHIFT + DV3_F16_ACT_SHIFT));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] *= kInv;
+    }
     // (batch, time) of this lane's output columns, recomputed from an opaque copy of the tile origin
     // instead of being carried through the main loop in registers
     int n0e = n0;
@@ -507,7 +550,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
 // packed fp32 [J][K][lda] -> split image [plane][j][k8][m][8]
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ src,
                                                          bf16x8* __restrict__ dst, int J, int K,
-                                                         int lda, int k8_total) {
+                                                         int lda, int k8_total, int dtype) {
   const int64_t n = (int64_t)J * k8_total * lda;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
@@ -519,18 +562,19 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
   for (int i = 0; i < 8; ++i) {
     const int k = k8 * 8 + i;
     v[i] = (k < K) ? src[((int64_t)j * K + k) * lda + m] : 0.f;
+    if (dtype == DV3_SPLIT_DTYPE_F16) v[i] *= (float)(1 << DV3_F16_WEIGHT_SHIFT);
   }
   bf16x8 hi, lo;
-  split8(v, hi, lo);
+  if (dtype == DV3_SPLIT_DTYPE_F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
   dst[idx] = hi;
   dst[n + idx] = lo;
 }
 
-template <int WM, int WN, int NI, bool MASK, int TERMS, int MI = 1, bool PP = false>
+template <int WM, int WN, int NI, bool MASK, int TERMS, int MI = 1, bool PP = false, bool F16 = false>
 int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP, F16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_gemm_bf16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -539,7 +583,7 @@ int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(a.n_blocks), block(WM * WN * 64);
-  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP, F16>), grid, block, lds, st, a);
   return dv3_check_launch("conv_gemm_bf16x3");
 }
 int g_x3_ablate = 0;   // debug: dv3_debug_set(); ablation variants of the 128x128 unmasked tile
@@ -554,6 +598,8 @@ int launch_x3_abl(const ConvArgs& a, size_t lds, hipStream_t st) {
 int g_x3_pingpong = 1;
 template <int WM, int WN, int NI, int MI, bool PP>
 int launch_x3_big_pp(const ConvArgs& a, size_t lds, hipStream_t st) {
+  if (a.d.split_terms == DV3_SPLIT_F16X3)
+    return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3, MI, PP, true>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3, MI, PP, true>(a, lds, st);
   if (a.d.split_terms == 1)
     return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 1, MI, PP>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 1, MI, PP>(a, lds, st);
   return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3, MI, PP>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3, MI, PP>(a, lds, st);
@@ -561,7 +607,7 @@ int launch_x3_big_pp(const ConvArgs& a, size_t lds, hipStream_t st) {
 template <int WM, int WN, int NI, int MI>
 int launch_x3_big(const ConvArgs& a, size_t lds, hipStream_t st) {
   if constexpr (WM == 2 && WN == 4 && MI == 1) {
-    if (g_x3_ablate == 10 && g_x3_pingpong && !a.d.xmask && a.d.split_terms != 1) {
+    if (g_x3_ablate == 10 && g_x3_pingpong && !a.d.xmask && (a.d.split_terms == 0 || a.d.split_terms == 3)) {
       (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<2, 4, 2, false, 10, 3, 1, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<2, 4, 2, false, 10, 3, 1, true>), dim3(a.n_blocks), dim3(512), lds, st, a);
@@ -575,7 +621,7 @@ int launch_x3_big(const ConvArgs& a, size_t lds, hipStream_t st) {
 }
 template <int WM, int WN, int NI>
 int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
-  if (g_x3_ablate && WM == 2 && WN == 2 && NI == 2 && !a.d.xmask && a.d.split_terms != 1) {
+  if (g_x3_ablate && WM == 2 && WN == 2 && NI == 2 && !a.d.xmask && (a.d.split_terms == 0 || a.d.split_terms == 3)) {
     switch (g_x3_ablate) {
       case 1: return launch_x3_abl<1>(a, lds, st);
       case 2: return launch_x3_abl<2>(a, lds, st);
@@ -588,6 +634,8 @@ int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
       case 9: return launch_x3_abl<9>(a, lds, st);
     }
   }
+  if (a.d.split_terms == DV3_SPLIT_F16X3)
+    return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3, 1, false, true>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3, 1, false, true>(a, lds, st);
   if (a.d.split_terms == 1)
     return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 1>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 1>(a, lds, st);
   return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3>(a, lds, st);
@@ -653,7 +701,7 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   const int64_t nb = (int64_t)a.m_tiles * a.n_tiles;
   DV3_REQUIRE(nb < (1ll << 31), "conv_gemm: grid too large");
   a.n_blocks = (int)nb;
-  g_dv3_last_conv = (d->split_terms == 1 ? 4000 : 3000) + best->id * 10 +
+  g_dv3_last_conv = (d->split_terms == 1 ? 4000 : d->split_terms == DV3_SPLIT_F16X3 ? 5000 : 3000) + best->id * 10 +
                     ((best->id >= 8 && g_x3_pingpong) ? 1 : 0);
   switch (best->id) {
     case 1: return launch_x3<2, 2, 2>(a, lds, st);
@@ -689,12 +737,13 @@ extern "C" int dv3_debug_read(int what, void* dst, int64_t bytes) {
 }
 
 extern "C" int dv3_split_pack_bf16(const float* packed, uint16_t* out, int32_t J, int32_t K,
-                                   int32_t lda, void* stream) {
+                                   int32_t lda, int32_t dtype, void* stream) {
+  DV3_REQUIRE(dtype == DV3_SPLIT_DTYPE_BF16 || dtype == DV3_SPLIT_DTYPE_F16, "split_pack: bad dtype");
   DV3_REQUIRE(packed && out, "split_pack: null pointer");
   DV3_REQUIRE(J >= 1 && K >= 1 && lda >= 1 && ((uintptr_t)out & 15) == 0, "split_pack: bad arguments");
   const int k8_total = (K + 31) / 32 * 4;
   const int64_t n = (int64_t)J * k8_total * lda;
   hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)dv3_cdiv64(n, 256)), dim3(256), 0,
-                     (hipStream_t)stream, packed, reinterpret_cast<bf16x8*>(out), J, K, lda, k8_total);
+                     (hipStream_t)stream, packed, reinterpret_cast<bf16x8*>(out), J, K, lda, k8_total, (int)dtype);
   return dv3_check_launch("split_pack_bf16");
 }

@@ -108,6 +108,20 @@ __device__ __forceinline__ void wn_split8(const float (&v)[8], wn_bf16x8& hi, wn
     lo[i] = (__bf16)(v[i] - (float)h);
   }
 }
+typedef _Float16 wn_f16x8 __attribute__((ext_vector_type(8)));
+// scaled fp16 split of the forward image (include/dv3hip.h "f16x3"): a = clamp(v * 2^8)
+__device__ __forceinline__ void wn_split8_f16(const float (&v)[8], wn_bf16x8& hi, wn_bf16x8& lo) {
+  wn_f16x8 h8, l8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float a = __builtin_amdgcn_fmed3f(v[i] * (float)(1 << DV3_F16_WEIGHT_SHIFT), -65504.f, 65504.f);
+    const _Float16 h = (_Float16)a;
+    h8[i] = h;
+    l8[i] = (_Float16)(a - (float)h);
+  }
+  hi = __builtin_bit_cast(wn_bf16x8, h8);
+  lo = __builtin_bit_cast(wn_bf16x8, l8);
+}
 __global__ __launch_bounds__(256) void wn_split_both_kernel(const dv3_wn_desc p, wn_bf16x8* __restrict__ fs,
                                                             wn_bf16x8* __restrict__ bs) {
   extern __shared__ float tile[];  // [32][32*J+1]
@@ -138,7 +152,7 @@ __global__ __launch_bounds__(256) void wn_split_both_kernel(const dv3_wn_desc p,
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[ol * LD + (q * 8 + e) * J + j];
     wn_bf16x8 hi, lo;
-    wn_split8(v, hi, lo);
+    if (p.fwd_dtype == DV3_SPLIT_DTYPE_F16) wn_split8_f16(v, hi, lo); else wn_split8(v, hi, lo);
     const int64_t g = ((int64_t)j * k8f + (i0 >> 3) + q) * p.lda + col;
     fs[g] = hi;
     fs[plane_f + g] = lo;
@@ -290,6 +304,7 @@ extern "C" int dv3_weight_norm_split_pack_bf16(const dv3_wn_desc* d, uint16_t* f
   DV3_REQUIRE(d->glu_cg == 0 || (2 * d->glu_cg == d->O && d->a_half >= d->glu_cg &&
                                  d->lda >= d->a_half + d->glu_cg), "wn_split_pack: bad GLU layout");
   DV3_REQUIRE(d->glu_cg > 0 || d->lda >= d->O, "wn_split_pack: lda < O");
+  DV3_REQUIRE(d->fwd_dtype == DV3_SPLIT_DTYPE_BF16 || d->fwd_dtype == DV3_SPLIT_DTYPE_F16, "wn_split_pack: bad fwd_dtype");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wn_inv_norm_kernel, dim3(d->O), dim3(256), 0, st, d->v, d->g, d->scale, d->I * d->J);
   const size_t lds = (size_t)32 * (32 * d->J + 1) * 4;

@@ -163,3 +163,227 @@ class PreprocessedDataset(torch.utils.data.Dataset):
         if self.multi_speaker:
             return text, mel, spec, int(r[4])
         return text, mel, spec
+
+
+class ListDataset(torch.utils.data.Dataset):
+    """Items held in host memory (synthetic benchmarks, tests); `repeat` makes the list appear that many
+    times longer without copying."""
+
+    def __init__(self, items, repeat=1):
+        self.items, self.repeat = list(items), int(repeat)
+        self.frame_lengths = [len(it[1]) for it in self.items] * self.repeat
+
+    def __len__(self):
+        return len(self.items) * self.repeat
+
+    def __getitem__(self, i):
+        return self.items[i % len(self.items)]
+
+
+class LengthBucketedSampler(object):
+    """The reference's PartialyRandomizedSimilarTimeLengthSampler (train.py:195-239) as a BATCH sampler
+    that is rank-aware: (1) sort by length, (2) shuffle inside groups of `batch_group_size`, (3) permute
+    whole mini-batches, (4) shuffle the tail that does not fill a group -- then cut the index stream into
+    consecutive mini-batches exactly as the reference's DataLoader(batch_size=...) does, and give rank r the
+    batches r, r + world, r + 2*world, ... (the reference sampler is not rank-aware).  Every
+    rank draws the same permutation (numpy RandomState(seed + epoch)), so the shards are disjoint and cover
+    the epoch; the batch list is truncated to a multiple of `world` so all ranks take the same number of
+    steps (a data-parallel step is collective)."""
+
+    def __init__(self, lengths, batch_size=16, batch_group_size=None, permutate=True, rank=0, world=1, seed=0,
+                 drop_last=False):
+        lengths = np.asarray(lengths, dtype=np.int64)
+        self.sorted_indices = np.argsort(lengths, kind="stable")
+        self.batch_size = int(batch_size)
+        n = len(lengths)
+        if batch_group_size is None:
+            batch_group_size = min(self.batch_size * 32, n)
+            if batch_group_size % self.batch_size != 0:
+                batch_group_size -= batch_group_size % self.batch_size
+        if batch_group_size <= 0 or batch_group_size % self.batch_size != 0:
+            raise ValueError("batch_group_size must be a positive multiple of batch_size")
+        self.batch_group_size = batch_group_size
+        self.permutate = permutate
+        self.rank, self.world, self.seed, self.epoch = int(rank), int(world), int(seed), 0
+        self.drop_last = drop_last
+        if not 0 <= self.rank < self.world:
+            raise ValueError("rank must be in [0, world)")
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def epoch_batches(self):
+        """all mini-batches of the epoch (every rank computes the same list)"""
+        rs = np.random.RandomState(self.seed + self.epoch)
+        idx = self.sorted_indices.copy()
+        g, bs = self.batch_group_size, self.batch_size
+        e = 0
+        for i in range(len(idx) // g):
+            s, e = i * g, (i + 1) * g
+            rs.shuffle(idx[s:e])
+        if self.permutate and e > 0:
+            perm = rs.permutation(e // bs)
+            idx[:e] = idx[:e].reshape(-1, bs)[perm].reshape(-1)
+        if e < len(idx):
+            rs.shuffle(idx[e:])
+        batches = [idx[i:i + bs] for i in range(0, len(idx), bs)]
+        if self.drop_last and batches and len(batches[-1]) < bs:
+            batches.pop()
+        return batches
+
+    def __iter__(self):
+        batches = self.epoch_batches()
+        usable = len(batches) - len(batches) % self.world
+        for b in batches[self.rank:usable:self.world]:
+            yield [int(i) for i in b]
+
+    def __len__(self):
+        n = len(self.sorted_indices)
+        nb = n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+        return nb // self.world
+
+
+class _Staging(object):
+    """one pinned staging slot: three flat host buffers that grow on demand"""
+
+    def __init__(self, pin):
+        self.pin, self.text, self.mel, self.lin, self.event = pin, None, None, None, None
+
+    def _fit(self, cur, shape, dtype):
+        n = int(np.prod(shape))
+        if cur is None or cur.numel() < n:
+            cur = torch.empty(int(n * 1.25) + 16, dtype=dtype)
+            if self.pin:
+                cur = cur.pin_memory()
+        return cur
+
+    def fill(self, items, pool):
+        in_len = np.array([len(it[0]) for it in items], dtype=np.int64)
+        tgt_len = np.array([len(it[1]) for it in items], dtype=np.int64)
+        for it in items:
+            if len(it[2]) != len(it[1]):
+                raise ValueError("mel and linear spectrogram of an item differ in frame count")
+        nm, nl = items[0][1].shape[1], items[0][2].shape[1]
+        nt, nf = int(in_len.sum()), int(tgt_len.sum())
+        self.text = self._fit(self.text, (nt,), torch.int64)
+        self.mel = self._fit(self.mel, (nf, nm), torch.float32)
+        self.lin = self._fit(self.lin, (nf, nl), torch.float32)
+        tv, mv, lv = self.text.numpy(), self.mel.numpy()[:nf * nm].reshape(nf, nm), self.lin.numpy()[:nf * nl].reshape(nf, nl)
+        to, fo = np.concatenate([[0], np.cumsum(in_len)]), np.concatenate([[0], np.cumsum(tgt_len)])
+
+        def put(i):
+            it = items[i]
+            tv[to[i]:to[i + 1]] = it[0]
+            mv[fo[i]:fo[i + 1]] = it[1]
+            lv[fo[i]:fo[i + 1]] = it[2]          # the big one: numpy releases the GIL for the copy
+        if pool is not None:
+            list(pool.map(put, range(len(items))))
+        else:
+            for i in range(len(items)):
+                put(i)
+        spk = np.array([it[3] for it in items], dtype=np.int64) if len(items[0]) == 4 else None
+        return PackedBatch(self.text[:nt], self.mel[:nf * nm].view(nf, nm), self.lin[:nf * nl].view(nf, nl),
+                           in_len, tgt_len, spk)
+
+
+class Prefetcher(object):
+    """Feeds train_step.Trainer.step with device-resident batches while the previous step computes
+    (the reference: DataLoader workers + 8 blocking .to(device) copies per step, train.py:619-663).
+    A producer thread walks the sampler; worker threads read the items and copy them back to back into a
+    pinned staging slot (no padded bytes cross PCIe); the H2D copies and the device-side collate
+    (dv3_ragged_pad_rows, positions, done flags) run on a side HIP stream; `depth` batches are kept in
+    flight.  next() makes the consumer's stream wait on the batch's event -- no host synchronisation."""
+
+    def __init__(self, dataset, batch_sampler, device, outputs_per_step=1, downsample_step=4, depth=2, workers=2,
+                 loop=False):
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        self.dataset, self.sampler = dataset, batch_sampler
+        self.device = torch.device(device)
+        self.r, self.ds = int(outputs_per_step), int(downsample_step)
+        self.loop = loop
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(self.device) if self.cuda else None
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self.slots = [_Staging(self.cuda) for _ in range(max(1, depth) + 2)]
+        self.pool = ThreadPoolExecutor(max(1, workers)) if workers > 0 else None
+        self._stop = threading.Event()
+        self._err = None
+        self.thread = threading.Thread(target=self._produce, name="dv3-prefetch", daemon=True)
+        self.thread.start()
+
+    def _produce(self):
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)
+            epoch, k = 0, 0
+            while not self._stop.is_set():
+                if hasattr(self.sampler, "set_epoch"):
+                    self.sampler.set_epoch(epoch)
+                for idx in self.sampler:
+                    if self._stop.is_set():
+                        return
+                    slot = self.slots[k % len(self.slots)]
+                    k += 1
+                    if slot.event is not None:
+                        slot.event.synchronize()         # the copies that read this slot have run
+                    if self.pool is not None:
+                        items = list(self.pool.map(self.dataset.__getitem__, idx))
+                    else:
+                        items = [self.dataset[i] for i in idx]
+                    packed = slot.fill(items, self.pool)
+                    if self.cuda:
+                        with torch.cuda.stream(self.side):
+                            batch = device_collate(packed, self.device, self.r, self.ds)
+                            ev = torch.cuda.Event()
+                            ev.record(self.side)
+                        slot.event = ev
+                    else:
+                        batch, ev = device_collate(packed, self.device, self.r, self.ds), None
+                    while not self._stop.is_set():
+                        try:
+                            self.q.put((batch, ev), timeout=0.1)
+                            break
+                        except Exception:
+                            continue
+                epoch += 1
+                if not self.loop:
+                    break
+            self.q.put(None)
+        except BaseException as e:      # surface in the consumer
+            self._err = e
+            try:
+                self.q.put_nowait(None)
+            except Exception:
+                pass
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self.q.get()
+        if item is None:
+            if self._err is not None:
+                raise self._err
+            raise StopIteration
+        batch, ev = item
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for t in (batch.text, batch.text_positions, batch.frame_positions, batch.mel, batch.y, batch.done,
+                      batch.input_lengths, batch.target_lengths, batch.decoder_lengths, batch.speaker_ids):
+                if t is not None:
+                    t.record_stream(cur)         # allocated on the side stream, consumed here
+        return batch
+
+    def close(self):
+        self._stop.set()
+        try:
+            while True:
+                self.q.get_nowait()
+        except Exception:
+            pass
+        self.thread.join(timeout=5)
+        if self.pool is not None:
+            self.pool.shutdown(wait=False)

@@ -37,23 +37,27 @@ _spec_loss_desc = STRUCTS["dv3_spec_loss_desc"]
 
 
 # ----------------------------------------------------------------------------------------------
-# GEMM arithmetic: "bf16x3" = split-bf16 operands on the bf16 matrix cores with fp32 accumulate
-# (include/dv3hip.h, "Split-bf16"; ~3e-6 relative error, 16/3 x the fp32-MFMA rate) -- the
-# default; "f32" = the exact fp32 MFMA chain (v_mfma_f32_32x32x2_f32); "bf16" = operands rounded to
-# bf16 at the matrix-core inputs (hi planes only, one MFMA per product, fp32 accumulate, fp32
-# master weights / activations in HBM) -- the arithmetic of BASELINE.json's bf16 configs.
-# DV3_GEMM=<mode> selects it.
+# GEMM arithmetic (include/dv3hip.h, "Split-bf16" / "f16x3"), DV3_GEMM=<mode>:
+#   "f16x3"  (default) forward GEMMs on scaled fp16 hi/lo operands (three fp16 MFMAs per product,
+#            2^-22-class operands: fp32-class outputs -- what the 1e-4 parity bar needs at the preset
+#            model sizes), gradient GEMMs on bf16 hi/lo operands (three bf16 MFMAs; bf16 has fp32's
+#            exponent range, so gradients need no scale search); 16/3 x the fp32-MFMA rate;
+#   "bf16x3" every GEMM on bf16 hi/lo operands (~5e-6 relative error per GEMM; passes 1e-4 on small
+#            models, ~1-3e-4 on the presets: kept for A/B measurements);
+#   "f32"    the exact fp32 MFMA chain (v_mfma_f32_32x32x2_f32);
+#   "bf16"   operands rounded to bf16 at the matrix-core inputs (hi planes only, one MFMA per
+#            product, fp32 accumulate, fp32 master weights) -- BASELINE.json's bf16 configs.
 # ----------------------------------------------------------------------------------------------
 import os as _os
 
-_GEMM_MODES = ("bf16x3", "f32", "bf16")
-_gemm_mode = _os.environ.get("DV3_GEMM", "bf16x3")
+_GEMM_MODES = ("f16x3", "bf16x3", "f32", "bf16")
+_gemm_mode = _os.environ.get("DV3_GEMM", "f16x3")
 if _gemm_mode not in _GEMM_MODES:
     raise RuntimeError("DV3_GEMM must be one of %s" % (_GEMM_MODES,))
 
 
 def set_gemm_precision(mode):
-    """'bf16x3' (default) or 'f32'; returns the previous mode."""
+    """one of _GEMM_MODES; returns the previous mode."""
     global _gemm_mode
     if mode not in _GEMM_MODES:
         raise ValueError("gemm precision must be one of %s" % (_GEMM_MODES,))
@@ -134,14 +138,19 @@ def dropout_bits(rows, T, p, device, name=None):
 # ----------------------------------------------------------------------------------------------
 class Packed(object):
     __slots__ = ("fwd", "bwd", "scale", "lda", "a_half", "ldb", "O", "I", "J", "transposed", "glu_cg",
-                 "fwd_s", "bwd_s")
+                 "fwd_s", "bwd_s", "fwd_f16")
 
 
-def split_pack(packed, J, K, ld):
-    """dv3_split_pack_bf16: fp32 packed image [J][K][ld] -> split-bf16 image (int16 storage)."""
+SPLIT_BF16, SPLIT_F16 = CONSTS["DV3_SPLIT_DTYPE_BF16"], CONSTS["DV3_SPLIT_DTYPE_F16"]
+
+
+def split_pack(packed, J, K, ld, dtype=SPLIT_BF16):
+    """dv3_split_pack_bf16: fp32 packed image [J][K][ld] -> split image (int16 storage), bf16 hi/lo or
+    scaled fp16 hi/lo."""
     kp = _round_up(K, 32)
     out = torch.empty(2 * J * kp * ld, dtype=torch.int16, device=packed.device)
-    _lib.call("dv3_split_pack_bf16", packed.data_ptr(), out.data_ptr(), J, K, ld, _stream())
+    _lib.call("dv3_split_pack_bf16", packed.data_ptr(), out.data_ptr(), J, K, ld, dtype, _stream())
+    out._dv3_f16 = dtype == SPLIT_F16       # conv_gemm reads the operand type off the image
     return out
 
 
@@ -154,6 +163,8 @@ def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True, split_only=Fal
     if v.dim() == 2:
         v = v.unsqueeze(-1)
     pk = Packed()
+    pk.fwd_f16 = _gemm_mode == "f16x3"
+    fdt = SPLIT_F16 if pk.fwd_f16 else SPLIT_BF16
     if split_only and not transposed and _gemm_mode != "f32":
         O, I, J = v.shape
         pk.O, pk.I, pk.J, pk.transposed, pk.glu_cg = O, I, J, False, glu_cg
@@ -172,6 +183,8 @@ def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True, split_only=Fal
         d.v, d.g, d.scale = v.data_ptr(), _ptr(_c(g) if g is not None else None), pk.scale.data_ptr()
         d.lda, d.a_half, d.ldb = pk.lda, pk.a_half, pk.ldb
         d.O, d.I, d.J, d.transposed, d.glu_cg = O, I, J, 0, glu_cg
+        d.fwd_dtype = fdt
+        pk.fwd_s._dv3_f16 = pk.fwd_f16
         _lib.call("dv3_weight_norm_split_pack_bf16", ctypes.byref(d), pk.fwd_s.data_ptr(), _ptr(pk.bwd_s), _stream())
         return pk
     if transposed:
@@ -203,14 +216,14 @@ def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True, split_only=Fal
     d.O, d.I, d.J, d.transposed, d.glu_cg = O, I, J, int(transposed), glu_cg
     _lib.call("dv3_weight_norm_pack_f32", ctypes.byref(d), _stream())
     pk.fwd_s = pk.bwd_s = None
-    if _gemm_mode in ("bf16x3", "bf16"):
+    if _gemm_mode != "f32":
         # operand K/M extents of the two tap-GEMMs: fwd [J'][K=I][lda], bwd [J'][K'][ldb]
         if transposed:
-            pk.fwd_s = split_pack(pk.fwd, 1, I, pk.lda)
+            pk.fwd_s = split_pack(pk.fwd, 1, I, pk.lda, fdt)
             if need_bwd:
                 pk.bwd_s = split_pack(pk.bwd, 1, J * O, pk.ldb)
         else:
-            pk.fwd_s = split_pack(pk.fwd, J, I, pk.lda)
+            pk.fwd_s = split_pack(pk.fwd, J, I, pk.lda, fdt)
             if need_bwd:
                 pk.bwd_s = split_pack(pk.bwd, J, O, pk.ldb)
     return pk
@@ -255,7 +268,11 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
     d.B, d.Cin, d.Tin, d.M, d.Cg, d.Tout, d.J, d.dil, d.padL = B, Cin, Tin, M, Cg, Tout, J, dil, padL
     d.mode, d.residual, d.store_mode, d.tile_hint = mode, residual, store_mode, tile_hint
     d.a_split = _ptr(a_split)
-    d.split_terms = 1 if (a_split is not None and _gemm_mode == "bf16") else 0
+    d.split_terms = 0
+    if a_split is not None:
+        # the image carries its operand type (split_pack / pack_weights tag it): scaled fp16 hi/lo or bf16
+        d.split_terms = CONSTS["DV3_SPLIT_F16X3"] if getattr(a_split, "_dv3_f16", False) else \
+            (1 if _gemm_mode == "bf16" else 0)
     _lib.call("dv3_conv_gemm_f32", ctypes.byref(d), _stream())
     return y
 
@@ -559,9 +576,13 @@ def conv_layer(x, v, g, bias, cfg, spk=None, r=None, r2=None, packed=None):
 # attention core (deepvoice3.py:143-171): S = q^T k -> mask/softmax/dropout -> ctx = v Pd^T sqrt(Tk)
 # q (B,E,Tq), k (B,E,Tk), v (B,E,Tk) all BCT; returns ctx (B,E,Tq) BCT and P (B,Tq,Tk).
 # ----------------------------------------------------------------------------------------------
-def _attn_split():
-    """the batched attention products (torch.bmm, deepvoice3.py:143,167) follow the GEMM mode; the
+def _attn_split(forward=False):
+    """the batched attention products (torch.bmm, deepvoice3.py:143,167) follow the GEMM mode; in the
+    default mode the FORWARD context product stays on the exact kernel like the scores (fp32-class
+    outputs; < 0.3 % of the step's FLOPs), the four gradient products use the bf16 split; the
     incremental decode (Tq == 1) keeps the exact kernel (a 1-row product is not MFMA work)"""
+    if forward and _gemm_mode == "f16x3":
+        return False
     return _gemm_mode != "f32"
 
 
@@ -588,7 +609,8 @@ class AttnCoreFn(torch.autograd.Function):
         _lib.call("dv3_attn_softmax_f32", ctypes.byref(d), _stream())
         P = S
         # context: out[b][e][t] = sum_n v[b][e][n] * pd[b][t][n]
-        ctxv = wgrad_gemm(v, pd, B=B, M=E, Cin=Tq, T=Tk, Tin=Tk, n_slabs=B, split_bf16=_attn_split()).view(B, E, Tq)
+        ctxv = wgrad_gemm(v, pd, B=B, M=E, Cin=Tq, T=Tk, Tin=Tk, n_slabs=B,
+                          split_bf16=_attn_split(forward=True)).view(B, E, Tq)
         if any(ctx.needs_input_grad[:3]):
             ctx.save_for_backward(q, k, v, P, pd)
             ctx.bits, ctx.bits_rs, ctx.dscale, ctx.pd_scale = bits, bits_rs, dscale, d.pd_scale

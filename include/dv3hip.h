@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 20
+#define DV3_ABI_VERSION 21
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -113,9 +113,12 @@ typedef struct dv3_conv_desc {
   int32_t tile_hint;                         /* 0 = auto; else forces a tile config (tests) */
   const uint16_t* a_split;                   /* split-bf16 image of `a` (dv3_split_pack_bf16) or
                                                 NULL.  Non-NULL selects the bf16x3 kernel (below) */
-  int32_t split_terms;                       /* 0 or 3: hi/lo split, three MFMAs per product (fp32
-                                                class accuracy); 1: hi planes only = plain bf16 MFMA
-                                                with fp32 accumulate (BASELINE.json bf16 configs)   */
+  int32_t split_terms;                       /* 0 or 3: hi/lo bf16 split, three MFMAs per product;
+                                                1: hi planes only = plain bf16 MFMA with fp32 accumulate
+                                                (BASELINE.json bf16 configs); DV3_SPLIT_F16X3 (19): `a_split`
+                                                is a SCALED FP16 hi/lo image (below), the activations are
+                                                split the same way while staging: three fp16 MFMAs per
+                                                product, 2^-22-class operands = fp32-class results      */
 } dv3_conv_desc;
 int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
 
@@ -133,9 +136,24 @@ int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
  *   out[plane][j][k8][m][8]   plane 0 = hi, 1 = lo; k8 = k/8 over Kp = round_up(K,32) (zero rows
  *   beyond K); m < lda; 8 consecutive k per 16-byte unit (one MFMA A-fragment lane).
  * `out` holds 2*J*Kp*lda uint16 elements.
+ *
+ * Scaled split-fp16 ("f16x3", dtype = DV3_SPLIT_DTYPE_F16): the same images with
+ *   a = clamp(v * 2^s, +-65504), hi = fp16_rn(a), lo = fp16_rn(a - hi)      (|a - hi - lo| <= 2^-23 |a|
+ *   while |a| >= 2^-3; below that the error is absolute, <= 2^-25 in a-units)
+ * s = DV3_F16_WEIGHT_SHIFT (8) for weights, DV3_F16_ACT_SHIFT (4) for activations (fixed powers of two:
+ * exact, no amax pass; weight-normed |w| <= |g| and O(1..100) activations sit far inside the range);
+ * the accumulators carry 2^12 x the result and the epilogue multiplies by 2^-12 (exact).  The forward
+ * tap-GEMM uses this form: at the preset model sizes the bf16 split's 2^-17 operands, amplified ~100x by
+ * the depth of the network, exceed the 1e-4 parity bar (tests/test_gpu_preset_scale.py measures both);
+ * the gradient GEMMs keep the bf16 split, whose exponent range covers gradients without a scale search.
  */
+#define DV3_SPLIT_DTYPE_BF16 0
+#define DV3_SPLIT_DTYPE_F16 1
+#define DV3_SPLIT_F16X3 19
+#define DV3_F16_WEIGHT_SHIFT 8
+#define DV3_F16_ACT_SHIFT 4
 int dv3_split_pack_bf16(const float* packed, uint16_t* out, int32_t J, int32_t K, int32_t lda,
-                        void* stream);
+                        int32_t dtype, void* stream);
 
 /*
  * dv3_wgrad_gemm_f32 -- weight-gradient GEMM (autograd of F.conv1d w.r.t. weight; also
@@ -179,6 +197,8 @@ typedef struct dv3_wn_desc {
   float* fwd_pack; int32_t lda; int32_t a_half;
   float* bwd_pack; int32_t ldb;
   int32_t O, I, J, transposed, glu_cg;
+  int32_t fwd_dtype;                         /* dv3_weight_norm_split_pack_bf16: DV3_SPLIT_DTYPE_* of the
+                                                FORWARD image (the input-gradient image is always bf16) */
 } dv3_wn_desc;
 int dv3_weight_norm_pack_f32(const dv3_wn_desc* d, void* stream);
 

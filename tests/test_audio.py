@@ -163,7 +163,7 @@ def test_hip_spectrogram_and_melspectrogram(dev):
     want = A.spectrogram(wav.astype(np.float64))
     assert S.shape == (B, 513, T)
     assert np.abs(S.cpu().numpy() - want).max() < 2e-5            # values live in [0, 1]
-    for mode in ("bf16x3", "f32"):
+    for mode in ("f16x3", "bf16x3", "f32"):
         from deepvoice3_pytorch_amd import ops
         prev = ops.set_gemm_precision(mode)
         M = audio.melspectrogram_batch(torch.from_numpy(wav).to(dev))

@@ -367,3 +367,113 @@ def test_device_collate_host_logic_equals_collate_fn(monkeypatch, seed):
     assert (got.speaker_ids is None) == (host.speaker_ids is None)
     if multi:
         assert torch.equal(got.speaker_ids, host.speaker_ids)
+
+
+def test_length_bucketed_sampler_shards_are_disjoint_and_cover():
+    """data.LengthBucketedSampler (the reference's PartialyRandomizedSimilarTimeLengthSampler, train.py:195-239,
+    made rank-aware): the shards of one epoch are disjoint, together they are the epoch's batch list, every rank
+    takes the same number of steps, batches hold items of similar length, epochs differ, seeds reproduce."""
+    from deepvoice3_pytorch_amd import data
+    lengths = np.random.RandomState(0).randint(100, 870, 1003)
+    for world in (1, 2, 8):
+        per_rank = []
+        for r in range(world):
+            s = data.LengthBucketedSampler(lengths, batch_size=16, rank=r, world=world, seed=7)
+            b = list(s)
+            assert len(b) == len(s)
+            per_rank.append(b)
+        assert len({len(b) for b in per_rank}) == 1
+        flat = [i for b in per_rank for x in b for i in x]
+        assert len(flat) == len(set(flat))
+        full = data.LengthBucketedSampler(lengths, 16, seed=7).epoch_batches()
+        usable = len(full) - len(full) % world
+        assert sorted(flat) == sorted(int(i) for b in full[:usable] for i in b)
+        for r in range(world):      # rank r holds batches r, r+world, ...
+            assert per_rank[r] == [[int(i) for i in b] for b in full[r:usable:world]]
+    s = data.LengthBucketedSampler(lengths, 16, seed=7)
+    e0 = list(s)
+    assert e0 == list(data.LengthBucketedSampler(lengths, 16, seed=7))
+    s.set_epoch(1)
+    assert list(s) != e0
+    # similar lengths inside a batch: items come from one sorted window of batch_group_size (= 32 batches, as
+    # in the reference), so the spread inside a batch is bounded by that window, well below a random draw's
+    spread = np.mean([np.ptp(lengths[b]) for b in e0 if len(b) == 16])
+    assert spread < 0.62 * np.ptp(lengths)
+    tight = data.LengthBucketedSampler(lengths, 16, batch_group_size=32, seed=7)
+    assert np.mean([np.ptp(lengths[b]) for b in tight if len(b) == 16]) < 0.06 * np.ptp(lengths)
+    with pytest.raises(ValueError):
+        data.LengthBucketedSampler(lengths, 16, batch_group_size=40)
+
+
+def _sampler_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deepvoice3_pytorch_amd import data
+    lengths = np.random.RandomState(1).randint(50, 500, 333)
+    s = data.LengthBucketedSampler(lengths, 8, rank=dist.get_rank(), world=dist.get_world_size(), seed=5)
+    mine = torch.zeros(333, dtype=torch.int32)
+    steps = 0
+    for b in s:
+        mine[b] += 1
+        steps += 1
+    tot = mine.clone()
+    dist.all_reduce(tot)
+    st = torch.tensor([steps, -steps])
+    dist.all_reduce(st, op=dist.ReduceOp.MAX)
+    q.put((rank, int(tot.max()), int((tot > 0).sum()), int(st[0]), int(-st[1])))
+    dist.destroy_process_group()
+
+
+def test_sampler_shards_over_gloo_world2():
+    """two processes (gloo): no index is drawn by both ranks, and both take the same number of steps"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sampler_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for _ in range(2):
+        rank, mx, covered, smax, smin = q.get(timeout=5)
+        assert mx == 1 and smax == smin and covered >= 333 - 2 * 8
+
+
+def test_prefetcher_yields_the_collated_batches(monkeypatch):
+    """data.Prefetcher (producer thread, worker threads filling staging slots, collate) hands out exactly
+    to_device_batch(collate_fn(items)) for the sampler's batches, in order, and loops over epochs when asked.
+    The padding kernel is emulated in numpy (CPU container); the GPU path: tests/test_gpu_model.py."""
+    from deepvoice3_pytorch_amd import data, ops
+    monkeypatch.setattr(ops, "ragged_pad_rows", _ragged_pad_rows_numpy)
+    rng = np.random.RandomState(3)
+    items = []
+    for i in range(37):
+        L, F = int(rng.randint(2, 30)), int(rng.randint(4, 90))
+        items.append((rng.randint(1, 40, L).astype(np.int64), rng.rand(F, 5).astype(np.float32),
+                      rng.rand(F, 7).astype(np.float32), int(rng.randint(4))))
+    ds = data.ListDataset(items)
+    sampler = data.LengthBucketedSampler(ds.frame_lengths, 4, seed=2)
+    want = list(sampler)
+    pf = data.Prefetcher(ds, sampler, "cpu", outputs_per_step=1, downsample_step=4, depth=2, workers=3)
+    got = list(pf)
+    pf.close()
+    assert len(got) == len(want) == 10
+    for idx, g in zip(want, got):
+        h = data.to_device_batch(data.collate_fn([items[i] for i in idx], 1, 4), "cpu", 1, 4)
+        for name in ("text", "text_positions", "frame_positions", "mel", "y", "done", "input_lengths",
+                     "target_lengths", "speaker_ids"):
+            assert torch.equal(getattr(g, name), getattr(h, name)), name
+    pf = data.Prefetcher(ds, sampler, "cpu", depth=1, workers=0, loop=True)
+    it = iter(pf)
+    n = sum(1 for _ in zip(range(25), it))      # more than one epoch
+    pf.close()
+    assert n == 25
+    # an item whose mel / linear lengths disagree surfaces in the consumer
+    bad = data.ListDataset([(items[0][0], items[0][1], items[1][2])])
+    pf = data.Prefetcher(bad, [[0]], "cpu", workers=0)
+    with pytest.raises(ValueError):
+        next(iter(pf))
+    pf.close()

@@ -15,10 +15,20 @@
   * preset-size outputs of the UNMODIFIED reference (tests/golden/preset_*.npz written by
     oracle/make_golden.py: weights regenerated from a seed, see tests/util.synth_state_dict).
 
-Tolerances (stated, BASELINE.json north_star: 1e-4 rel fp32): model outputs and loss terms 1e-4 in
-the `f32` and `bf16x3` GEMM modes; parameter gradients 5e-4 of each tensor's max (they pass through
-~40 layers of backward GEMMs); `bf16` mode (BASELINE configs 3/4): 3e-2 on outputs, 2e-2 on loss
-terms, gradient cosine > 0.995 per the bf16 arithmetic (8 significand bits).
+Tolerances, stated (BASELINE.json north_star: 1e-4 rel fp32):
+  * model outputs and loss terms: 1e-4 in the default `f16x3` mode and in `f32`.  `bf16x3` (every GEMM on bf16
+    hi/lo operands, kept for A/B runs) is held to 5e-4: its 2^-17 operands, amplified ~100x by the depth of
+    the preset networks, land at 1-3e-4 -- the measurement that made the scaled-fp16 split the default.
+  * parameter gradients: two fp32 evaluations of these networks already disagree by up to 1.6e-2 of a tensor's
+    max on single tensors (profiles/r02_fp32_floor.json: the fp32 oracle against the same oracle in fp64), so
+    a fixed per-tensor bound would test the oracle's own round-off.  Instead the oracle also runs in fp64 and
+    every tensor must satisfy  err(HIP vs fp64) <= max(5e-4, K * err(fp32 oracle vs fp64)),  K = 4 (f32) /
+    16 (f16x3, bf16x3: bf16-split gradient GEMMs, ~5e-6 per GEMM against fp32's ~1e-6); plus the whole gradient:
+    cosine > 1 - 1e-6 and norm within 1e-4.
+  * `bf16` mode (BASELINE configs 3/4; 8 significand bits, single MFMA per product): 2e-1 on outputs against
+    the fp32 reference (measured 2e-2..1.7e-1 at random initialisation -- any bf16 evaluation of these networks
+    shows it), 2e-2 on loss terms, gradient cosine > 0.995, and 2e-2 on outputs against the oracle run with
+    the SAME operand rounding (oracle.set_operand_rounding("bf16")).
 Every measured error is appended to gpurun_out/parity_scale.jsonl for profiles/.
 """
 import json
@@ -35,7 +45,13 @@ pytestmark = pytest.mark.gpu
 
 TOL_OUT = 1e-4
 TOL_GRAD = 5e-4
-BF16_OUT, BF16_LOSS, BF16_COS = 3e-2, 2e-2, 0.995
+GRAD_K = {"f32": 4.0, "f16x3": 16.0, "bf16x3": 16.0}
+BF16_OUT, BF16_LOSS, BF16_COS = 2e-1, 2e-2, 0.995
+BF16_OUT_SAME_ROUNDING = 2e-2
+
+
+def out_tol(mode):
+    return {"bf16": BF16_OUT, "bf16x3": 5e-4}.get(mode, TOL_OUT)
 
 
 def _record(**kw):
@@ -52,7 +68,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["bf16x3", "f32", "bf16"])
+@pytest.fixture(params=["f16x3", "bf16x3", "f32", "bf16"])
 def gemm_mode(request):
     from deepvoice3_pytorch_amd import ops
     prev = ops.set_gemm_precision(request.param)
@@ -122,14 +138,24 @@ def test_preset_eval_forward_matches_oracle(dev, preset, gemm_mode):
                     bt["text_positions"].to(dev), bt["frame_positions"].to(dev), bt["input_lengths"])
         want = O.model_forward(sd, spec, bt["text"], mel_ds, spk, bt["text_positions"], bt["frame_positions"],
                                bt["input_lengths"])
-    tol = BF16_OUT if gemm_mode == "bf16" else TOL_OUT
+    tol = out_tol(gemm_mode)
     errs = {}
     for g, w, n in zip(got, want, ("mel", "linear", "alignments", "done")):
         assert tuple(g.shape) == tuple(w.shape), n
         errs[n] = rel_err(g.cpu(), w)
+    if gemm_mode == "bf16":     # the same network with conv / linear / bmm operands rounded to bf16 on the CPU
+        O.set_operand_rounding("bf16")
+        try:
+            with torch.no_grad():
+                want_bf = O.model_forward(sd, spec, bt["text"], mel_ds, spk, bt["text_positions"],
+                                          bt["frame_positions"], bt["input_lengths"])
+        finally:
+            O.set_operand_rounding(None)
+        for g, w, n in zip(got, want_bf, ("mel", "linear", "alignments", "done")):
+            errs[n + "_vs_bf16_oracle"] = rel_err(g.cpu(), w)
     _record(test="eval_forward", preset=preset, gemm=gemm_mode, **errs)
     for n, e in errs.items():
-        assert e < tol, (n, e)
+        assert e < (BF16_OUT_SAME_ROUNDING if n.endswith("_vs_bf16_oracle") else tol), (n, e)
 
 
 @pytest.mark.parametrize("preset", PRESET_NAMES)
@@ -157,50 +183,65 @@ def test_preset_train_step_matches_oracle(dev, preset, gemm_mode):
         gnorm = float(trainer.norm_out[0])
         scal = {k: float(v) for k, v in scal.items()}
         drop = _drop_replay(ops)
-        sdc = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
-        mel_ds = bt["mel"][:, 0::4, :].contiguous()
-        out = O.model_forward(sdc, spec, bt["text"], mel_ds, spk, bt["text_positions"], bt["frame_positions"],
-                              bt["input_lengths"], drop=drop)
     finally:
+        rec = ops.dropout_state.record
         ops.dropout_state.record = None
     lhp = dict(outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5, binary_divergence_weight=0.1,
                use_guided_attention=True, guided_attention_sigma=sigma)
-    loss, parts = O.train_losses(spec, lhp, out, mel_ds, bt["y"], bt["done"], bt["input_lengths"],
-                                 bt["target_lengths"])
-    loss.backward()
+    mel_ds = bt["mel"][:, 0::4, :].contiguous()
+
+    def oracle(dt):
+        """the oracle's model_forward + train_losses + autograd in dtype dt with the replayed keep-bits"""
+        ops.dropout_state.record = rec
+        try:
+            sdc = {k: (v.to(dt) if v.dtype.is_floating_point else v).clone().requires_grad_(v.dtype.is_floating_point)
+                   for k, v in sd.items()}
+            out = O.model_forward(sdc, spec, bt["text"], mel_ds.to(dt), spk, bt["text_positions"],
+                                  bt["frame_positions"], bt["input_lengths"],
+                                  drop=lambda site, t, p, layout: drop(site, t, p, layout).to(dt))
+            loss, parts = O.train_losses(spec, lhp, out, mel_ds.to(dt), bt["y"].to(dt), bt["done"].to(dt),
+                                         bt["input_lengths"], bt["target_lengths"])
+            loss.backward()
+        finally:
+            ops.dropout_state.record = None
+        return {k: v.grad for k, v in sdc.items() if v.grad is not None}, {k: float(v) for k, v in parts.items()}
+    g32, parts = oracle(torch.float32)      # what the reference computes (fp32 torch-CPU ops)
+    g64, parts64 = oracle(torch.float64)    # ground truth, to tell the HIP path's error from the oracle's own
     bf = gemm_mode == "bf16"
     names = dict(loss="loss", mel_l1_loss="mel_l1", mel_binary_div_loss="mel_bd", linear_l1_loss="lin_l1",
                  linear_binary_div_loss="lin_bd", done_loss="done_loss", attn_loss="attn_loss")
-    lerr = {}
-    for k, ko in names.items():
-        w = float(parts[ko])
-        lerr[k] = abs(scal[k] - w) / max(abs(w), 1e-12)
+    lerr = {k: abs(scal[k] - parts[ko]) / max(abs(parts[ko]), 1e-12) for k, ko in names.items()}
     frozen = ("embed_query_positions.weight", "embed_keys_positions.weight")
     gl, gw = [], []
-    worst, n_par = ("", 0.0), 0
-    scale = max(float(v.grad.abs().max()) for v in sdc.values() if v.grad is not None)
+    worst, worst_ratio, n_par, fails = ("", 0.0, 0.0), ("", 0.0), 0, []
+    scale = max(float(v.abs().max()) for v in g64.values())
+    K = GRAD_K.get(gemm_mode, 0.0)
     for k, p in model.named_parameters():
         if k.endswith(frozen):
             continue
-        gc = sdc[k].grad
-        assert p.grad is not None and gc is not None, k
-        gl.append(p.grad.detach().cpu().reshape(-1).double())
-        gw.append(gc.reshape(-1).double())
-        gmax = float(gc.abs().max())
-        if gmax < 1e-5 * scale:       # mathematically-zero gradients: round-off only
-            assert float(p.grad.abs().max()) < 1e-4 * scale, k
+        assert p.grad is not None and k in g64, k
+        gh = p.grad.detach().cpu()
+        gl.append(gh.reshape(-1).double())
+        gw.append(g64[k].reshape(-1))
+        if float(g64[k].abs().max()) < 1e-5 * scale:       # mathematically-zero gradients: round-off only
+            assert float(gh.abs().max()) < 1e-4 * scale, k
             continue
-        e = rel_err(p.grad.cpu(), gc)
+        e, floor = rel_err(gh, g64[k]), rel_err(g32[k], g64[k])
         n_par += 1
         if e > worst[1]:
-            worst = (k, e)
+            worst = (k, e, floor)
+        if e / max(floor, 1e-12) > worst_ratio[1] and e > TOL_GRAD:
+            worst_ratio = (k, e / max(floor, 1e-12))
+        if not bf and e > max(TOL_GRAD, K * floor):
+            fails.append((k, e, floor))
     gl, gw = torch.cat(gl), torch.cat(gw)
     cos = float((gl * gw).sum() / (gl.norm() * gw.norm()))
     gn_want = float(gw.norm())
     gn_err = abs(gnorm - gn_want) / gn_want
     _record(test="train_step", preset=preset, gemm=gemm_mode, losses=lerr, grad_norm_err=gn_err,
-            grad_cos=cos, worst_param=worst[0], worst_param_err=worst[1], params_compared=n_par,
-            loss=scal["loss"], grad_norm=gnorm)
+            grad_cos=cos, worst_param=worst[0], worst_param_err=worst[1], worst_param_fp32_floor=worst[2],
+            worst_ratio_param=worst_ratio[0], worst_ratio_over_fp32_floor=worst_ratio[1],
+            params_compared=n_par, failing=len(fails), loss=scal["loss"], grad_norm=gnorm)
     for k, e in lerr.items():
         assert e < (BF16_LOSS if bf else TOL_OUT), (k, e)
     if bf:
@@ -208,8 +249,8 @@ def test_preset_train_step_matches_oracle(dev, preset, gemm_mode):
         assert gn_err < 5e-2, gn_err
     else:
         assert gn_err < TOL_OUT, gn_err
-        assert worst[1] < TOL_GRAD, worst
         assert cos > 1 - 1e-6, cos
+        assert not fails, fails[:5]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -238,7 +279,7 @@ def test_north_star_conv1dglu_full_tensor(dev, d, causal, gemm_mode):
     sd = {"l." + n: v.detach().cpu() for n, v in layer.state_dict().items()}
     torch.manual_seed(1)
     x = torch.randn(B, C, T)
-    tol = BF16_OUT if gemm_mode == "bf16" else 5e-5
+    tol = {"bf16": 1e-2, "f16x3": 5e-6, "f32": 5e-6}.get(gemm_mode, 5e-5)
     for training in (False, True):
         layer.train(training)
         ops.dropout_state.manual_seed(99)
@@ -260,10 +301,10 @@ def test_north_star_conv1dglu_full_tensor(dev, d, causal, gemm_mode):
         _record(test="north_star_fwd", d=d, causal=causal, training=training, gemm=gemm_mode, err=e,
                 variant=variant)
         assert e < tol, (d, causal, training, e)
-        if gemm_mode == "bf16x3":
-            assert variant == 3091, variant
-        elif gemm_mode == "bf16":
-            assert variant == 4091, variant
+        # the kernel bench.py's roofline times: 8-wave 128x256 ping-pong tile of the mode's operand family
+        want_variant = {"f16x3": 5091, "bf16x3": 3091, "bf16": 4091}.get(gemm_mode)
+        if want_variant is not None:
+            assert variant == want_variant, variant
         else:
             assert variant // 1000 == 1, variant
 
@@ -300,7 +341,7 @@ def test_north_star_conv1dglu_gradients_full_tensor(dev, d, causal, gemm_mode):
         errs[n] = rel_err(p.grad.cpu(), sd["l." + n].grad)
     _record(test="north_star_bwd", d=d, causal=causal, gemm=gemm_mode, wgrad_variant=wv, **errs)
     for n, e in errs.items():
-        assert e < (BF16_OUT if bf else 1e-4), (n, e)
+        assert e < (1e-2 if bf else 5e-5), (n, e)
     if gemm_mode != "f32":
         assert wv // 1000 == (4 if bf else 3), wv
 
@@ -333,7 +374,7 @@ def test_preset_forward_matches_reference_golden(dev, preset, gemm_mode):
                                       spk.to(dev) if spk is not None else None,
                                       bt["text_positions"].to(dev), bt["frame_positions"].to(dev),
                                       bt["input_lengths"])
-    tol = BF16_OUT if gemm_mode == "bf16" else TOL_OUT
+    tol = out_tol(gemm_mode)
     errs = dict(mel=rel_err(mel.cpu(), fx["out/mel"]), linear=rel_err(lin.cpu()[:, ::8], fx["out/linear_8"]),
                 alignments=rel_err(align.cpu(), fx["out/alignments"]), done=rel_err(done.cpu(), fx["out/done"]))
     _record(test="reference_golden_preset", preset=preset, gemm=gemm_mode, **errs)
