@@ -10,6 +10,7 @@ struct ConvArgs {
   int m_tiles, n_tiles, n_blocks;
   int a_scalar;  // packed operand not 16-byte aligned (per-batch A = an activation): scalar staging
   int kp;        // bf16x3: K extent of the split weight image (Cin rounded up to 32)
+  int stagger;   // planes kernel: s_sleep(127) repeats before the second co-resident workgroup starts
 };
 
 template <typename T>

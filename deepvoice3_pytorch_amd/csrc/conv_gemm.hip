@@ -311,9 +311,10 @@ int launch_cfg(const ConvArgs& a, int bkc, size_t lds, hipStream_t st) {
 }  // namespace
 
 int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st);  // conv_gemm_bf16x3.hip
+int dv3_conv_planes_dispatch(const dv3_conv_desc* d, hipStream_t st);       // conv_planes.hip
 
 extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
-  DV3_REQUIRE(d && d->x && (d->a || d->a_split) && d->y, "conv_gemm: null pointer");
+  DV3_REQUIRE(d && (d->x || d->x_planes) && (d->a || d->a_split) && d->y, "conv_gemm: null pointer");
   DV3_REQUIRE(d->B > 0 && d->Cin > 0 && d->Tin > 0 && d->M > 0 && d->Tout > 0, "conv_gemm: bad dims");
   DV3_REQUIRE(d->J >= 1 && d->J <= 16 && d->dil >= 1, "conv_gemm: bad taps J=%d dil=%d", d->J, d->dil);
   const bool a_scalar = (d->lda & 3) || (d->a_half & 3) || (d->a_bs & 3) || ((uintptr_t)d->a & 15);
@@ -333,6 +334,15 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
   if (d->ymask) DV3_REQUIRE(d->ymask_rs * 32 >= d->Tout, "conv_gemm: ymask row stride too small");
 
   DV3_REQUIRE(dv3_conv_fits32(d), "conv_gemm: a tensor exceeds the 4 GB the epilogue can address");
+  // both operands pre-split: the persistent planes kernel.  No silent fallback: the planes carry the dropout
+  // mask of the consuming layer, which the other kernels would have to be handed separately.
+  if (d->x_planes) {
+    DV3_REQUIRE(!d->xmask, "conv_gemm: x_planes already carry the dropout mask (xmask must be NULL)");
+    const int rc = dv3_conv_planes_dispatch(d, (hipStream_t)stream);
+    DV3_REQUIRE(rc != 1, "conv_gemm: shape not eligible for the planes kernel (needs a_split, Tin == Tout, "
+                         "(J-1)*dil <= 64, x_c8p == round_up(Cin,32)/8)");
+    return rc;
+  }
   // split-bf16 operands given: the bf16x3 kernel (tile_hint 0 = auto, 21..26 = forced tile);
   // hints 1..16 keep the exact fp32 kernels for A/B runs; ineligible shapes fall through
   if (d->a_split && (d->tile_hint == 0 || d->tile_hint > 20)) {

@@ -718,7 +718,9 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
 }
 
 extern int g_wgrad_tile;   // wgrad_gemm_bf16x3.hip
+int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 extern "C" int dv3_debug_set(int what, int value) {
+  if (what >= 4 && what <= 7) return dv3_planes_debug_set(what, value);
   if (what == 1) g_x3_ablate = value;
   if (what == 2) g_wgrad_tile = value;
   if (what == 3) g_x3_pingpong = value;

@@ -28,6 +28,7 @@ STORE_INTERLEAVE2 = CONSTS["DV3_STORE_INTERLEAVE2"]
 
 _conv_desc = STRUCTS["dv3_conv_desc"]
 _wgrad_desc = STRUCTS["dv3_wgrad_desc"]
+_planes_desc = STRUCTS["dv3_planes_desc"]
 _wn_desc = STRUCTS["dv3_wn_desc"]
 _wn_bwd_desc = STRUCTS["dv3_wn_bwd_desc"]
 _gate_bwd_desc = STRUCTS["dv3_gate_bwd_desc"]
@@ -230,28 +231,67 @@ def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True, split_only=Fal
 
 
 # ----------------------------------------------------------------------------------------------
+# operand planes of an activation tensor (include/dv3hip.h, dv3_split_planes_f32)
+# ----------------------------------------------------------------------------------------------
+# DV3_PLANES=1: every eligible conv layer splits its input once (one HBM pass) and runs the persistent planes
+# tap-GEMM; the default (0) keeps the kernels that split while staging.  (Chained layers get their planes from
+# the producing epilogue instead -- see ConvLayerFn.)
+use_planes = _os.environ.get("DV3_PLANES", "0") not in ("0", "")
+
+
+def split_planes(x, bits=None, bits_rs=0, scale=1.0, f16=False, B=None, C=None, T=None, x_bs=None, x_rs=None):
+    """x fp32 (B, C, T) -> int16 tensor [2][B][C8p][T][8] tagged with its operand type; dropout keep-bits and
+    their 1/(1-p) are applied here, once, for the consuming tap-GEMM."""
+    if B is None:
+        B, C, T = x.shape
+    c8p = _round_up(C, 32) // 8
+    out = torch.empty(2 * B * c8p * T * 8, dtype=torch.int16, device=x.device)
+    d = _planes_desc()
+    d.x = x.data_ptr()
+    d.x_bs = x_bs if x_bs is not None else x.stride(0)
+    d.x_rs = x_rs if x_rs is not None else x.stride(1)
+    d.mask, d.mask_rs, d.scale = _ptr(bits), bits_rs, scale
+    d.out = out.data_ptr()
+    d.B, d.C, d.T, d.dtype = B, C, T, SPLIT_F16 if f16 else SPLIT_BF16
+    _lib.call("dv3_split_planes_f32", ctypes.byref(d), _stream())
+    out._dv3_f16, out._dv3_c8p = bool(f16), c8p
+    return out
+
+
+def planes_eligible(J, dil, Tin, Tout):
+    """the shapes dv3_conv_planes_dispatch takes (the planes carry the dropout mask: no silent fallback)"""
+    return _gemm_mode != "f32" and Tin == Tout and (J - 1) * dil <= 64 and J <= 16
+
+
+# ----------------------------------------------------------------------------------------------
 # raw kernel wrappers
 # ----------------------------------------------------------------------------------------------
 def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mode=EPI_LINEAR,
               Cg=0, bias=None, spk=None, spk_strides=(0, 0, 0), r=None, r2=None, residual=0,
               y=None, y_rs=None, ab=None, xmask=None, xmask_rs=0, ymask=None, ymask_rs=0,
               drop_scale=1.0, a_bs=0, store_mode=STORE_BCT, x_bs=None, x_rs=None, tile_hint=0,
-              a_split=None):
-    """dv3_conv_gemm_f32.  x: [B][Cin][Tin] (strides overridable); returns y."""
+              a_split=None, x_planes=None):
+    """dv3_conv_gemm_f32.  x: [B][Cin][Tin] (strides overridable); returns y.  x_planes: the input already
+    split into operand planes (split_planes; x may then be None)."""
     gated = mode in (EPI_GLU, EPI_HIGHWAY)
     Cout = Cg if gated else (M // 2 if store_mode == STORE_INTERLEAVE2 else M)
     To = 2 * Tout if store_mode == STORE_INTERLEAVE2 else Tout
     if y is None:
-        y = torch.empty((B, Cout, To), dtype=torch.float32, device=x.device)
+        y = torch.empty((B, Cout, To), dtype=torch.float32, device=(x if x is not None else x_planes).device)
         y_bs, y_rs_ = Cout * To, To
     else:
         y_rs_ = y_rs if y_rs is not None else y.stride(1)
         y_bs = y.stride(0)
     d = _conv_desc()
-    d.x = x.data_ptr()
+    d.x = _ptr(x)
     d.a = _ptr(a)
-    d.x_bs = x_bs if x_bs is not None else x.stride(0)
-    d.x_rs = x_rs if x_rs is not None else x.stride(1)
+    if x is not None:
+        d.x_bs = x_bs if x_bs is not None else x.stride(0)
+        d.x_rs = x_rs if x_rs is not None else x.stride(1)
+    if x_planes is not None:
+        if a_split is None or getattr(a_split, "_dv3_f16", False) != x_planes._dv3_f16:
+            raise RuntimeError("x_planes and the split weight image must have the same operand type")
+        d.x_planes, d.x_c8p = x_planes.data_ptr(), x_planes._dv3_c8p
     d.a_bs, d.lda, d.a_half = a_bs, lda, a_half
     d.bias = _ptr(bias)
     d.spk = _ptr(spk)
@@ -456,11 +496,15 @@ class ConvLayerFn(torch.autograd.Function):
                 spk_strides = (spk.stride(0), spk.stride(1), 1)
         res_in = x if gated else (_c(r) if r is not None else None)
         r2c = _c(r2) if r2 is not None else None
+        xp = None
+        if use_planes and pk.fwd_s is not None and planes_eligible(1 if cfg.transposed else J, cfg.dil, T, Tout):
+            xp = split_planes(x, bits, bits_rs, dscale, f16=pk.fwd_f16)
         y = conv_gemm(x, pk.fwd, pk.lda, pk.a_half, B=B, Cin=Cin, Tin=T, M=M, Tout=Tout,
                       J=(1 if cfg.transposed else J), dil=cfg.dil, padL=padL, mode=mode, Cg=Cg,
                       bias=bias, spk=spk, spk_strides=spk_strides,
                       r=res_in if (mode == EPI_HIGHWAY or cfg.residual or not gated) else None,
-                      r2=r2c, residual=int(cfg.residual), ab=ab, xmask=bits, xmask_rs=bits_rs,
+                      r2=r2c, residual=int(cfg.residual), ab=ab, xmask=bits if xp is None else None,
+                      xmask_rs=bits_rs if xp is None else 0, x_planes=xp,
                       drop_scale=dscale, a_split=pk.fwd_s if _gemm_mode != "f32" else None,
                       store_mode=STORE_INTERLEAVE2 if cfg.transposed else STORE_BCT)
         if need_grad:
@@ -531,7 +575,10 @@ class ConvLayerFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # input gradient: transposed, tap-reversed weights; dropout mask on the output side
             Jd = 1 if cfg.transposed else J
-            dx = conv_gemm(gmat, pk.bwd, pk.ldb, 0, B=B, Cin=Mg, Tin=Tg, M=Cin, Tout=T, J=Jd,
+            gp = None
+            if use_planes and pk.bwd_s is not None and planes_eligible(Jd, cfg.dil, Tg, T):
+                gp = split_planes(gmat, f16=False)
+            dx = conv_gemm(gmat, pk.bwd, pk.ldb, 0, B=B, Cin=Mg, Tin=Tg, M=Cin, Tout=T, J=Jd, x_planes=gp,
                            dil=cfg.dil, padL=(Jd - 1) * cfg.dil - padL, mode=EPI_DGRAD, r=dres,
                            ymask=ctx.bits, ymask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
                            a_split=pk.bwd_s if _gemm_mode != "f32" else None)

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 21
+#define DV3_ABI_VERSION 22
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -39,7 +39,9 @@ int dv3_device_info(int dev, char* name, int name_len, int* n_cu);
 int dv3_sizeof(const char* name);
 /* Developer knobs for measurements (what = 1: ablation variant of the bf16x3 tap-GEMM, 0 = off;
  * what = 2: bf16x3 wgrad tile, 0 auto / 1 = 128x128 / 2 = 256x128; what = 3: 8-wave bf16x3
- * tap-GEMM tiles on the in-phase (0) or ping-pong (1, default) main loop). */
+ * tap-GEMM tiles on the in-phase (0) or ping-pong (1, default) main loop; what = 4: tile of the planes
+ * tap-GEMM, 0 auto / 1 = 128x128 (4 waves, two workgroups per CU) / 2 = 128x64 / 9 = 128x256 (8 waves);
+ * what = 5: start-up stagger of the second co-resident workgroup, -1 auto / n = n sleeps of ~4 us). */
 int dv3_debug_set(int what, int value);
 /* what = 1: phase timestamps left by the last dv3_debug_set(1, 10) launch of the 128x256 bf16x3 tile
  * ([8 waves][192 slots][2] uint64, host pointer). */
@@ -119,6 +121,12 @@ typedef struct dv3_conv_desc {
                                                 is a SCALED FP16 hi/lo image (below), the activations are
                                                 split the same way while staging: three fp16 MFMAs per
                                                 product, 2^-22-class operands = fp32-class results      */
+  const uint16_t* x_planes;                  /* the input ALREADY split into operand planes (dv3_split_planes_f32
+                                                layout, dtype matching split_terms; dropout already applied) or
+                                                NULL.  Non-NULL (with a_split) selects the persistent planes
+                                                kernel: both operands are staged with plain 16-byte copies.
+                                                `x` may then be NULL unless the epilogue reads it as `r`.     */
+  int32_t x_c8p;                             /* 8-channel blocks per batch item in x_planes (= round_up(Cin,32)/8) */
 } dv3_conv_desc;
 int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
 
@@ -154,6 +162,24 @@ int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
 #define DV3_F16_ACT_SHIFT 4
 int dv3_split_pack_bf16(const float* packed, uint16_t* out, int32_t J, int32_t K, int32_t lda,
                         int32_t dtype, void* stream);
+
+/*
+ * Operand planes of an activation tensor: what the tap-GEMM's B operand looks like after the split, written
+ * ONCE by whoever produces the tensor instead of being re-derived by every consuming workgroup.
+ *   out[plane][b][c8][t][8]  plane 0 = hi, 1 = lo; c8 < C8p = round_up(C,32)/8 (zero units beyond C);
+ *   one 16-byte unit = 8 consecutive channels of one (b, t) column = one MFMA B-fragment lane.
+ *   value = x * keep(mask bit) * scale, then  dtype BF16: hi = bf16_rn(v), lo = bf16_rn(v - hi)
+ *                                             dtype F16:  a = clamp(v * 2^DV3_F16_ACT_SHIFT), hi/lo = fp16 split
+ * `out` holds 2*B*C8p*T*8 uint16.  mask: dropout keep-bits [B*C rows][mask_rs words] or NULL.
+ */
+typedef struct dv3_planes_desc {
+  const float* x; int64_t x_bs, x_rs;        /* [B][C][T]                                   */
+  const uint32_t* mask; int32_t mask_rs;
+  float scale;                               /* 1/(1-p) of the consuming layer's dropout, or 1 */
+  uint16_t* out;
+  int32_t B, C, T, dtype;
+} dv3_planes_desc;
+int dv3_split_planes_f32(const dv3_planes_desc* d, void* stream);
 
 /*
  * dv3_wgrad_gemm_f32 -- weight-gradient GEMM (autograd of F.conv1d w.r.t. weight; also
