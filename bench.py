@@ -460,6 +460,7 @@ class TrainRun(object):
         t0 = time.perf_counter()
         for _ in range(steps):
             scal = self.step(nxt())
+        t_host = time.perf_counter() - t0       # all K steps enqueued; the GPU is still working if it is the bound
         torch.cuda.synchronize()
         if pg is not None:
             torch.distributed.barrier()
@@ -477,6 +478,7 @@ class TrainRun(object):
         value = float(frames.item()) / (dt / steps)
         tf = MFLOP_PER_FRAME[self.preset] * 1e6 * value / 1e12
         return dict(value=round(value, 1), ms_per_step=round(ms, 3), steps=steps, warmup=warmup,
+                    host_enqueue_ms_per_step=round(t_host / steps * 1e3, 3),
                     final_loss=round(loss, 5), frames_per_step=float(frames.item()),
                     step_flop_frac=dict(alg_mflop_per_frame=MFLOP_PER_FRAME[self.preset], achieved_tflops=round(tf, 1),
                                         peak=round(mfma_peak_tf(self.gemm), 1),
@@ -576,7 +578,9 @@ def main():
                                         "(fwd+losses+bwd+clip+Adam), synthetic LJSpeech-shaped batches" % (run.bname, args.preset),
                                per_gpu_batch=args.batch, global_batch=args.batch * world, text_len=args.text_len,
                                frames_per_item=args.frames, parallelism="dp%d" % world,
-                               hipgraph=bool(run.use_graph), gemm=gemm, final_loss=m["final_loss"]),
+                               hipgraph=bool(run.use_graph), gemm=gemm, final_loss=m["final_loss"],
+                               host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"],
+                               launch_bound=bool(m["host_enqueue_ms_per_step"] > 0.97 * m["ms_per_step"])),
                    step_flop_frac=m["step_flop_frac"])
     extras = not args.no_extras
     # ---- the same step fed through the input pipeline (sampler -> pinned staging -> side-stream H2D + device collate)

@@ -34,7 +34,9 @@ def _strip_comments(src):
 def _field_ctype(base, stars):
     if stars:
         return ctypes.c_void_p
-    return _CTYPES[base]
+    if base in _CTYPES:
+        return _CTYPES[base]
+    return ("struct", base)          # a descriptor nested by value: resolved when the classes are made
 
 
 def parse_header(path=_HEADER):
@@ -93,11 +95,15 @@ def parse_header(path=_HEADER):
 STRUCT_FIELDS, FUNCS, CONSTS = parse_header()
 
 
-def _make_struct(name, fields):
-    return type(name, (ctypes.Structure,), {"_fields_": fields})
+def _make_structs(all_fields):
+    out = {}
+    for name, fields in all_fields.items():      # header order: a nested struct is declared before its user
+        resolved = [(f, out[t[1]] if isinstance(t, tuple) else t) for f, t in fields]
+        out[name] = type(name, (ctypes.Structure,), {"_fields_": resolved})
+    return out
 
 
-STRUCTS = {n: _make_struct(n, f) for n, f in STRUCT_FIELDS.items()}
+STRUCTS = _make_structs(STRUCT_FIELDS)
 globals().update(CONSTS)
 
 

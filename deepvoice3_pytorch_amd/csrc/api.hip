@@ -48,6 +48,7 @@ extern "C" int dv3_sizeof(const char* name) {
   DV3_SZ(dv3_softmax_bwd_desc);
   DV3_SZ(dv3_spec_loss_desc);
   DV3_SZ(dv3_planes_desc);
+  DV3_SZ(dv3_wn_multi_entry);
 #undef DV3_SZ
   return -1;
 }

@@ -102,6 +102,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
   }
   if (p.mode == DV3_EPI_DGRAD) {
     const uint32_t ym_rs = (uint32_t)p.ymask_rs * 4u;
+    const float rsc = p.r_scale != 0.f ? p.r_scale : 1.0f;
     uint32_t ymb[NI], rbc[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -130,7 +131,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
           if (!okc[ni]) continue;
           float v = acc[h][ni][r];
           if (p.ymask) v = ((wv[r][ni] >> (tcol[ni] & 31)) & 1u) ? v * dscale : 0.f;
-          dv3_st(p.y, yb[ni] + mv[r] * y_rs, v + rv[r][ni]);
+          dv3_st(p.y, yb[ni] + mv[r] * y_rs, v + rsc * rv[r][ni]);
         }
       }
     }

@@ -10,11 +10,8 @@
 namespace {
 
 // scale[r] = 1/||v[r]||  (1 when g == NULL: plain weight).  One block per row.
-__global__ __launch_bounds__(256) void wn_inv_norm_kernel(const float* __restrict__ v,
-                                                          const float* __restrict__ g,
-                                                          float* __restrict__ scale, int len) {
-  __shared__ float red[4];
-  const int r = blockIdx.x;
+__device__ __forceinline__ void wn_inv_norm_row(const float* __restrict__ v, const float* __restrict__ g,
+                                                float* __restrict__ scale, int len, int r, float* red) {
   if (!g) {
     if (threadIdx.x == 0) scale[r] = 1.0f;
     return;
@@ -29,6 +26,12 @@ __global__ __launch_bounds__(256) void wn_inv_norm_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) scale[r] = 1.0f / sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void wn_inv_norm_kernel(const float* __restrict__ v,
+                                                          const float* __restrict__ g,
+                                                          float* __restrict__ scale, int len) {
+  __shared__ float red[4];
+  wn_inv_norm_row(v, g, scale, len, blockIdx.x, red);
 }
 
 // Forward pack, Conv1d/Linear: fwd[j][i][col(o)] = g[o]*scale[o]*v[o][i][j]
@@ -122,11 +125,10 @@ __device__ __forceinline__ void wn_split8_f16(const float (&v)[8], wn_bf16x8& hi
   hi = __builtin_bit_cast(wn_bf16x8, h8);
   lo = __builtin_bit_cast(wn_bf16x8, l8);
 }
-__global__ __launch_bounds__(256) void wn_split_both_kernel(const dv3_wn_desc p, wn_bf16x8* __restrict__ fs,
-                                                            wn_bf16x8* __restrict__ bs) {
-  extern __shared__ float tile[];  // [32][32*J+1]
+__device__ __forceinline__ void wn_split_both_block(const dv3_wn_desc& p, wn_bf16x8* __restrict__ fs,
+                                                    wn_bf16x8* __restrict__ bs, int bx, int by, float* tile) {
   const int O = p.O, I = p.I, J = p.J;
-  const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+  const int o0 = bx * 32, i0 = by * 32;
   const int W = 32 * J, LD = W + 1;
   for (int idx = threadIdx.x; idx < 32 * W; idx += 256) {
     const int ol = idx / W, q = idx % W;
@@ -174,6 +176,42 @@ __global__ __launch_bounds__(256) void wn_split_both_kernel(const dv3_wn_desc p,
   }
 }
 
+__global__ __launch_bounds__(256) void wn_split_both_kernel(const dv3_wn_desc p, wn_bf16x8* __restrict__ fs,
+                                                            wn_bf16x8* __restrict__ bs) {
+  extern __shared__ float tile[];  // [32][32*J+1]
+  wn_split_both_block(p, fs, bs, blockIdx.x, blockIdx.y, tile);
+}
+
+// ---- every weight-normed Conv1d / Linear layer of a model in TWO launches (the per-layer form costs two small
+// launches per layer and step: 84 launches, ~0.6 ms of a 18 ms step).  `tab` lives in device memory, is built once
+// (parameters, scales and images are views of fixed buffers) and lists the layers back to back; block b of the
+// grid serves layer l = the last one with first_block[l] <= b.
+__device__ __forceinline__ int wn_find_layer(const int32_t* __restrict__ first, int n, int b) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (first[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void wn_inv_norm_multi_kernel(const dv3_wn_multi_entry* __restrict__ tab,
+                                                                const int32_t* __restrict__ first_row, int n) {
+  __shared__ float red[4];
+  const int l = wn_find_layer(first_row, n, blockIdx.x);
+  const dv3_wn_desc& d = tab[l].d;
+  wn_inv_norm_row(d.v, d.g, d.scale, d.I * d.J, blockIdx.x - first_row[l], red);
+}
+__global__ __launch_bounds__(256) void wn_split_both_multi_kernel(const dv3_wn_multi_entry* __restrict__ tab,
+                                                                  const int32_t* __restrict__ first_block, int n) {
+  extern __shared__ float tile[];
+  const int l = wn_find_layer(first_block, n, blockIdx.x);
+  const dv3_wn_multi_entry e = tab[l];
+  const int b = blockIdx.x - first_block[l];
+  const int nbx = (e.d.O + 31) / 32;
+  wn_split_both_block(e.d, reinterpret_cast<wn_bf16x8*>(e.fwd_split), reinterpret_cast<wn_bf16x8*>(e.bwd_split),
+                      b % nbx, b / nbx, tile);
+}
+
 __global__ void zero_kernel(float* p, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -191,21 +229,33 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const dv3_wn_bwd_desc p) {
   const int len = p.transposed ? O * J : I * J;
   const float* vrow = p.v + (int64_t)r * len;
   float dot = 0.f;
-  for (int idx = threadIdx.x; idx < len; idx += 256) {
-    // element idx of row r <-> (i,j) [plain: idx = i*J + j] or (o,j) [transposed: idx = o*J + j]
+  // gather: walk the slabs in THEIR order (for a Conv1d row: J runs of I contiguous floats), several slab
+  // loads in flight per thread; the row lands in LDS in the parameter's (i, j) order
+  for (int q = threadIdx.x; q < len; q += 256) {
     int64_t off;
+    int idx;
     if (!p.transposed) {
-      const int i = idx / J, j = idx % J;
-      off = ((int64_t)j * O + r) * p.ldo + i;  // slab[j][o=r][i]
+      const int j = q / I, i = q - j * I;
+      off = ((int64_t)j * O + r) * p.ldo + i;  // slab[j][o=r][i]: consecutive threads, consecutive i
+      idx = i * J + j;
     } else {
-      const int o = idx / J, j = idx % J;
+      const int o = q / J, j = q % J;
       off = ((int64_t)j * O + o) * p.ldo + r;  // slab[0][j*O+o][i=r]
+      idx = q;
     }
-    float s = 0.f;
-    for (int k = 0; k < p.n_slabs; ++k) s += p.slabs[(int64_t)k * p.slab_ss + off];
-    dw[idx] = s;
-    dot += s * vrow[idx];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= p.n_slabs; k += 4) {
+      s0 += p.slabs[(int64_t)k * p.slab_ss + off];
+      s1 += p.slabs[(int64_t)(k + 1) * p.slab_ss + off];
+      s2 += p.slabs[(int64_t)(k + 2) * p.slab_ss + off];
+      s3 += p.slabs[(int64_t)(k + 3) * p.slab_ss + off];
+    }
+    for (; k < p.n_slabs; ++k) s0 += p.slabs[(int64_t)k * p.slab_ss + off];
+    dw[idx] = (s0 + s1) + (s2 + s3);
   }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < len; idx += 256) dot += dw[idx] * vrow[idx];
   dot = dv3_wave_sum(dot);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
   __syncthreads();
@@ -312,6 +362,19 @@ extern "C" int dv3_weight_norm_split_pack_bf16(const dv3_wn_desc* d, uint16_t* f
   hipLaunchKernelGGL(wn_split_both_kernel, dim3(dv3_cdiv(d->O, 32), dv3_cdiv(d->I, 32)), dim3(256), lds, st,
                      *d, reinterpret_cast<wn_bf16x8*>(fwd_split), reinterpret_cast<wn_bf16x8*>(bwd_split));
   return dv3_check_launch("weight_norm_split_pack_bf16");
+}
+
+extern "C" int dv3_weight_norm_split_pack_multi(const dv3_wn_multi_entry* table_dev, const int32_t* first_row_dev,
+                                               const int32_t* first_block_dev, int32_t n_layers, int32_t total_rows,
+                                               int32_t total_blocks, int32_t max_taps, void* stream) {
+  DV3_REQUIRE(table_dev && first_row_dev && first_block_dev, "wn_split_pack_multi: null pointer");
+  DV3_REQUIRE(n_layers > 0 && total_rows > 0 && total_blocks > 0 && max_taps > 0, "wn_split_pack_multi: bad counts");
+  const size_t lds = (size_t)32 * (32 * max_taps + 1) * 4;
+  DV3_REQUIRE(lds <= 64 * 1024, "wn_split_pack_multi: too many taps");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wn_inv_norm_multi_kernel, dim3(total_rows), dim3(256), 0, st, table_dev, first_row_dev, n_layers);
+  hipLaunchKernelGGL(wn_split_both_multi_kernel, dim3(total_blocks), dim3(256), lds, st, table_dev, first_block_dev, n_layers);
+  return dv3_check_launch("weight_norm_split_pack_multi");
 }
 
 extern "C" int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream) {

@@ -97,7 +97,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lhi = lane >> 5;
 
-  int pid = blockIdx.x;
+  // the m-tile x c-tile x tap blocks of one K slab read the same slices of g and x: give each XCD a contiguous
+  // run of logical block ids so they meet in ONE L2 (dispatch order spread them over all eight: 586 MB fetched
+  // per launch against 201 MB algorithmic at the north-star shape, profiles/r02_hbm_traffic.json)
+  int pid = dv3_xcd_remap(blockIdx.x, gridDim.x);
   const int mt = pid % args.m_tiles; pid /= args.m_tiles;
   const int ct = pid % args.c_tiles; pid /= args.c_tiles;
   const int j = pid % p.J;

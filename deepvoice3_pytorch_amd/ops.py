@@ -230,6 +230,73 @@ def pack_weights(v, g, glu_cg=0, transposed=False, need_bwd=True, split_only=Fal
     return pk
 
 
+class Prepack(object):
+    """Every weight-normed Conv1d / Linear layer of a model packed in TWO launches per step
+    (dv3_weight_norm_split_pack_multi) instead of two per layer: the scales and both split images of all
+    layers live in fixed buffers, the descriptor table in device memory is built once.  `layers`: [(v, g,
+    glu_cg)] with v (O,I[,J]) -- parameters whose storage does not move (the trainer's flat arena).
+    ConvLayerFn.forward picks the images up through `lookup` while `ops.prepacked` points here."""
+
+    def __init__(self, layers):
+        self.mode = _gemm_mode
+        if self.mode == "f32":
+            raise RuntimeError("Prepack serves the split-operand GEMM modes")
+        f16 = self.mode == "f16x3"
+        entry_t = STRUCTS["dv3_wn_multi_entry"]
+        tab = (entry_t * len(layers))()
+        first_row, first_block, rows, blocks, self.by_id, max_j = [], [], 0, 0, {}, 1
+        dev = layers[0][0].device
+        for n, (v, g, glu_cg) in enumerate(layers):
+            v3 = v if v.dim() == 3 else v.unsqueeze(-1)
+            if not v3.is_contiguous():
+                raise RuntimeError("Prepack needs contiguous weights")
+            O, I, J = v3.shape
+            pk = Packed()
+            pk.O, pk.I, pk.J, pk.transposed, pk.glu_cg, pk.fwd_f16 = O, I, J, False, glu_cg, f16
+            if glu_cg:
+                pk.a_half = _round_up(glu_cg, 4)
+                pk.lda = 2 * pk.a_half
+            else:
+                pk.a_half, pk.lda = 0, _round_up(O, 4)
+            pk.ldb = _round_up(I, 4)
+            pk.fwd = pk.bwd = None
+            pk.scale = torch.empty(O, dtype=torch.float32, device=dev)
+            pk.fwd_s = torch.zeros(2 * J * _round_up(I, 32) * pk.lda, dtype=torch.int16, device=dev)
+            pk.bwd_s = torch.zeros(2 * J * _round_up(O, 32) * pk.ldb, dtype=torch.int16, device=dev)
+            pk.fwd_s._dv3_f16 = f16
+            e = tab[n]
+            e.d.v, e.d.g, e.d.scale = v.data_ptr(), _ptr(g), pk.scale.data_ptr()
+            e.d.lda, e.d.a_half, e.d.ldb = pk.lda, pk.a_half, pk.ldb
+            e.d.O, e.d.I, e.d.J, e.d.transposed, e.d.glu_cg = O, I, J, 0, glu_cg
+            e.d.fwd_dtype = SPLIT_F16 if f16 else SPLIT_BF16
+            e.fwd_split, e.bwd_split = pk.fwd_s.data_ptr(), pk.bwd_s.data_ptr()
+            first_row.append(rows)
+            first_block.append(blocks)
+            rows += O
+            blocks += ((O + 31) // 32) * ((I + 31) // 32)
+            max_j = max(max_j, J)
+            self.by_id[id(v)] = (pk, v.data_ptr(), glu_cg)
+        raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8)
+        self.table = raw.to(dev)
+        self.first_row = torch.tensor(first_row, dtype=torch.int32, device=dev)
+        self.first_block = torch.tensor(first_block, dtype=torch.int32, device=dev)
+        self.n, self.rows, self.blocks, self.max_j = len(layers), rows, blocks, max_j
+        self.keep = layers            # the parameters the table points at stay alive with it
+
+    def run(self):
+        _lib.call("dv3_weight_norm_split_pack_multi", self.table.data_ptr(), self.first_row.data_ptr(),
+                  self.first_block.data_ptr(), self.n, self.rows, self.blocks, self.max_j, _stream())
+
+    def lookup(self, v, glu_cg):
+        hit = self.by_id.get(id(v))
+        if hit is None or hit[1] != v.data_ptr() or hit[2] != glu_cg or self.mode != _gemm_mode:
+            return None
+        return hit[0]
+
+
+prepacked = None      # set by the trainer for the duration of a training forward
+
+
 # ----------------------------------------------------------------------------------------------
 # operand planes of an activation tensor (include/dv3hip.h, dv3_split_planes_f32)
 # ----------------------------------------------------------------------------------------------
@@ -270,7 +337,7 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
               Cg=0, bias=None, spk=None, spk_strides=(0, 0, 0), r=None, r2=None, residual=0,
               y=None, y_rs=None, ab=None, xmask=None, xmask_rs=0, ymask=None, ymask_rs=0,
               drop_scale=1.0, a_bs=0, store_mode=STORE_BCT, x_bs=None, x_rs=None, tile_hint=0,
-              a_split=None, x_planes=None):
+              a_split=None, x_planes=None, r_scale=0.0):
     """dv3_conv_gemm_f32.  x: [B][Cin][Tin] (strides overridable); returns y.  x_planes: the input already
     split into operand planes (split_planes; x may then be None)."""
     gated = mode in (EPI_GLU, EPI_HIGHWAY)
@@ -305,6 +372,7 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
     d.xmask, d.xmask_rs = _ptr(xmask), xmask_rs
     d.ymask, d.ymask_rs = _ptr(ymask), ymask_rs
     d.drop_scale = drop_scale
+    d.r_scale = r_scale
     d.B, d.Cin, d.Tin, d.M, d.Cg, d.Tout, d.J, d.dil, d.padL = B, Cin, Tin, M, Cg, Tout, J, dil, padL
     d.mode, d.residual, d.store_mode, d.tile_hint = mode, residual, store_mode, tile_hint
     d.a_split = _ptr(a_split)
@@ -474,8 +542,11 @@ class ConvLayerFn(torch.autograd.Function):
         # the fused split-only packing when the split-bf16 tap-GEMM is sure to take the shape
         J_ = 1 if cfg.transposed else J
         split_only = (cfg.t_out is None or cfg.t_out == T) and (J_ - 1) * cfg.dil <= 64 and J_ <= 16
-        pk = packed if packed is not None else pack_weights(v, g, glu_cg=Cg, transposed=cfg.transposed,
-                                                            need_bwd=need_grad, split_only=split_only)
+        pk = packed
+        if pk is None and prepacked is not None and split_only and not cfg.transposed:
+            pk = prepacked.lookup(v, Cg)          # packed for the whole model at the top of the step
+        if pk is None:
+            pk = pack_weights(v, g, glu_cg=Cg, transposed=cfg.transposed, need_bwd=need_grad, split_only=split_only)
         bits, bits_rs, dscale = None, 0, 1.0
         if cfg.training and cfg.p > 0:
             bits, bits_rs = dropout_bits(B * Cin, T, cfg.p, x.device, cfg.site)
@@ -535,10 +606,14 @@ class ConvLayerFn(torch.autograd.Function):
         dy = _c(dy)
         rs2 = math.sqrt(0.5)
         dr = dr2 = dspk = None
+        r_scale = 0.0
         if gated:
+            # the skip path of a residual GLU passes sqrt(.5) * dy: the DGRAD epilogue reads dy itself
+            glu_skip = mode == EPI_GLU and cfg.residual
             dab, dres, part = gate_bwd(dy, saved, x if mode == EPI_HIGHWAY else None, B=B, C=Cg, T=T,
-                                       mode=mode, residual=int(cfg.residual),
-                                       want_dres=(mode == EPI_HIGHWAY or cfg.residual))
+                                       mode=mode, residual=int(cfg.residual), want_dres=(mode == EPI_HIGHWAY))
+            if glu_skip:
+                dres, r_scale = dy, rs2
             if ctx.spk_dim == 2:
                 dspk = part[:, :Cg].contiguous()
             elif ctx.spk_dim == 3:
@@ -579,7 +654,7 @@ class ConvLayerFn(torch.autograd.Function):
             if use_planes and pk.bwd_s is not None and planes_eligible(Jd, cfg.dil, Tg, T):
                 gp = split_planes(gmat, f16=False)
             dx = conv_gemm(gmat, pk.bwd, pk.ldb, 0, B=B, Cin=Mg, Tin=Tg, M=Cin, Tout=T, J=Jd, x_planes=gp,
-                           dil=cfg.dil, padL=(Jd - 1) * cfg.dil - padL, mode=EPI_DGRAD, r=dres,
+                           dil=cfg.dil, padL=(Jd - 1) * cfg.dil - padL, mode=EPI_DGRAD, r=dres, r_scale=r_scale,
                            ymask=ctx.bits, ymask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
                            a_split=pk.bwd_s if _gemm_mode != "f32" else None)
         if ctx.needs_input_grad[1]:

@@ -158,6 +158,7 @@ class Trainer(object):
                 p.requires_grad_(False)
         dev = self.arena.flat.device
         self.device = dev
+        self._prepack = None
         self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
         # (lr, 1-b1^t, sqrt(1-b2^t)) travel through a RING of pinned host slots: step() never waits for the
         # GPU, so the host may run steps ahead of it; a single staging buffer would be overwritten by step
@@ -217,6 +218,25 @@ class Trainer(object):
 Input text or decoder targget length exceeded the maximum length.
 Please set a larger value for ``max_position`` in hyper parameters.""".format(max_seq_len, self.cfg.max_positions))
 
+    def _prepack_all(self):
+        """weight norm + both split operand images of every Conv1d / Linear layer in two launches"""
+        if ops.gemm_precision() == "f32" or self.device.type != "cuda":
+            return None
+        if self._prepack is None or self._prepack.mode != ops.gemm_precision():
+            from . import conv as _conv, modules as _modules
+            gated = {id(m.conv): m.conv.out_channels // 2 for m in self.model.modules()
+                     if isinstance(m, _modules._GatedConv)}
+            layers = []
+            for m in self.model.modules():
+                if isinstance(m, _conv._WNLayer) and not m.transposed:
+                    v, g = m.wn_params()
+                    if v.is_contiguous() and (g is None or g.is_contiguous()):
+                        layers.append((v, g, gated.get(id(m), 0)))
+            self._prepack = ops.Prepack(layers) if layers else None
+        if self._prepack is not None:
+            self._prepack.run()
+        return self._prepack
+
     # ------------------------------------------------------------------------------------
     def forward_backward(self, batch):
         """model forward + losses + backward.  Returns the scalars as device tensors."""
@@ -226,9 +246,13 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         for p in self.arena.params:      # in-place gradient bookkeeping of ops.ConvLayerFn (uses this step)
             p._dv3_pending = 0
         self.model.train()
-        mel_out, lin_out, attn, done_hat = self.model(
-            batch.text, batch.mel, speaker_ids=batch.speaker_ids, text_positions=batch.text_positions,
-            frame_positions=batch.frame_positions, input_lengths=batch.input_lengths)
+        ops.prepacked = self._prepack_all()
+        try:
+            mel_out, lin_out, attn, done_hat = self.model(
+                batch.text, batch.mel, speaker_ids=batch.speaker_ids, text_positions=batch.text_positions,
+                frame_positions=batch.frame_positions, input_lengths=batch.input_lengths)
+        finally:
+            ops.prepacked = None
         wm, w = c.masked_loss_weight, c.binary_divergence_weight
         m4 = ops.spec_loss(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w)
         l4 = ops.spec_loss(lin_out, batch.y, batch.linear_mask_lengths if wm > 0 else None, r, wm, w)

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 22
+#define DV3_ABI_VERSION 23
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -127,6 +127,9 @@ typedef struct dv3_conv_desc {
                                                 kernel: both operands are staged with plain 16-byte copies.
                                                 `x` may then be NULL unless the epilogue reads it as `r`.     */
   int32_t x_c8p;                             /* 8-channel blocks per batch item in x_planes (= round_up(Cin,32)/8) */
+  float r_scale;                             /* DGRAD: y = acc * dropmask + r_scale * r (0 means 1).  The gradient
+                                                that reaches a residual Conv1dGLU's input through the skip path is
+                                                sqrt(.5) * dy: the epilogue reads dy itself instead of a scaled copy */
 } dv3_conv_desc;
 int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
 
@@ -235,6 +238,19 @@ int dv3_weight_norm_pack_f32(const dv3_wn_desc* d, void* stream);
  * only feed output rows the GEMM epilogue drops).                                          */
 int dv3_weight_norm_split_pack_bf16(const dv3_wn_desc* d, uint16_t* fwd_split, uint16_t* bwd_split,
                                     void* stream);
+
+/* The same for EVERY weight-normed Conv1d / Linear layer of a model in two launches.  `table_dev` (device memory,
+ * n_layers entries, each a dv3_wn_desc as above + its two image pointers), `first_row_dev[l]` = sum of O over the
+ * layers before l, `first_block_dev[l]` = sum of ceil(O/32)*ceil(I/32) before l (both int32, device memory);
+ * max_taps = max J.  The table holds raw pointers: build it once over fixed buffers (the trainer's flat parameter
+ * arena) and reuse it every step -- the call itself reads no host memory, so it can sit inside a captured graph. */
+typedef struct dv3_wn_multi_entry {
+  dv3_wn_desc d;
+  uint16_t* fwd_split; uint16_t* bwd_split;
+} dv3_wn_multi_entry;
+int dv3_weight_norm_split_pack_multi(const dv3_wn_multi_entry* table_dev, const int32_t* first_row_dev,
+                                     const int32_t* first_block_dev, int32_t n_layers, int32_t total_rows,
+                                     int32_t total_blocks, int32_t max_taps, void* stream);
 
 /*
  * Backward of weight norm from wgrad slabs: dW = sum_s slab[s]; dg, dv.
