@@ -49,6 +49,8 @@ extern "C" int dv3_sizeof(const char* name) {
   DV3_SZ(dv3_spec_loss_desc);
   DV3_SZ(dv3_planes_desc);
   DV3_SZ(dv3_wn_multi_entry);
+  DV3_SZ(dv3_conv_step_desc);
+  DV3_SZ(dv3_attn_step_desc);
 #undef DV3_SZ
   return -1;
 }

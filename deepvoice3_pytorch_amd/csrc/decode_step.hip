@@ -1,0 +1,271 @@
+// Autoregressive decode step kernels (reference: Decoder.incremental_forward, deepvoice3_pytorch/deepvoice3.py:397-473;
+// conv.Conv1d.incremental_forward, conv.py:17-46; AttentionLayer.forward with last_attended, deepvoice3.py:132-176).
+//
+// A decoder step at synthesis time is ~20 dependent, tiny problems (64 columns): the time is kernel-boundary latency,
+// not arithmetic.  Two fused kernels replace the ~100 launches of the module-by-module path:
+//   conv_step   one incremental conv layer: ring-buffer update (no window shifting: a device step counter t picks the
+//               slot t mod L), the k-tap GEMV over the window, and the whole layer tail -- bias, speaker bias,
+//               GLU / highway gate, ReLU / sigmoid, up to two sqrt(.5) residuals, the step's position encoding -- plus
+//               the optional sigmoid copy and the write into the stacked per-step output, in ONE launch;
+//   attn_step   one attention read: scores over the monotonic window [last-1, last+3) (or all keys), softmax,
+//               context, the argmax of batch item 0 for the next step's window, the stacked alignment.
+// Both read the step counter from device memory, so a captured hipGraph of one step replays for every step.
+// Arithmetic: plain fp32 FMA chains (exact fp32; a 64-column problem is not matrix-core work).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int NB = 4;   // batch items per workgroup
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// Workgroup = MT output channels x NB batch items; its 256 threads are MT channel lanes x KS slices of the K axis
+// (k-tap window x input channels), so a whole layer's weights are streamed by 16 x (B / NB) workgroups with 16 loads in
+// flight per thread: the layer is a latency problem (1.5 MB of weights, 64 columns), not a bandwidth or FLOP one.
+constexpr int MT = 16, KS = 16;
+__global__ __launch_bounds__(256) void conv_step_kernel(const dv3_conv_step_desc p) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, ml = tid & (MT - 1), ks = tid / MT;
+  const int mblk = blockIdx.x, b0 = blockIdx.y * NB;
+  const bool gated = p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY;
+  const int Mrows = gated ? p.Cg : p.M;
+  const int Cin = p.Cin, J = p.J, Ktot = J * Cin, B = p.B;
+  const int t = p.t ? p.t[0] : 0;
+  const int L = p.L;
+  const int slot = L > 0 ? t % L : 0;
+  float* Xs = lds;                          // [Ktot][NB]
+  float* red = lds + (size_t)Ktot * NB;     // [KS][MT][2*NB]
+
+  // ---- stage the window: tap J-1 is the new frame, tap j the frame (J-1-j)*dil steps back ----
+  for (int idx = tid; idx < Ktot * NB; idx += 256) {
+    const int nb = idx / Ktot, kk = idx - nb * Ktot;      // consecutive threads: consecutive channels (coalesced)
+    const int j = kk / Cin, c = kk - j * Cin;
+    const int b = b0 + nb;
+    float v = 0.f;
+    if (b < B) {
+      if (j == J - 1) {
+        v = p.x[(int64_t)b * p.x_bs + c];
+      } else {
+        int s = slot - (J - 1 - j) * p.dil;
+        s %= L;
+        if (s < 0) s += L;
+        v = p.ring[((int64_t)s * B + b) * Cin + c];
+      }
+    }
+    Xs[kk * NB + nb] = v;
+  }
+  // the new frame enters the ring (slot-major [L][B][Cin]); the taps above never read this slot ((J-1)*dil < L)
+  if (mblk == 0 && p.ring) {
+    for (int idx = tid; idx < NB * Cin; idx += 256) {
+      const int nb = idx / Cin, c = idx - nb * Cin;
+      const int b = b0 + nb;
+      if (b < B) p.ring[((int64_t)slot * B + b) * Cin + c] = p.x[(int64_t)b * p.x_bs + c];
+    }
+  }
+  __syncthreads();
+
+  // ---- GEMV ----
+  const int m = mblk * MT + ml;
+  const bool mok = m < Mrows;
+  const float* __restrict__ Aa = p.a + (mok ? m : 0);
+  const float* __restrict__ Ag = p.a + p.a_half + (mok ? m : 0);
+  float acc_a[NB], acc_g[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc_a[i] = acc_g[i] = 0.f;
+  const int kq = (Ktot + KS - 1) / KS;
+  const int k0 = ks * kq, k1 = min(Ktot, k0 + kq);
+  const f32x4* Xs4 = reinterpret_cast<const f32x4*>(Xs);
+  if (gated) {
+#pragma unroll 8
+    for (int kk = k0; kk < k1; ++kk) {
+      const float wa = Aa[(int64_t)kk * p.lda];
+      const float wg = Ag[(int64_t)kk * p.lda];
+      const f32x4 xv = Xs4[kk];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        acc_a[i] = fmaf(wa, xv[i], acc_a[i]);
+        acc_g[i] = fmaf(wg, xv[i], acc_g[i]);
+      }
+    }
+  } else {
+#pragma unroll 8
+    for (int kk = k0; kk < k1; ++kk) {
+      const float wa = Aa[(int64_t)kk * p.lda];
+      const f32x4 xv = Xs4[kk];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) acc_a[i] = fmaf(wa, xv[i], acc_a[i]);
+    }
+  }
+  float* my = red + ((size_t)ks * MT + ml) * (2 * NB);
+#pragma unroll
+  for (int i = 0; i < NB; ++i) { my[i] = acc_a[i]; my[NB + i] = acc_g[i]; }
+  __syncthreads();
+  if (ks != 0 || !mok) return;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) { acc_a[i] = 0.f; acc_g[i] = 0.f; }
+  for (int q = 0; q < KS; ++q) {          // fixed order: deterministic
+    const float* o = red + ((size_t)q * MT + ml) * (2 * NB);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) { acc_a[i] += o[i]; acc_g[i] += o[NB + i]; }
+  }
+
+  // ---- the layer tail ----
+  const float rs2 = 0.70710678118654752440f;
+  const float ba = p.bias ? p.bias[m] : 0.f;
+  const float bg = (gated && p.bias) ? p.bias[p.Cg + m] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int b = b0 + i;
+    if (b >= B) continue;
+    float y;
+    if (gated) {
+      float a = acc_a[i] + ba;
+      const float g = acc_g[i] + bg;
+      if (p.spk) a += p.spk[(int64_t)b * p.spk_bs + m];
+      const float s = sigmoidf_(g);
+      const float xr = (p.mode == DV3_EPI_HIGHWAY || p.residual) ? p.x[(int64_t)b * p.x_bs + m] : 0.f;
+      if (p.mode == DV3_EPI_GLU) y = p.residual ? (a * s + xr) * rs2 : a * s;
+      else y = s * a + (1.0f - s) * xr;
+      if (p.r2) y = (y + p.r2[(int64_t)b * p.r2_bs + m]) * rs2;
+    } else {
+      float v = acc_a[i] + ba;
+      if (p.mode == DV3_EPI_RELU) v = fmaxf(v, 0.f);
+      else if (p.mode == DV3_EPI_SIGMOID) v = sigmoidf_(v);
+      else if (p.mode == DV3_EPI_SOFTSIGN) v = v / (1.0f + fabsf(v));
+      if (p.r) v = (v + p.r[(int64_t)b * p.r_bs + m]) * rs2;
+      if (p.r2) v = (v + p.r2[(int64_t)b * p.r2_bs + m]) * rs2;
+      y = v;
+    }
+    if (p.post_add) y += p.post_add[(int64_t)t * p.post_add_ts + (int64_t)b * p.post_add_bs + m];
+    p.y[(int64_t)b * p.y_bs + m] = y;
+    float o = y;
+    if (p.y_act) {
+      o = sigmoidf_(y);
+      p.y_act[(int64_t)b * p.y_act_bs + m] = o;
+    }
+    if (p.out_seq) p.out_seq[(int64_t)t * p.out_seq_ts + (int64_t)b * p.out_seq_bs + m] = o;
+  }
+}
+
+// one workgroup per batch item
+__global__ __launch_bounds__(256) void attn_step_kernel(const dv3_attn_step_desc p) {
+  extern __shared__ float lds[];   // q [E] | scores / probabilities [Tk]
+  __shared__ float red[4];
+  __shared__ int redi[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, E = p.E, Tk = p.Tk;
+  const int t = p.t ? p.t[0] : 0;
+  float* q = lds;
+  float* sc = lds + E;
+  int lo = 0, hi = Tk;
+  if (p.last_attended) {       // deepvoice3.py:150-156
+    const int la = p.last_attended[t & 1];
+    const int back = la - p.win_back, ahead = la + p.win_ahead;
+    if (back > 0) lo = back;
+    if (ahead < Tk) hi = ahead;
+  }
+  for (int e = tid; e < E; e += 256) q[e] = p.q[(int64_t)b * p.q_bs + e];
+  __syncthreads();
+  const float* __restrict__ kb = p.k + (int64_t)b * E * Tk;
+  float mx = -INFINITY;
+  for (int n = tid; n < Tk; n += 256) {
+    float s = -INFINITY;
+    if (n >= lo && n < hi) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int e = 0;
+      for (; e + 4 <= E; e += 4) {
+        a0 = fmaf(q[e], kb[(int64_t)e * Tk + n], a0);
+        a1 = fmaf(q[e + 1], kb[(int64_t)(e + 1) * Tk + n], a1);
+        a2 = fmaf(q[e + 2], kb[(int64_t)(e + 2) * Tk + n], a2);
+        a3 = fmaf(q[e + 3], kb[(int64_t)(e + 3) * Tk + n], a3);
+      }
+      for (; e < E; ++e) a0 = fmaf(q[e], kb[(int64_t)e * Tk + n], a0);
+      s = (a0 + a1) + (a2 + a3);
+    }
+    sc[n] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = dv3_wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int n = tid; n < Tk; n += 256) {
+    const float e = (n >= lo && n < hi) ? expf(sc[n] - mx) : 0.f;
+    sc[n] = e;
+    sum += e;
+  }
+  sum = dv3_wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+  __syncthreads();
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int n = tid; n < Tk; n += 256) {
+    const float pr = sc[n] * inv;
+    sc[n] = pr;
+    if (p.attn) p.attn[(int64_t)b * Tk + n] = pr;
+    if (p.attn_seq) p.attn_seq[(int64_t)t * p.attn_seq_ts + (int64_t)b * Tk + n] = pr;
+    if (pr > best) { best = pr; bi = n; }
+  }
+  __syncthreads();
+  // context (deepvoice3.py:167-171): sum_n p[n] v[e][n] * (Tk * sqrt(1/Tk))
+  const float scale = (float)Tk * sqrtf(1.0f / (float)Tk);
+  const float* __restrict__ vb = p.v + (int64_t)b * E * Tk;
+  for (int e = tid; e < E; e += 256) {
+    float c = 0.f;
+    for (int n = lo; n < hi; ++n) c = fmaf(sc[n], vb[(int64_t)e * Tk + n], c);
+    p.ctx[(int64_t)b * p.ctx_bs + e] = c * scale;
+  }
+  // next step's window: argmax of batch item 0 (deepvoice3.py:445), first maximum
+  if (b == 0 && p.last_attended) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { red[wave] = best; redi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (red[w] > best || (red[w] == best && redi[w] < bi)) { best = red[w]; bi = redi[w]; }
+      p.last_attended[(t + 1) & 1] = bi;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dv3_conv_step_f32(const dv3_conv_step_desc* d, void* stream) {
+  DV3_REQUIRE(d && d->x && d->a && d->y, "conv_step: null pointer");
+  DV3_REQUIRE(d->B > 0 && d->Cin > 0 && d->M > 0 && d->J >= 1 && d->dil >= 1, "conv_step: bad dims");
+  const bool gated = d->mode == DV3_EPI_GLU || d->mode == DV3_EPI_HIGHWAY;
+  if (gated) {
+    DV3_REQUIRE(d->M == 2 * d->Cg && d->a_half >= d->Cg && d->lda >= d->a_half + d->Cg, "conv_step: bad gated layout");
+    DV3_REQUIRE(!(d->mode == DV3_EPI_HIGHWAY || d->residual) || d->Cin == d->Cg, "conv_step: residual needs Cin == Cout");
+  } else {
+    DV3_REQUIRE(d->lda >= d->M && d->mode >= DV3_EPI_LINEAR && d->mode <= DV3_EPI_SOFTSIGN && d->mode != DV3_EPI_DGRAD,
+                "conv_step: bad mode / lda");
+  }
+  if (d->J > 1) DV3_REQUIRE(d->ring && d->t && d->L >= (d->J - 1) * d->dil + 1, "conv_step: k > 1 needs ring, t and L >= (k-1)*d+1");
+  if (d->post_add || d->out_seq) DV3_REQUIRE(d->t, "conv_step: post_add / out_seq need the step counter");
+  const int rows = gated ? d->Cg : d->M;
+  const size_t lds = ((size_t)d->J * d->Cin * NB + (size_t)KS * MT * 2 * NB) * sizeof(float);
+  DV3_REQUIRE(lds <= 64 * 1024, "conv_step: window too large for LDS (%zu bytes)", lds);
+  hipLaunchKernelGGL(conv_step_kernel, dim3(dv3_cdiv(rows, MT), dv3_cdiv(d->B, NB)), dim3(256), lds, (hipStream_t)stream, *d);
+  return dv3_check_launch("conv_step");
+}
+
+extern "C" int dv3_attn_step_f32(const dv3_attn_step_desc* d, void* stream) {
+  DV3_REQUIRE(d && d->q && d->k && d->v && d->ctx, "attn_step: null pointer");
+  DV3_REQUIRE(d->B > 0 && d->E > 0 && d->Tk > 0, "attn_step: bad dims");
+  if (d->last_attended || d->attn_seq) DV3_REQUIRE(d->t, "attn_step: the window / stacked output need the step counter");
+  const size_t lds = ((size_t)d->E + d->Tk) * sizeof(float);
+  DV3_REQUIRE(lds <= 64 * 1024, "attn_step: E + Tk too large for LDS");
+  hipLaunchKernelGGL(attn_step_kernel, dim3(d->B), dim3(256), lds, (hipStream_t)stream, *d);
+  return dv3_check_launch("attn_step");
+}

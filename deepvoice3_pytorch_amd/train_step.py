@@ -374,7 +374,7 @@ def load_checkpoint(path_or_dict, trainer, reset_optimizer=False):
     """train.load_checkpoint (train.py:852-867): model weights, (unless reset_optimizer) the Adam
     moments, and the two counters.  Returns global_epoch.  Accepts files written by the reference:
     its optimizer enumerates get_trainable_parameters() in the same order the arena does."""
-    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu")
+    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu", weights_only=False)
     a = trainer.arena
     with torch.no_grad():     # copy INTO the arena views (load_state_dict would keep them too; be explicit)
         own = trainer.model.state_dict()
@@ -404,7 +404,7 @@ def load_checkpoint(path_or_dict, trainer, reset_optimizer=False):
 
 
 def _state_dict_of(path_or_dict):
-    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu")
+    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu", weights_only=False)
     return ck["state_dict"] if "state_dict" in ck else ck
 
 

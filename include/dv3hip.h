@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 23
+#define DV3_ABI_VERSION 24
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -414,6 +414,56 @@ int dv3_clip_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
                       const float* grad_norm, float clip, const float* hyper, float beta1,
                       float beta2, float eps, float weight_decay, float grad_prescale,
                       void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Autoregressive decode step (Decoder.incremental_forward, deepvoice3.py:397-473): two fused kernels per
+ * layer kind instead of the ~100 launches of the module-by-module path.  Both read the 0-based step counter
+ * `t` from DEVICE memory, so one captured hipGraph of a step replays for every step.
+ *
+ * dv3_conv_step_f32 -- one incremental conv layer (conv.py:17-46) with its whole tail:
+ *   window: tap J-1 = the new frame x (B, Cin); tap j = the frame (J-1-j)*dil steps back, kept in `ring`
+ *   [L][B][Cin] (slot t mod L holds step t; the call stores x there; L >= (J-1)*dil + 1; zero the ring to
+ *   start a sequence = conv.py clear_buffer);  acc[b][m] = sum_{j,c} a[j][c][m] * window[b][j][c]
+ *   (a = dv3_weight_norm_pack_f32's fwd_pack);  then, by mode:
+ *     GLU / HIGHWAY  (+bias, +spk[b][m] on the `a` half) gate with the new frame as residual / highway carry
+ *                    (modules.py:157-164, 224-226), then r2: y = (y + r2) * sqrt(.5)
+ *     LINEAR / RELU / SIGMOID / SOFTSIGN  activation, then r and r2 residuals, each (y + r) * sqrt(.5)
+ *   then y += post_add[t*post_add_ts + b*post_add_bs + m] (the step's position encoding, deepvoice3.py:430);
+ *   y -> (B, Cout); y_act (optional) = sigmoid(y); out_seq (optional) [t][b][m] = y_act if given else y.
+ * dv3_attn_step_f32 -- one attention read (deepvoice3.py:143-171 at Tq = 1): scores q.k over the window
+ *   [last-win_back, last+win_ahead) (all keys when last_attended is NULL), softmax, ctx = P v * Tk*sqrt(1/Tk);
+ *   attn (B, Tk) and / or attn_seq [t][b][n]; last_attended is a PAIR of device ints: slot t&1 is read, the
+ *   argmax of batch item 0 (deepvoice3.py:445) is stored in slot (t+1)&1.
+ * ------------------------------------------------------------------------------------ */
+typedef struct dv3_conv_step_desc {
+  const float* x; int64_t x_bs;
+  float* ring; int32_t L;
+  const int32_t* t;
+  const float* a; int32_t lda, a_half;
+  const float* bias;
+  const float* spk; int64_t spk_bs;
+  const float* r;  int64_t r_bs;
+  const float* r2; int64_t r2_bs;
+  const float* post_add; int64_t post_add_ts, post_add_bs;
+  float* y; int64_t y_bs;
+  float* y_act; int64_t y_act_bs;
+  float* out_seq; int64_t out_seq_ts, out_seq_bs;
+  int32_t B, Cin, M, Cg, J, dil, mode, residual;
+} dv3_conv_step_desc;
+int dv3_conv_step_f32(const dv3_conv_step_desc* d, void* stream);
+
+typedef struct dv3_attn_step_desc {
+  const float* q; int64_t q_bs;              /* (B, E)                                       */
+  const float* k; const float* v;            /* (B, E, Tk) each, BCT                         */
+  int32_t* last_attended;                    /* [2] device ints or NULL                      */
+  int32_t win_back, win_ahead;
+  const int32_t* t;
+  float* ctx; int64_t ctx_bs;                /* (B, E)                                       */
+  float* attn;                               /* (B, Tk) or NULL                              */
+  float* attn_seq; int64_t attn_seq_ts;      /* [t][B][Tk] or NULL                           */
+  int32_t B, E, Tk;
+} dv3_attn_step_desc;
+int dv3_attn_step_f32(const dv3_attn_step_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Audio inverse (audio.py:37-43, synthesis.py:64-71): linear spectrogram -> waveform on the

@@ -317,6 +317,57 @@ def gen_audio_helpers():
     print("audio_helpers", len(out))
 
 
+def gen_checkpoint():
+    """A checkpoint file written by the reference's OWN train.save_checkpoint (train.py:788-809) after one
+    train.train() step (weights + torch.optim.Adam state + counters), and the weights the reference reaches one
+    step later from it.  tests: the file loads into train_step.Trainer and the next step lands on those weights."""
+    import glob
+    import shutil
+    import tempfile
+    train, hparams, Writer = refimport.load_train_module()
+    import deepvoice3_pytorch.frontend as fe
+    hparams.parse_json(open(os.path.join(refimport.REF_ROOT, "presets", "deepvoice3_ljspeech.json")).read())
+    hp_over = dict(dropout=0.0, text_embed_dim=24, encoder_channels=48, decoder_channels=32,
+                   converter_channels=32, num_mels=20, fft_size=64, batch_size=3, max_positions=128)
+    for k, v in hp_over.items():
+        setattr(hparams, k, v)
+    train._frontend = fe.en
+    torch.manual_seed(777)
+    model = train.build_model()
+    rng = np.random.RandomState(13)
+    items = []
+    for n_frames, n_text in [(41, 10), (33, 8), (52, 12)]:
+        text = np.concatenate([rng.randint(2, 149, size=n_text - 1), [1]]).astype(np.int32)
+        items.append((text, rng.rand(n_frames, 20).astype(np.float32), rng.rand(n_frames, 33).astype(np.float32)))
+    batch = train.collate_fn(items)
+    optimizer = torch.optim.Adam(model.get_trainable_parameters(), lr=hparams.initial_learning_rate,
+                                 betas=(hparams.adam_beta1, hparams.adam_beta2), eps=hparams.adam_eps,
+                                 weight_decay=hparams.weight_decay, amsgrad=hparams.amsgrad)
+    tmp = tempfile.mkdtemp()
+    train.global_step, train.global_epoch = 3999, 0
+    kw = dict(init_lr=hparams.initial_learning_rate, checkpoint_dir=tmp, checkpoint_interval=10 ** 9,
+              clip_thresh=hparams.clip_thresh)
+    train.train(torch.device("cpu"), model, [batch], optimizer, Writer(), nepochs=1, **kw)
+    train.save_checkpoint(model, optimizer, train.global_step, tmp, train.global_epoch, True, True)
+    (path,) = glob.glob(os.path.join(tmp, "checkpoint_step*.pth"))
+    dst = os.path.join(OUT, "reference_" + os.path.basename(path))
+    shutil.copy(path, dst)
+    writer = Writer()
+    train.train(torch.device("cpu"), model, [batch], optimizer, writer, nepochs=2, **kw)    # one more step
+    out = {"hp_over": json.dumps(hp_over), "ckpt_file": os.path.basename(dst), "global_step": np.int64(train.global_step)}
+    for k, v in model.state_dict().items():
+        out["sd_next/" + k] = _np(v)
+    x, in_len, mel, y, (tp, fp), done, tgt_len, _ = batch
+    out.update({"in/text": _np(x), "in/input_lengths": _np(in_len), "in/mel": _np(mel), "in/y": _np(y),
+                "in/text_positions": _np(tp), "in/frame_positions": _np(fp), "in/done": _np(done),
+                "in/target_lengths": _np(tgt_len)})
+    for k, v in writer.scalars.items():
+        out["scalar/" + k.replace(" ", "_")] = np.array([s[1] for s in v], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "checkpoint_resume.npz"), **out)
+    shutil.rmtree(tmp)
+    print("wrote", dst, "and checkpoint_resume.npz; step after:", train.global_step)
+
+
 def gen_presets():
     """Preset-size outputs of the unmodified reference (BASELINE.json configs 2-4 at their real channel
     counts, bench-shaped batch B=2, Tt=150, 800 frames).  The 100 MB state_dicts are not stored: the
@@ -365,6 +416,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "presets":
         gen_presets()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":
+        gen_checkpoint()
+        return
     for name, b, hp in MODELS:
         gen_model(name, b, hp)
     gen_losses()
@@ -373,6 +427,7 @@ def main():
     gen_collate()
     gen_audio_helpers()
     gen_presets()
+    gen_checkpoint()
 
 
 if __name__ == "__main__":

@@ -477,3 +477,58 @@ def test_prefetcher_yields_the_collated_batches(monkeypatch):
     with pytest.raises(ValueError):
         next(iter(pf))
     pf.close()
+
+
+def _resume_fixture():
+    import json
+    from deepvoice3_pytorch_amd import builder, train_step
+    fx = load_golden("checkpoint_resume")
+    hpo = json.loads(str(fx["hp_over"]))
+    hp = dict(n_vocab=149, embed_dim=hpo["text_embed_dim"], mel_dim=hpo["num_mels"], linear_dim=hpo["fft_size"] // 2 + 1,
+              r=1, downsample_step=4, padding_idx=0, dropout=0.0, kernel_size=3, encoder_channels=hpo["encoder_channels"],
+              decoder_channels=hpo["decoder_channels"], converter_channels=hpo["converter_channels"],
+              use_memory_mask=True, force_monotonic_attention=True, use_decoder_state_for_postnet_input=True,
+              max_positions=hpo["max_positions"], key_projection=True, value_projection=True)
+    cfg = train_step.TrainConfig(max_positions=hpo["max_positions"])
+    path = os.path.join(ROOT, "tests", "golden", str(fx["ckpt_file"]))
+    return fx, hp, cfg, path
+
+
+def test_checkpoint_written_by_the_reference_loads():
+    """tests/golden/reference_checkpoint_step*.pth was written by the reference's OWN train.save_checkpoint
+    (train.py:788-809; oracle/make_golden.py gen_checkpoint) after one train.train() step: weights, the
+    torch.optim.Adam state_dict and the counters must land in the model, the flat moment arenas and the trainer;
+    what train_step.save_checkpoint writes back must have the reference's layout again."""
+    from deepvoice3_pytorch_amd import builder, train_step
+    fx, hp, cfg, path = _resume_fixture()
+    ck = torch.load(path, map_location="cpu", weights_only=False)   # as the reference loads it
+    model = builder.deepvoice3(**hp)
+    trainer = train_step.Trainer(model, cfg)
+    epoch = train_step.load_checkpoint(path, trainer)
+    assert epoch == int(ck["global_epoch"]) and trainer.global_step == int(ck["global_step"]) == 4000
+    assert trainer.adam_step == 1
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, ck["state_dict"][k]), k
+    a = trainer.arena
+    for i, (o, n, p) in enumerate(zip(a.offsets, a.sizes, a.params)):
+        st = ck["optimizer"]["state"][i]
+        assert torch.equal(a.exp_avg[o:o + n].view(p.shape), st["exp_avg"])
+        assert torch.equal(a.exp_avg_sq[o:o + n].view(p.shape), st["exp_avg_sq"])
+    back = train_step.checkpoint_dict(trainer, global_epoch=epoch)
+    assert set(back) == set(ck) and set(back["optimizer"]) == set(ck["optimizer"])
+    assert set(back["state_dict"]) == set(ck["state_dict"])
+    assert sorted(back["optimizer"]["state"]) == sorted(ck["optimizer"]["state"])
+    ref_opt = torch.optim.Adam(builder.deepvoice3(**hp).get_trainable_parameters())
+    ref_opt.load_state_dict(back["optimizer"])        # torch accepts what we write
+
+
+def test_torch_library_shim_loads_and_registers_every_operator():
+    """TORCH_LIBRARY(dv3hip) (csrc/torch_ops.cpp): the shim loads next to libdv3hip.so, agrees on the ABI version
+    and registers the operators; on a CPU tensor they refuse (no fallback) instead of computing."""
+    from deepvoice3_pytorch_amd import torch_ops, _lib
+    ops = torch_ops.load()
+    assert ops.abi_version() == _lib.CONSTS["DV3_ABI_VERSION"]
+    for name in ("weight_norm_split_pack", "conv1d_glu", "conv1x1", "sincos_pos", "grad_sqnorm", "clip_adam_"):
+        assert hasattr(ops, name), name
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        ops.grad_sqnorm(torch.zeros(8))

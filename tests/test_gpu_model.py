@@ -468,3 +468,119 @@ def test_eval_after_training_uses_current_weights(dev, gemm_mode):
     y2 = ev(fresh)
     assert rel_err(y1.cpu(), y2.cpu()) < 1e-6
     assert rel_err(y1.cpu(), y0.cpu()) > 1e-4   # the weights did move
+
+
+@pytest.mark.gpu
+def test_resume_from_reference_checkpoint_matches_reference_next_step(dev, gemm_mode):
+    """Load the file the reference's own train.save_checkpoint wrote after ONE of its train.train() steps
+    (weights + torch Adam state + counters), take the next optimisation step here, and land on the weights the
+    reference itself reached one step later (tests/golden/checkpoint_resume.npz) -- optimizer-state interop,
+    not only weight interop."""
+    from deepvoice3_pytorch_amd import builder, train_step
+    from tests.test_cpu_host import _resume_fixture
+    fx, hp, cfg, path = _resume_fixture()
+    model = builder.deepvoice3(**hp).to(dev)
+    trainer = train_step.Trainer(model, cfg)
+    train_step.load_checkpoint(path, trainer)
+    sd_loaded = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x = {k[3:]: torch.from_numpy(val) for k, val in fx.items() if k.startswith("in/")}
+    batch = train_step.Batch.from_collate(x["text"], x["input_lengths"], x["mel"], x["y"], x["text_positions"],
+                                          x["frame_positions"], x["done"], x["target_lengths"], None,
+                                          downsample_step=4, device=dev)
+    scal = trainer.step(batch)
+    assert trainer.global_step == int(fx["global_step"]) == 4001
+    assert abs(float(scal["loss"]) - fx["scalar/loss"][0]) < 2e-4 * fx["scalar/loss"][0]
+    for k, v in model.state_dict().items():
+        if k.endswith("positions.weight"):
+            continue
+        moved = float(np.abs(fx["sd_next/" + k] - sd_loaded[k].numpy()).max())
+        diff = float(np.abs(v.cpu().numpy() - fx["sd_next/" + k]).max())
+        assert diff < 0.1 * max(moved, 1e-6) + 1e-6, (k, diff, moved)
+
+
+@pytest.mark.gpu
+def test_save_load_step_equals_uninterrupted_step(dev, gemm_mode, tmp_path):
+    """train 2 steps -> save_checkpoint -> fresh model + trainer -> load_checkpoint -> 2 more steps must equal 4
+    uninterrupted steps bit for bit (dropout on, the Philox stream re-seeded per step from the step counter the
+    checkpoint carries)."""
+    from deepvoice3_pytorch_amd import builder, ops, train_step
+    fx, b, hp, sd, x, _ = _build("dv3_preset_like", dev)
+    xg = _to(x, dev)
+    B, Td = x["mel"].shape[0], x["mel"].shape[1]
+    rng = np.random.RandomState(1)
+    batch = train_step.Batch(xg["text"], xg["text_positions"], xg["frame_positions"], xg["mel"],
+                             torch.from_numpy(rng.rand(B, Td * 4, hp["linear_dim"]).astype(np.float32)).to(dev),
+                             torch.zeros(B, Td, 1, device=dev), x["input_lengths"].numpy(),
+                             np.full(B, Td * 4 - 4), None, 1, 4, dev)
+    cfg = train_step.TrainConfig(max_positions=hp.get("max_positions", 512), initial_learning_rate=2e-3)
+
+    def fresh():
+        m = getattr(builder, b)(**hp)
+        m.load_state_dict(sd)
+        return m.to(dev)
+
+    def run(trainer, n):
+        for _ in range(n):
+            ops.dropout_state.manual_seed(9000 + trainer.global_step)
+            trainer.step(batch)
+    ta = train_step.Trainer(fresh(), cfg)
+    run(ta, 4)
+    tb = train_step.Trainer(fresh(), cfg)
+    run(tb, 2)
+    path = train_step.save_checkpoint(tb, str(tmp_path))
+    tc = train_step.Trainer(fresh(), cfg)
+    train_step.load_checkpoint(path, tc)
+    assert tc.global_step == 2 and tc.adam_step == 2
+    run(tc, 2)
+    for (k, va), vc in zip(ta.model.state_dict().items(), tc.model.state_dict().values()):
+        assert torch.equal(va, vc), k
+    assert torch.equal(ta.arena.exp_avg, tc.arena.exp_avg) and torch.equal(ta.arena.exp_avg_sq, tc.arena.exp_avg_sq)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dv3_tiny", "dv3_preset_like", "dv3_multispeaker"])
+def test_fast_decode_equals_module_by_module_decode(dev, name, gemm_mode):
+    """Decoder.incremental_forward on the fused decode-step kernels (decoder.fast_decode, 17 launches per step:
+    dv3_conv_step_f32 / dv3_attn_step_f32, ring buffers on a device step counter) against the module-by-module
+    path it replaces: teacher-forced and free-running, eager and with the per-step hipGraph."""
+    if gemm_mode != "f16x3":
+        pytest.skip("the decode step kernels are fp32 FMA chains in every mode")
+    fx, b, hp, sd, x, model = _build(name, dev)
+    model.eval()
+    dec = model.seq2seq.decoder
+    xg = _to(x, dev)
+    B = int(fx["inc_batch"])
+    text, tp, mel = xg["text"][:B], xg["text_positions"][:B], xg["mel"][:B]
+    spk = xg["speaker_ids"][:B] if "speaker_ids" in xg else None
+    r = hp.get("r", 4)
+    mel_r = mel.view(B, mel.size(1) // r, -1)
+    res = {}
+    for fast in (False, True):
+        dec.fast_decode = fast
+        with torch.no_grad():
+            se = model.embed_speakers(spk) if spk is not None else None
+            enc = model.seq2seq.encoder(text, lengths=None, speaker_embed=se)
+            dec.start_fresh_sequence()
+            tf = dec.incremental_forward(enc, tp, speaker_embed=se, test_inputs=mel_r)
+            dec.max_decoder_steps = dec.min_decoder_steps = 12
+            dec.use_step_graph = False
+            dec.start_fresh_sequence()
+            fr = dec.incremental_forward(enc, tp, speaker_embed=se)
+            dec.use_step_graph = True
+            dec.start_fresh_sequence()
+            fg = dec.incremental_forward(enc, tp, speaker_embed=se)
+            dec.use_step_graph = False
+        res[fast] = (tf, fr, fg)
+    dec.fast_decode = True
+    for which, tag in ((0, "teacher-forced"), (1, "free-running"), (2, "free-running, step graph")):
+        slow, fast = res[False][which], res[True][which]
+        for a, bb, nm in zip(slow, fast, ("outputs", "alignments", "dones", "states")):
+            a = torch.stack(a) if isinstance(a, (list, tuple)) else a
+            bb = torch.stack(bb) if isinstance(bb, (list, tuple)) else bb
+            assert a.shape == bb.shape, (tag, nm, a.shape, bb.shape)
+            assert rel_err(bb.cpu(), a.cpu()) < (2e-5 if which == 0 else 2e-4), (tag, nm)
+    # the graph replay must equal the eager fast path exactly
+    for a, bb in zip(res[True][1], res[True][2]):
+        a = torch.stack(a) if isinstance(a, (list, tuple)) else a
+        bb = torch.stack(bb) if isinstance(bb, (list, tuple)) else bb
+        assert torch.equal(a, bb)
