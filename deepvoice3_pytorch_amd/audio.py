@@ -134,12 +134,16 @@ def melspectrogram_batch(wav, cfg=None, num_mels=80, fmin=125.0, fmax=7600.0):
 
 def griffin_lim(mag, hop, n_iter, init_phasor=None):
     """Griffin & Lim: alternate projections between the given magnitudes and consistent STFTs."""
-    ph = init_phasor
-    y = istft(mag, ph, hop)
-    T = mag.shape[1]
-    for _ in range(n_iter):
-        ph, _ = stft(y, T, hop)
-        y = istft(mag, ph, hop)
+    y = istft(mag, init_phasor, hop)
+    B, T, _ = mag.shape
+    if n_iter > 0:
+        frames = torch.empty((B, T, N_FFT), dtype=torch.float32, device=mag.device)
+        y2 = torch.empty_like(y)
+        for _ in range(n_iter):
+            # stft -> unit phase -> x magnitude -> inverse FFT -> window in one launch (the phasors never reach HBM)
+            _lib.call("dv3_gl_project_f32", y.data_ptr(), mag.data_ptr(), frames.data_ptr(), B, T, hop, _stream())
+            _lib.call("dv3_overlap_add_f32", frames.data_ptr(), y2.data_ptr(), B, T, hop, _stream())
+            y, y2 = y2, y
     return y
 
 

@@ -30,10 +30,21 @@ __device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.x - b.x, a.y - 
 
 __device__ __forceinline__ float hann(int n) { return 0.5f - 0.5f * cospif(2.0f * (float)n / (float)NFFT); }
 
+// W[j] = exp(+2 pi i j / 1024), filled once per workgroup (4 sincospif per thread instead of 3 per butterfly and
+// pass: the transcendental calls were most of a frame's instructions).  hann(n) = 0.5 - 0.5 * Re W[n].
+__device__ __forceinline__ void fill_twiddles(cplx* W, int tid) {
+  for (int j = tid; j < NFFT; j += 256) {
+    float s, c;
+    sincospif(2.0f * (float)j / (float)NFFT, &s, &c);
+    W[j] = cplx{c, s};
+  }
+}
+__device__ __forceinline__ float hann_t(const cplx* W, int n) { return 0.5f - 0.5f * W[n].x; }
+
 // In-LDS 1024-point complex FFT (SIGN = -1 forward, +1 inverse, unnormalised).  `a` holds the
 // input in natural order; the result ends in `b` (5 passes: a->b->a->b->a->b).  256 threads.
 template <int SIGN>
-__device__ __forceinline__ void fft1024(cplx* a, cplx* b, int tid) {
+__device__ __forceinline__ void fft1024(cplx* a, cplx* b, int tid, const cplx* W = nullptr) {
   cplx* src = a;
   cplx* dst = b;
 #pragma unroll
@@ -46,9 +57,14 @@ __device__ __forceinline__ void fft1024(cplx* a, cplx* b, int tid) {
     for (int r = 0; r < 4; ++r) {
       v[r] = src[tid + r * (NFFT / 4)];
       if (r) {
-        float s, c;
-        sincospif(ang * (float)r, &s, &c);
-        v[r] = cmul(v[r], cplx{c, s});
+        if (W) {       // exp(SIGN * 2 pi i k r / (4 ns)) = W[k r 256/ns] (conjugated for SIGN < 0); k r / (4 ns) < 3/4
+          const cplx w = W[k * r * (NFFT / 4 / ns)];
+          v[r] = cmul(v[r], cplx{w.x, SIGN < 0 ? -w.y : w.y});
+        } else {
+          float s, c;
+          sincospif(ang * (float)r, &s, &c);
+          v[r] = cmul(v[r], cplx{c, s});
+        }
       }
     }
     // radix-4 DFT, natural order: X[q] = sum_m v[m] * w^(q*m), w = exp(SIGN * i*pi/2)
@@ -152,6 +168,40 @@ __global__ __launch_bounds__(256) void stft_phase_kernel(const float* __restrict
       phasor[(fr * NBIN + k) * 2 + 1] = z.y * inv;
     }
   }
+}
+
+// One Griffin-Lim projection per frame without leaving LDS: STFT of the current signal estimate -> unit phase ->
+// times the target magnitude -> inverse FFT -> synthesis window.  Equals stft_phase_kernel followed by
+// istft_frames_kernel (same arithmetic, same order) minus the phasor round trip through HBM (8 KB per frame).
+__global__ __launch_bounds__(256) void gl_project_kernel(const float* __restrict__ y, const float* __restrict__ mag,
+                                                         float* __restrict__ frames, int T, int hop, int L) {
+  __shared__ cplx A[NFFT], Bf[NFFT], W[NFFT];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / T, t = blockIdx.x - b * T;
+  const float* yb = y + (int64_t)b * L;
+  fill_twiddles(W, tid);
+  __syncthreads();
+  for (int n = tid; n < NFFT; n += 256) {
+    int i = t * hop + n - NFFT / 2;
+    if (i < 0) i = -i;
+    if (i >= L) i = 2 * (L - 1) - i;
+    A[n] = cplx{yb[i] * hann_t(W, n), 0.f};
+  }
+  fft1024<-1>(A, Bf, tid, W);
+  const int64_t fr = blockIdx.x;
+  const float* m = mag + fr * NBIN;
+  for (int k = tid; k <= NFFT / 2; k += 256) {
+    const cplx z = Bf[k];
+    const float inv = 1.0f / fmaxf(sqrtf(z.x * z.x + z.y * z.y), 1e-8f);
+    const float px = z.x * inv, py = z.y * inv;       // the unit phasor stft_phase_kernel would store
+    cplx w{m[k] * px, m[k] * py};
+    if (k == 0 || k == NFFT / 2) w.y = 0.f;
+    A[k] = w;
+    if (k > 0 && k < NFFT / 2) A[NFFT - k] = cplx{w.x, -w.y};
+  }
+  fft1024<+1>(A, Bf, tid, W);
+  float* out = frames + fr * NFFT;
+  for (int n = tid; n < NFFT; n += 256) out[n] = Bf[n].x * (1.0f / NFFT) * hann_t(W, n);
 }
 
 // y[n] = x[n] + coef * y[n-1] per row (scipy.signal.lfilter([1], [1, -coef]); audio.py:26-28), in
@@ -263,6 +313,16 @@ extern "C" int dv3_stft_phase_f32(const float* y, float* phasor, float* spec, fl
   hipLaunchKernelGGL(stft_phase_kernel, dim3((unsigned)((int64_t)B * T)), dim3(256), 0,
                      (hipStream_t)stream, y, phasor, spec, mag_bct, T, hop, L);
   return dv3_check_launch("stft_phase");
+}
+
+extern "C" int dv3_gl_project_f32(const float* y, const float* mag, float* frames, int32_t B, int32_t T, int32_t hop,
+                                  void* stream) {
+  DV3_REQUIRE(y && mag && frames && B > 0 && T > 1 && hop > 0, "gl_project: bad arguments");
+  const int L = hop * (T - 1);
+  DV3_REQUIRE(L > 512, "gl_project: signal shorter than the reflect padding");
+  hipLaunchKernelGGL(gl_project_kernel, dim3((unsigned)((int64_t)B * T)), dim3(256), 0, (hipStream_t)stream, y, mag,
+                     frames, T, hop, L);
+  return dv3_check_launch("gl_project");
 }
 
 extern "C" int dv3_deemphasis_f32(float* y, int32_t B, int32_t L, float coef, void* stream) {

@@ -476,7 +476,7 @@ int dv3_attn_step_f32(const dv3_attn_step_desc* d, void* stream);
  *   phasor  [B][T][513][2]   unit complex phase estimate (re, im)
  *   frames  [B][T][1024]     windowed time-domain frames
  *   y       [B][L]
- * One Griffin-Lim iteration = istft_frames -> overlap_add -> stft_phase.
+ * One Griffin-Lim iteration = istft_frames -> overlap_add -> stft_phase, or fused: gl_project -> overlap_add.
  * ------------------------------------------------------------------------------------ */
 /* mag = (10^((clip(x,0,1)*(-min_db) + min_db + ref_db)/20))^power   audio.py:39-41,84-93 */
 int dv3_gl_prepare_f32(const float* lin, float* mag, int64_t n, float min_level_db,
@@ -485,6 +485,9 @@ int dv3_istft_frames_f32(const float* mag, const float* phasor /* NULL: zero pha
                          float* frames, int32_t B, int32_t T, void* stream);
 int dv3_overlap_add_f32(const float* frames, float* y, int32_t B, int32_t T, int32_t hop,
                         void* stream);
+/* one Griffin-Lim projection, fused: frames = istft_frames(mag, phase(stft(y))) without storing the phasors */
+int dv3_gl_project_f32(const float* y, const float* mag, float* frames, int32_t B, int32_t T, int32_t hop,
+                       void* stream);
 /* outputs (each may be NULL): phasor, spec = the complex STFT [B][T][513][2], mag_bct = |STFT|
  * as [B][513][T] (the channel-major operand of the mel filterbank GEMM)                     */
 int dv3_stft_phase_f32(const float* y, float* phasor, float* spec, float* mag_bct, int32_t B,
