@@ -31,9 +31,6 @@ class MultiSpeakerTTSModel(nn.Module):
                  use_decoder_state_for_postnet_input=False, speaker_embedding_weight_std=0.01,
                  freeze_embedding=False):
         nn.Module.__init__(self)
-        if trainable_positional_encodings:
-            raise NotImplementedError("trainable_positional_encodings=True is not supported by the HIP path "
-                                      "(no preset of the reference enables it)")
         self.seq2seq, self.postnet = seq2seq, postnet
         self.mel_dim, self.linear_dim = mel_dim, linear_dim
         self.n_speakers, self.speaker_embed_dim = n_speakers, speaker_embed_dim
@@ -58,7 +55,7 @@ class MultiSpeakerTTSModel(nn.Module):
         """Everything except the frozen sinusoid tables (and the text embedding when
         freeze_embedding is set), as a generator -- reference __init__.py:48-63."""
         dec, enc = self.seq2seq.decoder, self.seq2seq.encoder
-        frozen = [dec.embed_query_positions, dec.embed_keys_positions]
+        frozen = [] if self.trainable_positional_encodings else [dec.embed_query_positions, dec.embed_keys_positions]
         if self.freeze_embedding:
             frozen.append(enc.embed_tokens)
         skip = {id(p) for mod in frozen for p in mod.parameters()}

@@ -404,6 +404,35 @@ __global__ __launch_bounds__(256) void sincos_pos_bwd_kernel(const int64_t* __re
   if (threadIdx.x == 0) dw[b] = red[0] + red[1] + red[2] + red[3];
 }
 
+// dtable[p][c] = sum over the (b, t) with pos[b][t] == p of dout[b][c][t] * d enc / d table   (p >= 1; row 0 is the
+// padding row, F.embedding(padding_idx=0) gives it no gradient: modules.py:45-64 with trainable position tables).
+// One workgroup per table row, lanes over channels, a fixed (b, t) scan order: deterministic, no atomics.
+__global__ __launch_bounds__(256) void sincos_pos_table_bwd_kernel(const int64_t* __restrict__ pos,
+                                                                   const float* __restrict__ table,
+                                                                   const float* __restrict__ w, int w_per_batch,
+                                                                   const float* __restrict__ dout,
+                                                                   float* __restrict__ dtable, int B, int T, int C,
+                                                                   int n_pos, int apply_sincos) {
+  const int p = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    if (p > 0) {
+      const float a = table[(int64_t)p * C + c];
+      for (int b = 0; b < B; ++b) {
+        const float rate = w ? w[w_per_batch ? b : 0] : 1.0f;
+        float de = rate;
+        if (apply_sincos) de = (c & 1) ? -sinf(rate * a) * rate : cosf(rate * a) * rate;
+        for (int t = 0; t < T; ++t) {
+          int64_t q = pos[(int64_t)b * T + t];
+          q = q < 0 ? 0 : (q >= n_pos ? n_pos - 1 : q);
+          if (q == p) acc += dout[((int64_t)b * C + c) * T + t] * de;
+        }
+      }
+    }
+    dtable[(int64_t)p * C + c] = acc;
+  }
+}
+
 // Ragged -> padded rows of 32-bit words (the padding half of train.collate_fn, train.py:293-360, on the
 // device): one workgroup per output row.  HBM-bound byte mover: each output word is written once, each
 // source word read at most once, both coalesced along the row.
@@ -429,6 +458,15 @@ extern "C" int dv3_sincos_pos_bwd_f32(const int64_t* pos, const float* table, co
   hipLaunchKernelGGL(sincos_pos_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pos, table, w,
                      w_per_batch, dout, dw, T, C, n_pos);
   return dv3_check_launch("sincos_pos_bwd_f32");
+}
+
+extern "C" int dv3_sincos_pos_table_bwd_f32(const int64_t* pos, const float* table, const float* w, int32_t w_per_batch,
+                                            const float* dout, float* dtable, int32_t B, int32_t T, int32_t C,
+                                            int32_t n_pos, int32_t apply_sincos, void* stream) {
+  DV3_REQUIRE(pos && table && dout && dtable && B > 0 && T > 0 && C > 0 && n_pos > 0, "sincos_pos_table_bwd: bad args");
+  hipLaunchKernelGGL(sincos_pos_table_bwd_kernel, dim3(n_pos), dim3(256), 0, (hipStream_t)stream, pos, table, w,
+                     w_per_batch, dout, dtable, B, T, C, n_pos, apply_sincos);
+  return dv3_check_launch("sincos_pos_table_bwd_f32");
 }
 
 extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {

@@ -858,13 +858,24 @@ def sincos_pos_bct(pos, table, w=None, base=None, apply_sincos=True):
 
 
 class _PosEncFn(torch.autograd.Function):
-    """out = base + PE(pos; table, w).  Gradient flows to `base` (identity) and to the rate `w`
-    when it is a tensor (multi-speaker: deepvoice3.py:304-315); the table is frozen."""
+    """out = base + PE(pos; table, w).  Gradient flows to `base` (identity), to the rate `w` when it is a
+    tensor (multi-speaker: deepvoice3.py:304-315) and to the table when it is trainable
+    (trainable_positional_encodings=True; frozen in every preset)."""
 
     @staticmethod
     def forward(ctx, base, pos, table, w, apply_sincos):
         out = sincos_pos_bct(pos, table, w, base, apply_sincos)
         ctx.has_base = base is not None
+        ctx.table_grad = None
+        if table.requires_grad:
+            wt, per_batch = None, 0
+            if w is not None:
+                if torch.is_tensor(w):
+                    wt = _c(w.detach().float().view(-1))
+                    per_batch = 1 if wt.numel() > 1 else 0
+                else:
+                    wt = torch.full((1,), float(w), dtype=torch.float32, device=table.device)
+            ctx.table_grad = (_c(pos.long()), table.detach(), wt, per_batch, int(apply_sincos))
         if torch.is_tensor(w) and w.requires_grad:
             if not apply_sincos:
                 raise RuntimeError("a learnable rate needs the raw-angle table")
@@ -874,7 +885,14 @@ class _PosEncFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        dw = None
+        dw = dtable = None
+        if ctx.table_grad is not None and ctx.needs_input_grad[2]:
+            pos, table, wt, per_batch, apply = ctx.table_grad
+            dout_c = _c(dout)
+            B, C, T = dout_c.shape
+            dtable = torch.empty_like(table)
+            _lib.call("dv3_sincos_pos_table_bwd_f32", pos.data_ptr(), _c(table).data_ptr(), _ptr(wt), per_batch,
+                      dout_c.data_ptr(), dtable.data_ptr(), B, T, C, table.shape[0], apply, _stream())
         if ctx.needs_input_grad[3]:
             pos, table, w = ctx.saved_tensors
             dout_c = _c(dout)
@@ -885,7 +903,7 @@ class _PosEncFn(torch.autograd.Function):
             _lib.call("dv3_sincos_pos_bwd_f32", _c(pos.long()).data_ptr(), _c(table).data_ptr(), wt.data_ptr(),
                       per_batch, dout_c.data_ptr(), dwb.data_ptr(), B, T, C, table.shape[0], _stream())
             dw = (dwb if per_batch else dwb.sum(0, keepdim=True)).view(ctx.w_shape)
-        return (dout if ctx.has_base else None), None, None, dw, None
+        return (dout if ctx.has_base else None), None, dtable, dw, None
 
 
 def add_position_encoding(base, pos, table, w=None, apply_sincos=True):

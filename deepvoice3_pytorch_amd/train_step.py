@@ -25,7 +25,8 @@ class TrainConfig(object):
     """The hparams train.train() reads (hparams.py:96-121; presets/*.json)."""
 
     def __init__(self, outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5,
-                 binary_divergence_weight=0.1, priority_freq_weight=0.0, use_guided_attention=True,
+                 binary_divergence_weight=0.1, priority_freq_weight=0.0, priority_freq=3000, sample_rate=22050,
+                 use_guided_attention=True,
                  guided_attention_sigma=0.2, clip_thresh=0.1, adam_beta1=0.5, adam_beta2=0.9,
                  adam_eps=1e-6, weight_decay=0.0, initial_learning_rate=5e-4,
                  lr_schedule="noam_learning_rate_decay", lr_schedule_kwargs=None, max_positions=512):
@@ -33,8 +34,8 @@ class TrainConfig(object):
         self.downsample_step = downsample_step
         self.masked_loss_weight = masked_loss_weight
         self.binary_divergence_weight = binary_divergence_weight
-        if priority_freq_weight > 0:
-            raise NotImplementedError("priority_freq_weight > 0 (0 in every reference preset)")
+        # train.py:562-569,718-722: extra L1 weight on the bins below priority_freq (0 in every preset)
+        self.priority_freq_weight, self.priority_freq, self.sample_rate = priority_freq_weight, priority_freq, sample_rate
         self.use_guided_attention = use_guided_attention
         self.guided_attention_sigma = guided_attention_sigma
         self.clip_thresh = clip_thresh
@@ -255,11 +256,20 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
             ops.prepacked = None
         wm, w = c.masked_loss_weight, c.binary_divergence_weight
         m4 = ops.spec_loss(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w)
-        l4 = ops.spec_loss(lin_out, batch.y, batch.linear_mask_lengths if wm > 0 else None, r, wm, w)
+        lin_len = batch.linear_mask_lengths if wm > 0 else None
+        l4 = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, w)
+        lin_loss = l4[2]
+        if c.priority_freq_weight > 0:
+            # l1 := (1 - pw) * l1 + pw * l1(first n bins)   (train.py:562-569): two more passes of the fused loss
+            # kernel with the binary-divergence weight 0, whose third output IS the (masked) L1 and carries gradient
+            n_pri = int(c.priority_freq / (c.sample_rate * 0.5) * lin_out.size(-1))
+            l1_all = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, 0.0)[2]
+            l1_pri = ops.spec_loss(lin_out[:, :, :n_pri], batch.y[:, :, :n_pri], lin_len, r, wm, 0.0)[2]
+            lin_loss = lin_loss + (1.0 - w) * c.priority_freq_weight * (l1_pri - l1_all)
         done_loss = ops.bce_loss(done_hat, batch.done)
-        loss = m4[2] + l4[2] + done_loss[0]
+        loss = m4[2] + lin_loss + done_loss[0]
         scal = dict(mel_l1_loss=m4[0], mel_binary_div_loss=m4[1], mel_loss=m4[2], linear_l1_loss=l4[0],
-                    linear_binary_div_loss=l4[1], linear_loss=l4[2], done_loss=done_loss[0])
+                    linear_binary_div_loss=l4[1], linear_loss=lin_loss, done_loss=done_loss[0])
         if c.use_guided_attention:
             attn_loss = ops.guided_attention_loss(attn, batch.input_lengths, batch.decoder_lengths,
                                                   c.guided_attention_sigma)

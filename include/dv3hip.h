@@ -353,6 +353,11 @@ int dv3_sincos_pos_bct_f32(const int64_t* pos, const float* table, const float* 
                            int32_t w_per_batch, const float* base, float* out, int32_t B,
                            int32_t T, int32_t C, int32_t n_pos, int32_t apply_sincos,
                            void* stream);
+/* gradient w.r.t. the TABLE (trainable_positional_encodings=True, deepvoice3_pytorch/__init__.py:53-57): dtable
+ * [n_pos][C], row 0 (padding) zero; w NULL = rate 1; apply_sincos 0 = plain embedding rows (nyanko.py:162-169) */
+int dv3_sincos_pos_table_bwd_f32(const int64_t* pos, const float* table, const float* w, int32_t w_per_batch,
+                                 const float* dout, float* dtable, int32_t B, int32_t T, int32_t C,
+                                 int32_t n_pos, int32_t apply_sincos, void* stream);
 /* gradient of the encoding w.r.t. the rate: dw[b] = sum_{c,t} dout[b][c][t] * d enc/d w
  * (multi-speaker models learn the rate through speaker_proj1/2, deepvoice3.py:304-315).   */
 int dv3_sincos_pos_bwd_f32(const int64_t* pos, const float* table, const float* w,

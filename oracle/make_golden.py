@@ -187,6 +187,12 @@ def gen_losses():
         out[tag + "/bd"] = _np(bd.reshape(-1)[0])
         out[tag + "/grad"] = _np(yh.grad)
     out.update({"spec/y_hat": _np(y_hat), "spec/y": _np(y), "spec/lengths": _np(lengths)})
+    # priority-frequency L1 (train.py:562-569): first 3 of the 7 bins weighted 0.3
+    hparams.masked_loss_weight, hparams.binary_divergence_weight = 0.5, 0.1
+    yh = y_hat.clone().requires_grad_(True)
+    l1, bd = train.spec_loss(yh[:, :-r, :], y[:, r:, :], mask, priority_bin=3, priority_w=0.3)
+    ((1 - 0.1) * l1 + 0.1 * bd).sum().backward()
+    out.update({"spec_priority/l1": _np(l1), "spec_priority/bd": _np(bd.reshape(-1)[0]), "spec_priority/grad": _np(yh.grad)})
     hparams.masked_loss_weight = 0.5
     hparams.binary_divergence_weight = 0.1
     il, tl = np.array([9, 5, 7]), np.array([12, 8, 3])

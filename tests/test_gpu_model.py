@@ -584,3 +584,53 @@ def test_fast_decode_equals_module_by_module_decode(dev, name, gemm_mode):
         a = torch.stack(a) if isinstance(a, (list, tuple)) else a
         bb = torch.stack(bb) if isinstance(bb, (list, tuple)) else bb
         assert torch.equal(a, bb)
+
+
+@pytest.mark.gpu
+def test_priority_freq_weight_and_trainable_position_tables(dev, gemm_mode):
+    """the two options no preset enables but the reference supports: hparams.priority_freq_weight > 0 (train.py:562-569,
+    718-722) in the trainer's loss, and trainable_positional_encodings=True (deepvoice3_pytorch/__init__.py:53-57:
+    the position tables take gradient through sin / cos of rate * angle) -- loss terms and gradients against the oracle."""
+    from deepvoice3_pytorch_amd import builder, train_step
+    fx = load_golden("model_dv3_preset_like")
+    b, hp, sd, x = split_model_fixture(fx)
+    hp = dict(hp, trainable_positional_encodings=True, dropout=0.0)
+    model = getattr(builder, b)(**hp)
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    assert any(k.endswith("embed_query_positions.weight") for k, _ in
+               zip([n for n, p in model.named_parameters()], model.get_trainable_parameters()))
+    n_train = len(list(model.get_trainable_parameters()))
+    assert n_train == len(list(model.parameters()))          # nothing frozen now
+    cfg = train_step.TrainConfig(max_positions=hp.get("max_positions", 512), priority_freq_weight=0.3,
+                                 priority_freq=4000, sample_rate=22050)
+    trainer = train_step.Trainer(model, cfg)
+    xg = _to(x, dev)
+    B, Td = x["mel"].shape[0], x["mel"].shape[1]
+    rng = np.random.RandomState(2)
+    yl = torch.from_numpy(rng.rand(B, Td * 4, hp["linear_dim"]).astype(np.float32))
+    done = torch.zeros(B, Td, 1)
+    tgt = np.array([Td * 4 - 4, Td * 4 - 12, Td * 4 - 8][:B])
+    batch = train_step.Batch(xg["text"], xg["text_positions"], xg["frame_positions"], xg["mel"], yl.to(dev),
+                             done.to(dev), x["input_lengths"].numpy(), tgt, None, 1, 4, dev)
+    trainer.arena.grad.zero_()
+    scal = {k: float(v) for k, v in trainer.forward_backward(batch).items()}
+    spec = O.build_spec(b, **hp)
+    sdc = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    out = O.model_forward(sdc, spec, x["text"], x["mel"], None, x["text_positions"], x["frame_positions"],
+                          x["input_lengths"].numpy())
+    lhp = dict(outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5, binary_divergence_weight=0.1,
+               use_guided_attention=True, guided_attention_sigma=0.2, priority_freq_weight=0.3, priority_freq=4000,
+               sample_rate=22050)
+    loss, parts = O.train_losses(spec, lhp, out, x["mel"], yl, done, x["input_lengths"].numpy(), tgt)
+    loss.backward()
+    assert abs(scal["loss"] - float(loss)) < 1e-4 * float(loss)
+    assert abs(scal["linear_loss"] - float(parts["lin_loss"])) < 1e-4 * float(parts["lin_loss"])
+    scale = max(float(v.grad.abs().max()) for v in sdc.values() if v.grad is not None)
+    for k, p in model.named_parameters():
+        gc = sdc[k].grad
+        if gc is None or float(gc.abs().max()) < 1e-5 * scale:
+            continue
+        assert rel_err(p.grad.cpu(), gc) < 5e-4, k
+    for k in ("seq2seq.decoder.embed_query_positions.weight", "seq2seq.decoder.embed_keys_positions.weight"):
+        assert float(sdc[k].grad.abs().max()) > 0 and float(dict(model.named_parameters())[k].grad[0].abs().max()) == 0.0
