@@ -217,7 +217,8 @@ def wgrad_roofline(dev, iters=50, mode=None):
     bits, rs = ops.dropout_bits(B * C, T, 0.05, dev)
     x3 = mode != "f32"
     tiles = ((2 * C + 127) // 128) * ((C + 127) // 128) * k
-    S = ops._ksplit_count(B * ((T + 31) // 32), tiles) if x3 else ops._slab_count(B, tiles)
+    # as ops.ConvLayerFn.backward sizes it: one 8-wave workgroup per (tile, slab) serves the three taps
+    S = ops._ksplit_count(B * ((T + 31) // 32), tiles // k, slots=256) if x3 else ops._slab_count(B, tiles)
     out_t = torch.empty((S, k, 2 * C, C), dtype=torch.float32, device=dev)
 
     def launch():

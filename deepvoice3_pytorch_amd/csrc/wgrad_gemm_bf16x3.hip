@@ -305,9 +305,208 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// All taps in one workgroup (JT = 3, the models' kernel size): the per-tap form above runs J workgroups per tile that
+// each fetch, split and store the SAME g panel; here the g panel is staged once per K step and serves the three
+// shifted x panels.  8 waves: wave (wm, wc) owns 64 gradient rows x 32 input channels for all three taps, so its four g
+// fragments feed 18 MFMAs per k16 block (10 fragment reads per 18 MFMAs instead of 8 per 12) and a workgroup stages
+// 2048 units per 288 MFMAs instead of 3 x 1024.  Same arithmetic and accumulation order per output element (one tap's
+// products in K order), same slab output, so the two forms agree bit for bit.
+template <bool MASK, int TERMS>
+__global__ __launch_bounds__(512, 2) void wgrad_taps_kernel(const WgradArgs args) {
+  constexpr int JT = 3, BM = 128, BN = 128, NT = 512;
+  constexpr int LDM = BM + PAD, LDN = BN + PAD;
+  constexpr int GBUF = 2 * KB * LDM, XTAP = 2 * KB * LDN, BUF = GBUF + JT * XTAP;
+  const dv3_wgrad_desc& p = args.d;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_t[];
+  bf16x8* const smem = reinterpret_cast<bf16x8*>(smem_raw_t);       // [2 buffers][G hi, G lo | 3 x (X hi, X lo)]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wc = wave & 3;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  int pid = dv3_xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = pid % args.m_tiles; pid /= args.m_tiles;
+  const int ct = pid % args.c_tiles;
+  const int s = pid / args.c_tiles;
+  const int m0 = mt * BM, c0 = ct * BN;
+  const int T = p.T, Tin = p.Tin, M = p.M, Cin = p.Cin;
+
+  // this thread's staging unit: (row, k8) -- the same for the g panel and the three x panels
+  const int urow = tid >> 2, uk8 = tid & 3;
+  float rg[1][8], rx[1][JT][8];      // one register set: the next step's operands are fetched before this step's MFMAs
+  uint32_t gval[1], xval[1][JT];
+  const int n_tc = (T + BKT - 1) / BKT;
+  int nsteps, step0 = 0;
+  {
+    const int total = p.B * n_tc, q = (total + p.n_slabs - 1) / p.n_slabs;
+    step0 = s * q;
+    nsteps = max(0, min(q, total - step0));
+  }
+  const int g_total = (p.B - 1) * (int)p.g_bs + (M - 1) * (int)p.g_rs + T;
+  const int x_total = (p.B - 1) * (int)p.x_bs + (Cin - 1) * (int)p.x_rs + Tin;
+  const int wl = (Tin + 31) / 32 - 1;
+  const int gm = m0 + urow, xc = c0 + urow;
+  const bool grow_ok = gm < M, xrow_ok = xc < Cin;
+  const int grow_off = (grow_ok ? gm : M - 1) * (int)p.g_rs + uk8 * 8;
+  const int xcc = xrow_ok ? xc : Cin - 1;
+  const int xrow_off = xcc * (int)p.x_rs + uk8 * 8;
+  const int xm_off = xcc * p.xmask_rs;
+
+  auto load_step = [&](int step, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
+    const int gs = step0 + step;
+    const int b = gs / n_tc, tc = gs - b * n_tc;
+    const int t0 = tc * BKT;
+    const int gb = b * (int)p.g_bs + t0, xb = b * (int)p.x_bs + t0;
+    load8_raw(p.g, gb + grow_off, g_total, rg[S]);
+    uint32_t vm = 0xffu;
+    if (t0 + BKT > T) vm = valid8(t0 + uk8 * 8, T);
+    gval[S] = grow_ok ? vm : 0u;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const int shift = j * p.dil - p.padL;
+      const bool x_edge = t0 + shift < 0 || t0 + BKT + shift > Tin;
+      load8_raw(p.x, xb + xrow_off + shift, x_total, rx[S][j]);
+      const int tx = t0 + uk8 * 8 + shift;
+      uint32_t xm = 0xffu;
+      if (x_edge) xm = valid8(tx, Tin);
+      if (!xrow_ok) xm = 0u;
+      if (MASK) {
+        const uint32_t mo = (uint32_t)(b * Cin * p.xmask_rs + xm_off);
+        const int txc = max(tx, 0);
+        const int w0 = min(txc >> 5, wl);
+        const uint32_t lo = ldg_off<uint32_t>(p.xmask, (mo + (uint32_t)w0) * 4u);
+        const uint32_t hi = ldg_off<uint32_t>(p.xmask, (mo + (uint32_t)min(w0 + 1, wl)) * 4u);
+        uint32_t bits = __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(txc & 31));
+        if (x_edge && tx < 0) bits = (-tx < 32) ? bits << (-tx) : 0u;
+        xm &= bits;
+      }
+      xval[S][j] = xm;
+    }
+  };
+  auto write_step = [&](int buf, auto set_c) {
+    constexpr int S = decltype(set_c)::value;
+    bf16x8* dst = smem + buf * BUF;
+    {
+      if (__any((gval[S] & 0xffu) != 0xffu)) mask8(rg[S], gval[S]);
+      bf16x8 hi, lo;
+      split8(rg[S], hi, lo);
+      const int o = uk8 * LDM + urow;
+      dst[o] = hi;
+      if (TERMS == 3) dst[KB * LDM + o] = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      bf16x8* dx = dst + GBUF + j * XTAP;
+      if (MASK || __any((xval[S][j] & 0xffu) != 0xffu)) mask8(rx[S][j], xval[S][j]);
+      bf16x8 hi, lo;
+      split8(rx[S][j], hi, lo);
+      const int o = uk8 * LDN + urow;
+      dx[o] = hi;
+      if (TERMS == 3) dx[KB * LDN + o] = lo;
+    }
+  };
+
+  f32x16 acc[JT][2];
+#pragma unroll
+  for (int j = 0; j < JT; ++j)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][a][r] = 0.f;
+
+  auto mfma_step = [&](int cur) {
+    const bf16x8* GsH = smem + cur * BUF;
+    const bf16x8* GsL = GsH + KB * LDM;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int k8 = 2 * ks + lhi;
+      const int ai = k8 * LDM + wm * 64 + l31;
+      const bf16x8 ah0 = GsH[ai], ah1 = GsH[ai + 32];
+      bf16x8 al0 = ah0, al1 = ah1;
+      if (TERMS == 3) { al0 = GsL[ai]; al1 = GsL[ai + 32]; }
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        const bf16x8* XsH = GsH + GBUF + j * XTAP;
+        const int xi = k8 * LDN + wc * 32 + l31;
+        const bf16x8 bh = XsH[xi];
+        if (TERMS == 1) {
+          acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[j][0], 0, 0, 0);
+          acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[j][1], 0, 0, 0);
+          continue;
+        }
+        const bf16x8 bl = XsH[KB * LDN + xi];
+        acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, acc[j][0], 0, 0, 0);
+        acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc[j][1], 0, 0, 0);
+        acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, acc[j][0], 0, 0, 0);
+        acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc[j][1], 0, 0, 0);
+        acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[j][0], 0, 0, 0);
+        acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[j][1], 0, 0, 0);
+      }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+
+  if (nsteps > 0) {
+    load_step(0, S0{});
+    write_step(0, S0{});
+  }
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    if (step + 1 < nsteps) load_step(step + 1, S0{});
+    mfma_step(step & 1);
+    if (step + 1 < nsteps) write_step((step + 1) & 1, S0{});
+    __syncthreads();
+  }
+
+  const float oscale = MASK ? p.drop_scale : 1.0f;
+  const int c = c0 + wc * 32 + l31;
+  if (c < Cin) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      float* __restrict__ ob = p.out + (int64_t)s * p.out_ss + (int64_t)j * M * p.ldo;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (m < M) ob[(int64_t)m * p.ldo + c] = acc[j][mi][r] * oscale;
+        }
+    }
+  }
+}
+
 }  // namespace
 
-int g_wgrad_tile = 0;   // debug (dv3_debug_set(2, v)): 0 auto, 1 force 128x128, 2 force 256x128
+int g_wgrad_taps_default = 1;   // the all-taps form measured 7-14 % faster at every model shape (scripts/wgrad_ab.py)
+int g_wgrad_tile = 0;   // debug (dv3_debug_set(2, v)): 0 auto, 1 force 128x128 per tap, 2 force 256x128 per tap, 3 force all-taps
+
+template <bool MASK, int TERMS>
+static int launch_wgrad_taps_t(const WgradArgs& a, int64_t nb, hipStream_t st) {
+  constexpr int LDM = 128 + PAD;
+  constexpr size_t lds = (size_t)2 * (2 * KB * LDM + 3 * 2 * KB * LDM) * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_taps_kernel<MASK, TERMS>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      dv3_set_error("wgrad_taps: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DV3_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_taps_kernel<MASK, TERMS>), dim3((unsigned)nb), dim3(512), lds, st, a);
+  return dv3_check_launch("wgrad_taps");
+}
+static int launch_wgrad_taps(const WgradArgs& a, int64_t nb, hipStream_t st) {
+  const dv3_wgrad_desc* d = &a.d;
+  if (d->split_bf16 == 2)
+    return d->xmask ? launch_wgrad_taps_t<true, 1>(a, nb, st) : launch_wgrad_taps_t<false, 1>(a, nb, st);
+  return d->xmask ? launch_wgrad_taps_t<true, 3>(a, nb, st) : launch_wgrad_taps_t<false, 3>(a, nb, st);
+}
 
 template <int WM, int WN>
 static int launch_wgrad_x3(const WgradArgs& a, int64_t nb, hipStream_t st) {
@@ -336,6 +535,15 @@ int dv3_wgrad_gemm_bf16x3_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
     return 1;   // caller falls back to the exact kernel
   WgradArgs a;
   a.d = *d;
+  // three taps, K split over contiguous ranges: one 8-wave workgroup per (m-tile, c-tile, slab) serves all taps
+  if (d->J == 3 && d->k_split && (g_wgrad_tile == 3 || (g_wgrad_tile == 0 && g_wgrad_taps_default))) {
+    a.m_tiles = dv3_cdiv(d->M, 128);
+    a.c_tiles = dv3_cdiv(d->Cin, 128);
+    const int64_t nb = (int64_t)a.m_tiles * a.c_tiles * d->n_slabs;
+    DV3_REQUIRE(nb < (1ll << 31), "wgrad_gemm: grid too large");
+    g_dv3_last_wgrad = (d->split_bf16 == 2 ? 4000 : 3000) + 30;
+    return launch_wgrad_taps(a, nb, st);
+  }
   // 128 x 128 (4 waves, two workgroups per CU).  The 256 x 128 8-wave variant (one workgroup per CU)
   // measured within run-to-run noise of it (+-5 %, scripts/x3_check.py): kept behind the debug knob.
   const bool big = g_wgrad_tile == 2;

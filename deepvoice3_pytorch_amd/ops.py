@@ -661,7 +661,10 @@ class ConvLayerFn(torch.autograd.Function):
             Jd = 1 if cfg.transposed else J
             tiles = ((Mg + 127) // 128) * ((Cin + 127) // 128) * Jd
             x3 = _gemm_mode != "f32" and not (Mg <= 64 and Cin <= 64)
-            if x3:   # split-K over contiguous (batch, chunk) ranges: size the grid to 2 workgroups per CU
+            if x3 and Jd == 3 and _os.environ.get("DV3_WGRAD_TILE", "0") in ("0", "3"):
+                # one 8-wave workgroup per (tile, slab) serves the three taps: one workgroup per CU
+                S = _ksplit_count(B * ((Tg + 31) // 32), tiles // 3, slots=256)
+            elif x3:   # split-K over contiguous (batch, chunk) ranges: size the grid to 2 workgroups per CU
                 S = _ksplit_count(B * ((Tg + 31) // 32), tiles)
             else:
                 S = _slab_count(B, tiles)
