@@ -30,21 +30,40 @@ __device__ __forceinline__ void dv3_st(void* base, uint32_t byte_off, float v) {
 // the straightforward 64-bit form made this fully unrolled tail ~10k instructions -- more than
 // the instruction cache, i.e. a fixed ~40 us of fetch stalls per launch at the north-star shape.
 // ABL: measurement variants (dv3_debug_set): 7 = no residual load, 8 = no store.
-template <int BM, int BMH, int NI, int ABL = 0>
+// bf16 storage (IOB instantiations = the single-term bf16 kernels): activations may be bf16 tensors; loads widen
+// exactly, stores round to nearest even.  The flags are wave-uniform.
+__device__ __forceinline__ float dv3_ld_act(const void* base, uint32_t byte_off, bool bf) {
+  if (bf) return __uint_as_float((uint32_t)dv3_ld<uint16_t>(base, byte_off) << 16);
+  return dv3_ld<float>(base, byte_off);
+}
+__device__ __forceinline__ void dv3_st_act(void* base, uint32_t byte_off, float v, bool bf) {
+  if (bf) {
+    const __bf16 h = (__bf16)v;
+    *reinterpret_cast<__bf16*>(reinterpret_cast<char*>(base) + byte_off) = h;
+  } else {
+    dv3_st(base, byte_off, v);
+  }
+}
+
+template <int BM, int BMH, int NI, int ABL = 0, bool IOB = false>
 __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], bool gated,
                                               int mt, int row0, int lhi, const int (&bcol)[NI],
                                               const int (&tcol)[NI], const bool (&okc)[NI]) {
   const float dscale = p.drop_scale;
   const uint32_t Tout = (uint32_t)p.Tout, M = (uint32_t)p.M, Cg = (uint32_t)p.Cg;
   const float rs2 = 0.70710678118654752440f;
-  const uint32_t y_rs = (uint32_t)p.y_rs * 4u, r_rs = (uint32_t)p.r_rs * 4u, r2_rs = (uint32_t)p.r2_rs * 4u;
+  const bool inb = IOB && (p.io_bf16 & DV3_IO_IN_BF16), outb = IOB && (p.io_bf16 & DV3_IO_OUT_BF16);
+  const bool abb16 = outb || (IOB && (p.io_bf16 & DV3_IO_AB_BF16));
+  const uint32_t isz = inb ? 2u : 4u, osz = outb ? 2u : 4u;      // element sizes of the r / r2 and y tensors
+  const uint32_t absz = abb16 ? 2u : 4u;                          // ... and of the saved pre-gate pair
+  const uint32_t y_rs = (uint32_t)p.y_rs * osz, r_rs = (uint32_t)p.r_rs * isz, r2_rs = (uint32_t)p.r2_rs * isz;
   const bool il2 = p.store_mode == DV3_STORE_INTERLEAVE2;
   uint32_t yb[NI], rb[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const uint32_t b = (uint32_t)bcol[ni], t = (uint32_t)tcol[ni];
-    yb[ni] = (b * (uint32_t)p.y_bs + (il2 ? 2u * t : t)) * 4u;
-    rb[ni] = (b * (uint32_t)p.r_bs + t) * 4u;
+    yb[ni] = (b * (uint32_t)p.y_bs + (il2 ? 2u * t : t)) * osz;
+    rb[ni] = (b * (uint32_t)p.r_bs + t) * isz;
   }
   // Loads are issued as one batch per 32x(NI*32) half (clamped to valid addresses so they need no
   // predicate) and only then consumed: a load -> use -> store chain per element would serialise
@@ -58,7 +77,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const uint32_t b = (uint32_t)bcol[ni], t = (uint32_t)tcol[ni];
-      abb[ni] = (b * M * Tout + t) * 4u;
+      abb[ni] = (b * M * Tout + t) * absz;
       sb[ni] = (b * (uint32_t)p.spk_bs + t * (uint32_t)p.spk_ts) * 4u;
       rbc[ni] = okc[ni] ? rb[ni] : 0u;
     }
@@ -75,7 +94,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        xr[r][ni] = (has_r && ABL != 7) ? dv3_ld<float>(p.r, rbc[ni] + chc * r_rs) : 0.f;
+        xr[r][ni] = (has_r && ABL != 7) ? dv3_ld_act(p.r, rbc[ni] + chc * r_rs, inb) : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -88,14 +107,14 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
         const float g = acc[1][ni][r] + bg[r];
         if (p.spk) a += dv3_ld<float>(p.spk, sb[ni] + ch * spk_rs);
         if (p.ab) {
-          const uint32_t o = abb[ni] + ch * Tout * 4u;
-          dv3_st(p.ab, o, a);
-          dv3_st(p.ab, o + Cg * Tout * 4u, g);
+          const uint32_t o = abb[ni] + ch * Tout * absz;
+          dv3_st_act(p.ab, o, a, abb16);
+          dv3_st_act(p.ab, o + Cg * Tout * absz, g, abb16);
         }
         const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
         // GLU: (a*s [+ x]) * (sqrt(.5) | 1)      HIGHWAY: s*a + (1-s)*x
         const float y = glu ? (a * s + xr[r][ni]) * oscale : s * a + (1.0f - s) * xr[r][ni];
-        if (ABL != 8 || y == 1.2345e30f) dv3_st(p.y, yb[ni] + ch * y_rs, y);
+        if (ABL != 8 || y == 1.2345e30f) dv3_st_act(p.y, yb[ni] + ch * y_rs, y, outb);
       }
     }
     return;
@@ -120,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           wv[r][ni] = p.ymask ? dv3_ld<uint32_t>(p.ymask, ymb[ni] + mc * ym_rs) : 0xffffffffu;
-          rv[r][ni] = p.r ? dv3_ld<float>(p.r, rbc[ni] + mc * r_rs) : 0.f;
+          rv[r][ni] = p.r ? dv3_ld_act(p.r, rbc[ni] + mc * r_rs, inb) : 0.f;
         }
       }
 #pragma unroll
@@ -131,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
           if (!okc[ni]) continue;
           float v = acc[h][ni][r];
           if (p.ymask) v = ((wv[r][ni] >> (tcol[ni] & 31)) & 1u) ? v * dscale : 0.f;
-          dv3_st(p.y, yb[ni] + mv[r] * y_rs, v + rsc * rv[r][ni]);
+          dv3_st_act(p.y, yb[ni] + mv[r] * y_rs, v + rsc * rv[r][ni], outb);
         }
       }
     }
@@ -141,7 +160,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
   uint32_t r2b[NI], rbc[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    r2b[ni] = okc[ni] ? ((uint32_t)bcol[ni] * (uint32_t)p.r2_bs + (uint32_t)tcol[ni]) * 4u : 0u;
+    r2b[ni] = okc[ni] ? ((uint32_t)bcol[ni] * (uint32_t)p.r2_bs + (uint32_t)tcol[ni]) * isz : 0u;
     rbc[ni] = okc[ni] ? rb[ni] : 0u;
   }
   const uint32_t Mo = M >> 1;
@@ -158,8 +177,8 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
       bv[r] = p.bias ? p.bias[mo] : 0.f;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        rv[r][ni] = p.r ? dv3_ld<float>(p.r, rbc[ni] + mc * r_rs) : 0.f;
-        r2v[r][ni] = p.r2 ? dv3_ld<float>(p.r2, r2b[ni] + mc * r2_rs) : 0.f;
+        rv[r][ni] = p.r ? dv3_ld_act(p.r, rbc[ni] + mc * r_rs, inb) : 0.f;
+        r2v[r][ni] = p.r2 ? dv3_ld_act(p.r2, r2b[ni] + mc * r2_rs, inb) : 0.f;
       }
     }
 #pragma unroll
@@ -177,7 +196,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
         else if (mode == DV3_EPI_SOFTSIGN) v = v * __builtin_amdgcn_rcpf(1.0f + fabsf(v));
         if (p.r) v = (v + rv[r][ni]) * rs2;
         if (p.r2) v = (v + r2v[r][ni]) * rs2;
-        dv3_st(p.y, yb[ni] + mo * y_rs + odd, v);
+        dv3_st_act(p.y, yb[ni] + mo * y_rs + (odd ? osz : 0u), v, outb);
       }
     }
   }

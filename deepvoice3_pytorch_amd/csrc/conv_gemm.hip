@@ -334,6 +334,8 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
   if (d->ymask) DV3_REQUIRE(d->ymask_rs * 32 >= d->Tout, "conv_gemm: ymask row stride too small");
 
   DV3_REQUIRE(dv3_conv_fits32(d), "conv_gemm: a tensor exceeds the 4 GB the epilogue can address");
+  DV3_REQUIRE(d->io_bf16 == 0 || (d->a_split && d->split_terms == 1 && (d->tile_hint == 0 || d->tile_hint > 20)),
+              "conv_gemm: bf16 activation storage is served by the single-term bf16 kernels only");
   // both operands pre-split: the persistent planes kernel.  No silent fallback: the planes carry the dropout
   // mask of the consuming layer, which the other kernels would have to be handed separately.
   if (d->x_planes) {
@@ -349,6 +351,8 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
     const int rc = dv3_conv_gemm_bf16x3_dispatch(d, (hipStream_t)stream);
     if (rc != 1) return rc;
   }
+  DV3_REQUIRE(d->io_bf16 == 0, "conv_gemm: shape not eligible for the split kernels, which alone take bf16 activations "
+                               "(Tin == Tout, (J-1)*dil <= 64, no per-batch operand)");
   DV3_REQUIRE(d->tile_hint <= 20, "conv_gemm: tile_hint %d needs split-bf16 operands", d->tile_hint);
   DV3_REQUIRE(d->a, "conv_gemm: shape not eligible for the split-bf16 kernel and no fp32 operand image given");
   const int rows_half = gated ? d->Cg : 0;

@@ -169,7 +169,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   int xsh[MASK ? XI : 1];           // bit position t & 31
   int xk8[XI];
   const int n_items = KB * BNH;
-  const uint32_t x_rsb = (uint32_t)p.x_rs * 4u, m_rsb = (uint32_t)p.xmask_rs * 4u;
+  // bf16 storage (single-term kernels): x may be a bf16 tensor -- half the bytes, widened exactly while staging
+  const bool xbf = (TERMS == 1) && (p.io_bf16 & DV3_IO_IN_BF16);
+  const uint32_t xsz = xbf ? 2u : 4u;
+  const uint32_t x_rsb = (uint32_t)p.x_rs * xsz, m_rsb = (uint32_t)p.xmask_rs * 4u;
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
     const int idx = tid + i * NT;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
       tf = f - bf * T;
     }
     xk8[i] = k8 < KB ? k8 * 8 : 0;
-    xoff[i] = ((uint32_t)bf * (uint32_t)p.x_bs + (uint32_t)tf) * 4u + (uint32_t)xk8[i] * x_rsb;
+    xoff[i] = ((uint32_t)bf * (uint32_t)p.x_bs + (uint32_t)tf) * xsz + (uint32_t)xk8[i] * x_rsb;
     if (MASK) {
       xmo[i] = ((uint32_t)(bf * Cin) * (uint32_t)p.xmask_rs + (uint32_t)(tf >> 5)) * 4u + (uint32_t)xk8[i] * m_rsb;
       xsh[i] = tf & 31;
@@ -229,12 +232,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
       // per item -> every load is the SGPR-base form with no address arithmetic
       const char* xb = reinterpret_cast<const char*>(p.x) + (int64_t)c0 * x_rsb;
       const char* mb = reinterpret_cast<const char*>(xmask) + (int64_t)c0 * m_rsb;
+      if (TERMS == 1 && xbf) {      // bf16 tensor: one 2-byte load per element, widened exactly (uniform branch, hoisted)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 8; ++e) {
 #pragma unroll
-        for (int i = 0; i < XI; ++i) {
-          rx[i][e] = ldg_off<float>(xb + (int64_t)e * x_rsb, xoff[i]);
-          if (MASK) rm[i][e] = ldg_off<uint32_t>(mb + (int64_t)e * m_rsb, xmo[i]);
+          for (int i = 0; i < XI; ++i) {
+            rx[i][e] = __uint_as_float((uint32_t)ldg_off<uint16_t>(xb + (int64_t)e * x_rsb, xoff[i]) << 16);
+            if (MASK) rm[i][e] = ldg_off<uint32_t>(mb + (int64_t)e * m_rsb, xmo[i]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+          for (int i = 0; i < XI; ++i) {
+            rx[i][e] = ldg_off<float>(xb + (int64_t)e * x_rsb, xoff[i]);
+            if (MASK) rm[i][e] = ldg_off<uint32_t>(mb + (int64_t)e * m_rsb, xmo[i]);
+          }
         }
       }
     } else {
@@ -246,7 +260,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         for (int e = 0; e < 8; ++e) {
           // row relative to this item's k8 block (mod 2^32: may be "negative" when Cin < k8*8)
           const uint32_t dc = (uint32_t)(min(c0 + xk8[i] + e, Cin - 1) - xk8[i]);
-          rx[i][e] = ldg_off<float>(p.x, xoff[i] + dc * x_rsb);
+          rx[i][e] = xbf ? __uint_as_float((uint32_t)ldg_off<uint16_t>(p.x, xoff[i] + dc * x_rsb) << 16)
+                         : ldg_off<float>(p.x, xoff[i] + dc * x_rsb);
           if (MASK) rm[i][e] = ldg_off<uint32_t>(xmask, xmo[MASK ? i : 0] + dc * m_rsb);
         }
       }
@@ -540,9 +555,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
       bcol[ni] = n / T;
       tcol[ni] = n - bcol[ni] * T;
     }
-    conv_epilogue<BM, BMH, NI, ABL>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+    conv_epilogue<BM, BMH, NI, ABL, TERMS == 1>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
     if (MI == 2)
-      conv_epilogue<BM, BMH, NI, ABL>(p, acc[MI - 1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+      conv_epilogue<BM, BMH, NI, ABL, TERMS == 1>(p, acc[MI - 1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
   }
   stamp();                         // last slot: epilogue stores issued
 }

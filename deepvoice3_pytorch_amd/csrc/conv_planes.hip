@@ -415,7 +415,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_planes_kernel(const ConvA
         tcol[ni] = n - bcol[ni] * T;
       }
       if ((ABL != 4 && ABL != 8) || acc[0][0][0] + acc[1][NI - 1][7] == 1.2345e30f)
-        conv_epilogue<BM, BMH, NI, 0>(p, acc, gated, mt, wm * 32, lhi, bcol, tcol, okc);
+        conv_epilogue<BM, BMH, NI, 0, TERMS == 1>(p, acc, gated, mt, wm * 32, lhi, bcol, tcol, okc);
     }
     if (!has_next) break;
     tile = next;

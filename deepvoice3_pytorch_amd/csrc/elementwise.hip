@@ -22,6 +22,10 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
   if (p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY) {
     const float* a = p.ab_or_y + ((int64_t)b * 2 * C + ch) * T;
     const float* g = a + (int64_t)C * T;
+    // bf16 pre-gate save: the same element offsets in a 2-byte tensor
+    const uint16_t* a16 = reinterpret_cast<const uint16_t*>(p.ab_or_y) + ((int64_t)b * 2 * C + ch) * T;
+    const uint16_t* g16 = a16 + (int64_t)C * T;
+    const bool ab16 = p.ab_bf16 != 0;
     float* da = p.dab + ((int64_t)b * 2 * C + ch) * T;
     float* dg = da + (int64_t)C * T;
     const float k = (p.mode == DV3_EPI_GLU && p.residual) ? 0.70710678118654752440f : 1.0f;
@@ -51,7 +55,16 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
       f32x4* dg4 = reinterpret_cast<f32x4*>(dg);
       f32x4* dres4 = reinterpret_cast<f32x4*>(dres);
       for (int q = lane; q < (T >> 2); q += 64) {
-        const f32x4 dv = dy4[q], av = a4[q], gv = g4[q];
+        const f32x4 dv = dy4[q];
+        f32x4 av, gv;
+        if (ab16) {         // 4 bf16 = 8 bytes per lane and operand
+          const uint2 ua = reinterpret_cast<const uint2*>(a16)[q], ug = reinterpret_cast<const uint2*>(g16)[q];
+          av = f32x4{__uint_as_float(ua.x << 16), __uint_as_float(ua.x & 0xffff0000u), __uint_as_float(ua.y << 16), __uint_as_float(ua.y & 0xffff0000u)};
+          gv = f32x4{__uint_as_float(ug.x << 16), __uint_as_float(ug.x & 0xffff0000u), __uint_as_float(ug.y << 16), __uint_as_float(ug.y & 0xffff0000u)};
+        } else {
+          av = a4[q];
+          gv = g4[q];
+        }
         f32x4 xv = {0.f, 0.f, 0.f, 0.f};
         if (!glu) xv = x4[q];
         f32x4 oa, og, orr;
@@ -70,7 +83,9 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
     } else {
       for (int t = lane; t < T; t += 64) {
         float va, vg, vr;
-        elem(dy[t], a[t], g[t], glu ? 0.f : x[t], va, vg, vr);
+        const float at = ab16 ? __uint_as_float((uint32_t)a16[t] << 16) : a[t];
+        const float gt = ab16 ? __uint_as_float((uint32_t)g16[t] << 16) : g[t];
+        elem(dy[t], at, gt, glu ? 0.f : x[t], va, vg, vr);
         if (dres) dres[t] = vr;
         da[t] = va;
         dg[t] = vg;
@@ -483,6 +498,7 @@ extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
   const int64_t rows = (int64_t)d->B * d->C;
   // 16 bytes per lane when every row starts 16-byte aligned (gated modes; the others are small)
   const uintptr_t ptrs = (uintptr_t)d->dy | (uintptr_t)d->ab_or_y | (uintptr_t)d->dab | (uintptr_t)d->x | (uintptr_t)d->dres;
+  DV3_REQUIRE(!d->ab_bf16 || gated, "gate_bwd: ab_bf16 is for the gated modes");
   if (gated && (d->T & 3) == 0 && (ptrs & 15) == 0)
     hipLaunchKernelGGL(gate_bwd_kernel<true>, dim3((unsigned)dv3_cdiv64(rows, 4)), dim3(256), 0,
                        (hipStream_t)stream, *d);

@@ -337,14 +337,26 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
               Cg=0, bias=None, spk=None, spk_strides=(0, 0, 0), r=None, r2=None, residual=0,
               y=None, y_rs=None, ab=None, xmask=None, xmask_rs=0, ymask=None, ymask_rs=0,
               drop_scale=1.0, a_bs=0, store_mode=STORE_BCT, x_bs=None, x_rs=None, tile_hint=0,
-              a_split=None, x_planes=None, r_scale=0.0):
+              a_split=None, x_planes=None, r_scale=0.0, out_dtype=torch.float32):
     """dv3_conv_gemm_f32.  x: [B][Cin][Tin] (strides overridable); returns y.  x_planes: the input already
     split into operand planes (split_planes; x may then be None)."""
     gated = mode in (EPI_GLU, EPI_HIGHWAY)
     Cout = Cg if gated else (M // 2 if store_mode == STORE_INTERLEAVE2 else M)
     To = 2 * Tout if store_mode == STORE_INTERLEAVE2 else Tout
+    # bf16 storage (single-term bf16 kernels): x / r / r2 may be bf16 tensors (all three alike), y / ab are written in
+    # out_dtype
+    in_bf16 = x is not None and x.dtype == torch.bfloat16
+    for t_ in (r, r2):
+        if t_ is not None and (t_.dtype == torch.bfloat16) != in_bf16:
+            raise RuntimeError("conv_gemm: x, r and r2 must share one dtype")
+    if y is not None:
+        out_dtype = y.dtype
+    out_bf16 = out_dtype == torch.bfloat16
+    ab_bf16 = ab is not None and ab.dtype == torch.bfloat16
+    if ab is not None and out_bf16 and not ab_bf16:
+        raise RuntimeError("conv_gemm: a bf16 output needs a bf16 pre-gate save")
     if y is None:
-        y = torch.empty((B, Cout, To), dtype=torch.float32, device=(x if x is not None else x_planes).device)
+        y = torch.empty((B, Cout, To), dtype=out_dtype, device=(x if x is not None else x_planes).device)
         y_bs, y_rs_ = Cout * To, To
     else:
         y_rs_ = y_rs if y_rs is not None else y.stride(1)
@@ -373,6 +385,8 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
     d.ymask, d.ymask_rs = _ptr(ymask), ymask_rs
     d.drop_scale = drop_scale
     d.r_scale = r_scale
+    d.io_bf16 = (CONSTS["DV3_IO_IN_BF16"] if in_bf16 else 0) | (CONSTS["DV3_IO_OUT_BF16"] if out_bf16 else 0) | \
+        (CONSTS["DV3_IO_AB_BF16"] if (ab_bf16 and not out_bf16) else 0)
     d.B, d.Cin, d.Tin, d.M, d.Cg, d.Tout, d.J, d.dil, d.padL = B, Cin, Tin, M, Cg, Tout, J, dil, padL
     d.mode, d.residual, d.store_mode, d.tile_hint = mode, residual, store_mode, tile_hint
     d.a_split = _ptr(a_split)
@@ -421,6 +435,7 @@ def gate_bwd(dy, ab_or_y, x, *, B, C, T, mode, residual=0, alpha=1.0, want_dres=
     d.dab, d.dres, d.bias_part = _ptr(dab), _ptr(dres), part.data_ptr()
     d.alpha = alpha
     d.B, d.C, d.T, d.mode, d.residual = B, C, T, mode, residual
+    d.ab_bf16 = int(gated and ab_or_y is not None and ab_or_y.dtype == torch.bfloat16)
     _lib.call("dv3_gate_bwd_f32", ctypes.byref(d), _stream())
     return dab, dres, part
 
@@ -557,7 +572,10 @@ class ConvLayerFn(torch.autograd.Function):
         Tout = cfg.t_out if cfg.t_out is not None else T
         if gated and Tout != T:
             raise ValueError("gated layers keep the sequence length")
-        ab = torch.empty((B, M, T), dtype=torch.float32, device=x.device) if (gated and need_grad) else None
+        # the saved pre-gate pair: bf16 in the bf16 GEMM mode (BASELINE configs 3/4), where it is the largest tensor a
+        # training forward writes and the operands are rounded to bf16 anyway; fp32 in the fp32-class modes
+        ab_dtype = torch.bfloat16 if (_gemm_mode == "bf16" and pk.fwd_s is not None and split_only) else torch.float32
+        ab = torch.empty((B, M, T), dtype=ab_dtype, device=x.device) if (gated and need_grad) else None
         spk_strides = (0, 0, 0)
         if spk is not None:
             spk = _c(spk)

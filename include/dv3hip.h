@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 24
+#define DV3_ABI_VERSION 25
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -130,7 +130,15 @@ typedef struct dv3_conv_desc {
   float r_scale;                             /* DGRAD: y = acc * dropmask + r_scale * r (0 means 1).  The gradient
                                                 that reaches a residual Conv1dGLU's input through the skip path is
                                                 sqrt(.5) * dy: the epilogue reads dy itself instead of a scaled copy */
+  int32_t io_bf16;                           /* bf16 STORAGE (BASELINE configs 3/4: "bf16 activations ... fp32 accum"),
+                                                single-term bf16 kernels (split_terms == 1) only: DV3_IO_IN_BF16 = x, r
+                                                and r2 are bf16 tensors (same element strides), DV3_IO_OUT_BF16 = y and
+                                                ab are written as bf16 (round to nearest even).  0 = fp32 everywhere.  */
 } dv3_conv_desc;
+#define DV3_IO_IN_BF16 1
+#define DV3_IO_OUT_BF16 2
+#define DV3_IO_AB_BF16 4   /* only the saved pre-gate pair `ab` is bf16 (y stays fp32): halves the largest tensor a
+                              training forward writes; dv3_gate_bwd_desc.ab_bf16 reads it back */
 int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
 
 /*
@@ -283,6 +291,7 @@ typedef struct dv3_gate_bwd_desc {
   float* dab; float* dres; float* bias_part;
   float alpha;                               /* non-gated modes: dy is scaled by alpha first */
   int32_t B, C, T, mode, residual;
+  int32_t ab_bf16;                           /* gated modes: ab_or_y is a bf16 tensor (DV3_IO_AB_BF16 / _OUT_BF16)  */
 } dv3_gate_bwd_desc;
 int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream);
 
