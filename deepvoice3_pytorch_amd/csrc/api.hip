@@ -51,6 +51,7 @@ extern "C" int dv3_sizeof(const char* name) {
   DV3_SZ(dv3_wn_multi_entry);
   DV3_SZ(dv3_conv_step_desc);
   DV3_SZ(dv3_attn_step_desc);
+  DV3_SZ(dv3_attn_fwd_desc);
 #undef DV3_SZ
   return -1;
 }

@@ -74,6 +74,112 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const dv3_softmax
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fused attention forward (AttentionLayer.forward's core, deepvoice3.py:143-171): scores = q^T k on the fp32 matrix
+// cores -> padding mask -> softmax -> dropout * sqrt(Tk) -> context = v pd^T on the fp32 matrix cores, ONE launch per
+// layer instead of five (scores GEMM, softmax, dropout bits aside, context GEMM, and no transposes).  Exact fp32 MFMA
+// (v_mfma_f32_32x32x2_f32): attention is < 0.5 % of the step's FLOPs and feeds the 1e-4 parity of the outputs.
+// One workgroup = 32 queries of one batch item, 4 waves:
+//   phase 1  wave w computes the 32 x 32 score tiles of key tiles w, w+4, ...; both operands are read straight from
+//            the BCT tensors in MFMA fragment order (lane = query / key, 32 lanes = 128 contiguous bytes), K = channels;
+//            the scores land in LDS [32][Tk + 1]
+//   phase 2  8 threads per query row: max, exp, sum; P (the returned alignment) and pd = P * keep * scale go to HBM
+//            once, pd also stays in LDS
+//   phase 3  wave w computes the 32 x 32 context tiles of channel tiles w, w+4, ...: A = v^T rows ([Tk][E], lanes =
+//            channels, contiguous), B = pd from LDS, K = keys; ctx[b][e][t] stored with lanes along t
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const dv3_attn_fwd_desc p) {
+  extern __shared__ float sc[];            // [32][ld], ld = Tk + 1 (odd: conflict-free column reads)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int b = blockIdx.y, t0 = blockIdx.x * 32;
+  const int E = p.E, Tq = p.Tq, Tk = p.Tk;
+  const int ld = Tk + 1;
+  const int nkt = (Tk + 31) / 32;
+  const float* __restrict__ qb = p.q + (int64_t)b * E * Tq;
+  const float* __restrict__ kb = p.k + (int64_t)b * E * Tk;
+  const int tq = min(t0 + l31, Tq - 1);     // clamped: rows beyond Tq are computed and dropped
+  // ---- phase 1: scores ----
+  for (int kt = wave; kt < nkt; kt += 4) {
+    const int n = min(kt * 32 + l31, Tk - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int e = 0; e < E; e += 2) {
+      const int ee = min(e + lhi, E - 1);
+      float a = qb[(int64_t)ee * Tq + tq];
+      float bb = kb[(int64_t)ee * Tk + n];
+      if (e + lhi >= E) a = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+    }
+    // C layout: col = lane & 31 (key), row = (r & 3) + 8 * (r >> 2) + 4 * lhi (query)
+    const int col = kt * 32 + l31;
+    if (col < Tk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[((r & 3) + 8 * (r >> 2) + 4 * lhi) * ld + col] = acc[r];
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: softmax over keys, 8 threads per query row ----
+  {
+    const int row = tid >> 3, sub = tid & 7;
+    const int t = t0 + row;
+    int hi = Tk;
+    if (p.key_len) hi = min(hi, p.key_len[b]);
+    float* s = sc + row * ld;
+    float mx = -INFINITY;
+    for (int n = sub; n < hi; n += 8) mx = fmaxf(mx, s[n]);
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.f;
+    for (int n = sub; n < hi; n += 8) sum += expf(s[n] - mx);
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float inv = 1.0f / sum;
+    const int64_t grow = (int64_t)b * Tq + t;
+    for (int n = sub; n < Tk; n += 8) {
+      float v = 0.f;
+      if (n < hi) v = expf(s[n] - mx) * inv;
+      float d = v;
+      if (p.mask && t < Tq) d = dv3_keep(p.mask, grow, p.mask_rs, n) ? v * p.drop_scale : 0.f;
+      d *= p.pd_scale;
+      s[n] = d;
+      if (t < Tq) {
+        p.P[grow * Tk + n] = v;
+        p.pd[grow * Tk + n] = d;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: context[e][t] = sum_n vT[n][e] * pd[t][n] ----
+  const float* __restrict__ vtb = p.vT + (int64_t)b * Tk * E;
+  for (int et = wave; et * 32 < E; et += 4) {
+    const int e = min(et * 32 + l31, E - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+    for (int n = 0; n < Tk; n += 2) {
+      const int nn = min(n + lhi, Tk - 1);
+      float a = vtb[(int64_t)nn * E + e];
+      float bb = sc[l31 * ld + nn];
+      if (n + lhi >= Tk) a = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+    }
+    // C: col = lane & 31 (query), rows = channels
+    const int t = t0 + l31;
+    if (t < Tq) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ec = et * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (ec < E) p.ctx[((int64_t)b * E + ec) * Tq + t] = acc[r];
+      }
+    }
+  }
+}
+
 // argmax over keys of row (b = 0, last query) -> last_attended (deepvoice3.py:445: the
 // reference takes batch item 0 only)
 __global__ __launch_bounds__(64) void attn_argmax_kernel(const float* __restrict__ p, int Tk,
@@ -112,6 +218,16 @@ extern "C" int dv3_attn_softmax_bwd_f32(const dv3_softmax_bwd_desc* d, void* str
   hipLaunchKernelGGL(attn_softmax_bwd_kernel, dim3((unsigned)dv3_cdiv64(rows, 4)), dim3(256), 0,
                      (hipStream_t)stream, *d);
   return dv3_check_launch("attn_softmax_bwd_f32");
+}
+
+extern "C" int dv3_attn_fwd_f32(const dv3_attn_fwd_desc* d, void* stream) {
+  DV3_REQUIRE(d && d->q && d->k && d->vT && d->ctx && d->P && d->pd, "attn_fwd: null pointer");
+  DV3_REQUIRE(d->B > 0 && d->E > 0 && d->Tq > 0 && d->Tk > 0 && d->B <= 65535, "attn_fwd: bad dims");
+  if (d->mask) DV3_REQUIRE(d->mask_rs * 32 >= d->Tk, "attn_fwd: mask row stride too small");
+  const size_t lds = (size_t)32 * (d->Tk + 1) * sizeof(float);
+  DV3_REQUIRE(lds <= 64 * 1024, "attn_fwd: Tk = %d too long for the fused kernel (use the unfused path)", d->Tk);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(dv3_cdiv(d->Tq, 32), d->B), dim3(256), lds, (hipStream_t)stream, *d);
+  return dv3_check_launch("attn_fwd");
 }
 
 extern "C" int dv3_attn_argmax_i32(const float* p_row, int32_t Tk, int32_t* out, void* stream) {

@@ -34,6 +34,7 @@ _wn_bwd_desc = STRUCTS["dv3_wn_bwd_desc"]
 _gate_bwd_desc = STRUCTS["dv3_gate_bwd_desc"]
 _softmax_desc = STRUCTS["dv3_softmax_desc"]
 _softmax_bwd_desc = STRUCTS["dv3_softmax_bwd_desc"]
+_attn_fwd_desc = STRUCTS["dv3_attn_fwd_desc"]
 _spec_loss_desc = STRUCTS["dv3_spec_loss_desc"]
 
 
@@ -295,6 +296,7 @@ class Prepack(object):
 
 
 prepacked = None      # set by the trainer for the duration of a training forward
+fused_attention = _os.environ.get("DV3_FUSED_ATTN", "1") not in ("0", "")   # one launch for the attention forward
 
 
 # ----------------------------------------------------------------------------------------------
@@ -737,12 +739,29 @@ class AttnCoreFn(torch.autograd.Function):
         Tk = k.shape[2]
         p_drop, training, win_back, win_ahead, site = cfg
         dev = q.device
-        # scores: per-batch operand A = q[b] as [Cin=E][lda=Tq]
-        S = conv_gemm(k, q, Tq, 0, B=B, Cin=E, Tin=Tk, M=Tq, Tout=Tk, a_bs=E * Tq)
         bits, bits_rs, dscale = None, 0, 1.0
         if training and p_drop > 0:
             bits, bits_rs = dropout_bits(B * Tq, Tk, p_drop, dev, site)
             dscale = 1.0 / (1.0 - p_drop)
+        if fused_attention and last_attended is None and Tk <= 511 and Tq > 1:
+            # scores -> mask -> softmax -> dropout -> context in ONE launch (exact fp32 MFMA, csrc/attention.hip)
+            vT = transpose(v)                                   # (B, Tk, E): the values in the reference's layout
+            ctxv = torch.empty((B, E, Tq), dtype=torch.float32, device=dev)
+            P = torch.empty((B, Tq, Tk), dtype=torch.float32, device=dev)
+            pd = torch.empty_like(P)
+            d = _attn_fwd_desc()
+            d.q, d.k, d.vT, d.key_len = q.data_ptr(), k.data_ptr(), vT.data_ptr(), _ptr(key_len)
+            d.mask, d.mask_rs, d.drop_scale = _ptr(bits), bits_rs, dscale
+            d.pd_scale = Tk * math.sqrt(1.0 / Tk)
+            d.ctx, d.P, d.pd = ctxv.data_ptr(), P.data_ptr(), pd.data_ptr()
+            d.B, d.E, d.Tq, d.Tk = B, E, Tq, Tk
+            _lib.call("dv3_attn_fwd_f32", ctypes.byref(d), _stream())
+            if any(ctx.needs_input_grad[:3]):
+                ctx.save_for_backward(q, k, v, P, pd)
+                ctx.bits, ctx.bits_rs, ctx.dscale, ctx.pd_scale = bits, bits_rs, dscale, d.pd_scale
+            return ctxv, P
+        # scores: per-batch operand A = q[b] as [Cin=E][lda=Tq]
+        S = conv_gemm(k, q, Tq, 0, B=B, Cin=E, Tin=Tk, M=Tq, Tout=Tk, a_bs=E * Tq)
         pd = torch.empty_like(S)
         d = _softmax_desc()
         d.s, d.pd, d.key_len, d.last_attended = S.data_ptr(), pd.data_ptr(), _ptr(key_len), _ptr(last_attended)

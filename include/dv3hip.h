@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 25
+#define DV3_ABI_VERSION 26
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -334,6 +334,20 @@ typedef struct dv3_softmax_bwd_desc {
   int32_t B, Tq, Tk;
 } dv3_softmax_bwd_desc;
 int dv3_attn_softmax_bwd_f32(const dv3_softmax_bwd_desc* d, void* stream);
+/* Fused attention forward (deepvoice3.py:143-171, teacher-forced / training: no monotonic window): scores = q^T k
+ * (exact fp32 MFMA) -> -inf beyond key_len[b] -> softmax -> P; pd = P * keep(mask) * drop_scale * pd_scale;
+ * ctx[b][e][t] = sum_n v[b][e][n] * pd[b][t][n] (exact fp32 MFMA), one launch.  q (B,E,Tq), k (B,E,Tk) BCT;
+ * vT (B,Tk,E) = the values in the reference's own (B,T,C) layout; P, pd (B,Tq,Tk) are both written once (P is the
+ * alignment the layer returns, both are what dv3_attn_softmax_bwd_f32 and the gradient products read).  Tk <= 511. */
+typedef struct dv3_attn_fwd_desc {
+  const float* q; const float* k; const float* vT;
+  const int32_t* key_len;
+  const uint32_t* mask; int32_t mask_rs; float drop_scale;
+  float pd_scale;
+  float* ctx; float* P; float* pd;
+  int32_t B, E, Tq, Tk;
+} dv3_attn_fwd_desc;
+int dv3_attn_fwd_f32(const dv3_attn_fwd_desc* d, void* stream);
 /* argmax over keys of one probability row -> last_attended (deepvoice3.py:445)          */
 int dv3_attn_argmax_i32(const float* p_row, int32_t Tk, int32_t* out, void* stream);
 

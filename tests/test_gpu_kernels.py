@@ -547,3 +547,39 @@ def test_torch_ops_dv3hip(dev, gemm_mode):
     hyper = torch.tensor([5e-4, 1 - 0.5, math.sqrt(1 - 0.9)], device=dev)
     T_.clip_adam_(pg, gg, mg, vg, out2, 0.1, hyper, 0.5, 0.9, 1e-6, 0.0, 1.0)
     assert rel_err(out2[0].cpu(), gn) < 1e-5 and rel_err(pg.cpu(), pc) < 1e-6
+
+
+@pytest.mark.parametrize("B,E,Tq,Tk,p", [(3, 48, 50, 37, 0.0), (2, 256, 201, 150, 0.05), (4, 20, 33, 64, 0.1),
+                                         (1, 8, 2, 5, 0.0), (2, 64, 70, 511, 0.0)])
+def test_fused_attention_forward_equals_unfused(dev, gemm_mode, B, E, Tq, Tk, p):
+    """dv3_attn_fwd_f32 (scores -> mask -> softmax -> dropout -> context in one launch, exact fp32 MFMA) against the
+    five-launch path it replaces and against the oracle arithmetic (deepvoice3.py:143-171); gradients flow through
+    the unchanged backward from the P / pd it saves"""
+    if gemm_mode != "f16x3":
+        pytest.skip("the fused kernel is exact fp32 in every mode")
+    ops = _ops()
+    rng = np.random.RandomState(B + E + Tq + Tk)
+    q = torch.from_numpy(rng.randn(B, E, Tq).astype(np.float32) * 0.3)
+    k = torch.from_numpy(rng.randn(B, E, Tk).astype(np.float32) * 0.3)
+    v = torch.from_numpy(rng.randn(B, E, Tk).astype(np.float32))
+    key_len = torch.tensor([Tk] + [max(1, Tk - 3 * (i + 1)) for i in range(B - 1)], dtype=torch.int32)
+    res = {}
+    for fused in (False, True):
+        ops.fused_attention = fused
+        try:
+            qg, kg, vg = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
+            ops.dropout_state.manual_seed(31)
+            ctx, P = ops.attention_core(qg, kg, vg, key_len.to(dev), None, p, p > 0)
+            w = torch.from_numpy(np.random.RandomState(1).randn(B, E, Tq).astype(np.float32)).to(dev)
+            ((ctx * w).sum() + (P * P).sum()).backward()
+            res[fused] = [t.detach().cpu() for t in (ctx, P, qg.grad, kg.grad, vg.grad)]
+        finally:
+            ops.fused_attention = True
+    for a, b_, nm in zip(res[False], res[True], ("ctx", "P", "dq", "dk", "dv")):
+        assert rel_err(b_, a) < 2e-5, nm
+    if p == 0.0:      # against the reference arithmetic directly
+        S = torch.bmm(q.transpose(1, 2), k)
+        m = torch.arange(Tk)[None, None, :] >= key_len[:, None, None]
+        Pw = torch.softmax(S.masked_fill(m, -float("inf")), dim=-1)
+        want = torch.bmm(Pw, v.transpose(1, 2)).transpose(1, 2) * (Tk * math.sqrt(1.0 / Tk))
+        assert rel_err(res[True][1], Pw) < 1e-5 and rel_err(res[True][0], want) < 1e-5
