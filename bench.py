@@ -83,6 +83,17 @@ DTYPE_NOTE = {
     "bf16x3": "fp32 operands as bf16 hi+lo on the matrix cores, 3 MFMAs per product, fp32 accumulate, fp32 storage",
     "f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
     "bf16": "operands rounded to bf16 at the matrix cores, 1 MFMA per product, fp32 accumulate, fp32 master weights"}
+BF16_STORAGE_NOTE = ("; activations, saved pre-gates and activation gradients of the conv stacks stored in HBM as "
+                     "channel-blocked bf16 (c8, include/dv3hip.h)")
+
+
+def dtype_note(mode):
+    """the arithmetic / storage description that goes with a `dtype` token"""
+    note = DTYPE_NOTE[mode]
+    if mode == "bf16":
+        from deepvoice3_pytorch_amd import ops
+        note += BF16_STORAGE_NOTE if ops.bf16_storage else "; fp32 activations in HBM (DV3_BF16_STORAGE=0)"
+    return note
 
 
 def mfma_peak_tf(mode):
@@ -486,6 +497,8 @@ class TrainRun(object):
                                         frac=round(tf / mfma_peak_tf(self.gemm), 4)))
 
     def close(self):
+        if self.runner is not None:
+            self.runner.close()
         self.trainer.close()
         self.ops.dropout_state.dev_offset = None
         self.ops.set_gemm_precision(self.prev_mode)
@@ -503,7 +516,7 @@ def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup):
         run.close()
     return dict(metric="mel-frames/sec/node (train step, %s)" % preset, value=m["value"], unit="mel-frames/s",
                 n_gpus=world, steps=steps, warmup=warmup, ms_per_step=m["ms_per_step"], dtype=gemm,
-                dtype_note=DTYPE_NOTE[gemm], step_flop_frac=m["step_flop_frac"],
+                dtype_note=dtype_note(gemm), step_flop_frac=m["step_flop_frac"],
                 config=dict(workload="builder=%s preset=%s train step" % (PRESETS[preset][0], preset),
                             per_gpu_batch=args.batch, global_batch=args.batch * world, final_loss=m["final_loss"]))
 
@@ -572,7 +585,7 @@ def main():
         out = dict(metric="mel-frames/sec/node (train step, %s)" % args.preset, value=m["value"],
                    unit="mel-frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=m["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype=gemm, dtype_note=DTYPE_NOTE[gemm],
+                   dtype=gemm, dtype_note=dtype_note(gemm),
                    data="synthetic (fixed-shape LJSpeech-like: Tt=%d, %d frames/item; random-init weights)"
                    % (args.text_len, args.frames),
                    config=dict(workload="builder=%s preset=%s train step "
@@ -631,7 +644,7 @@ def main():
             e = side_config(dev, pg, rank, world, args.preset, "f32", args, 5, 2)
             if rank == 0:
                 out["value_exact_f32"] = dict(value=e["value"], ms_per_step=e["ms_per_step"], steps=5, dtype="f32",
-                                              dtype_note=DTYPE_NOTE["f32"], step_flop_frac=e["step_flop_frac"])
+                                              dtype_note=dtype_note("f32"), step_flop_frac=e["step_flop_frac"])
         cfgs = {}
         cfgs["nyanko_bf16"] = side_config(dev, pg, rank, world, "nyanko_ljspeech", "bf16", args, 20, 8)
         cfgs["vctk_bf16"] = side_config(dev, pg, rank, world, "deepvoice3_vctk", "bf16", args, 20, 8)

@@ -98,12 +98,13 @@ class Conv1d(_WNLayer):
         return "{}, {}, kernel_size={}, padding={}, dilation={}".format(
             self.in_channels, self.out_channels, self.kernel_size, self.padding, self.dilation)
 
-    def forward(self, x, mode=ops.EPI_LINEAR, r=None, r2=None):
+    def forward(self, x, mode=ops.EPI_LINEAR, r=None, r2=None, out_c8=None):
         """nn.Conv1d forward: symmetric zero padding `self.padding`, output length
-        T + 2*pad - dil*(k-1)."""
+        T + 2*pad - dil*(k-1).  x may be a channel-blocked bf16 tensor (ops.to_c8); out_c8 forces the output
+        layout (None: like the input)."""
         k, d, pad = self.kernel_size[0], self.dilation[0], self.padding[0]
-        T = x.size(-1)
-        cfg = ops.LayerCfg(k=k, dil=d, mode=mode)
+        T = x.size(2)
+        cfg = ops.LayerCfg(k=k, dil=d, mode=mode, out_c8=out_c8)
         cfg.pad_left, cfg.t_out = pad, T + 2 * pad - d * (k - 1)
         v, g = self.wn_params()
         return ops.conv_layer(x, v, g, self.bias, cfg, r=r, r2=r2, packed=self.packed())
@@ -172,9 +173,9 @@ class Linear(_WNLayer):
     def extra_repr(self):
         return "in_features={}, out_features={}".format(self.in_features, self.out_features)
 
-    def forward_bct(self, x, mode=ops.EPI_LINEAR, r=None, r2=None):
-        """x (B, in, T) -> (B, out, T)."""
-        cfg = ops.LayerCfg(k=1, dil=1, mode=mode)
+    def forward_bct(self, x, mode=ops.EPI_LINEAR, r=None, r2=None, out_c8=None):
+        """x (B, in, T) -> (B, out, T); x / the output may be channel-blocked bf16 tensors (see Conv1d.forward)."""
+        cfg = ops.LayerCfg(k=1, dil=1, mode=mode, out_c8=out_c8)
         v, g = self.wn_params()
         return ops.conv_layer(x, v, g, self.bias, cfg, r=r, r2=r2, packed=self.packed())
 

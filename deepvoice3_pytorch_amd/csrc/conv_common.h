@@ -202,6 +202,195 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue of the bf16-storage path: y (and the saved pre-gate pair, the residual inputs, the DGRAD addend and its
+// keep-mask) live in the channel-blocked "c8" layout  bf16 [B][C8][T][8],  C8 = round_up(C,32)/8  (include/dv3hip.h).
+// The 32x32 accumulator tile gives every lane four CONSECUTIVE channels (r&3) of four 8-channel groups (r>>2) at
+// one frame, i.e. one 8-byte half of a 16-byte unit: 4 x NI eight-byte loads / stores per half tile instead of
+// 16 x NI scalar ones, and a wave's store covers 32 whole units = 512 contiguous bytes.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dv3_unpack4(const uint2 u, float (&v)[4]) {
+  v[0] = __uint_as_float(u.x << 16);
+  v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16);
+  v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+__device__ __forceinline__ uint2 dv3_pack4(const float (&v)[4]) {
+  typedef __bf16 dv3_bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float dv3_f32x2 __attribute__((ext_vector_type(2)));
+  const dv3_f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+  const dv3_bf16x2 ha = __builtin_convertvector(a, dv3_bf16x2), hb = __builtin_convertvector(b, dv3_bf16x2);
+  uint2 o;
+  o.x = __builtin_bit_cast(uint32_t, ha);
+  o.y = __builtin_bit_cast(uint32_t, hb);
+  return o;
+}
+__device__ __forceinline__ void dv3_st8(void* base, uint32_t byte_off, const uint2 v) {
+  *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+template <int BM, int BMH, int NI>
+__device__ __forceinline__ void conv_epilogue_c8(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], bool gated,
+                                                 int mt, int row0, int lhi, const int (&bcol)[NI],
+                                                 const int (&tcol)[NI], const bool (&okc)[NI]) {
+  const uint32_t T = (uint32_t)p.Tout, M = (uint32_t)p.M, Cg = (uint32_t)p.Cg;
+  const uint32_t Cout = gated ? Cg : M;
+  const uint32_t c8y = (Cout + 31u) / 32u * 4u;        // 8-channel groups per batch item of y / r / r2
+  const uint32_t gsz = T * 16u;                        // bytes between consecutive channel groups
+  const uint32_t half = lhi ? 8u : 0u;
+  const float rs2 = 0.70710678118654752440f;
+  uint32_t ub[NI], ubc[NI];                            // byte offset of this lane's half of unit (b, group 0, t)
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    ub[ni] = ((uint32_t)bcol[ni] * c8y * T + (uint32_t)tcol[ni]) * 16u + half;
+    ubc[ni] = okc[ni] ? ub[ni] : half;                 // loads of dead columns read unit 0
+  }
+  if (gated) {
+    const bool glu = p.mode == DV3_EPI_GLU;
+    const bool has_r = !glu || p.residual;
+    const float oscale = (glu && p.residual) ? rs2 : 1.0f;
+    const uint32_t c8ab = (M + 31u) / 32u * 4u, gate8 = Cg >> 3;
+    const uint32_t spk_rs = (uint32_t)p.spk_rs * 4u;
+    uint32_t uab[NI], sb[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      uab[ni] = ((uint32_t)bcol[ni] * c8ab * T + (uint32_t)tcol[ni]) * 16u + half;
+      sb[ni] = ((uint32_t)bcol[ni] * (uint32_t)p.spk_bs + (uint32_t)tcol[ni] * (uint32_t)p.spk_ts) * 4u;
+    }
+    uint2 xr[4][NI];
+    uint32_t g8v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g8v[k] = (uint32_t)(mt * BMH + row0) / 8u + (uint32_t)k;
+      const uint32_t g8c = g8v[k] * 8u < Cg ? g8v[k] : 0u;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        xr[k][ni] = has_r ? dv3_ld<uint2>(p.r, ubc[ni] + g8c * gsz) : uint2{0u, 0u};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t g8 = g8v[k];
+      if (g8 * 8u >= Cg) continue;
+      const uint32_t ch0 = g8 * 8u + (lhi ? 4u : 0u);
+      float ba[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ba[e] = p.bias[ch0 + e];
+          bg[e] = p.bias[Cg + ch0 + e];
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if (!okc[ni]) continue;
+        float xv[4], a[4], g[4], yv[4];
+        dv3_unpack4(xr[k][ni], xv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = acc[0][ni][4 * k + e] + ba[e];
+          g[e] = acc[1][ni][4 * k + e] + bg[e];
+          if (p.spk) a[e] += dv3_ld<float>(p.spk, sb[ni] + (ch0 + e) * spk_rs);
+        }
+        if (p.ab) {
+          dv3_st8(p.ab, uab[ni] + g8 * gsz, dv3_pack4(a));
+          dv3_st8(p.ab, uab[ni] + (gate8 + g8) * gsz, dv3_pack4(g));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-g[e]));
+          yv[e] = glu ? (a[e] * s + xv[e]) * oscale : s * a[e] + (1.0f - s) * xv[e];
+        }
+        dv3_st8(p.y, ub[ni] + g8 * gsz, dv3_pack4(yv));
+      }
+    }
+    return;
+  }
+  if (p.mode == DV3_EPI_DGRAD) {
+    const float dscale = p.drop_scale;
+    const float rsc = p.r_scale != 0.f ? p.r_scale : 1.0f;
+    const uint8_t* const ym = p.ymask_c8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint2 rv[4][NI];
+      uint32_t kb[4][NI], g8v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        g8v[k] = (uint32_t)(mt * BM + h * BMH + row0) / 8u + (uint32_t)k;
+        const uint32_t g8c = g8v[k] * 8u < M ? g8v[k] : 0u;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          rv[k][ni] = p.r ? dv3_ld<uint2>(p.r, ubc[ni] + g8c * gsz) : uint2{0u, 0u};
+          kb[k][ni] = ym ? (uint32_t)dv3_ld<uint8_t>(ym, (ubc[ni] + g8c * gsz) >> 4) : 0xffu;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (g8v[k] * 8u >= M) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if (!okc[ni]) continue;
+          float r4[4], v[4];
+          dv3_unpack4(rv[k][ni], r4);
+          const uint32_t bits = kb[k][ni] >> (lhi ? 4 : 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a = acc[h][ni][4 * k + e];
+            if (ym) a = ((bits >> e) & 1u) ? a * dscale : 0.f;
+            v[e] = a + rsc * r4[e];
+          }
+          dv3_st8(p.y, ub[ni] + g8v[k] * gsz, dv3_pack4(v));
+        }
+      }
+    }
+    return;
+  }
+  // LINEAR / RELU / SIGMOID / SOFTSIGN (+ up to two fused residuals)
+  const int mode = p.mode;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint2 rv[4][NI], r2v[4][NI];
+    uint32_t g8v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g8v[k] = (uint32_t)(mt * BM + h * BMH + row0) / 8u + (uint32_t)k;
+      const uint32_t g8c = g8v[k] * 8u < M ? g8v[k] : 0u;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        rv[k][ni] = p.r ? dv3_ld<uint2>(p.r, ubc[ni] + g8c * gsz) : uint2{0u, 0u};
+        r2v[k][ni] = p.r2 ? dv3_ld<uint2>(p.r2, ubc[ni] + g8c * gsz) : uint2{0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (g8v[k] * 8u >= M) continue;
+      const uint32_t ch0 = g8v[k] * 8u + (lhi ? 4u : 0u);
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = p.bias[ch0 + e];
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if (!okc[ni]) continue;
+        float r4[4], q4[4], v[4];
+        dv3_unpack4(rv[k][ni], r4);
+        dv3_unpack4(r2v[k][ni], q4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = acc[h][ni][4 * k + e] + bv[e];
+          if (mode == DV3_EPI_RELU) a = fmaxf(a, 0.f);
+          else if (mode == DV3_EPI_SIGMOID) a = __builtin_amdgcn_rcpf(1.0f + __expf(-a));
+          else if (mode == DV3_EPI_SOFTSIGN) a = a * __builtin_amdgcn_rcpf(1.0f + fabsf(a));
+          if (p.r) a = (a + r4[e]) * rs2;
+          if (p.r2) a = (a + q4[e]) * rs2;
+          v[e] = a;
+        }
+        dv3_st8(p.y, ub[ni] + g8v[k] * gsz, dv3_pack4(v));
+      }
+    }
+  }
+}
+
 // the epilogue addresses every tensor with 32-bit byte offsets
 static inline bool dv3_conv_fits32(const dv3_conv_desc* d) {
   const int64_t lim = (1ll << 30);  // elements (4-byte)

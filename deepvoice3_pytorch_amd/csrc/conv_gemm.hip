@@ -336,6 +336,23 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
   DV3_REQUIRE(dv3_conv_fits32(d), "conv_gemm: a tensor exceeds the 4 GB the epilogue can address");
   DV3_REQUIRE(d->io_bf16 == 0 || (d->a_split && d->split_terms == 1 && (d->tile_hint == 0 || d->tile_hint > 20)),
               "conv_gemm: bf16 activation storage is served by the single-term bf16 kernels only");
+  if (d->io_bf16 & DV3_IO_OUT_C8) {   // channel-blocked bf16 outputs / residuals (include/dv3hip.h)
+    const int Cout = gated ? d->Cg : d->M;
+    DV3_REQUIRE(d->store_mode == DV3_STORE_BCT && (Cout & 7) == 0 && (d->M & 7) == 0,
+                "conv_gemm: c8 storage needs channel counts that are multiples of 8 and the plain store");
+    DV3_REQUIRE(!(d->io_bf16 & (DV3_IO_IN_BF16 | DV3_IO_OUT_BF16 | DV3_IO_AB_BF16)) && !d->ymask,
+                "conv_gemm: c8 storage excludes the BCT bf16 flags and the bit-mask form of ymask");
+    DV3_REQUIRE((((uintptr_t)d->y | (uintptr_t)d->r | (uintptr_t)d->r2 | (uintptr_t)d->ab) & 15) == 0,
+                "conv_gemm: c8 tensors must be 16-byte aligned");
+    const int64_t c8y = (Cout + 31) / 32 * 4, c8ab = (d->M + 31) / 32 * 4;
+    DV3_REQUIRE((int64_t)d->B * c8y * d->Tout * 16 < (1ll << 32) && (!d->ab || (int64_t)d->B * c8ab * d->Tout * 16 < (1ll << 32)),
+                "conv_gemm: a c8 tensor exceeds the 4 GB the epilogue can address");
+  } else {
+    DV3_REQUIRE(!d->ymask_c8, "conv_gemm: ymask_c8 belongs to a c8 DGRAD output");
+  }
+  DV3_REQUIRE(!d->ymask_c8 || d->mode == DV3_EPI_DGRAD, "conv_gemm: ymask_c8 is a DGRAD input");
+  DV3_REQUIRE(!d->xmask_c8 || (d->x_planes && d->split_terms == 1 && d->mode != DV3_EPI_DGRAD),
+              "conv_gemm: xmask_c8 masks a c8 input (x_planes, split_terms == 1) of a forward layer");
   // both operands pre-split: the persistent planes kernel.  No silent fallback: the planes carry the dropout
   // mask of the consuming layer, which the other kernels would have to be handed separately.
   if (d->x_planes) {

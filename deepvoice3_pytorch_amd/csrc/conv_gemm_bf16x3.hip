@@ -555,9 +555,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
       bcol[ni] = n / T;
       tcol[ni] = n - bcol[ni] * T;
     }
-    conv_epilogue<BM, BMH, NI, ABL, TERMS == 1>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
-    if (MI == 2)
-      conv_epilogue<BM, BMH, NI, ABL, TERMS == 1>(p, acc[MI - 1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+    if (TERMS == 1 && (p.io_bf16 & DV3_IO_OUT_C8)) {   // bf16 storage: channel-blocked y / ab / residuals
+      conv_epilogue_c8<BM, BMH, NI>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+      if (MI == 2) conv_epilogue_c8<BM, BMH, NI>(p, acc[MI - 1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+    } else {
+      conv_epilogue<BM, BMH, NI, ABL, TERMS == 1>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+      if (MI == 2)
+        conv_epilogue<BM, BMH, NI, ABL, TERMS == 1>(p, acc[MI - 1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+    }
   }
   stamp();                         // last slot: epilogue stores issued
 }

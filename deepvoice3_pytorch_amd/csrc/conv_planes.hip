@@ -51,6 +51,19 @@ __device__ __forceinline__ T ldg_off(const void* base, uint32_t byte_off) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// c8 input with dropout: zero the dropped channels of one unit (bit e of the keep-byte = channel e)
+__device__ __forceinline__ bf16x8 keep8(const bf16x8& v, uint32_t m) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 d = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)m, 2 * i, 1) & 0xffffu;
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)m, 2 * i + 1, 1) << 16;
+    d[i] &= (lo | hi);
+  }
+  return __builtin_bit_cast(bf16x8, d);
+}
+
 template <int NI>
 struct Frags {
   bf16x8 ah[2], al[2], bh[NI], bl[NI];
@@ -141,6 +154,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_planes_kernel(const ConvA
   uint32_t xoff[XI];   // byte offset of unit (b, k8, t) inside a plane, chunk 0
   uint32_t aoff[AU];   // byte offset of this thread's weight units inside a (tap, chunk) panel row
   bf16x8 ra[PL][AU], rx[PL][XI];
+  // bf16 storage (single-term kernel): the c8 input may carry dropout keep-bytes, one per unit (uniform pointer)
+  const uint8_t* __restrict__ const xkeep = TERMS == 1 ? p.xmask_c8 : nullptr;
+  uint32_t rk[TERMS == 1 ? XI : 1];
 
   auto tile_offsets = [&](int mt, int n0) {
     int h0b, h1b;
@@ -188,9 +204,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_planes_kernel(const ConvA
     for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
       for (int i = 0; i < XI; ++i) rx[pl][i] = ldg_off<bf16x8>(src + pl * xplane, xoff[i]);
+    if (TERMS == 1 && xkeep) {
+      const uint8_t* mk = xkeep + (int64_t)c * KB * T;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) rk[TERMS == 1 ? i : 0] = ldg_off<uint8_t>(mk, xoff[i] >> 4);
+    }
   };
   auto write_X = [&](int buf) {
     bf16x8* dst = Xs + buf * xbuf;
+    if (TERMS == 1 && xkeep) {
+#pragma unroll
+      for (int i = 0; i < XI; ++i) rx[0][i] = keep8(rx[0][i], rk[TERMS == 1 ? i : 0]);
+    }
 #pragma unroll
     for (int i = 0; i < XI; ++i)
 #pragma unroll
@@ -414,7 +439,18 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_planes_kernel(const ConvA
         bcol[ni] = n / T;
         tcol[ni] = n - bcol[ni] * T;
       }
-      if ((ABL != 4 && ABL != 8) || acc[0][0][0] + acc[1][NI - 1][7] == 1.2345e30f)
+      if (TERMS == 1 && xkeep) {      // x * keep / (1-p): the 1/(1-p) of a masked c8 input, exact on the accumulators
+        const float ds = p.drop_scale;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[h][ni][r] *= ds;
+      }
+      if (TERMS == 1 && (p.io_bf16 & DV3_IO_OUT_C8))
+        conv_epilogue_c8<BM, BMH, NI>(p, acc, gated, mt, wm * 32, lhi, bcol, tcol, okc);
+      else if ((ABL != 4 && ABL != 8) || acc[0][0][0] + acc[1][NI - 1][7] == 1.2345e30f)
         conv_epilogue<BM, BMH, NI, 0, TERMS == 1>(p, acc, gated, mt, wm * 32, lhi, bcol, tcol, okc);
     }
     if (!has_next) break;
@@ -475,6 +511,49 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const dv3_planes_desc
   const int64_t u = ((int64_t)b * c8p + c8) * p.T + t;
   out[u] = hi;
   out[(int64_t)p.B * c8p * p.T + u] = lo;
+}
+
+// ---- fp32 (B,C,T) <-> c8 (bf16 [B][C8][T][8]) and keep-bits -> keep-bytes: one thread per unit (b, group, t), t fastest
+__global__ __launch_bounds__(256) void to_c8_kernel(const float* __restrict__ x, int64_t x_bs, int64_t x_rs,
+                                                    bf16x8* __restrict__ out, int C, int T, int c8p) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  bf16x8 u;
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const int ch = g * 8 + e;
+    const f32x2 f = {ch < C ? x[(int64_t)b * x_bs + (int64_t)ch * x_rs + t] : 0.f,
+                     ch + 1 < C ? x[(int64_t)b * x_bs + (int64_t)(ch + 1) * x_rs + t] : 0.f};
+    const bf16x2 h = __builtin_convertvector(f, bf16x2);
+    u[e] = h[0]; u[e + 1] = h[1];
+  }
+  out[((int64_t)b * c8p + g) * T + t] = u;
+}
+__global__ __launch_bounds__(256) void from_c8_kernel(const bf16x8* __restrict__ x, float* __restrict__ out,
+                                                      int64_t out_bs, int64_t out_rs, int C, int T, int c8p) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const bf16x8 u = x[((int64_t)b * c8p + g) * T + t];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = g * 8 + e;
+    if (ch < C) out[(int64_t)b * out_bs + (int64_t)ch * out_rs + t] = (float)u[e];
+  }
+}
+__global__ __launch_bounds__(256) void mask_bits_to_c8_kernel(const uint32_t* __restrict__ bits, int rs,
+                                                              uint8_t* __restrict__ out, int C, int T, int c8p) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  uint32_t m = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = g * 8 + e;
+    if (ch < C) m |= ((bits[((int64_t)b * C + ch) * rs + (t >> 5)] >> (t & 31)) & 1u) << e;
+  }
+  out[((int64_t)b * c8p + g) * T + t] = (uint8_t)m;
 }
 
 int g_planes_tile = 0;      // dv3_debug_set(4, v)
@@ -556,6 +635,37 @@ extern "C" int dv3_split_planes_f32(const dv3_planes_desc* d, void* stream) {
   DV3_REQUIRE(c8p <= 65535 && d->B <= 65535, "split_planes: grid too large");
   hipLaunchKernelGGL(split_planes_kernel, dim3(dv3_cdiv(d->T, 256), c8p, d->B), dim3(256), 0, (hipStream_t)stream, *d, c8p);
   return dv3_check_launch("split_planes");
+}
+
+extern "C" int dv3_to_c8_f32(const float* x, int64_t x_bs, int64_t x_rs, uint16_t* out, int32_t B, int32_t C,
+                             int32_t T, void* stream) {
+  DV3_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "to_c8: bad arguments");
+  DV3_REQUIRE(((uintptr_t)out & 15) == 0, "to_c8: out must be 16-byte aligned");
+  const int c8p = (C + 31) / 32 * 4;
+  DV3_REQUIRE(c8p <= 65535 && B <= 65535, "to_c8: grid too large");
+  hipLaunchKernelGGL(to_c8_kernel, dim3(dv3_cdiv(T, 256), c8p, B), dim3(256), 0, (hipStream_t)stream, x, x_bs, x_rs,
+                     reinterpret_cast<bf16x8*>(out), C, T, c8p);
+  return dv3_check_launch("to_c8");
+}
+extern "C" int dv3_from_c8_f32(const uint16_t* x, float* out, int64_t out_bs, int64_t out_rs, int32_t B, int32_t C,
+                               int32_t T, void* stream) {
+  DV3_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "from_c8: bad arguments");
+  DV3_REQUIRE(((uintptr_t)x & 15) == 0, "from_c8: x must be 16-byte aligned");
+  const int c8p = (C + 31) / 32 * 4;
+  DV3_REQUIRE(c8p <= 65535 && B <= 65535, "from_c8: grid too large");
+  hipLaunchKernelGGL(from_c8_kernel, dim3(dv3_cdiv(T, 256), dv3_cdiv(C, 8), B), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const bf16x8*>(x), out, out_bs, out_rs, C, T, c8p);
+  return dv3_check_launch("from_c8");
+}
+extern "C" int dv3_mask_bits_to_c8(const uint32_t* bits, int32_t bits_rs, uint8_t* out, int32_t B, int32_t C,
+                                   int32_t T, void* stream) {
+  DV3_REQUIRE(bits && out && B > 0 && C > 0 && T > 0, "mask_bits_to_c8: bad arguments");
+  DV3_REQUIRE(bits_rs * 32 >= T, "mask_bits_to_c8: mask row stride too small");
+  const int c8p = (C + 31) / 32 * 4;
+  DV3_REQUIRE(c8p <= 65535 && B <= 65535, "mask_bits_to_c8: grid too large");
+  hipLaunchKernelGGL(mask_bits_to_c8_kernel, dim3(dv3_cdiv(T, 256), c8p, B), dim3(256), 0, (hipStream_t)stream, bits,
+                     bits_rs, out, C, T, c8p);
+  return dv3_check_launch("mask_bits_to_c8");
 }
 
 // called by dv3_conv_gemm_f32 (conv_gemm.hip) when d->x_planes != NULL; returns 1 when the shape is not

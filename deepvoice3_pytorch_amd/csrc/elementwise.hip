@@ -116,6 +116,100 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
 }
 
 // ------------------------------------------------------------------------------------------
+// Gate backward on channel-blocked bf16 tensors (include/dv3hip.h "c8": bf16 [B][C8][T][8]).  One workgroup per
+// (b, 8-channel group), threads along time: every access is a whole 16-byte unit; the eight per-channel row sums
+// (x2 for the gate half) are reduced across the workgroup for the deterministic bias reduction.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void gate_bwd_c8_kernel(const dv3_gate_bwd_desc p) {
+  __shared__ float red[4][16];
+  const int C = p.C, T = p.T, G = C >> 3;
+  const int g = blockIdx.x % G, b = blockIdx.x / G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool gated = p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY;
+  const int c8y = (C + 31) / 32 * 4, c8ab = (2 * C + 31) / 32 * 4;
+  const gb_bf16x8* dy = reinterpret_cast<const gb_bf16x8*>(p.dy) + ((int64_t)b * c8y + g) * T;
+  float sa[8], sg[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sa[e] = sg[e] = 0.f;
+  if (gated) {
+    const gb_bf16x8* au = reinterpret_cast<const gb_bf16x8*>(p.ab_or_y) + ((int64_t)b * c8ab + g) * T;
+    const gb_bf16x8* gu = au + (int64_t)G * T;
+    gb_bf16x8* dau = reinterpret_cast<gb_bf16x8*>(p.dab) + ((int64_t)b * c8ab + g) * T;
+    gb_bf16x8* dgu = dau + (int64_t)G * T;
+    const gb_bf16x8* xu = p.x ? reinterpret_cast<const gb_bf16x8*>(p.x) + ((int64_t)b * c8y + g) * T : nullptr;
+    gb_bf16x8* dru = p.dres ? reinterpret_cast<gb_bf16x8*>(p.dres) + ((int64_t)b * c8y + g) * T : nullptr;
+    const bool glu = p.mode == DV3_EPI_GLU;
+    const float k = (glu && p.residual) ? 0.70710678118654752440f : 1.0f;
+    for (int t = tid; t < T; t += 256) {
+      const gb_bf16x8 dv = dy[t], av = au[t], gv = gu[t];
+      gb_bf16x8 xv = dv;
+      if (!glu) xv = xu[t];
+      gb_bf16x8 oa, og, orr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)dv[e] * k;
+        const float sgm = 1.0f / (1.0f + expf(-(float)gv[e]));
+        const float va = d * sgm;
+        float vg, vr;
+        if (glu) {
+          vg = d * (float)av[e] * sgm * (1.0f - sgm);
+          vr = d;
+        } else {
+          vg = d * ((float)av[e] - (float)xv[e]) * sgm * (1.0f - sgm);
+          vr = d * (1.0f - sgm);
+        }
+        oa[e] = (__bf16)va; og[e] = (__bf16)vg; orr[e] = (__bf16)vr;
+        sa[e] += va;
+        sg[e] += vg;
+      }
+      dau[t] = oa;
+      dgu[t] = og;
+      if (dru) dru[t] = orr;
+    }
+  } else {
+    const gb_bf16x8* yu = p.ab_or_y ? reinterpret_cast<const gb_bf16x8*>(p.ab_or_y) + ((int64_t)b * c8y + g) * T : nullptr;
+    gb_bf16x8* du = p.dab ? reinterpret_cast<gb_bf16x8*>(p.dab) + ((int64_t)b * c8y + g) * T : nullptr;
+    for (int t = tid; t < T; t += 256) {
+      const gb_bf16x8 dv = dy[t];
+      gb_bf16x8 yv = dv, od;
+      if (yu) yv = yu[t];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float d = (float)dv[e] * p.alpha;
+        const float y = (float)yv[e];
+        if (p.mode == DV3_EPI_RELU) d = y > 0.f ? d : 0.f;
+        else if (p.mode == DV3_EPI_SIGMOID) d = d * y * (1.0f - y);
+        else if (p.mode == DV3_EPI_SOFTSIGN) { const float q = 1.0f - fabsf(y); d = d * q * q; }
+        od[e] = (__bf16)d;
+        sa[e] += d;
+      }
+      if (du) du[t] = od;
+    }
+  }
+  if (!p.bias_part) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sa[e] = dv3_wave_sum(sa[e]);
+    sg[e] = dv3_wave_sum(sg[e]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[wave][e] = sa[e];
+      red[wave][8 + e] = sg[e];
+    }
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    const int ch = g * 8 + (tid & 7);
+    if (gated) p.bias_part[(int64_t)b * 2 * C + (tid >= 8 ? C : 0) + ch] = v;
+    else if (tid < 8) p.bias_part[(int64_t)b * C + ch] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Philox4x32-10 keep-bit generator (replaces F.dropout's bernoulli_: modules.py:147,210).
 // One thread per 32-bit mask word = 4 Philox calls x 8 sixteen-bit uniforms.
 // ------------------------------------------------------------------------------------------
@@ -496,6 +590,13 @@ extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
     DV3_REQUIRE(d->mode != DV3_EPI_DGRAD, "gate_bwd: bad mode");
   }
   const int64_t rows = (int64_t)d->B * d->C;
+  if (d->c8) {
+    const uintptr_t pc = (uintptr_t)d->dy | (uintptr_t)d->ab_or_y | (uintptr_t)d->dab | (uintptr_t)d->x | (uintptr_t)d->dres;
+    DV3_REQUIRE((d->C & 7) == 0 && (pc & 15) == 0 && !d->ab_bf16, "gate_bwd: c8 tensors need C % 8 == 0 and 16-byte alignment");
+    DV3_REQUIRE(rows / 8 < (1ll << 31), "gate_bwd: grid too large");
+    hipLaunchKernelGGL(gate_bwd_c8_kernel, dim3((unsigned)(rows / 8)), dim3(256), 0, (hipStream_t)stream, *d);
+    return dv3_check_launch("gate_bwd_c8");
+  }
   // 16 bytes per lane when every row starts 16-byte aligned (gated modes; the others are small)
   const uintptr_t ptrs = (uintptr_t)d->dy | (uintptr_t)d->ab_or_y | (uintptr_t)d->dab | (uintptr_t)d->x | (uintptr_t)d->dres;
   DV3_REQUIRE(!d->ab_bf16 || gated, "gate_bwd: ab_bf16 is for the gated modes");

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wgrad_gemm_f32_kernel(const Wgrad
 }  // namespace
 
 int dv3_wgrad_gemm_bf16x3_dispatch(const dv3_wgrad_desc* d, hipStream_t st);  // wgrad_gemm_bf16x3.hip
+int dv3_wgrad_c8_dispatch(const dv3_wgrad_desc* d, hipStream_t st);           // wgrad_c8.hip
 
 extern "C" int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream) {
   DV3_REQUIRE(d && d->g && d->x && d->out, "wgrad_gemm: null pointer");
@@ -121,9 +122,11 @@ extern "C" int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream) {
               "wgrad_gemm: bad J/dil/slabs");
   DV3_REQUIRE(d->ldo >= d->Cin, "wgrad_gemm: ldo < Cin");
   if (d->xmask) DV3_REQUIRE(d->xmask_rs * 32 >= d->Tin, "wgrad_gemm: xmask row stride too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (d->c8) return dv3_wgrad_c8_dispatch(d, st);
+  DV3_REQUIRE(!d->xmask_c8, "wgrad_gemm: xmask_c8 belongs to the c8 form");
   WgradArgs a;
   a.d = *d;
-  hipStream_t st = (hipStream_t)stream;
   const bool small = (d->M <= 64 && d->Cin <= 64);
   DV3_REQUIRE(!d->k_split || (d->split_bf16 && !small), "wgrad_gemm: k_split needs the split-bf16 kernel");
   if (d->split_bf16 && !small) {

@@ -43,27 +43,54 @@ def _drop_speaker_embed(speaker_embed, T, p, training, site):
     return bct.transpose(1, 2)
 
 
-def _run_stack(modules, x, speaker_embed_btc, first=0):
+def _c8_enter(x):
+    """bf16 storage (ops.storage_c8: the bf16 GEMM mode): fp32 (B, C, T) -> channel-blocked bf16 at a stack entry"""
+    if ops.storage_c8() and not ops.is_c8(x) and x.size(1) % 8 == 0:
+        return ops.to_c8(x)
+    return x
+
+
+def _c8_leave(x, C=None):
+    return ops.from_c8(x, C) if ops.is_c8(x) else x
+
+
+def _conv1d_c8(f, x, last, **kw):
+    """a plain Conv1d inside a stack: its output follows the storage mode -- c8 whenever the channel count allows,
+    fp32 (B, C, T) for the last layer of the stack (what the callers consume) and for odd channel counts"""
+    if not (ops.is_c8(x) or ops.storage_c8()):
+        return f(x, **kw)
+    return f(x, out_c8=(not last) and f.out_channels % 8 == 0, **kw)
+
+
+def _run_stack(modules, x, speaker_embed_btc, first=0, keep_c8=False):
     """Run a ModuleList of {Conv1d, nn.ReLU, Conv1dGLU, ConvTranspose1d} on BCT x, fusing each
-    Conv1d + ReLU pair into one launch."""
+    Conv1d + ReLU pair into one launch.  In the bf16 GEMM mode the activations between the layers are
+    channel-blocked bf16 tensors (ops.to_c8); the result is fp32 (B, C, T) unless keep_c8."""
     n = len(modules)
     i = first
+    C = x.size(1)               # channel count of x (a c8 tensor pads it to a multiple of 32)
+    x = _c8_enter(x)
     while i < n:
         f = modules[i]
         if isinstance(f, Conv1dGLU):
             x = f(x, speaker_embed_btc)
+            C = f.conv.out_channels // 2
         elif isinstance(f, _conv.Conv1d):
-            if i + 1 < n and isinstance(modules[i + 1], nn.ReLU):
-                x = f(x, mode=ops.EPI_RELU)
-                i += 1
-            else:
-                x = f(x)
+            relu = i + 1 < n and isinstance(modules[i + 1], nn.ReLU)
+            last = (i + (2 if relu else 1) >= n) and not keep_c8
+            x = _conv1d_c8(f, x, last, mode=ops.EPI_RELU if relu else ops.EPI_LINEAR)
+            C = f.out_channels
+            i += int(relu)
         elif isinstance(f, nn.ReLU):
             x = torch.relu(x)
+        elif ops.is_c8(x):          # ConvTranspose1d: fp32 layer between two conversions
+            x = _c8_enter(f(_c8_leave(x, C)))
+            C = f.out_channels
         else:
             x = f(x)
+            C = getattr(f, "out_channels", C)
         i += 1
-    return x
+    return x if keep_c8 else _c8_leave(x, C)
 
 
 def _name_sites(root, prefix):
@@ -184,18 +211,19 @@ class AttentionLayer(nn.Module):
         """All BCT: query (B,C,Tq), keys (B,E,Tk), values (B,E,Tk).  outer_residual: the decoder's
         `(x + residual) * sqrt(0.5)` (deepvoice3.py:348-349) fused into the out-projection."""
         query = query.contiguous()
+        c8 = ops.is_c8(query)       # bf16 storage: c8 query / residuals, fp32 attention core, c8 result
         if self.value_projection is not None:
             values = self.value_projection.forward_bct(values.contiguous())
         if self.key_projection is not None:
             keys = self.key_projection.forward_bct(keys.contiguous())
-        q = self.query_projection.forward_bct(query)
+        q = self.query_projection.forward_bct(query, out_c8=False if c8 else None)
         la = last_attended
         if la is not None and not torch.is_tensor(la):
             la = torch.tensor([int(la)], dtype=torch.int32, device=query.device)
         ctx, attn = ops.attention_core(q, keys, values, key_len, la, self.dropout, self.training,
                                        self.window_backward, self.window_ahead,
                                        getattr(self, "_dv3_site", None))
-        x = self.out_projection.forward_bct(ctx, r=query, r2=outer_residual)
+        x = self.out_projection.forward_bct(ctx, r=query, r2=outer_residual, out_c8=True if c8 else None)
         return x, attn
 
 
@@ -310,7 +338,9 @@ class Decoder(nn.Module):
         x = inputs.transpose(1, 2).contiguous()
         x = ops.dropout(x, self.dropout, self.training, site + ".inputs")
 
-        x = _run_stack(self.preattention, x, speaker_embed_btc)
+        x = _run_stack(self.preattention, x, speaker_embed_btc, keep_c8=True)
+        if ops.is_c8(x) and frame_pos_embed is not None:
+            frame_pos_embed = ops.to_c8(frame_pos_embed)
 
         alignments = []
         for f, attention in zip(self.convolutions, self.attention):
@@ -326,10 +356,13 @@ class Decoder(nn.Module):
                                                      outer_residual=residual)
                 alignments += [alignment]
 
+        x8 = x
+        x = _c8_leave(x, self.last_conv.in_channels)
         decoder_states = x.transpose(1, 2).contiguous()
         decoder_states._dv3_bct = x
-        outputs = self.last_conv(x, mode=ops.EPI_SIGMOID).transpose(1, 2)
-        pre = self.last_conv(x)
+        c8o = False if ops.is_c8(x8) else None
+        outputs = self.last_conv(x8, mode=ops.EPI_SIGMOID, out_c8=c8o).transpose(1, 2)
+        pre = self.last_conv(x8, out_c8=c8o)
         done = self.fc.forward_bct(pre, ops.EPI_SIGMOID).transpose(1, 2)
         return outputs, torch.stack(alignments), done, decoder_states
 
@@ -710,28 +743,31 @@ class Converter(nn.Module):
         site = getattr(self, "_dv3_site", "postnet")
         bct = getattr(x, "_dv3_bct", None)
         x = bct if bct is not None else x.transpose(1, 2).contiguous()
-        speaker_embed_btc = _drop_speaker_embed(speaker_embed, x.size(-1), self.dropout, self.training,
-                                                "%s.speaker_embed.t%d" % (site, x.size(-1)))
+        speaker_embed_btc = _drop_speaker_embed(speaker_embed, x.size(2), self.dropout, self.training,
+                                                "%s.speaker_embed.t%d" % (site, x.size(2)))
         mods = self.convolutions
         n = len(mods)
         i = 0
+        x = _c8_enter(x)            # bf16 storage: channel-blocked bf16 between the layers (see _run_stack)
         while i < n:
             f = mods[i]
-            if speaker_embed_btc is not None and speaker_embed_btc.size(1) != x.size(-1):
-                speaker_embed_btc = _drop_speaker_embed(speaker_embed, x.size(-1), self.dropout, self.training,
-                                                        "%s.speaker_embed.t%d" % (site, x.size(-1)))
+            if speaker_embed_btc is not None and speaker_embed_btc.size(1) != x.size(2):
+                speaker_embed_btc = _drop_speaker_embed(speaker_embed, x.size(2), self.dropout, self.training,
+                                                        "%s.speaker_embed.t%d" % (site, x.size(2)))
             last = (i == n - 1)
             if isinstance(f, Conv1dGLU):
                 x = f(x, speaker_embed_btc)
             elif isinstance(f, _conv.Conv1d):
                 if last:
-                    x = f(x, mode=ops.EPI_SIGMOID)      # torch.sigmoid(x) of deepvoice3.py:604, fused
+                    x = _conv1d_c8(f, x, True, mode=ops.EPI_SIGMOID)      # torch.sigmoid(x) of deepvoice3.py:604, fused
                 elif i + 1 < n and isinstance(mods[i + 1], nn.ReLU):
-                    x = f(x, mode=ops.EPI_RELU)
+                    x = _conv1d_c8(f, x, False, mode=ops.EPI_RELU)
                     i += 1
                 else:
-                    x = f(x)
+                    x = _conv1d_c8(f, x, False)
+            elif ops.is_c8(x):      # ConvTranspose1d: fp32 layer between two conversions
+                x = _c8_enter(f(_c8_leave(x, f.in_channels)))
             else:
                 x = f(x)
             i += 1
-        return x.transpose(1, 2)
+        return _c8_leave(x, self.out_dim).transpose(1, 2)

@@ -14,7 +14,7 @@ from . import conv as _conv
 from .modules import Embedding, Linear, Conv1d, ConvTranspose1d
 from .modules import HighwayConv1d, get_mask_from_lengths, key_lengths_i32
 from .modules import position_encoding_init
-from .deepvoice3 import AttentionLayer
+from .deepvoice3 import AttentionLayer, _c8_enter, _c8_leave, _conv1d_c8
 
 
 def _run_seq(mods, x):
@@ -23,26 +23,29 @@ def _run_seq(mods, x):
     mods = list(mods)
     n = len(mods)
     i = 0
+    C = x.size(1)           # channel count of x (a c8 tensor pads it to a multiple of 32)
+    x = _c8_enter(x)        # bf16 GEMM mode: channel-blocked bf16 between the layers, fp32 (B, C, T) result
     while i < n:
         f = mods[i]
+        C = getattr(f, "out_channels", C) if not isinstance(f, HighwayConv1d) else C
         if isinstance(f, _conv.Conv1d):
             nxt = mods[i + 1] if i + 1 < n else None
-            if isinstance(nxt, nn.ReLU):
-                x = f(x, mode=ops.EPI_RELU)
-                i += 1
-            elif isinstance(nxt, nn.Sigmoid):
-                x = f(x, mode=ops.EPI_SIGMOID)
-                i += 1
-            else:
-                x = f(x)
+            fused = isinstance(nxt, (nn.ReLU, nn.Sigmoid))
+            last = i + (2 if fused else 1) >= n
+            mode = ops.EPI_RELU if isinstance(nxt, nn.ReLU) else ops.EPI_SIGMOID if isinstance(nxt, nn.Sigmoid) \
+                else ops.EPI_LINEAR
+            x = _conv1d_c8(f, x, last, mode=mode)
+            i += int(fused)
         elif isinstance(f, nn.ReLU):
             x = torch.relu(x)
         elif isinstance(f, nn.Sigmoid):
             x = torch.sigmoid(x)
+        elif isinstance(f, _conv.ConvTranspose1d) and ops.is_c8(x):   # fp32 layer between two conversions
+            x = _c8_enter(f(_c8_leave(x, f.in_channels)))
         else:
             x = f(x)
         i += 1
-    return x
+    return _c8_leave(x, C)
 
 
 def _run_seq_incremental(mods, x):

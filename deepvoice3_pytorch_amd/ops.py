@@ -333,18 +333,123 @@ def planes_eligible(J, dil, Tin, Tout):
 
 
 # ----------------------------------------------------------------------------------------------
+# bf16 activation storage, channel-blocked ("c8", include/dv3hip.h): a (B, C, T) activation as a bf16 tensor
+# (B, C8, T, 8), C8 = round_up(C,32)/8.  BASELINE configs 3/4 ("bf16 activations ... fp32 accum"): with
+# set_gemm_precision("bf16") the conv stacks keep their activations, saved pre-gates and activation gradients in
+# this layout -- every tap-GEMM stages it with plain 16-byte copies and every epilogue writes whole 8-byte halves
+# of units.  DV3_BF16_STORAGE=0 keeps fp32 (B, C, T) activations in the bf16 GEMM mode.
+# ----------------------------------------------------------------------------------------------
+bf16_storage = _os.environ.get("DV3_BF16_STORAGE", "1") not in ("0", "")
+
+
+def storage_c8():
+    """True when the conv stacks should run on channel-blocked bf16 activations"""
+    return bf16_storage and _gemm_mode == "bf16"
+
+
+def c8_groups(C):
+    return _round_up(C, 32) // 8
+
+
+def is_c8(t):
+    return t is not None and t.dim() == 4 and t.dtype == torch.bfloat16 and t.shape[-1] == 8
+
+
+def _c8_empty(B, C, T, device):
+    """uninitialised c8 tensor; zero-filled when C leaves padding channels (they meet zero weight rows, but must
+    not be NaN)"""
+    if C % 8:
+        raise RuntimeError("c8 storage needs a channel count that is a multiple of 8, got %d" % C)
+    shape = (B, c8_groups(C), T, 8)
+    t = torch.zeros(shape, dtype=torch.bfloat16, device=device) if C % 32 else \
+        torch.empty(shape, dtype=torch.bfloat16, device=device)
+    t._dv3_C = C
+    return t
+
+
+def _c8_C(t, C=None):
+    c = getattr(t, "_dv3_C", None)
+    if c is None:
+        c = C if C is not None else t.shape[1] * 8
+    return c
+
+
+class _ToC8Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(_chk(x, "x"))
+        B, C, T = x.shape
+        out = _c8_empty(B, C, T, x.device)
+        _lib.call("dv3_to_c8_f32", x.data_ptr(), C * T, T, out.data_ptr(), B, C, T, _stream())
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _from_c8_raw(_c(g), ctx.C)
+
+
+def _from_c8_raw(xc8, C):
+    B, G, T, _ = xc8.shape
+    out = torch.empty((B, C, T), dtype=torch.float32, device=xc8.device)
+    _lib.call("dv3_from_c8_f32", xc8.data_ptr(), out.data_ptr(), C * T, T, B, C, T, _stream())
+    return out
+
+
+class _FromC8Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xc8, C):
+        return _from_c8_raw(_c(xc8), C)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        B, C, T = g.shape
+        out = _c8_empty(B, C, T, g.device)
+        _lib.call("dv3_to_c8_f32", g.data_ptr(), C * T, T, out.data_ptr(), B, C, T, _stream())
+        return out, None
+
+
+def to_c8(x):
+    """fp32 (B, C, T) -> c8 (differentiable); the tensor remembers its channel count in `_dv3_C`"""
+    out = _ToC8Fn.apply(x)
+    out._dv3_C = x.shape[1]
+    return out
+
+
+def from_c8(xc8, C=None):
+    """c8 -> fp32 (B, C, T) (differentiable)"""
+    return _FromC8Fn.apply(xc8, _c8_C(xc8, C))
+
+
+def mask_bits_to_c8(bits, bits_rs, B, C, T):
+    """dropout keep-bits [B*C][rs] -> keep-bytes [B][C8][T] for the c8 consumers"""
+    out = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=bits.device)
+    _lib.call("dv3_mask_bits_to_c8", bits.data_ptr(), bits_rs, out.data_ptr(), B, C, T, _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
 # raw kernel wrappers
 # ----------------------------------------------------------------------------------------------
 def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mode=EPI_LINEAR,
               Cg=0, bias=None, spk=None, spk_strides=(0, 0, 0), r=None, r2=None, residual=0,
               y=None, y_rs=None, ab=None, xmask=None, xmask_rs=0, ymask=None, ymask_rs=0,
               drop_scale=1.0, a_bs=0, store_mode=STORE_BCT, x_bs=None, x_rs=None, tile_hint=0,
-              a_split=None, x_planes=None, r_scale=0.0, out_dtype=torch.float32):
+              a_split=None, x_planes=None, r_scale=0.0, out_dtype=torch.float32, x_c8=None, out_c8=False,
+              xmask_c8=None, ymask_c8=None):
     """dv3_conv_gemm_f32.  x: [B][Cin][Tin] (strides overridable); returns y.  x_planes: the input already
-    split into operand planes (split_planes; x may then be None)."""
+    split into operand planes (split_planes; x may then be None).  bf16 storage: x_c8 = the input as a c8 tensor
+    (with its keep-bytes xmask_c8), out_c8 = y / ab written and r / r2 read in c8 (ymask_c8 for DGRAD)."""
     gated = mode in (EPI_GLU, EPI_HIGHWAY)
     Cout = Cg if gated else (M // 2 if store_mode == STORE_INTERLEAVE2 else M)
     To = 2 * Tout if store_mode == STORE_INTERLEAVE2 else Tout
+    if x_c8 is not None or out_c8:
+        return _conv_gemm_c8(x, a, lda, a_half, B=B, Cin=Cin, Tin=Tin, M=M, Tout=Tout, J=J, dil=dil, padL=padL,
+                             mode=mode, Cg=Cg, bias=bias, spk=spk, spk_strides=spk_strides, r=r, r2=r2,
+                             residual=residual, ab=ab, xmask=xmask, xmask_rs=xmask_rs, ymask=ymask,
+                             ymask_rs=ymask_rs, drop_scale=drop_scale, a_split=a_split, r_scale=r_scale, x_c8=x_c8,
+                             out_c8=out_c8, xmask_c8=xmask_c8, ymask_c8=ymask_c8, Cout=Cout)
     # bf16 storage (single-term bf16 kernels): x / r / r2 may be bf16 tensors (all three alike), y / ab are written in
     # out_dtype
     in_bf16 = x is not None and x.dtype == torch.bfloat16
@@ -399,6 +504,82 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
             (1 if _gemm_mode == "bf16" else 0)
     _lib.call("dv3_conv_gemm_f32", ctypes.byref(d), _stream())
     return y
+
+
+def _conv_gemm_c8(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J, dil, padL, mode, Cg, bias, spk, spk_strides, r, r2,
+                  residual, ab, xmask, xmask_rs, ymask, ymask_rs, drop_scale, a_split, r_scale, x_c8, out_c8, xmask_c8,
+                  ymask_c8, Cout):
+    """the bf16-storage forms of dv3_conv_gemm_f32 (single-term bf16 kernels): c8 in and / or c8 out"""
+    if _gemm_mode != "bf16" or a_split is None:
+        raise RuntimeError("c8 activations need the bf16 GEMM mode and a split weight image")
+    dev = (x_c8 if x_c8 is not None else x).device
+    if out_c8:
+        y = _c8_empty(B, Cout, Tout, dev)
+        for t_ in (r, r2):
+            if t_ is not None and not is_c8(t_):
+                raise RuntimeError("conv_gemm: a c8 output reads its residual inputs in c8")
+        if ab is not None and not is_c8(ab):
+            raise RuntimeError("conv_gemm: a c8 output saves its pre-gate pair in c8")
+    else:
+        if r is not None or r2 is not None or ab is not None:
+            raise RuntimeError("conv_gemm: c8 input with an fp32 output takes no residual / pre-gate save")
+        y = torch.empty((B, Cout, Tout), dtype=torch.float32, device=dev)
+    d = _conv_desc()
+    if x_c8 is not None:
+        if x_c8.shape[1] != c8_groups(Cin) or x_c8.shape[2] != Tin or not x_c8.is_contiguous():
+            raise RuntimeError("conv_gemm: c8 input shape %s does not match Cin=%d Tin=%d" % (tuple(x_c8.shape), Cin, Tin))
+        d.x_planes, d.x_c8p = x_c8.data_ptr(), x_c8.shape[1]
+        d.xmask_c8 = _ptr(xmask_c8)
+    else:
+        d.x, d.x_bs, d.x_rs = x.data_ptr(), x.stride(0), x.stride(1)
+        d.xmask, d.xmask_rs = _ptr(xmask), xmask_rs
+    d.a, d.a_bs, d.lda, d.a_half = _ptr(a), 0, lda, a_half
+    d.bias, d.spk = _ptr(bias), _ptr(spk)
+    d.spk_bs, d.spk_rs, d.spk_ts = spk_strides
+    d.r, d.r2 = _ptr(r), _ptr(r2)
+    d.y, d.ab = y.data_ptr(), _ptr(ab)
+    if not out_c8:
+        d.y_bs, d.y_rs = Cout * Tout, Tout
+        d.ymask, d.ymask_rs = _ptr(ymask), ymask_rs
+    else:
+        d.ymask_c8 = _ptr(ymask_c8)
+    d.drop_scale, d.r_scale = drop_scale, r_scale
+    d.io_bf16 = CONSTS["DV3_IO_OUT_C8"] if out_c8 else 0
+    d.B, d.Cin, d.Tin, d.M, d.Cg, d.Tout, d.J, d.dil, d.padL = B, Cin, Tin, M, Cg, Tout, J, dil, padL
+    d.mode, d.residual, d.store_mode, d.tile_hint = mode, residual, STORE_BCT, 0
+    d.a_split, d.split_terms = a_split.data_ptr(), 1
+    _lib.call("dv3_conv_gemm_f32", ctypes.byref(d), _stream())
+    return y
+
+
+def wgrad_gemm_c8(g8, x8, *, B, M, Cin, T, J, dil, padL, n_slabs, xmask_c8=None, drop_scale=1.0):
+    """dv3_wgrad_gemm_f32, c8 form: g8 (B, M/8.., T, 8), x8 (B, Cin/8.., T, 8) -> out [S][J][M][Cin]"""
+    out = torch.empty((n_slabs, J, M, Cin), dtype=torch.float32, device=g8.device)
+    d = _wgrad_desc()
+    d.g, d.x = g8.data_ptr(), x8.data_ptr()
+    d.xmask_c8, d.drop_scale = _ptr(xmask_c8), drop_scale
+    d.out, d.out_ss, d.ldo = out.data_ptr(), J * M * Cin, Cin
+    d.B, d.M, d.Cin, d.T, d.Tin, d.J, d.dil, d.padL, d.n_slabs = B, M, Cin, T, T, J, dil, padL, n_slabs
+    d.split_bf16, d.k_split, d.c8 = 2, 1, 1
+    _lib.call("dv3_wgrad_gemm_f32", ctypes.byref(d), _stream())
+    return out
+
+
+def gate_bwd_c8(dy, ab_or_y, x, *, B, C, T, mode, residual=0, alpha=1.0, want_dres=False, want_dpre=True):
+    """dv3_gate_bwd_f32 on c8 tensors -> (dab_or_dpre c8, dres c8, bias_part fp32 [B][rows])"""
+    gated = mode in (EPI_GLU, EPI_HIGHWAY)
+    dev = dy.device
+    rows = 2 * C if gated else C
+    dab = _c8_empty(B, rows, T, dev) if (gated or want_dpre) else None
+    dres = _c8_empty(B, C, T, dev) if (gated and want_dres) else None
+    part = torch.empty((B, rows), dtype=torch.float32, device=dev)
+    d = _gate_bwd_desc()
+    d.dy, d.ab_or_y, d.x = dy.data_ptr(), _ptr(ab_or_y), _ptr(x)
+    d.dab, d.dres, d.bias_part = _ptr(dab), _ptr(dres), part.data_ptr()
+    d.alpha = alpha
+    d.B, d.C, d.T, d.mode, d.residual, d.c8 = B, C, T, mode, residual, 1
+    _lib.call("dv3_gate_bwd_f32", ctypes.byref(d), _stream())
+    return dab, dres, part
 
 
 def wgrad_gemm(g, x, *, B, M, Cin, T, Tin, J=1, dil=1, padL=0, n_slabs=1, xmask=None, xmask_rs=0,
@@ -516,13 +697,14 @@ def _slab_count(B, tiles):
 # ----------------------------------------------------------------------------------------------
 class LayerCfg(object):
     __slots__ = ("k", "dil", "causal", "mode", "residual", "p", "training", "transposed", "site",
-                 "pad_left", "t_out")
+                 "pad_left", "t_out", "out_c8")
 
     def __init__(self, k=1, dil=1, causal=False, mode=EPI_LINEAR, residual=False, p=0.0,
-                 training=False, transposed=False, site=None, pad_left=None, t_out=None):
+                 training=False, transposed=False, site=None, pad_left=None, t_out=None, out_c8=None):
         self.k, self.dil, self.causal, self.mode = k, dil, causal, mode
         self.residual, self.p, self.training, self.transposed, self.site = residual, p, training, transposed, site
         self.pad_left, self.t_out = pad_left, t_out   # None: "same" length output (all model layers)
+        self.out_c8 = out_c8                           # bf16 storage: None = like the input, True / False forced
 
 
 def _pad_left(k, dil, causal):
@@ -713,7 +895,198 @@ class ConvLayerFn(torch.autograd.Function):
         return dx, dv, dg, dbias, dspk, dr, dr2, None, None
 
 
+class ConvLayerC8Fn(torch.autograd.Function):
+    """ConvLayerFn on bf16 channel-blocked activations (bf16 GEMM mode, BASELINE configs 3/4).  x is a c8 tensor
+    or an fp32 (B, C, T) one; the output is c8 when cfg.out_c8 (default: when x is), else fp32 (B, C, T).  With a
+    c8 output the residual inputs r / r2, the saved pre-gate pair and the incoming gradient are c8 as well.
+    Same-length Conv1d / Linear layers with 1 or 3 taps (everything inside the model stacks)."""
+
+    @staticmethod
+    def forward(ctx, x, v, g, bias, spk, r, r2, cfg, packed):
+        x8 = is_c8(x)
+        out8 = x8 if cfg.out_c8 is None else bool(cfg.out_c8)
+        if not (x8 or out8) or cfg.transposed:
+            raise RuntimeError("ConvLayerC8Fn: needs a c8 side and a plain Conv1d / Linear layer")
+        x = _c(x)
+        mode = cfg.mode
+        gated = mode in (EPI_GLU, EPI_HIGHWAY)
+        O = v.shape[0]
+        Cin = v.shape[1]
+        J = v.shape[2] if v.dim() == 3 else 1
+        B, T = x.shape[0], x.shape[2]
+        if (x.shape[1] != c8_groups(Cin)) if x8 else (x.shape[1] != Cin):
+            raise RuntimeError("conv layer: input %s does not carry %d channels" % (tuple(x.shape), Cin))
+        M, Cg = O, (O // 2 if gated else 0)
+        if gated and not (x8 and out8):
+            raise RuntimeError("gated c8 layers run c8 -> c8 (convert at the stack entry)")
+        if J not in (1, 3) or (cfg.t_out is not None and cfg.t_out != T) or (J - 1) * cfg.dil > 64:
+            raise RuntimeError("c8 layers: same-length convolutions with 1 or 3 taps")
+        need_grad = any(ctx.needs_input_grad[:7])
+        pk = packed
+        if pk is not None and (pk.fwd_s is None or (need_grad and pk.bwd_s is None)):
+            pk = None
+        if pk is None and prepacked is not None:
+            pk = prepacked.lookup(v, Cg)
+        if pk is None:
+            pk = pack_weights(v, g, glu_cg=Cg, need_bwd=need_grad, split_only=True)
+        bits, bits_rs, dscale, keep8 = None, 0, 1.0, None
+        if cfg.training and cfg.p > 0:
+            bits, bits_rs = dropout_bits(B * Cin, T, cfg.p, x.device, cfg.site)
+            dscale = 1.0 / (1.0 - cfg.p)
+            if x8:
+                keep8 = mask_bits_to_c8(bits, bits_rs, B, Cin, T)
+        padL = cfg.pad_left if cfg.pad_left is not None else _pad_left(J, cfg.dil, cfg.causal)
+        ab = _c8_empty(B, M, T, x.device) if (gated and need_grad) else None
+        spk_strides = (0, 0, 0)
+        if spk is not None:
+            spk = _c(spk)
+            spk_strides = (spk.stride(0), 1, 0) if spk.dim() == 2 else (spk.stride(0), spk.stride(1), 1)
+        if gated:
+            res_in = x if (mode == EPI_HIGHWAY or cfg.residual) else None
+        else:
+            res_in = _c(r) if r is not None else None
+        r2c = _c(r2) if r2 is not None else None
+        y = conv_gemm(None if x8 else x, None, pk.lda, pk.a_half, B=B, Cin=Cin, Tin=T, M=M, Tout=T, J=J, dil=cfg.dil,
+                      padL=padL, mode=mode, Cg=Cg, bias=bias, spk=spk, spk_strides=spk_strides, r=res_in, r2=r2c,
+                      residual=int(cfg.residual), ab=ab, xmask=None if x8 else bits, xmask_rs=0 if x8 else bits_rs,
+                      drop_scale=dscale, a_split=pk.fwd_s, x_c8=x if x8 else None, out_c8=out8, xmask_c8=keep8)
+        if need_grad:
+            leaves = [t for t in (v, g, bias) if t is not None]
+            ctx.inplace = bool(leaves) and all(getattr(t, "_dv3_grad_inplace", False) and t.grad is not None and
+                                               t.requires_grad for t in leaves)
+            ctx.leaves = (v, g, bias) if ctx.inplace else None
+            if ctx.inplace:
+                v._dv3_pending = getattr(v, "_dv3_pending", 0) + 1
+            ctx.cfg, ctx.pk, ctx.dims = cfg, pk, (B, Cin, T, M, Cg, J, padL)
+            ctx.bits, ctx.bits_rs, ctx.dscale, ctx.keep8 = bits, bits_rs, dscale, keep8
+            ctx.x8, ctx.out8 = x8, out8
+            ctx.spk_dim = spk.dim() if spk is not None else 0
+            ctx.has_r, ctx.has_r2, ctx.has_bias = (r is not None), (r2 is not None), bias is not None
+            ctx.save_for_backward(x, v, g, ab if gated else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg, pk = ctx.cfg, ctx.pk
+        B, Cin, T, M, Cg, J, padL = ctx.dims
+        x, v, g, saved = ctx.saved_tensors
+        mode = cfg.mode
+        gated = mode in (EPI_GLU, EPI_HIGHWAY)
+        dy = _c(dy)
+        rs2 = math.sqrt(0.5)
+        dr = dr2 = dspk = None
+        dres, r_scale = None, 0.0
+        if gated:          # c8 -> c8
+            glu_skip = mode == EPI_GLU and cfg.residual
+            gmat, dres, part = gate_bwd_c8(dy, saved, x if mode == EPI_HIGHWAY else None, B=B, C=Cg, T=T, mode=mode,
+                                           residual=int(cfg.residual), want_dres=(mode == EPI_HIGHWAY))
+            if glu_skip:
+                dres, r_scale = dy, rs2
+            if ctx.spk_dim == 2:
+                dspk = part[:, :Cg].contiguous()
+            elif ctx.spk_dim == 3:
+                dspk = _from_c8_raw(gmat, M)[:, :Cg, :]
+            g8 = gmat
+        else:
+            alpha = 1.0
+            if ctx.has_r2:
+                dr2 = dy * rs2
+                alpha *= rs2
+            if ctx.has_r:
+                dr = dy * (alpha * rs2)
+                alpha *= rs2
+            need_y = mode in (EPI_RELU, EPI_SIGMOID, EPI_SOFTSIGN)
+            if need_y and (ctx.has_r or ctx.has_r2):
+                raise RuntimeError("activation + fused residual is not used by any layer")
+            if ctx.out8:
+                plain = mode == EPI_LINEAR and alpha == 1.0
+                gm, _, part = gate_bwd_c8(dy, saved if need_y else None, None, B=B, C=M, T=T, mode=mode, alpha=alpha,
+                                          want_dpre=not plain)
+                g8 = dy if plain else gm
+                gmat = g8
+            else:          # fp32 (B, M, T) gradient of a c8 -> fp32 layer
+                if mode == EPI_LINEAR and alpha == 1.0:
+                    _, _, part = gate_bwd(dy, None, None, B=B, C=M, T=T, mode=EPI_LINEAR, want_dpre=False)
+                    gmat = dy
+                else:
+                    gmat, _, part = gate_bwd(dy, saved if need_y else None, None, B=B, C=M, T=T, mode=mode, alpha=alpha)
+                g8 = None
+        dx = dv = dg = dbias = None
+        if ctx.needs_input_grad[0]:
+            dpad = (J - 1) * cfg.dil - padL
+            if ctx.x8:      # dx in c8: keep-bytes of the input dropout on the output side
+                dx = conv_gemm(None if g8 is not None else gmat, None, pk.ldb, 0, B=B, Cin=M, Tin=T, M=Cin, Tout=T, J=J,
+                               dil=cfg.dil, padL=dpad, mode=EPI_DGRAD, r=dres, r_scale=r_scale, drop_scale=ctx.dscale,
+                               a_split=pk.bwd_s, x_c8=g8, out_c8=True, ymask_c8=ctx.keep8)
+            else:           # fp32 input (the attention context): c8 gradient operand, fp32 (B, Cin, T) result
+                dx = conv_gemm(None, None, pk.ldb, 0, B=B, Cin=M, Tin=T, M=Cin, Tout=T, J=J, dil=cfg.dil, padL=dpad,
+                               mode=EPI_DGRAD, ymask=ctx.bits, ymask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
+                               a_split=pk.bwd_s, x_c8=g8, out_c8=False)
+        if ctx.needs_input_grad[1]:
+            tiles = ((M + 127) // 128) * ((Cin + 127) // 128)
+            if g8 is None and M % 8:
+                # an fp32 output whose channel count has no c8 form (the 513-bin linear spectrogram): the gradient
+                # operand stays fp32 (B, M, T) and the input is widened once for the fp32-storage wgrad kernel
+                x3 = not (M <= 64 and Cin <= 64)
+                S = _ksplit_count(B * ((T + 31) // 32), tiles * J) if x3 else _slab_count(B, tiles * J)
+                slabs = wgrad_gemm(gmat, _from_c8_raw(x, Cin), B=B, M=M, Cin=Cin, T=T, Tin=T, J=J, dil=cfg.dil,
+                                   padL=padL, n_slabs=S, xmask=ctx.bits, xmask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
+                                   split_bf16=x3, k_split=x3)
+            else:
+                if g8 is None:
+                    g8 = _ToC8Fn.apply(gmat)
+                if ctx.x8:
+                    x8t, keep8 = x, ctx.keep8
+                else:
+                    x8t = _ToC8Fn.apply(x)
+                    keep8 = mask_bits_to_c8(ctx.bits, ctx.bits_rs, B, Cin, T) if ctx.bits is not None else None
+                S = _ksplit_count(B * ((T + 31) // 32), tiles, slots=256)
+                slabs = wgrad_gemm_c8(g8, x8t, B=B, M=M, Cin=Cin, T=T, J=J, dil=cfg.dil, padL=padL, n_slabs=S,
+                                      xmask_c8=keep8, drop_scale=ctx.dscale)
+            v3 = v if v.dim() == 3 else v.unsqueeze(-1)
+            if ctx.inplace:
+                pv, pg, pb = ctx.leaves
+                weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None, pk.scale, part, B,
+                                pk.O, pk.I, pk.J, False, want_bias=ctx.has_bias,
+                                into=(pv.grad, pg.grad if pg is not None else None,
+                                      pb.grad if pb is not None else None))
+                pv._dv3_pending -= 1
+                if pv._dv3_pending == 0:
+                    for hook in grad_ready_hooks:
+                        for t in (pv, pg, pb):
+                            if t is not None:
+                                hook(t)
+            else:
+                dv, dg, dbias = weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None,
+                                                pk.scale, part, B, pk.O, pk.I, pk.J, False, want_bias=ctx.has_bias)
+                dv = dv.view_as(v)
+        return dx, dv, dg, dbias, dspk, dr, dr2, None, None
+
+
+def _c8_layer_ok(v, cfg, out8):
+    """the layer forms the c8 kernels serve: same-length Conv1d / Linear with 1 or 3 taps, channel counts that are
+    multiples of 8 on every c8 side"""
+    J = v.shape[2] if v.dim() == 3 else 1
+    if cfg.transposed or J not in (1, 3) or cfg.t_out is not None or (J - 1) * cfg.dil > 64 or v.shape[1] % 8:
+        return False
+    return (not out8) or v.shape[0] % 16 == 0 or (cfg.mode not in (EPI_GLU, EPI_HIGHWAY) and v.shape[0] % 8 == 0)
+
+
 def conv_layer(x, v, g, bias, cfg, spk=None, r=None, r2=None, packed=None):
+    x8, want8 = is_c8(x), getattr(cfg, "out_c8", None)
+    if (x8 or want8) and not _c8_layer_ok(v, cfg, x8 if want8 is None else bool(want8)):
+        # a form the c8 kernels do not serve (5- or 7-tap layers of small configurations): this layer runs on
+        # fp32 (B, C, T) tensors between two conversions
+        y = ConvLayerFn.apply(from_c8(x, v.shape[1]) if x8 else x, v, g, bias, spk,
+                              from_c8(r) if is_c8(r) else r, from_c8(r2) if is_c8(r2) else r2, cfg, packed)
+        out8 = x8 if want8 is None else bool(want8)
+        return to_c8(y) if (out8 and y.shape[1] % 8 == 0) else y
+    if x8 or want8:
+        y = ConvLayerC8Fn.apply(x, v, g, bias, spk, r, r2, cfg, packed)
+        if is_c8(y):
+            gated = cfg.mode in (EPI_GLU, EPI_HIGHWAY)
+            y._dv3_C = v.shape[0] // 2 if gated else v.shape[0]
+        return y
     return ConvLayerFn.apply(x, v, g, bias, spk, r, r2, cfg, packed)
 
 

@@ -316,6 +316,7 @@ class GraphedTrainer(object):
         trainer.check_lengths(static_batch)
         dev = trainer.device
         self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._prev_offset = ops.dropout_state.dev_offset        # restored by close()
         ops.dropout_state.dev_offset = self.seed_offset
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -346,6 +347,13 @@ class GraphedTrainer(object):
         ops.bump_param_epoch()           # the replayed clip/Adam wrote the parameters
         self.t.global_step += 1
         return self.scal
+
+    def close(self):
+        """Give the process-wide dropout state back: the device seed offset installed for the replays would
+        otherwise keep shifting the masks of every later (eager) forward in the process."""
+        if ops.dropout_state.dev_offset is self.seed_offset:
+            ops.dropout_state.dev_offset = self._prev_offset
+        self._prev_offset = None
 
 
 # ------------------------------------------------------------------------------------------------

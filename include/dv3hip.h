@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 26
+#define DV3_ABI_VERSION 27
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -134,12 +134,35 @@ typedef struct dv3_conv_desc {
                                                 single-term bf16 kernels (split_terms == 1) only: DV3_IO_IN_BF16 = x, r
                                                 and r2 are bf16 tensors (same element strides), DV3_IO_OUT_BF16 = y and
                                                 ab are written as bf16 (round to nearest even).  0 = fp32 everywhere.  */
+  const uint8_t* xmask_c8;                   /* c8 input (x_planes, split_terms == 1): dropout keep-BYTES [B][x_c8p][Tin],
+                                                bit e of byte (b, g, t) = keep channel 8g+e at frame t
+                                                (dv3_mask_bits_to_c8); applied while staging, 1/(1-p) = drop_scale in
+                                                the epilogue.  NULL = no dropout.                                     */
+  const uint8_t* ymask_c8;                   /* DGRAD with DV3_IO_OUT_C8: keep-bytes over the output rows            */
 } dv3_conv_desc;
 #define DV3_IO_IN_BF16 1
 #define DV3_IO_OUT_BF16 2
 #define DV3_IO_AB_BF16 4   /* only the saved pre-gate pair `ab` is bf16 (y stays fp32): halves the largest tensor a
                               training forward writes; dv3_gate_bwd_desc.ab_bf16 reads it back */
+/*
+ * Channel-blocked bf16 activation storage ("c8", BASELINE configs 3/4: bf16 activations in HBM, fp32 accumulate):
+ * a (B, C, T) activation is held as  bf16 [B][C8][T][8],  C8 = round_up(C,32)/8 -- channel c of frame t is element
+ * c%8 of the 16-byte unit (b, c/8, t); channels >= C are zero.  This IS plane 0 of dv3_split_planes_f32's layout: a
+ * tensor written by one layer's epilogue is the next layer's `x_planes` (split_terms == 1) with no conversion, the
+ * tap-GEMM stages it with plain 16-byte copies, and the epilogue's accumulator tile maps to whole 8-byte halves of
+ * units (csrc/conv_common.h).  C % 8 == 0 is required of every tensor stored this way.
+ *   DV3_IO_OUT_C8   y (and ab) are written in c8; r / r2 (and the DGRAD addend) are READ in c8
+ * (the tensors on the two sides of an epilogue share one layout; x is c8 exactly when x_planes is given).
+ */
+#define DV3_IO_OUT_C8 16
 int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
+
+/* fp32 (B,C,T) <-> c8 converters (stack entry / exit and their gradients); x strides in elements.            */
+int dv3_to_c8_f32(const float* x, int64_t x_bs, int64_t x_rs, uint16_t* out, int32_t B, int32_t C, int32_t T, void* stream);
+int dv3_from_c8_f32(const uint16_t* x, float* out, int64_t out_bs, int64_t out_rs, int32_t B, int32_t C, int32_t T,
+                    void* stream);
+/* dropout keep-bits [B*C][rs words] (dv3_dropout_bits) -> keep-bytes [B][C8][T] for c8 consumers             */
+int dv3_mask_bits_to_c8(const uint32_t* bits, int32_t bits_rs, uint8_t* out, int32_t B, int32_t C, int32_t T, void* stream);
 
 /*
  * Split-bf16 ("bf16x3") operand form.  The fp32 matrix cores run at 1/16 of the bf16 rate on
@@ -215,6 +238,10 @@ typedef struct dv3_wgrad_desc {
                                                 result); 1 (split-bf16 kernels): slab s = the s-th
                                                 contiguous range of the (batch item, 32-step chunk)
                                                 sequence -- any S, so the grid can match the chip  */
+  int32_t c8;                                /* g and x are channel-blocked bf16 tensors (DV3_IO_OUT_C8 layout, over M and
+                                                Cin channels; the stride fields are unused): the bf16-storage form --
+                                                split_bf16 == 2, k_split, T == Tin, J in {1, 3}                     */
+  const uint8_t* xmask_c8;                   /* c8: dropout keep-bytes over x [B][round_up(Cin,32)/8][Tin], or NULL   */
 } dv3_wgrad_desc;
 int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream);
 
@@ -292,6 +319,8 @@ typedef struct dv3_gate_bwd_desc {
   float alpha;                               /* non-gated modes: dy is scaled by alpha first */
   int32_t B, C, T, mode, residual;
   int32_t ab_bf16;                           /* gated modes: ab_or_y is a bf16 tensor (DV3_IO_AB_BF16 / _OUT_BF16)  */
+  int32_t c8;                                /* every activation tensor (dy, ab_or_y, x, dab, dres) is channel-blocked
+                                                bf16 (DV3_IO_OUT_C8 layout; C % 8 == 0); bias_part stays fp32        */
 } dv3_gate_bwd_desc;
 int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream);
 

@@ -1,0 +1,213 @@
+# coding: utf-8
+"""-m gpu: the bf16-storage path of the bf16 GEMM mode (BASELINE configs 3/4: "bf16 activations ... fp32 accum").
+Activations between the layers of a conv stack are channel-blocked bf16 tensors ("c8", include/dv3hip.h); every
+layer form is run forward + backward on c8 tensors and compared with
+  * the oracle (oracle/dv3_oracle.py) evaluated in fp32 -- tolerance 2e-2 of the tensor's max: the operands AND the
+    stored activations carry 8 significand bits (measured 3.5e-3 .. 5e-3; a wrong channel / frame mapping gives O(1));
+  * the exact-fp32 HIP mode (itself held to 1e-4 against the oracle in test_gpu_kernels.py) for the gradients, 5e-2.
+Converters and the keep-byte form of the dropout mask are bit-exact checks."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dv3_oracle as O
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL_FWD, TOL_GRAD = 2e-2, 5e-2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def modes():
+    """restore the GEMM mode and the storage switch after the test"""
+    from deepvoice3_pytorch_amd import ops
+    prev = (ops.gemm_precision(), ops.bf16_storage)
+    yield ops
+    ops.set_gemm_precision(prev[0])
+    ops.bf16_storage = prev[1]
+
+
+@pytest.mark.parametrize("B,C,T", [(3, 40, 37), (2, 64, 150), (2, 320, 50), (1, 8, 1)])
+def test_c8_converters_and_keep_bytes(dev, modes, B, C, T):
+    ops = modes
+    x = torch.randn(B, C, T, device=dev)
+    x8 = ops.to_c8(x)
+    assert tuple(x8.shape) == (B, (C + 31) // 32 * 4, T, 8) and x8.dtype == torch.bfloat16
+    assert torch.equal(ops.from_c8(x8, C), x.to(torch.bfloat16).float())        # round to nearest even, exact back
+    ref = torch.zeros(B, x8.shape[1] * 8, T, device=dev)
+    ref[:, :C] = x
+    assert torch.equal(x8.float(), ref.view(B, -1, 8, T).permute(0, 1, 3, 2).to(torch.bfloat16).float())
+    bits, rs = ops.dropout_bits(B * C, T, 0.3, dev)
+    k8 = ops.mask_bits_to_c8(bits, rs, B, C, T).cpu().numpy()
+    keep = O.unpack_keep_bits(bits.cpu().numpy().view(np.uint32), B * C, rs, T).reshape(B, C, T).astype(np.uint8)
+    want = np.zeros((B, x8.shape[1], T), np.uint8)
+    for e in range(8):
+        sel = keep[:, e::8, :]
+        want[:, :sel.shape[1], :] |= (sel << e).astype(np.uint8)
+    assert np.array_equal(k8, want)
+    # gradients of the converters are the converters
+    xin = x.clone().requires_grad_(True)
+    w = torch.randn(B, C, T, device=dev)
+    (ops.from_c8(ops.to_c8(xin), C) * w).sum().backward()
+    assert torch.equal(xin.grad, w.to(torch.bfloat16).float())
+
+
+def _run(layer, x, storage, mode, ops, seed=3, record=None):
+    ops.set_gemm_precision(mode)
+    ops.bf16_storage = storage
+    for p in layer.parameters():
+        p.grad = None
+    xin = x.clone().requires_grad_(True)
+    ops.dropout_state.manual_seed(seed)
+    ops.dropout_state.record = record
+    try:
+        c8 = storage and mode == "bf16"
+        y = layer(ops.to_c8(xin) if c8 else xin)
+        assert ops.is_c8(y) == c8
+        y = ops.from_c8(y) if c8 else y
+        w = torch.linspace(-1, 1, y.numel(), device=x.device).view_as(y)
+        (y * w).sum().backward()
+    finally:
+        ops.dropout_state.record = None
+    return y.detach(), xin.grad.detach(), {k: p.grad.detach().clone() for k, p in layer.named_parameters()}
+
+
+GATED = [("glu", 64, 3, 2, False, 75, 3), ("glu", 40, 3, 1, True, 37, 2), ("glu", 256, 3, 27, False, 150, 2),
+         ("glu", 128, 1, 1, False, 50, 3), ("glu_nores", 64, 3, 3, False, 61, 2), ("highway", 64, 3, 2, False, 75, 3),
+         ("highway", 40, 3, 1, True, 37, 2), ("highway", 128, 1, 1, False, 50, 3)]
+
+
+@pytest.mark.parametrize("kind,C,k,d,causal,T,B", GATED)
+def test_c8_gated_layers_forward_backward(dev, modes, kind, C, k, d, causal, T, B):
+    """Conv1dGLU (modules.py:112-167) / HighwayConv1d (modules.py:170-229), dropout on, c8 in and out"""
+    ops = modes
+    from deepvoice3_pytorch_amd import modules, _lib
+    torch.manual_seed(0)
+    if kind == "highway":
+        layer = modules.HighwayConv1d(C, C, k, dilation=d, causal=causal, dropout=0.1)
+    else:
+        layer = modules.Conv1dGLU(1, 16, C, C, k, dropout=0.2, dilation=d, causal=causal, residual=(kind == "glu"))
+    layer = layer.to(dev).train()
+    layer._dv3_site = "l"
+    with torch.no_grad():
+        layer.conv.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(B, C, T, device=dev)
+    rec = {}
+    y8, dx8, dp8 = _run(layer, x, True, "bf16", ops, record=rec)
+    assert _lib.lib().dv3_debug_get(10) // 1000 == 8            # the planes kernel, single-term bf16
+    assert _lib.lib().dv3_debug_get(11) in (5001, 5003)         # the c8 wgrad kernel
+    # forward against the oracle with the recorded keep-bits
+    bits, rows, Tm = rec["l"]
+    keep = torch.from_numpy(O.unpack_keep_bits(bits.cpu().numpy().view(np.uint32), rows, (Tm + 31) // 32, Tm)).float()
+    p = layer.dropout
+    sd = {"l.conv." + n: v.detach().cpu() for n, v in layer.conv.state_dict().items()}
+    def drop(site, t, p_, layout):
+        return t * keep.view(t.shape) / (1 - p_)
+    if kind == "highway":
+        want = O.highway_conv1d(sd, "l", x.cpu(), k, d, causal, p=p, drop=drop)
+    else:
+        want = O.conv1d_glu(sd, "l", x.cpu(), k, d, causal, kind == "glu", p=p, drop=drop)
+    assert rel_err(y8.cpu(), want) < TOL_FWD
+    yr, dxr, dpr = _run(layer, x, False, "f32", ops)       # same seed -> same keep-bits
+    assert rel_err(yr.cpu(), want) < 1e-4
+    assert rel_err(dx8.cpu(), dxr.cpu()) < TOL_GRAD
+    for n in dpr:
+        assert rel_err(dp8[n].cpu(), dpr[n].cpu()) < TOL_GRAD, n
+
+
+def test_c8_plain_layers(dev, modes):
+    """1x1 Conv1d / Linear forms around the gated layers: c8 -> c8 (+ ReLU, on the forward's own decisions),
+    c8 -> fp32 with a channel count that has no c8 form (513 linear bins), fp32 -> c8 with two c8 residuals (the
+    attention out-projection, deepvoice3.py:175 + 348-349)"""
+    ops = modes
+    from deepvoice3_pytorch_amd import modules
+    B, T = 3, 61
+    torch.manual_seed(4)
+    f = modules.Conv1d(64, 128, 1, dropout=0.0).to(dev).train()
+    ops.set_gemm_precision("bf16")
+    ops.bf16_storage = True
+    x = torch.randn(B, 64, T, device=dev)
+    xin = x.clone().requires_grad_(True)
+    y = ops.from_c8(f(ops.to_c8(xin), mode=ops.EPI_RELU, out_c8=True))
+    wgt = torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)
+    (y * wgt).sum().backward()
+    W = f.effective_weight().detach()[:, :, 0]
+    dpre = wgt.to(torch.bfloat16).float() * (y.detach() > 0)
+    xb = x.to(torch.bfloat16).float()
+    assert rel_err(y.detach().cpu(), torch.relu(torch.einsum("oi,bit->bot", W, xb) + f.bias.detach()[None, :, None]).cpu()) < TOL_FWD
+    assert rel_err(xin.grad.cpu(), torch.einsum("oi,bot->bit", W, dpre).cpu()) < TOL_FWD
+    assert rel_err(f.bias.grad.cpu(), dpre.sum((0, 2)).cpu()) < TOL_FWD
+
+    def both(make, call, n_in):
+        outs = {}
+        for tag, storage, gm in (("ref", False, "f32"), ("c8", True, "bf16")):
+            ops.set_gemm_precision(gm)
+            ops.bf16_storage = storage
+            layer = make()
+            ins = [t.clone().requires_grad_(True) for t in n_in]
+            ops.dropout_state.manual_seed(5)
+            y = call(layer, ins, storage and gm == "bf16")
+            y = ops.from_c8(y) if ops.is_c8(y) else y
+            (y * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+            outs[tag] = [y.detach()] + [t.grad.detach() for t in ins] + [p.grad.detach().clone() for p in layer.parameters()]
+        for a, b in zip(outs["c8"], outs["ref"]):
+            assert rel_err(a.cpu(), b.cpu()) < TOL_GRAD
+
+    for (Ci, Co, mode) in ((64, 128, ops.EPI_SOFTSIGN), (128, 64, ops.EPI_LINEAR), (64, 513, ops.EPI_SIGMOID)):
+        def make(Ci=Ci, Co=Co):
+            torch.manual_seed(1)
+            return modules.Conv1d(Ci, Co, 1, dropout=0.1).to(dev).train()
+        both(make, lambda l, ins, c8, mode=mode, Co=Co: l(ops.to_c8(ins[0]) if c8 else ins[0], mode=mode,
+                                                        out_c8=(Co % 8 == 0) if c8 else None),
+             [torch.randn(B, Ci, T, device=dev)])
+
+    def make_lin():
+        torch.manual_seed(2)
+        return modules.Linear(64, 128).to(dev).train()
+    both(make_lin, lambda l, ins, c8: l.forward_bct(ins[0], r=ops.to_c8(ins[1]) if c8 else ins[1],
+                                                    r2=ops.to_c8(ins[2]) if c8 else ins[2], out_c8=True if c8 else None),
+         [torch.randn(B, 64, T, device=dev), torch.randn(B, 128, T, device=dev), torch.randn(B, 128, T, device=dev)])
+
+
+@pytest.mark.parametrize("preset", ["deepvoice3_ljspeech", "nyanko_ljspeech", "deepvoice3_vctk"])
+def test_c8_train_step_tracks_fp32_storage(dev, modes, preset):
+    """one training forward + backward of the three preset models (preset channel counts, short sequences): the c8
+    storage mode against the exact-fp32 mode and against the fp32-storage bf16 mode it replaces"""
+    ops = modes
+    import bench
+    from deepvoice3_pytorch_amd import builder, train_step
+    bname, hp, sigma = bench.PRESETS[preset]
+    hp = dict(hp)
+    res = {}
+    for tag, storage, gm in (("f32", False, "f32"), ("bf16", False, "bf16"), ("c8", True, "bf16")):
+        ops.set_gemm_precision(gm)
+        ops.bf16_storage = storage
+        torch.manual_seed(5)
+        model = getattr(builder, bname)(**hp).to(dev)
+        rng = np.random.RandomState(3)
+        bt = bench.synth_batch(rng, 2, 60, 160, hp, fixed=True)
+        spk = torch.from_numpy(rng.randint(0, hp["n_speakers"], 2)) if hp["n_speakers"] > 1 else None
+        tr = train_step.Trainer(model, train_step.TrainConfig(max_positions=hp["max_positions"],
+                                                              guided_attention_sigma=sigma))
+        batch = train_step.Batch.from_collate(bt["text"], bt["input_lengths"], bt["mel"], bt["y"], bt["text_positions"],
+                                              bt["frame_positions"], bt["done"], bt["target_lengths"], spk,
+                                              downsample_step=4, device=dev)
+        ops.dropout_state.manual_seed(9)
+        tr.arena.grad.zero_()
+        scal = tr.forward_backward(batch)
+        res[tag] = (float(scal["loss"]), tr.arena.grad.detach().clone())
+        tr.close()
+
+    def cos(a, b):
+        return float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()))
+    l32, g32 = res["f32"]
+    assert abs(res["c8"][0] - l32) < 2e-2 * abs(l32), (res["c8"][0], l32)
+    assert cos(res["c8"][1], g32) > 0.995
+    assert cos(res["c8"][1], res["bf16"][1]) > 0.995

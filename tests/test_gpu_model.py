@@ -302,15 +302,21 @@ def test_graphed_train_step_matches_reference_golden(dev):
     batch = train_step.Batch.from_collate(x["text"], x["input_lengths"], x["mel"], x["y"],
                                           x["text_positions"], x["frame_positions"], x["done"],
                                           x["target_lengths"], None, downsample_step=4, device=dev)
+    from deepvoice3_pytorch_amd import ops
     runner = train_step.GraphedTrainer(trainer, batch, warmup=1)     # step 1 (eager, on a side stream)
-    scal = {k: float(v) for k, v in runner.step().items()}          # step 2 (graph replay)
-    assert np.isfinite(scal["loss"])
-    assert abs(scal["loss"] - fx["scalar/loss"][1]) < 2e-4 * fx["scalar/loss"][1]
-    assert abs(scal["attn_loss"] - fx["scalar/attn_loss"][1]) < 2e-4 * fx["scalar/attn_loss"][1]
-    assert abs(scal["grad_norm"] - fx["scalar/gradient_norm"][1]) < 2e-3 * fx["scalar/gradient_norm"][1]
-    for _ in range(3):
-        scal = runner.step()
-    assert np.isfinite(float(scal["loss"]))
+    try:
+        scal = {k: float(v) for k, v in runner.step().items()}      # step 2 (graph replay)
+        assert np.isfinite(scal["loss"])
+        assert abs(scal["loss"] - fx["scalar/loss"][1]) < 2e-4 * fx["scalar/loss"][1]
+        assert abs(scal["attn_loss"] - fx["scalar/attn_loss"][1]) < 2e-4 * fx["scalar/attn_loss"][1]
+        assert abs(scal["grad_norm"] - fx["scalar/gradient_norm"][1]) < 2e-3 * fx["scalar/gradient_norm"][1]
+        for _ in range(3):
+            scal = runner.step()
+        assert np.isfinite(float(scal["loss"]))
+        assert ops.dropout_state.dev_offset is runner.seed_offset
+    finally:
+        runner.close()
+    assert ops.dropout_state.dev_offset is None      # the process-wide dropout state is handed back
 
 
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
