@@ -127,14 +127,19 @@ __global__ void ola_kernel(const float* __restrict__ frames, float* __restrict__
   if (p - NFFT + 1 <= 0) t_lo = 0;
   float acc = 0.f, wsum = 0.f;
   const float* fb = frames + (int64_t)b * T * NFFT;
+  // interior samples of the hop = N/4 periodic-Hann framing meet four frames whose squared windows sum to exactly 3/2
+  // (sum_j sin^4(x + j pi/4) = 3/2): no transcendental per tap there; the edges keep the general form
+  const bool interior = hop * 4 == NFFT && t_hi - t_lo == 3 && p - t_lo * hop < NFFT && p - t_hi * hop >= 0;
   for (int t = t_lo; t <= t_hi; ++t) {
     const int n = p - t * hop;
     if (n < 0 || n >= NFFT) continue;
-    const float w = hann(n);
     acc += fb[(int64_t)t * NFFT + n];
-    wsum += w * w;
+    if (!interior) {
+      const float w = hann(n);
+      wsum += w * w;
+    }
   }
-  y[(int64_t)b * L + i] = acc / wsum;
+  y[(int64_t)b * L + i] = interior ? acc * (2.0f / 3.0f) : acc / wsum;
 }
 
 // phasor[b][t][k] = Z / max(|Z|, 1e-8), Z = rfft(hann * reflect_pad(y[b])[t*hop : t*hop + NFFT])[k]
@@ -202,6 +207,56 @@ __global__ __launch_bounds__(256) void gl_project_kernel(const float* __restrict
   fft1024<+1>(A, Bf, tid, W);
   float* out = frames + fr * NFFT;
   for (int n = tid; n < NFFT; n += 256) out[n] = Bf[n].x * (1.0f / NFFT) * hann_t(W, n);
+}
+
+// The same projection for TWO frames per workgroup: both input frames are real, so they ride one complex FFT as
+// z = x1 + i x2 (X1[k] = (Z[k] + conj Z[N-k]) / 2, X2[k] = (Z[k] - conj Z[N-k]) / 2i), and the two Hermitian target
+// spectra ride one inverse FFT as V = Y1 + i Y2 (y1 = Re v, y2 = Im v): half the FFT passes -- the LDS traffic that
+// bounds this kernel -- per frame.  Frames (2q, 2q+1) of one batch item; an odd last frame pairs with nothing.
+__global__ __launch_bounds__(256) void gl_project2_kernel(const float* __restrict__ y, const float* __restrict__ mag,
+                                                          float* __restrict__ frames, int T, int hop, int L, int TP) {
+  __shared__ cplx A[NFFT], Bf[NFFT], W[NFFT];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / TP, t1 = 2 * (blockIdx.x - b * TP);
+  const bool two = t1 + 1 < T;
+  const float* yb = y + (int64_t)b * L;
+  fill_twiddles(W, tid);
+  __syncthreads();
+  for (int n = tid; n < NFFT; n += 256) {
+    int i1 = t1 * hop + n - NFFT / 2, i2 = i1 + hop;
+    if (i1 < 0) i1 = -i1;
+    if (i1 >= L) i1 = 2 * (L - 1) - i1;
+    if (i2 < 0) i2 = -i2;
+    if (i2 >= L) i2 = 2 * (L - 1) - i2;
+    const float h = hann_t(W, n);
+    A[n] = cplx{yb[i1] * h, two ? yb[i2] * h : 0.f};
+  }
+  fft1024<-1>(A, Bf, tid, W);
+  const int64_t fr = (int64_t)b * T + t1;
+  const float* m1 = mag + fr * NBIN;
+  const float* m2 = m1 + (two ? NBIN : 0);
+  for (int k = tid; k <= NFFT / 2; k += 256) {
+    const cplx zk = Bf[k], zn = Bf[(NFFT - k) & (NFFT - 1)];
+    // X1 = (zk + conj zn) / 2, X2 = (zk - conj zn) / (2i) = ((zk.y + zn.y) - i (zk.x - zn.x)) / 2
+    const cplx x1{0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)};
+    const cplx x2{0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x)};
+    const float inv1 = 1.0f / fmaxf(sqrtf(x1.x * x1.x + x1.y * x1.y), 1e-8f);
+    const float inv2 = 1.0f / fmaxf(sqrtf(x2.x * x2.x + x2.y * x2.y), 1e-8f);
+    cplx w1{m1[k] * (x1.x * inv1), m1[k] * (x1.y * inv1)};
+    cplx w2{m2[k] * (x2.x * inv2), m2[k] * (x2.y * inv2)};
+    if (k == 0 || k == NFFT / 2) w1.y = w2.y = 0.f;
+    if (!two) w2 = cplx{0.f, 0.f};
+    // V[k] = w1 + i w2 ; V[N-k] = conj(w1) + i conj(w2)
+    A[k] = cplx{w1.x - w2.y, w1.y + w2.x};
+    if (k > 0 && k < NFFT / 2) A[NFFT - k] = cplx{w1.x + w2.y, -w1.y + w2.x};
+  }
+  fft1024<+1>(A, Bf, tid, W);
+  float* out = frames + fr * NFFT;
+  for (int n = tid; n < NFFT; n += 256) {
+    const float h = hann_t(W, n) * (1.0f / NFFT);
+    out[n] = Bf[n].x * h;
+    if (two) out[NFFT + n] = Bf[n].y * h;
+  }
 }
 
 // y[n] = x[n] + coef * y[n-1] per row (scipy.signal.lfilter([1], [1, -coef]); audio.py:26-28), in
@@ -320,8 +375,9 @@ extern "C" int dv3_gl_project_f32(const float* y, const float* mag, float* frame
   DV3_REQUIRE(y && mag && frames && B > 0 && T > 1 && hop > 0, "gl_project: bad arguments");
   const int L = hop * (T - 1);
   DV3_REQUIRE(L > 512, "gl_project: signal shorter than the reflect padding");
-  hipLaunchKernelGGL(gl_project_kernel, dim3((unsigned)((int64_t)B * T)), dim3(256), 0, (hipStream_t)stream, y, mag,
-                     frames, T, hop, L);
+  const int TP = (T + 1) / 2;     // two real frames per complex FFT
+  hipLaunchKernelGGL(gl_project2_kernel, dim3((unsigned)((int64_t)B * TP)), dim3(256), 0, (hipStream_t)stream, y, mag,
+                     frames, T, hop, L, TP);
   return dv3_check_launch("gl_project");
 }
 

@@ -227,13 +227,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict__ bits,
-                                                           int64_t n_words, uint32_t thr,
-                                                           uint64_t seed, uint64_t site,
-                                                           const uint64_t* __restrict__ dev_off) {
-  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (w >= n_words) return;
-  if (dev_off) seed += dev_off[0];
+__device__ __forceinline__ uint32_t philox_keep_word(int64_t w, uint32_t thr, uint64_t seed, uint64_t site) {
   uint32_t word = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -248,7 +242,63 @@ __global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict_
       word |= (uint32_t)(hi >= thr) << (8 * q + 2 * e + 1);
     }
   }
-  bits[w] = word;
+  return word;
+}
+
+__global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict__ bits,
+                                                           int64_t n_words, uint32_t thr,
+                                                           uint64_t seed, uint64_t site,
+                                                           const uint64_t* __restrict__ dev_off) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_words) return;
+  if (dev_off) seed += dev_off[0];
+  bits[w] = philox_keep_word(w, thr, seed, site);
+}
+
+// The same keep decisions written straight as keep-BYTES of the channel-blocked layout ([B][C8][T], bit e of byte
+// (b, g, t) = channel 8g+e; include/dv3hip.h "c8") -- what dv3_dropout_bits followed by dv3_mask_bits_to_c8 produce,
+// in one launch.  One thread per (b, group, 32-frame word): eight Philox words, an 8 x 32 bit transpose, 32 bytes.
+__global__ __launch_bounds__(256) void dropout_keep_c8_kernel(uint8_t* __restrict__ out, int B, int C, int T, int rs,
+                                                              int c8p, uint32_t thr, uint64_t seed, uint64_t site,
+                                                              const uint64_t* __restrict__ dev_off) {
+  __shared__ uint32_t tile[256][9];                                // 32 keep-bytes per entry (+1 word: bank spread)
+  const int64_t n_ent = (int64_t)B * c8p * rs;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;     // ((b * c8p) + g) * rs + wi
+  if (dev_off) seed += dev_off[0];
+  if (idx < n_ent) {
+    const int wi = (int)(idx % rs);
+    const int64_t bg = idx / rs;
+    const int g = (int)(bg % c8p), b = (int)(bg / c8p);
+    uint32_t wd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = g * 8 + e;
+      wd[e] = ch < C ? philox_keep_word(((int64_t)b * C + ch) * rs + wi, thr, seed, site) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {          // bytes 4q .. 4q+3 of this entry
+      uint32_t pack = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m |= ((wd[e] >> (4 * q + i)) & 1u) << e;
+        pack |= m << (8 * i);
+      }
+      tile[threadIdx.x][q] = pack;
+    }
+  }
+  __syncthreads();
+  // 32 consecutive lanes write the 32 consecutive bytes of one entry
+  const int lane32 = threadIdx.x & 31;
+  for (int e = threadIdx.x >> 5; e < 256; e += 8) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + e;
+    if (id >= n_ent) break;
+    const int wi = (int)(id % rs);
+    const int64_t bg = id / rs;
+    const int t = wi * 32 + lane32;
+    if (t < T) out[bg * T + t] = (uint8_t)(tile[e][lane32 >> 2] >> (8 * (lane32 & 3)));
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -617,6 +667,18 @@ extern "C" int dv3_dropout_bits(uint32_t* bits, int64_t n_words, float p, uint64
   hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)dv3_cdiv64(n_words, 256)), dim3(256), 0,
                      (hipStream_t)stream, bits, n_words, thr, seed, site, dev_seed_offset);
   return dv3_check_launch("dropout_bits");
+}
+
+extern "C" int dv3_dropout_keep_c8(uint8_t* out, int32_t B, int32_t C, int32_t T, float p, uint64_t seed, uint64_t site,
+                                   const uint64_t* dev_seed_offset, void* stream) {
+  DV3_REQUIRE(out && B > 0 && C > 0 && T > 0, "dropout_keep_c8: bad args");
+  DV3_REQUIRE(p >= 0.f && p < 1.f, "dropout_keep_c8: p out of range");
+  const uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
+  const int rs = (T + 31) / 32, c8p = (C + 31) / 32 * 4;
+  const int64_t n = (int64_t)B * c8p * rs;
+  hipLaunchKernelGGL(dropout_keep_c8_kernel, dim3((unsigned)dv3_cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, out,
+                     B, C, T, rs, c8p, thr, seed, site, dev_seed_offset);
+  return dv3_check_launch("dropout_keep_c8");
 }
 
 extern "C" int dv3_dropout_apply_f32(const float* x, const uint32_t* bits, int32_t bits_rs,

@@ -422,6 +422,20 @@ def from_c8(xc8, C=None):
     return _FromC8Fn.apply(xc8, _c8_C(xc8, C))
 
 
+def dropout_keep_c8(B, C, T, p, device, name=None):
+    """keep-bytes [B][C8][T] of a dropout site over a c8 tensor -- the decisions dropout_bits(B*C, T, ...) draws for
+    the same site.  When a test records masks the bits are generated too (and converted), so the record holds the
+    layout-independent form the oracle replays."""
+    if dropout_state.record is not None and name is not None:
+        bits, rs = dropout_bits(B * C, T, p, device, name)
+        return mask_bits_to_c8(bits, rs, B, C, T)
+    out = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=device)
+    site = dropout_state.next_site()
+    _lib.call("dv3_dropout_keep_c8", out.data_ptr(), B, C, T, float(p), dropout_state.seed, site,
+              _ptr(dropout_state.dev_offset), _stream())
+    return out
+
+
 def mask_bits_to_c8(bits, bits_rs, B, C, T):
     """dropout keep-bits [B*C][rs] -> keep-bytes [B][C8][T] for the c8 consumers"""
     out = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=bits.device)
@@ -931,10 +945,13 @@ class ConvLayerC8Fn(torch.autograd.Function):
             pk = pack_weights(v, g, glu_cg=Cg, need_bwd=need_grad, split_only=True)
         bits, bits_rs, dscale, keep8 = None, 0, 1.0, None
         if cfg.training and cfg.p > 0:
-            bits, bits_rs = dropout_bits(B * Cin, T, cfg.p, x.device, cfg.site)
             dscale = 1.0 / (1.0 - cfg.p)
-            if x8:
-                keep8 = mask_bits_to_c8(bits, bits_rs, B, Cin, T)
+            if x8 and (out8 or M % 8 == 0):
+                keep8 = dropout_keep_c8(B, Cin, T, cfg.p, x.device, cfg.site)
+            else:       # fp32 input, or the wgrad of this layer runs on fp32 operands (M has no c8 form): keep-bits
+                bits, bits_rs = dropout_bits(B * Cin, T, cfg.p, x.device, cfg.site)
+                if x8:
+                    keep8 = mask_bits_to_c8(bits, bits_rs, B, Cin, T)
         padL = cfg.pad_left if cfg.pad_left is not None else _pad_left(J, cfg.dil, cfg.causal)
         ab = _c8_empty(B, M, T, x.device) if (gated and need_grad) else None
         spk_strides = (0, 0, 0)
@@ -1063,18 +1080,19 @@ class ConvLayerC8Fn(torch.autograd.Function):
         return dx, dv, dg, dbias, dspk, dr, dr2, None, None
 
 
-def _c8_layer_ok(v, cfg, out8):
+def _c8_layer_ok(v, cfg, out8, T):
     """the layer forms the c8 kernels serve: same-length Conv1d / Linear with 1 or 3 taps, channel counts that are
     multiples of 8 on every c8 side"""
     J = v.shape[2] if v.dim() == 3 else 1
-    if cfg.transposed or J not in (1, 3) or cfg.t_out is not None or (J - 1) * cfg.dil > 64 or v.shape[1] % 8:
+    if cfg.transposed or J not in (1, 3) or (cfg.t_out is not None and cfg.t_out != T) or (J - 1) * cfg.dil > 64 or \
+            v.shape[1] % 8:
         return False
     return (not out8) or v.shape[0] % 16 == 0 or (cfg.mode not in (EPI_GLU, EPI_HIGHWAY) and v.shape[0] % 8 == 0)
 
 
 def conv_layer(x, v, g, bias, cfg, spk=None, r=None, r2=None, packed=None):
     x8, want8 = is_c8(x), getattr(cfg, "out_c8", None)
-    if (x8 or want8) and not _c8_layer_ok(v, cfg, x8 if want8 is None else bool(want8)):
+    if (x8 or want8) and not _c8_layer_ok(v, cfg, x8 if want8 is None else bool(want8), x.shape[2]):
         # a form the c8 kernels do not serve (5- or 7-tap layers of small configurations): this layer runs on
         # fp32 (B, C, T) tensors between two conversions
         y = ConvLayerFn.apply(from_c8(x, v.shape[1]) if x8 else x, v, g, bias, spk,

@@ -334,6 +334,11 @@ int dv3_dropout_bits(uint32_t* bits, int64_t n_words, float p, uint64_t seed,
                      uint64_t site, const uint64_t* dev_seed_offset /* added to seed; NULL = 0 */,
                      void* stream);
 
+/* The same keep decisions as dv3_dropout_bits over rows [B*C] (same seed / site / offset), written as the keep-BYTES
+ * [B][round_up(C,32)/8][T] the c8 consumers read (= dv3_dropout_bits + dv3_mask_bits_to_c8 in one launch).      */
+int dv3_dropout_keep_c8(uint8_t* out, int32_t B, int32_t C, int32_t T, float p, uint64_t seed, uint64_t site,
+                        const uint64_t* dev_seed_offset, void* stream);
+
 /* out[row][t] = x[row][t] * keep(bits,row,t) * scale -- a standalone F.dropout for the few
  * sites whose dropped tensor is shared by several consumers (deepvoice3.py:78-80,290,321:
  * the time-expanded speaker embedding and the decoder input).  Its own backward.          */

@@ -52,6 +52,12 @@ def test_c8_converters_and_keep_bytes(dev, modes, B, C, T):
         sel = keep[:, e::8, :]
         want[:, :sel.shape[1], :] |= (sel << e).astype(np.uint8)
     assert np.array_equal(k8, want)
+    # the one-launch Philox -> keep-bytes form draws the same decisions as dropout_bits for the same seed / site
+    ops.dropout_state.manual_seed(21)
+    direct = ops.dropout_keep_c8(B, C, T, 0.3, dev)
+    ops.dropout_state.manual_seed(21)
+    b2, rs2 = ops.dropout_bits(B * C, T, 0.3, dev)
+    assert torch.equal(direct, ops.mask_bits_to_c8(b2, rs2, B, C, T))
     # gradients of the converters are the converters
     xin = x.clone().requires_grad_(True)
     w = torch.randn(B, C, T, device=dev)
