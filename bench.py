@@ -20,6 +20,8 @@ accumulate; 1e-4 parity with the fp32 reference at the preset sizes), bf16x3, f3
                       pass for THIS kernel has been collected)
   roofline_wgrad      the weight-gradient GEMM of the same layer, same way
   roofline_exact_f32  the exact-fp32 forward kernel on the same launch, for the record
+  roofline_bf16_c8    the same layer as the bf16 configs run it (single-term bf16 MFMA, channel-blocked bf16
+                      input / residual / output) against the 2500 TF bf16 roof and the 8 TB/s HBM roof
   step_flop_frac      whole step: algorithmic FLOPs per mel-frame x frames / step time vs the
                       same MFMA roof
   value_exact_f32     the same step with every GEMM on the exact fp32 MFMA chain (5 steps)
@@ -168,10 +170,11 @@ def _traffic(kernel_key):
         return None, None
 
 
-def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None):
-    """Conv1dGLU forward at the north-star shape, one tap-GEMM launch per iteration."""
+def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None, c8=False):
+    """Conv1dGLU forward at the north-star shape, one tap-GEMM launch per iteration.  c8: the bf16-storage form
+    (bf16 GEMM mode, channel-blocked bf16 input / residual / output)."""
     from deepvoice3_pytorch_amd import ops, _lib
-    mode = mode or ops.gemm_precision()
+    mode = "bf16" if c8 else (mode or ops.gemm_precision())
     prev = ops.set_gemm_precision(mode)
     B, C, T, k, d = 64, 256, 1024, 3, dil
     torch.manual_seed(0)
@@ -182,28 +185,39 @@ def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None):
     pk = ops.pack_weights(v, g, glu_cg=C, need_bwd=False)
     y = torch.empty(B, C, T, device=dev)
 
+    x8 = ops.to_c8(x) if c8 else None
+
     def launch():
-        ops.conv_gemm(x, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
-                      padL=(k - 1) // 2 * d, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x, residual=1, y=y,
-                      tile_hint=tile_hint, a_split=pk.fwd_s)
+        if c8:
+            ops.conv_gemm(None, None, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
+                          padL=(k - 1) // 2 * d, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x8, residual=1,
+                          a_split=pk.fwd_s, x_c8=x8, out_c8=True)
+        else:
+            ops.conv_gemm(x, pk.fwd, pk.lda, pk.a_half, B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d,
+                          padL=(k - 1) // 2 * d, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x, residual=1, y=y,
+                          tile_hint=tile_hint, a_split=pk.fwd_s)
     us = _time_launches(launch, iters)
     variant = _lib.lib().dv3_debug_get(10)
     ops.set_gemm_precision(prev)
     flops = 2.0 * B * T * (2 * C) * (k * C)                     # 51.54 GFLOP
     byts = 4.0 * (B * C * T * 2 + 2 * C * C * k + 2 * C)         # x + y + weights + bias: 135.8 MB
+    if c8:
+        byts = 2.0 * (B * C * T * 2) + 2.0 * 2 * C * C * k + 4.0 * 2 * C   # bf16 x + y, bf16 weight image, fp32 bias
     tf = flops / (us * 1e-6) / 1e12
     fam = variant // 1000
-    peak = {1: PEAK_F32_MFMA_TF, 2: PEAK_F32_MFMA_TF, 4: PEAK_16BIT_MFMA_TF}.get(fam, PEAK_16BIT_MFMA_TF / 3.0)
+    peak = {1: PEAK_F32_MFMA_TF, 2: PEAK_F32_MFMA_TF, 4: PEAK_16BIT_MFMA_TF,
+            8: PEAK_16BIT_MFMA_TF}.get(fam, PEAK_16BIT_MFMA_TF / 3.0)
     kname = {1: "conv_gemm_f32_stream_kernel", 2: "conv_gemm_f32_kernel", 3: "conv_gemm_bf16x3_kernel<bf16 hi/lo>",
              4: "conv_gemm_bf16x3_kernel<bf16 x1>", 5: "conv_gemm_bf16x3_kernel<fp16 hi/lo>",
-             6: "conv_planes_kernel<fp16 hi/lo>", 7: "conv_planes_kernel<bf16>"}.get(fam, "?")
+             6: "conv_planes_kernel<fp16 hi/lo>", 7: "conv_planes_kernel<bf16>",
+             8: "conv_planes_kernel<bf16 x1, c8 storage>"}.get(fam, "?")
     key = "conv_fwd:%d" % variant
     out = dict(bound="mfma", kernel="%s variant %d (Conv1dGLU fwd B=64 C=256 T=1024 k=3)" % (kname, variant),
                achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
                traffic=None, us_per_launch=round(us, 2), alg_flops=flops, alg_bytes=byts,
                hbm_gbs=round(byts / (us * 1e-6) / 1e9, 1),
                hbm_frac=round(byts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4), variant=variant)
-    if dil == 1 and tile_hint == 0:
+    if dil == 1 and tile_hint == 0 and not c8:
         out["traffic"], src = _traffic(key)
         if src:
             out["traffic_source"] = src
@@ -668,6 +682,12 @@ def main():
             rf = conv_roofline(dev, mode="f32", iters=30)
             out["roofline_exact_f32"] = dict(kernel=rf["kernel"], achieved=rf["achieved"], peak=rf["peak"],
                                              frac=rf["frac"], us_per_launch=rf["us_per_launch"])
+        from deepvoice3_pytorch_amd import ops as _ops
+        if _ops.bf16_storage:   # the same layer as the bf16 configs run it: single-term bf16 on c8 tensors
+            rc = conv_roofline(dev, c8=True)
+            out["roofline_bf16_c8"] = {k: rc[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+                                                           "us_per_launch", "alg_flops", "alg_bytes", "hbm_gbs",
+                                                           "hbm_frac", "variant")}
     if not args.no_cpu_baseline and world == 1 and args.preset == "deepvoice3_ljspeech":
         out["cpu_baseline"] = cpu_baseline(args.batch, args.text_len, args.frames)
     print(json.dumps(out))

@@ -332,11 +332,12 @@ __device__ __forceinline__ void conv_epilogue_c8(const dv3_conv_desc& p, f32x16 
           float r4[4], v[4];
           dv3_unpack4(rv[k][ni], r4);
           const uint32_t bits = kb[k][ni] >> (lhi ? 4 : 0);
+          const uint32_t ch0 = g8v[k] * 8u + (lhi ? 4u : 0u);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float a = acc[h][ni][4 * k + e];
             if (ym) a = ((bits >> e) & 1u) ? a * dscale : 0.f;
-            v[e] = a + rsc * r4[e];
+            v[e] = ch0 + e < M ? a + rsc * r4[e] : 0.f;      // channels >= M of the last group stay zero
           }
           dv3_st8(p.y, ub[ni] + g8v[k] * gsz, dv3_pack4(v));
         }
@@ -367,7 +368,7 @@ __device__ __forceinline__ void conv_epilogue_c8(const dv3_conv_desc& p, f32x16 
       float bv[4] = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = p.bias[ch0 + e];
+        for (int e = 0; e < 4; ++e) bv[e] = p.bias[ch0 + e < M ? ch0 + e : M - 1u];
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
@@ -383,7 +384,7 @@ __device__ __forceinline__ void conv_epilogue_c8(const dv3_conv_desc& p, f32x16 
           else if (mode == DV3_EPI_SOFTSIGN) a = a * __builtin_amdgcn_rcpf(1.0f + fabsf(a));
           if (p.r) a = (a + r4[e]) * rs2;
           if (p.r2) a = (a + q4[e]) * rs2;
-          v[e] = a;
+          v[e] = ch0 + e < M ? a : 0.f;                       // channels >= M of the last group stay zero
         }
         dv3_st8(p.y, ub[ni] + g8v[k] * gsz, dv3_pack4(v));
       }

@@ -338,8 +338,8 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
               "conv_gemm: bf16 activation storage is served by the single-term bf16 kernels only");
   if (d->io_bf16 & DV3_IO_OUT_C8) {   // channel-blocked bf16 outputs / residuals (include/dv3hip.h)
     const int Cout = gated ? d->Cg : d->M;
-    DV3_REQUIRE(d->store_mode == DV3_STORE_BCT && (Cout & 7) == 0 && (d->M & 7) == 0,
-                "conv_gemm: c8 storage needs channel counts that are multiples of 8 and the plain store");
+    DV3_REQUIRE(d->store_mode == DV3_STORE_BCT && (!gated || (d->Cg & 7) == 0),
+                "conv_gemm: c8 storage needs the plain store and, for gated layers, Cg % 8 == 0");
     DV3_REQUIRE(!(d->io_bf16 & (DV3_IO_IN_BF16 | DV3_IO_OUT_BF16 | DV3_IO_AB_BF16)) && !d->ymask,
                 "conv_gemm: c8 storage excludes the BCT bf16 flags and the bit-mask form of ymask");
     DV3_REQUIRE((((uintptr_t)d->y | (uintptr_t)d->r | (uintptr_t)d->r2 | (uintptr_t)d->ab) & 15) == 0,

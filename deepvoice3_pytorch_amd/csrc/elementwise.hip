@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
 typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void gate_bwd_c8_kernel(const dv3_gate_bwd_desc p) {
   __shared__ float red[4][16];
-  const int C = p.C, T = p.T, G = C >> 3;
+  const int C = p.C, T = p.T, G = (C + 7) >> 3;     // channels >= C of the last group are zero in every c8 tensor
   const int g = blockIdx.x % G, b = blockIdx.x / G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool gated = p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void gate_bwd_c8_kernel(const dv3_gate_bwd_des
     const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     const int ch = g * 8 + (tid & 7);
     if (gated) p.bias_part[(int64_t)b * 2 * C + (tid >= 8 ? C : 0) + ch] = v;
-    else if (tid < 8) p.bias_part[(int64_t)b * C + ch] = v;
+    else if (tid < 8 && ch < C) p.bias_part[(int64_t)b * C + ch] = v;
   }
 }
 
@@ -261,43 +261,35 @@ __global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict_
 __global__ __launch_bounds__(256) void dropout_keep_c8_kernel(uint8_t* __restrict__ out, int B, int C, int T, int rs,
                                                               int c8p, uint32_t thr, uint64_t seed, uint64_t site,
                                                               const uint64_t* __restrict__ dev_off) {
-  __shared__ uint32_t tile[256][9];                                // 32 keep-bytes per entry (+1 word: bank spread)
-  const int64_t n_ent = (int64_t)B * c8p * rs;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;     // ((b * c8p) + g) * rs + wi
+  // a workgroup = 32 entries (b, group, 32-frame word) x 8 channels: one Philox word per thread, the 8 x 32 bit
+  // transpose through LDS, then thread (entry, q) writes bytes 4q .. 4q+3 of its entry (a wave covers 8 entries =
+  // 256 contiguous bytes when T is a multiple of 32)
+  __shared__ uint32_t words[32][9];
+  const uint32_t n_ent = (uint32_t)B * (uint32_t)c8p * (uint32_t)rs;             // < 2^31 (host-checked)
+  const uint32_t ent = blockIdx.x * 32u + (threadIdx.x >> 3);                      // ((b * c8p) + g) * rs + wi
+  const uint32_t e = threadIdx.x & 7;
   if (dev_off) seed += dev_off[0];
-  if (idx < n_ent) {
-    const int wi = (int)(idx % rs);
-    const int64_t bg = idx / rs;
-    const int g = (int)(bg % c8p), b = (int)(bg / c8p);
-    uint32_t wd[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int ch = g * 8 + e;
-      wd[e] = ch < C ? philox_keep_word(((int64_t)b * C + ch) * rs + wi, thr, seed, site) : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {          // bytes 4q .. 4q+3 of this entry
-      uint32_t pack = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint32_t m = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) m |= ((wd[e] >> (4 * q + i)) & 1u) << e;
-        pack |= m << (8 * i);
-      }
-      tile[threadIdx.x][q] = pack;
-    }
+  uint32_t wi = 0, bg = 0;
+  if (ent < n_ent) {
+    wi = ent % (uint32_t)rs;
+    bg = ent / (uint32_t)rs;
+    const uint32_t g = bg % (uint32_t)c8p, b = bg / (uint32_t)c8p;
+    const uint32_t ch = g * 8u + e;
+    words[threadIdx.x >> 3][e] = ch < (uint32_t)C ? philox_keep_word(((int64_t)b * C + ch) * rs + wi, thr, seed, site) : 0u;
   }
   __syncthreads();
-  // 32 consecutive lanes write the 32 consecutive bytes of one entry
-  const int lane32 = threadIdx.x & 31;
-  for (int e = threadIdx.x >> 5; e < 256; e += 8) {
-    const int64_t id = (int64_t)blockIdx.x * 256 + e;
-    if (id >= n_ent) break;
-    const int wi = (int)(id % rs);
-    const int64_t bg = id / rs;
-    const int t = wi * 32 + lane32;
-    if (t < T) out[bg * T + t] = (uint8_t)(tile[e][lane32 >> 2] >> (8 * (lane32 & 3)));
+  if (ent >= n_ent) return;
+  const uint32_t q = e;                    // bytes 4q .. 4q+3
+  const uint32_t* w = words[threadIdx.x >> 3];
+  const uint32_t t0 = wi * 32u + 4u * q;
+  uint8_t* o = out + (size_t)bg * T + t0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (t0 + i >= (uint32_t)T) break;
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) m |= ((w[c] >> (4 * q + i)) & 1u) << c;
+    o[i] = (uint8_t)m;
   }
 }
 
@@ -642,9 +634,11 @@ extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
   const int64_t rows = (int64_t)d->B * d->C;
   if (d->c8) {
     const uintptr_t pc = (uintptr_t)d->dy | (uintptr_t)d->ab_or_y | (uintptr_t)d->dab | (uintptr_t)d->x | (uintptr_t)d->dres;
-    DV3_REQUIRE((d->C & 7) == 0 && (pc & 15) == 0 && !d->ab_bf16, "gate_bwd: c8 tensors need C % 8 == 0 and 16-byte alignment");
-    DV3_REQUIRE(rows / 8 < (1ll << 31), "gate_bwd: grid too large");
-    hipLaunchKernelGGL(gate_bwd_c8_kernel, dim3((unsigned)(rows / 8)), dim3(256), 0, (hipStream_t)stream, *d);
+    DV3_REQUIRE((!gated || (d->C & 7) == 0) && (pc & 15) == 0 && !d->ab_bf16,
+                "gate_bwd: c8 tensors need 16-byte alignment and, in the gated modes, C % 8 == 0");
+    const int64_t blocks = (int64_t)d->B * ((d->C + 7) / 8);
+    DV3_REQUIRE(blocks < (1ll << 31), "gate_bwd: grid too large");
+    hipLaunchKernelGGL(gate_bwd_c8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d);
     return dv3_check_launch("gate_bwd_c8");
   }
   // 16 bytes per lane when every row starts 16-byte aligned (gated modes; the others are small)
@@ -676,7 +670,8 @@ extern "C" int dv3_dropout_keep_c8(uint8_t* out, int32_t B, int32_t C, int32_t T
   const uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
   const int rs = (T + 31) / 32, c8p = (C + 31) / 32 * 4;
   const int64_t n = (int64_t)B * c8p * rs;
-  hipLaunchKernelGGL(dropout_keep_c8_kernel, dim3((unsigned)dv3_cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, out,
+  DV3_REQUIRE((int64_t)B * c8p * T < (1ll << 31), "dropout_keep_c8: mask exceeds the 2 GB the kernel can address");
+  hipLaunchKernelGGL(dropout_keep_c8_kernel, dim3((unsigned)dv3_cdiv64(n, 32)), dim3(256), 0, (hipStream_t)stream, out,
                      B, C, T, rs, c8p, thr, seed, site, dev_seed_offset);
   return dv3_check_launch("dropout_keep_c8");
 }

@@ -206,8 +206,7 @@ int dv3_wgrad_c8_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
   DV3_REQUIRE(d->J == 1 || d->J == 3, "wgrad_gemm: the c8 form serves 1 and 3 taps (J=%d)", d->J);
   DV3_REQUIRE(d->T == d->Tin && d->k_split && d->split_bf16 == 2, "wgrad_gemm: the c8 form is the single-term bf16, "
               "same-length, contiguous-K-split kernel");
-  DV3_REQUIRE((d->M & 7) == 0 && (d->Cin & 7) == 0 && (((uintptr_t)d->g | (uintptr_t)d->x) & 15) == 0,
-              "wgrad_gemm: c8 tensors need channel counts that are multiples of 8 and 16-byte alignment");
+  DV3_REQUIRE((((uintptr_t)d->g | (uintptr_t)d->x) & 15) == 0, "wgrad_gemm: c8 tensors need 16-byte alignment");
   DV3_REQUIRE(!d->xmask, "wgrad_gemm: the c8 form takes keep-bytes (xmask_c8), not keep-bits");
   const int64_t c8g = (d->M + 31) / 32 * 4, c8x = (d->Cin + 31) / 32 * 4;
   DV3_REQUIRE((int64_t)d->B * c8g * d->T < (1ll << 28) && (int64_t)d->B * c8x * d->T < (1ll << 28),

@@ -45,7 +45,7 @@ def _drop_speaker_embed(speaker_embed, T, p, training, site):
 
 def _c8_enter(x):
     """bf16 storage (ops.storage_c8: the bf16 GEMM mode): fp32 (B, C, T) -> channel-blocked bf16 at a stack entry"""
-    if ops.storage_c8() and not ops.is_c8(x) and x.size(1) % 8 == 0:
+    if ops.storage_c8() and not ops.is_c8(x):
         return ops.to_c8(x)
     return x
 
@@ -55,11 +55,11 @@ def _c8_leave(x, C=None):
 
 
 def _conv1d_c8(f, x, last, **kw):
-    """a plain Conv1d inside a stack: its output follows the storage mode -- c8 whenever the channel count allows,
-    fp32 (B, C, T) for the last layer of the stack (what the callers consume) and for odd channel counts"""
+    """a plain Conv1d inside a stack: its output follows the storage mode -- c8 between the layers, fp32 (B, C, T)
+    for the last layer of the stack (what the callers consume)"""
     if not (ops.is_c8(x) or ops.storage_c8()):
         return f(x, **kw)
-    return f(x, out_c8=(not last) and f.out_channels % 8 == 0, **kw)
+    return f(x, out_c8=not last, **kw)
 
 
 def _run_stack(modules, x, speaker_embed_btc, first=0, keep_c8=False):

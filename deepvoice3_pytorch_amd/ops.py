@@ -356,10 +356,8 @@ def is_c8(t):
 
 
 def _c8_empty(B, C, T, device):
-    """uninitialised c8 tensor; zero-filled when C leaves padding channels (they meet zero weight rows, but must
-    not be NaN)"""
-    if C % 8:
-        raise RuntimeError("c8 storage needs a channel count that is a multiple of 8, got %d" % C)
+    """uninitialised c8 tensor; zero-filled when C leaves padding channels / groups (the kernels write whole valid
+    groups only; padding must read as zero)"""
     shape = (B, c8_groups(C), T, 8)
     t = torch.zeros(shape, dtype=torch.bfloat16, device=device) if C % 32 else \
         torch.empty(shape, dtype=torch.bfloat16, device=device)
@@ -946,12 +944,10 @@ class ConvLayerC8Fn(torch.autograd.Function):
         bits, bits_rs, dscale, keep8 = None, 0, 1.0, None
         if cfg.training and cfg.p > 0:
             dscale = 1.0 / (1.0 - cfg.p)
-            if x8 and (out8 or M % 8 == 0):
+            if x8:
                 keep8 = dropout_keep_c8(B, Cin, T, cfg.p, x.device, cfg.site)
-            else:       # fp32 input, or the wgrad of this layer runs on fp32 operands (M has no c8 form): keep-bits
+            else:       # fp32 input: keep-bits for the staging of the fp32 operand
                 bits, bits_rs = dropout_bits(B * Cin, T, cfg.p, x.device, cfg.site)
-                if x8:
-                    keep8 = mask_bits_to_c8(bits, bits_rs, B, Cin, T)
         padL = cfg.pad_left if cfg.pad_left is not None else _pad_left(J, cfg.dil, cfg.causal)
         ab = _c8_empty(B, M, T, x.device) if (gated and need_grad) else None
         spk_strides = (0, 0, 0)
@@ -1041,25 +1037,16 @@ class ConvLayerC8Fn(torch.autograd.Function):
                                a_split=pk.bwd_s, x_c8=g8, out_c8=False)
         if ctx.needs_input_grad[1]:
             tiles = ((M + 127) // 128) * ((Cin + 127) // 128)
-            if g8 is None and M % 8:
-                # an fp32 output whose channel count has no c8 form (the 513-bin linear spectrogram): the gradient
-                # operand stays fp32 (B, M, T) and the input is widened once for the fp32-storage wgrad kernel
-                x3 = not (M <= 64 and Cin <= 64)
-                S = _ksplit_count(B * ((T + 31) // 32), tiles * J) if x3 else _slab_count(B, tiles * J)
-                slabs = wgrad_gemm(gmat, _from_c8_raw(x, Cin), B=B, M=M, Cin=Cin, T=T, Tin=T, J=J, dil=cfg.dil,
-                                   padL=padL, n_slabs=S, xmask=ctx.bits, xmask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
-                                   split_bf16=x3, k_split=x3)
+            if g8 is None:
+                g8 = _ToC8Fn.apply(gmat)
+            if ctx.x8:
+                x8t, keep8 = x, ctx.keep8
             else:
-                if g8 is None:
-                    g8 = _ToC8Fn.apply(gmat)
-                if ctx.x8:
-                    x8t, keep8 = x, ctx.keep8
-                else:
-                    x8t = _ToC8Fn.apply(x)
-                    keep8 = mask_bits_to_c8(ctx.bits, ctx.bits_rs, B, Cin, T) if ctx.bits is not None else None
-                S = _ksplit_count(B * ((T + 31) // 32), tiles, slots=256)
-                slabs = wgrad_gemm_c8(g8, x8t, B=B, M=M, Cin=Cin, T=T, J=J, dil=cfg.dil, padL=padL, n_slabs=S,
-                                      xmask_c8=keep8, drop_scale=ctx.dscale)
+                x8t = _ToC8Fn.apply(x)
+                keep8 = mask_bits_to_c8(ctx.bits, ctx.bits_rs, B, Cin, T) if ctx.bits is not None else None
+            S = _ksplit_count(B * ((T + 31) // 32), tiles, slots=256)
+            slabs = wgrad_gemm_c8(g8, x8t, B=B, M=M, Cin=Cin, T=T, J=J, dil=cfg.dil, padL=padL, n_slabs=S,
+                                  xmask_c8=keep8, drop_scale=ctx.dscale)
             v3 = v if v.dim() == 3 else v.unsqueeze(-1)
             if ctx.inplace:
                 pv, pg, pb = ctx.leaves
@@ -1081,13 +1068,12 @@ class ConvLayerC8Fn(torch.autograd.Function):
 
 
 def _c8_layer_ok(v, cfg, out8, T):
-    """the layer forms the c8 kernels serve: same-length Conv1d / Linear with 1 or 3 taps, channel counts that are
-    multiples of 8 on every c8 side"""
+    """the layer forms the c8 kernels serve: same-length Conv1d / Linear with 1 or 3 taps"""
     J = v.shape[2] if v.dim() == 3 else 1
-    if cfg.transposed or J not in (1, 3) or (cfg.t_out is not None and cfg.t_out != T) or (J - 1) * cfg.dil > 64 or \
-            v.shape[1] % 8:
+    if cfg.transposed or J not in (1, 3) or (cfg.t_out is not None and cfg.t_out != T) or (J - 1) * cfg.dil > 64:
         return False
-    return (not out8) or v.shape[0] % 16 == 0 or (cfg.mode not in (EPI_GLU, EPI_HIGHWAY) and v.shape[0] % 8 == 0)
+    # gated layers: the a / gate halves must start on group boundaries; plain layers take any channel count
+    return cfg.mode not in (EPI_GLU, EPI_HIGHWAY) or v.shape[0] % 16 == 0
 
 
 def conv_layer(x, v, g, bias, cfg, spk=None, r=None, r2=None, packed=None):
@@ -1098,7 +1084,7 @@ def conv_layer(x, v, g, bias, cfg, spk=None, r=None, r2=None, packed=None):
         y = ConvLayerFn.apply(from_c8(x, v.shape[1]) if x8 else x, v, g, bias, spk,
                               from_c8(r) if is_c8(r) else r, from_c8(r2) if is_c8(r2) else r2, cfg, packed)
         out8 = x8 if want8 is None else bool(want8)
-        return to_c8(y) if (out8 and y.shape[1] % 8 == 0) else y
+        return to_c8(y) if out8 else y
     if x8 or want8:
         y = ConvLayerC8Fn.apply(x, v, g, bias, spk, r, r2, cfg, packed)
         if is_c8(y):

@@ -150,7 +150,8 @@ typedef struct dv3_conv_desc {
  * c%8 of the 16-byte unit (b, c/8, t); channels >= C are zero.  This IS plane 0 of dv3_split_planes_f32's layout: a
  * tensor written by one layer's epilogue is the next layer's `x_planes` (split_terms == 1) with no conversion, the
  * tap-GEMM stages it with plain 16-byte copies, and the epilogue's accumulator tile maps to whole 8-byte halves of
- * units (csrc/conv_common.h).  C % 8 == 0 is required of every tensor stored this way.
+ * units (csrc/conv_common.h).  Any C: the kernels write whole valid groups and keep the padding channels zero;
+ * gated layers need Cg % 8 == 0 (the a and gate halves of the saved pre-gate pair start on group boundaries).
  *   DV3_IO_OUT_C8   y (and ab) are written in c8; r / r2 (and the DGRAD addend) are READ in c8
  * (the tensors on the two sides of an epilogue share one layout; x is c8 exactly when x_planes is given).
  */

@@ -34,7 +34,7 @@ def modes():
     ops.bf16_storage = prev[1]
 
 
-@pytest.mark.parametrize("B,C,T", [(3, 40, 37), (2, 64, 150), (2, 320, 50), (1, 8, 1)])
+@pytest.mark.parametrize("B,C,T", [(3, 40, 37), (2, 64, 150), (2, 320, 50), (1, 8, 1), (2, 513, 33), (2, 3, 70)])
 def test_c8_converters_and_keep_bytes(dev, modes, B, C, T):
     ops = modes
     x = torch.randn(B, C, T, device=dev)
@@ -166,12 +166,15 @@ def test_c8_plain_layers(dev, modes):
         for a, b in zip(outs["c8"], outs["ref"]):
             assert rel_err(a.cpu(), b.cpu()) < TOL_GRAD
 
-    for (Ci, Co, mode) in ((64, 128, ops.EPI_SOFTSIGN), (128, 64, ops.EPI_LINEAR), (64, 513, ops.EPI_SIGMOID)):
+    # (in, out, mode, c8 output): incl. channel counts that are not multiples of 8 on either side (the 513 linear bins)
+    for (Ci, Co, mode, o8) in ((64, 128, ops.EPI_SOFTSIGN, True), (128, 64, ops.EPI_LINEAR, True),
+                               (64, 513, ops.EPI_SIGMOID, False), (64, 513, ops.EPI_SOFTSIGN, True),
+                               (513, 64, ops.EPI_LINEAR, True), (513, 513, ops.EPI_SIGMOID, False)):
         def make(Ci=Ci, Co=Co):
             torch.manual_seed(1)
             return modules.Conv1d(Ci, Co, 1, dropout=0.1).to(dev).train()
-        both(make, lambda l, ins, c8, mode=mode, Co=Co: l(ops.to_c8(ins[0]) if c8 else ins[0], mode=mode,
-                                                        out_c8=(Co % 8 == 0) if c8 else None),
+        both(make, lambda l, ins, c8, mode=mode, o8=o8: l(ops.to_c8(ins[0]) if c8 else ins[0], mode=mode,
+                                                        out_c8=o8 if c8 else None),
              [torch.randn(B, Ci, T, device=dev)])
 
     def make_lin():
