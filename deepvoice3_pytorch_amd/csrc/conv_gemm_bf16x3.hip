@@ -661,6 +661,7 @@ int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
   return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3>(a, lds, st);
 }
 
+int g_x3_rel2 = 112;   // dv3_debug_set(9, v): relative cost (percent) of the 128x64 tile in the picker below
 // bf16x3 tile choice: padded work over the FLAT column axis, weight-panel traffic penalised
 // (a block re-reads its A panel every K step, so narrow column tiles starve the matrix pipe).
 const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
@@ -684,7 +685,8 @@ const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
     // 8-wave 256-wide tiles (one workgroup per CU): less weight-panel traffic per MFMA; the
     // 128-row-per-wave tile (7, one wave per SIMD) measured slower everywhere: opt-in only (hint 27)
     static const double kRel[10] = {0, 1.0, 1.12, 2.0, 2.2, 1.8, 2.0, 9.9, 0.93, 0.87};
-    const double cost = rounds * BM * BN * kRel[c.id];
+    const double rel = c.id == 2 ? g_x3_rel2 * 0.01 : kRel[c.id];
+    const double cost = rounds * BM * BN * rel;
     if (!best || cost < best_cost) {
       best = &c;
       best_cost = cost;
@@ -740,7 +742,8 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
 extern int g_wgrad_tile;   // wgrad_gemm_bf16x3.hip
 int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 extern "C" int dv3_debug_set(int what, int value) {
-  if (what >= 4 && what <= 7) return dv3_planes_debug_set(what, value);
+  if (what >= 4 && what <= 8) return dv3_planes_debug_set(what, value);
+  if (what == 9) g_x3_rel2 = value;
   if (what == 1) g_x3_ablate = value;
   if (what == 2) g_wgrad_tile = value;
   if (what == 3) g_x3_pingpong = value;

@@ -557,6 +557,8 @@ __global__ __launch_bounds__(256) void mask_bits_to_c8_kernel(const uint32_t* __
 }
 
 int g_planes_tile = 0;      // dv3_debug_set(4, v)
+int g_planes_mid_thr = 1;   // dv3_debug_set(8, v): 128x128 tiles once they number v/2 x the CUs, else 128x64 (measured:
+                            // 1 -> nyanko bf16 step 13.12 ms, 2 -> 13.25, 4 -> 13.90; scripts/tile_thr_ab.py)
 int g_planes_stagger = -1;  // dv3_debug_set(5, v)
 int g_planes_abl = 0;       // dv3_debug_set(6, v)
 
@@ -688,7 +690,8 @@ int dv3_conv_planes_dispatch(const dv3_conv_desc* d, hipStream_t st) {
     // measured at the north-star shape (profiles/r02c_planes_kernel_ablation.md): the 8-wave 128x256 tile is the
     // fastest where it fills the chip; two co-resident 128x128 workgroups otherwise; 128x64 for small problems
     const int64_t cols128 = dv3_cdiv64(ntot, 128);
-    id = (mt * dv3_cdiv64(ntot, 256) >= (int64_t)dv3_num_cus()) ? 9 : (mt * cols128 >= 2 * (int64_t)dv3_num_cus()) ? 1 : 2;
+    id = (mt * dv3_cdiv64(ntot, 256) >= (int64_t)dv3_num_cus()) ? 9
+         : (2 * mt * cols128 >= g_planes_mid_thr * (int64_t)dv3_num_cus()) ? 1 : 2;
   }
   const int BM = 128, BMH = 64, BN = id == 1 ? 128 : id == 2 ? 64 : 256;
   const int NT = id == 9 ? 512 : 256;
@@ -727,5 +730,6 @@ int dv3_planes_debug_set(int what, int value) {
   if (what == 5) g_planes_stagger = value;
   if (what == 6) g_planes_abl = value;
   if (what == 7) g_planes_steady = value;
+  if (what == 8) g_planes_mid_thr = value;
   return DV3_OK;
 }

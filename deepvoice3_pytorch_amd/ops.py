@@ -388,7 +388,7 @@ class _ToC8Fn(torch.autograd.Function):
 
 
 def _from_c8_raw(xc8, C):
-    B, G, T, _ = xc8.shape
+    B, _, T, _ = xc8.shape
     out = torch.empty((B, C, T), dtype=torch.float32, device=xc8.device)
     _lib.call("dv3_from_c8_f32", xc8.data_ptr(), out.data_ptr(), C * T, T, B, C, T, _stream())
     return out
