@@ -651,9 +651,13 @@ extern "C" int dv3_to_c8_f32(const float* x, int64_t x_bs, int64_t x_rs, uint16_
 }
 extern "C" int dv3_from_c8_f32(const uint16_t* x, float* out, int64_t out_bs, int64_t out_rs, int32_t B, int32_t C,
                                int32_t T, void* stream) {
+  return dv3_from_c8_head_f32(x, (C + 31) / 32 * 4, out, out_bs, out_rs, B, C, T, stream);
+}
+extern "C" int dv3_from_c8_head_f32(const uint16_t* x, int32_t c8p, float* out, int64_t out_bs, int64_t out_rs,
+                                    int32_t B, int32_t C, int32_t T, void* stream) {
   DV3_REQUIRE(x && out && B > 0 && C > 0 && T > 0, "from_c8: bad arguments");
   DV3_REQUIRE(((uintptr_t)x & 15) == 0, "from_c8: x must be 16-byte aligned");
-  const int c8p = (C + 31) / 32 * 4;
+  DV3_REQUIRE(c8p * 8 >= C, "from_c8: the tensor holds fewer than C channels");
   DV3_REQUIRE(c8p <= 65535 && B <= 65535, "from_c8: grid too large");
   hipLaunchKernelGGL(from_c8_kernel, dim3(dv3_cdiv(T, 256), dv3_cdiv(C, 8), B), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const bf16x8*>(x), out, out_bs, out_rs, C, T, c8p);

@@ -122,10 +122,10 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
 // ------------------------------------------------------------------------------------------
 typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void gate_bwd_c8_kernel(const dv3_gate_bwd_desc p) {
-  __shared__ float red[4][16];
+  __shared__ float part[16][256];
   const int C = p.C, T = p.T, G = (C + 7) >> 3;     // channels >= C of the last group are zero in every c8 tensor
   const int g = blockIdx.x % G, b = blockIdx.x / G;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const bool gated = p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY;
   const int c8y = (C + 31) / 32 * 4, c8ab = (2 * C + 31) / 32 * 4;
   const gb_bf16x8* dy = reinterpret_cast<const gb_bf16x8*>(p.dy) + ((int64_t)b * c8y + g) * T;
@@ -188,24 +188,25 @@ __global__ __launch_bounds__(256) void gate_bwd_c8_kernel(const dv3_gate_bwd_des
     }
   }
   if (!p.bias_part) return;
+  // 16 row sums over 256 threads: partials through LDS ([value][thread], conflict free), thread (value, slice) adds 16 of
+  // them in a fixed order, a 16-lane butterfly finishes (row-local shuffles; a 64-lane butterfly per value and wave
+  // was most of this kernel's time at T = 200)
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    sa[e] = dv3_wave_sum(sa[e]);
-    sg[e] = dv3_wave_sum(sg[e]);
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      red[wave][e] = sa[e];
-      red[wave][8 + e] = sg[e];
-    }
+    part[e][tid] = sa[e];
+    part[8 + e][tid] = sg[e];
   }
   __syncthreads();
-  if (tid < 16) {
-    const float v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-    const int ch = g * 8 + (tid & 7);
-    if (gated) p.bias_part[(int64_t)b * 2 * C + (tid >= 8 ? C : 0) + ch] = v;
-    else if (tid < 8 && ch < C) p.bias_part[(int64_t)b * C + ch] = v;
+  const int v = tid >> 4, sl = tid & 15;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc += part[v][sl + 16 * i];
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+  if (sl == 0) {
+    const int ch = g * 8 + (v & 7);
+    if (gated) p.bias_part[(int64_t)b * 2 * C + (v >= 8 ? C : 0) + ch] = acc;
+    else if (v < 8 && ch < C) p.bias_part[(int64_t)b * C + ch] = acc;
   }
 }
 

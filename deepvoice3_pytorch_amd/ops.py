@@ -997,8 +997,10 @@ class ConvLayerC8Fn(torch.autograd.Function):
                 dres, r_scale = dy, rs2
             if ctx.spk_dim == 2:
                 dspk = part[:, :Cg].contiguous()
-            elif ctx.spk_dim == 3:
-                dspk = _from_c8_raw(gmat, M)[:, :Cg, :]
+            elif ctx.spk_dim == 3:      # per-frame speaker bias: the gradient of the `a` half, fp32 (B, Cg, T)
+                dspk = torch.empty((B, Cg, T), dtype=torch.float32, device=gmat.device)
+                _lib.call("dv3_from_c8_head_f32", gmat.data_ptr(), gmat.shape[1], dspk.data_ptr(), Cg * T, T, B, Cg, T,
+                          _stream())
             g8 = gmat
         else:
             alpha = 1.0

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 27
+#define DV3_ABI_VERSION 28
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -162,6 +162,10 @@ int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
 int dv3_to_c8_f32(const float* x, int64_t x_bs, int64_t x_rs, uint16_t* out, int32_t B, int32_t C, int32_t T, void* stream);
 int dv3_from_c8_f32(const uint16_t* x, float* out, int64_t out_bs, int64_t out_rs, int32_t B, int32_t C, int32_t T,
                     void* stream);
+/* the first C channels of a c8 tensor that holds c8p groups per batch item (the `a` half of a pre-gate gradient:
+ * the per-frame speaker-bias gradient of a multi-speaker Conv1dGLU, modules.py:157-160)                     */
+int dv3_from_c8_head_f32(const uint16_t* x, int32_t c8p, float* out, int64_t out_bs, int64_t out_rs, int32_t B,
+                         int32_t C, int32_t T, void* stream);
 /* dropout keep-bits [B*C][rs words] (dv3_dropout_bits) -> keep-bytes [B][C8][T] for c8 consumers             */
 int dv3_mask_bits_to_c8(const uint32_t* bits, int32_t bits_rs, uint8_t* out, int32_t B, int32_t C, int32_t T, void* stream);
 
