@@ -532,3 +532,32 @@ def test_torch_library_shim_loads_and_registers_every_operator():
         assert hasattr(ops, name), name
     with pytest.raises((RuntimeError, NotImplementedError)):
         ops.grad_sqnorm(torch.zeros(8))
+
+
+def test_c8_storage_host_logic():
+    """bf16 storage bookkeeping that needs no GPU: group counts, which layer forms take the c8 kernels, layout test"""
+    import torch
+    from deepvoice3_pytorch_amd import ops
+    assert [ops.c8_groups(c) for c in (1, 8, 32, 33, 80, 256, 513)] == [4, 4, 4, 8, 12, 32, 68]
+    assert ops.is_c8(torch.zeros(2, 4, 5, 8, dtype=torch.bfloat16))
+    assert not ops.is_c8(torch.zeros(2, 4, 5, 8)) and not ops.is_c8(torch.zeros(2, 32, 5, dtype=torch.bfloat16))
+    assert not ops.is_c8(None)
+    v3, v1, v5 = torch.zeros(512, 256, 3), torch.zeros(513, 256), torch.zeros(64, 64, 5)
+    glu = ops.LayerCfg(k=3, dil=27, mode=ops.EPI_GLU)
+    assert ops._c8_layer_ok(v3, glu, True, 200)
+    assert not ops._c8_layer_ok(torch.zeros(40, 256, 3), glu, True, 200)          # gated: Cg = 20 is not a group multiple
+    assert ops._c8_layer_ok(v1, ops.LayerCfg(mode=ops.EPI_SIGMOID), False, 200)   # plain layers: any channel count
+    assert ops._c8_layer_ok(v1, ops.LayerCfg(mode=ops.EPI_LINEAR), True, 200)
+    assert not ops._c8_layer_ok(v5, ops.LayerCfg(k=5), True, 200)                 # 5 taps: fp32 between conversions
+    assert not ops._c8_layer_ok(v3, ops.LayerCfg(k=3, dil=33), True, 200)         # halo > 64
+    assert not ops._c8_layer_ok(v3, ops.LayerCfg(k=3, t_out=198), True, 200)      # not a same-length layer
+    assert ops._c8_layer_ok(v3, ops.LayerCfg(k=3, t_out=200), True, 200)
+    assert not ops._c8_layer_ok(torch.zeros(256, 256, 2), ops.LayerCfg(k=2, transposed=True), True, 200)
+    prev = ops.gemm_precision()
+    try:
+        ops.set_gemm_precision("bf16")
+        assert ops.storage_c8() == ops.bf16_storage
+        ops.set_gemm_precision("f16x3")
+        assert not ops.storage_c8()
+    finally:
+        ops.set_gemm_precision(prev)
