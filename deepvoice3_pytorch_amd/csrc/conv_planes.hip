@@ -448,10 +448,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_planes_kernel(const ConvA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[h][ni][r] *= ds;
       }
-      if (TERMS == 1 && (p.io_bf16 & DV3_IO_OUT_C8))
-        conv_epilogue_c8<BM, BMH, NI>(p, acc, gated, mt, wm * 32, lhi, bcol, tcol, okc);
-      else if ((ABL != 4 && ABL != 8) || acc[0][0][0] + acc[1][NI - 1][7] == 1.2345e30f)
-        conv_epilogue<BM, BMH, NI, 0, TERMS == 1>(p, acc, gated, mt, wm * 32, lhi, bcol, tcol, okc);
+      if ((ABL != 4 && ABL != 8) || acc[0][0][0] + acc[1][NI - 1][7] == 1.2345e30f) {
+        if (TERMS == 1 && (p.io_bf16 & DV3_IO_OUT_C8))
+          conv_epilogue_c8<BM, BMH, NI>(p, acc, gated, mt, wm * 32, lhi, bcol, tcol, okc);
+        else
+          conv_epilogue<BM, BMH, NI, 0, TERMS == 1>(p, acc, gated, mt, wm * 32, lhi, bcol, tcol, okc);
+      }
     }
     if (!has_next) break;
     tile = next;
@@ -570,6 +572,14 @@ int launch_planes_abl(const ConvArgs& a, size_t lds, int grid, hipStream_t st) {
   return dv3_check_launch("conv_planes(abl)");
 }
 
+template <int WM, int WN, int NI, int ABL>
+int launch_planes_abl1(const ConvArgs& a, size_t lds, int grid, hipStream_t st) {    // single-term bf16 (c8) ablations
+  (void)hipFuncSetAttribute((const void*)conv_planes_kernel<WM, WN, NI, 1, false, ABL>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((conv_planes_kernel<WM, WN, NI, 1, false, ABL>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
+  return dv3_check_launch("conv_planes(abl)");
+}
+
 template <int WM, int WN, int NI, int TERMS, bool F16, int JT>
 int launch_planes_j(const ConvArgs& a, size_t lds, int grid, hipStream_t st) {
   static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation
@@ -585,11 +595,16 @@ int launch_planes_j(const ConvArgs& a, size_t lds, int grid, hipStream_t st) {
   hipLaunchKernelGGL((conv_planes_kernel<WM, WN, NI, TERMS, F16, 0, JT>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
   return dv3_check_launch("conv_planes");
 }
-int g_planes_steady = 0;    // dv3_debug_set(7, v): 1 = unrolled steady state with the issue-order requests (measured slower)
+// dv3_debug_set(7, v): the unrolled steady state with the issue-order requests: 0 off, 1 on, -1 (default) = on for the
+// single-term kernel only.  Three-term kernels: measured slower (reads land late behind 24 MFMAs).  Single-term: its
+// 8 MFMAs per step do not cover the generic loop's scalar bookkeeping -- 3-8 % faster unrolled, bit-identical
+// (scripts/planes_steady_c8.py: 80.4 -> 74.8 us eval, 92.3 -> 87.7 us training forward at the north-star shape).
+int g_planes_steady = -1;
 template <int WM, int WN, int NI, int TERMS, bool F16>
 int launch_planes_t(const ConvArgs& a, size_t lds, int grid, hipStream_t st) {
-  if (g_planes_steady && a.d.J == 3) return launch_planes_j<WM, WN, NI, TERMS, F16, 3>(a, lds, grid, st);
-  if (g_planes_steady && a.d.J == 1) return launch_planes_j<WM, WN, NI, TERMS, F16, 1>(a, lds, grid, st);
+  const bool steady = g_planes_steady < 0 ? TERMS == 1 : g_planes_steady != 0;
+  if (steady && a.d.J == 3) return launch_planes_j<WM, WN, NI, TERMS, F16, 3>(a, lds, grid, st);
+  if (steady && a.d.J == 1) return launch_planes_j<WM, WN, NI, TERMS, F16, 1>(a, lds, grid, st);
   return launch_planes_j<WM, WN, NI, TERMS, F16, 0>(a, lds, grid, st);
 }
 template <int WM, int WN, int NI>
@@ -605,6 +620,17 @@ int launch_planes(const ConvArgs& a, size_t lds, int grid, hipStream_t st) {
       case 7: return launch_planes_abl<WM, WN, NI, 7>(a, lds, grid, st);
       case 8: return launch_planes_abl<WM, WN, NI, 8>(a, lds, grid, st);
       case 9: return launch_planes_abl<WM, WN, NI, 9>(a, lds, grid, st);
+    }
+  }
+  if (g_planes_abl && a.d.split_terms == 1 && NI == 2) {
+    switch (g_planes_abl) {
+      case 1: return launch_planes_abl1<WM, WN, NI, 1>(a, lds, grid, st);
+      case 2: return launch_planes_abl1<WM, WN, NI, 2>(a, lds, grid, st);
+      case 3: return launch_planes_abl1<WM, WN, NI, 3>(a, lds, grid, st);
+      case 4: return launch_planes_abl1<WM, WN, NI, 4>(a, lds, grid, st);
+      case 5: return launch_planes_abl1<WM, WN, NI, 5>(a, lds, grid, st);
+      case 6: return launch_planes_abl1<WM, WN, NI, 6>(a, lds, grid, st);
+      case 8: return launch_planes_abl1<WM, WN, NI, 8>(a, lds, grid, st);
     }
   }
   if (a.d.split_terms == DV3_SPLIT_F16X3) return launch_planes_t<WM, WN, NI, 3, true>(a, lds, grid, st);
