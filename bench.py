@@ -217,7 +217,7 @@ def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None, c8=False):
                traffic=None, us_per_launch=round(us, 2), alg_flops=flops, alg_bytes=byts,
                hbm_gbs=round(byts / (us * 1e-6) / 1e9, 1),
                hbm_frac=round(byts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4), variant=variant)
-    if dil == 1 and tile_hint == 0 and not c8:
+    if dil == 1 and tile_hint == 0:
         out["traffic"], src = _traffic(key)
         if src:
             out["traffic_source"] = src
@@ -685,7 +685,7 @@ def main():
         from deepvoice3_pytorch_amd import ops as _ops
         if _ops.bf16_storage:   # the same layer as the bf16 configs run it: single-term bf16 on c8 tensors
             rc = conv_roofline(dev, c8=True)
-            out["roofline_bf16_c8"] = {k: rc[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac",
+            out["roofline_bf16_c8"] = {k: rc[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                            "us_per_launch", "alg_flops", "alg_bytes", "hbm_gbs",
                                                            "hbm_frac", "variant")}
     if not args.no_cpu_baseline and world == 1 and args.preset == "deepvoice3_ljspeech":

@@ -1,5 +1,6 @@
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes, calibrated on a known copy as MI355X_MICROARCH.md prescribes)
-# of the kernels bench.py's rooflines time: forward tap-GEMM (variant 5091) and wgrad (3010) at the north-star shape.
+# of the kernels bench.py's rooflines time at the north-star shape: forward tap-GEMM (variant 5091), wgrad (3030, all taps)
+# and the single-term planes tap-GEMM on c8 tensors (8090).
 # Writes profiles-ready JSON to gpurun_out/r02_hbm_traffic.json.
 R=$PWD; mkdir -p $R/gpurun_out; cd /tmp; export TMPDIR=/tmp; export R
 cat > /tmp/pmc_run.py <<'PY'
@@ -11,6 +12,7 @@ from deepvoice3_pytorch_amd import ops
 dev = torch.device("cuda:0")
 print("VARIANT conv", bench.conv_roofline(dev, iters=5)["variant"])
 print("VARIANT wgrad", bench.wgrad_roofline(dev, iters=5)["variant"])
+print("VARIANT convc8", bench.conv_roofline(dev, iters=5, c8=True)["variant"])
 a = torch.randn(64 * 1024 * 1024, device="cuda")   # calibration: axpby reads 256 MiB, writes 256 MiB
 for _ in range(3):
     ops.axpby(a, None, 2.0)
@@ -39,7 +41,9 @@ fcal, wcal = 262144.0 / cf, 262144.0 / cw
 log = open("gpurun_out/pmc_r2_FETCH_SIZE.log").read()
 var = dict(re.findall(r"VARIANT (\w+) (\d+)", log))
 res = {}
-for key, name, alg in (("conv_fwd:%s" % var.get("conv"), "conv_gemm_bf16x3_kernel", 135792640), ("wgrad:%s" % var.get("wgrad"), "wgrad_gemm_bf16x3_kernel", None)):
+wname = "wgrad_taps_kernel" if var.get("wgrad", "").endswith("30") else "wgrad_gemm_bf16x3_kernel"
+for key, name, alg in (("conv_fwd:%s" % var.get("conv"), "conv_gemm_bf16x3_kernel", 135792640), ("wgrad:%s" % var.get("wgrad"), wname, None),
+                       ("conv_fwd:%s" % var.get("convc8"), "conv_planes_kernel", 67897344)):
     kn, f = pick(F, name); _, w = pick(W, name)
     rd, wr = f * fcal * 1024, w * wcal * 1024
     res[key] = dict(kernel=kn[:140], fetch_size_kb_raw=f, write_size_kb_raw=w, fetch_calibration=round(fcal, 4), write_calibration=round(wcal, 4),
