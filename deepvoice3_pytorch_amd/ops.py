@@ -1019,18 +1019,18 @@ class ConvLayerC8Fn(torch.autograd.Function):
                                           want_dpre=not plain)
                 g8 = dy if plain else gm
                 gmat = g8
-            else:          # fp32 (B, M, T) gradient of a c8 -> fp32 layer
+            else:          # fp32 (B, M, T) gradient of a c8 -> fp32 layer: blocked once, for both gradient GEMMs
                 if mode == EPI_LINEAR and alpha == 1.0:
                     _, _, part = gate_bwd(dy, None, None, B=B, C=M, T=T, mode=EPI_LINEAR, want_dpre=False)
                     gmat = dy
                 else:
                     gmat, _, part = gate_bwd(dy, saved if need_y else None, None, B=B, C=M, T=T, mode=mode, alpha=alpha)
-                g8 = None
+                g8 = _ToC8Fn.apply(gmat)
         dx = dv = dg = dbias = None
         if ctx.needs_input_grad[0]:
             dpad = (J - 1) * cfg.dil - padL
             if ctx.x8:      # dx in c8: keep-bytes of the input dropout on the output side
-                dx = conv_gemm(None if g8 is not None else gmat, None, pk.ldb, 0, B=B, Cin=M, Tin=T, M=Cin, Tout=T, J=J,
+                dx = conv_gemm(None, None, pk.ldb, 0, B=B, Cin=M, Tin=T, M=Cin, Tout=T, J=J,
                                dil=cfg.dil, padL=dpad, mode=EPI_DGRAD, r=dres, r_scale=r_scale, drop_scale=ctx.dscale,
                                a_split=pk.bwd_s, x_c8=g8, out_c8=True, ymask_c8=ctx.keep8)
             else:           # fp32 input (the attention context): c8 gradient operand, fp32 (B, Cin, T) result
@@ -1039,8 +1039,6 @@ class ConvLayerC8Fn(torch.autograd.Function):
                                a_split=pk.bwd_s, x_c8=g8, out_c8=False)
         if ctx.needs_input_grad[1]:
             tiles = ((M + 127) // 128) * ((Cin + 127) // 128)
-            if g8 is None:
-                g8 = _ToC8Fn.apply(gmat)
             if ctx.x8:
                 x8t, keep8 = x, ctx.keep8
             else:
