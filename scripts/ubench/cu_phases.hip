@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ITER = 256;
-enum Role { IDLE = 0, MFMA24, LDSR16, GLD2, DSW2, VALU96, BARRIER, STAMP, PHASE_L, PHASE_C };
+enum Role { IDLE = 0, MFMA24, LDSR16, GLD2, DSW2, VALU96, BARRIER, STAMP, PHASE_L, PHASE_C, PIPE_R, PIPE_ALL, PIPE_M, PIPE_MA, PIPE_RA, SCHED_R };
 
 struct Args {
   const f32x4* gsrc;          // >= 256 * 16 KB, L2-resident after the first touch
@@ -85,6 +85,69 @@ __global__ __launch_bounds__(512) void k(const Args a) {
 #pragma unroll
     for (int q = 0; q < 96; ++q) vacc = vacc * 1.0001f + 0.5f;
   };
+  // Intra-wave software pipeline (the shape a one-wave-per-SIMD tap-GEMM needs): 24 MFMAs on the CURRENT fragment
+  // set while the 16 ds_read_b128 of the NEXT set (and, ALL: 2 ds_write_b128 + 2 global_load_dwordx4) are issued in
+  // the gaps between them; the only wait is at the end of the phase.  Two phases per call so the two register sets
+  // swap roles without copies.
+  bf16x8 ga[4], gb[4];
+  for (int i = 0; i < 4; ++i) { ga[i] = fa[i]; gb[i] = fb[i]; }
+  // (raw instructions: the compiler's scheduler clusters volatile LDS loads in front of the MFMAs whatever
+  // sched_group_barrier asks for, so the phase is written as inline asm in exactly the intended issue order)
+  auto pipe_phase = [&](bf16x8 (&ca)[4], bf16x8 (&cb)[4], bf16x8 (&na)[4], bf16x8 (&nb)[4], int it, auto all_c,
+                        auto reads_c, auto agpr_c) {
+    constexpr bool ALL = decltype(all_c)::value, READS = decltype(reads_c)::value, AGPR = decltype(agpr_c)::value;
+    const unsigned base = (unsigned)((it & 1) * 2048 + wave * 256 + (lane >> 5) * 128 + (lane & 31)) * 16u;
+    const unsigned wbase = (unsigned)(4096 + (it & 1) * 1024 + tid) * 16u;
+    const f32x4* gp = a.gsrc + (size_t)blockIdx.x * 1024 + ((tid + it * 64) & 511);
+    bf16x8 v[16];
+    f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+#define MF(I, Q)                                                                                                          \
+    if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[I]) : "v"(ca[((I) + (Q)) & 3]), "v"(cb[I])); \
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[I]) : "v"(ca[((I) + (Q)) & 3]), "v"(cb[I]));
+#define RD(R)                                                                                                              \
+    if constexpr (READS) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[R]) : "v"(base), "n"((((R) * 64) % 1536 + ((R) >> 2) * 16) * 16)); \
+    else v[R] = ca[(R) & 3];
+    // 24 MFMAs; reads R0..R15 behind MFMAs 0..15, then (ALL) two panel stores and two global loads
+    MF(0, 0) RD(0) MF(1, 0) RD(1) MF(2, 0) RD(2) MF(3, 0) RD(3)
+    MF(0, 1) RD(4) MF(1, 1) RD(5) MF(2, 1) RD(6) MF(3, 1) RD(7)
+    MF(0, 2) RD(8) MF(1, 2) RD(9) MF(2, 2) RD(10) MF(3, 2) RD(11)
+    MF(0, 3) RD(12) MF(1, 3) RD(13) MF(2, 3) RD(14) MF(3, 3) RD(15)
+    MF(0, 4)
+    if constexpr (ALL) asm volatile("ds_write_b128 %0, %1" : : "v"(wbase), "v"(ca[0]) : "memory");
+    MF(1, 4)
+    if constexpr (ALL) asm volatile("ds_write_b128 %0, %1 offset:32768" : : "v"(wbase), "v"(cb[0]) : "memory");
+    MF(2, 4)
+    if constexpr (ALL) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x0) : "v"(gp) : "memory");
+    MF(3, 4)
+    if constexpr (ALL) asm volatile("global_load_dwordx4 %0, %1, off offset:4080" : "=v"(x1) : "v"(gp) : "memory");
+    MF(0, 5) MF(1, 5) MF(2, 5) MF(3, 5)
+#undef MF
+#undef RD
+    if constexpr (ALL) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (ALL) gacc += x0 + x1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { na[i] = v[4 * i]; nb[i] = v[4 * i + 1]; }
+  };
+  // The same pipeline with compiler-scheduled instructions: builtin MFMAs, plain (non-volatile) LDS loads of the NEXT
+  // phase's eight fragments -- every load feeds an MFMA of the next phase, so none is dead -- and sched_group_barrier
+  // requests "one ds_read behind each of the first eight MFMAs".  Two phases per call (sets swap roles).
+  typedef __attribute__((address_space(3))) bf16x8 lds_plain;
+  lds_plain* ldp = (lds_plain*)smem_raw;
+  auto sched_phase = [&](bf16x8 (&ca)[4], bf16x8 (&cb)[4], bf16x8 (&na)[4], bf16x8 (&nb)[4], int it) {
+    const int base = ((it & 1) * 2048 + wave * 256 + (lane >> 5) * 128 + (lane & 31));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { na[i] = ldp[base + i * 64]; nb[i] = ldp[base + 512 + i * 64 + 16]; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[(i + q) & 3], cb[i], acc[i], 0, 0, 0);
+#define SG(K) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); if ((K) < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    SG(0) SG(1) SG(2) SG(3) SG(4) SG(5) SG(6) SG(7) SG(8) SG(9) SG(10) SG(11)
+    SG(12) SG(13) SG(14) SG(15) SG(16) SG(17) SG(18) SG(19) SG(20) SG(21) SG(22) SG(23)
+#undef SG
+  };
   auto body = [&](auto role_c, int it) {          // straight-line per role: no dispatch inside the timed loop
     constexpr int ROLE = decltype(role_c)::value;
     if constexpr (ROLE == MFMA24 || ROLE == PHASE_C) mfma24();
@@ -94,6 +157,17 @@ __global__ __launch_bounds__(512) void k(const Args a) {
     if constexpr (ROLE == VALU96) valu96();
     if constexpr (ROLE == STAMP) st += __builtin_readcyclecounter() & 1;
     if constexpr (ROLE == PHASE_L) { ldsr16(it); dsw2(it); gld2(it); }   // a LOAD phase minus the activation tile
+    if constexpr (ROLE == SCHED_R) {                                      // one iteration = TWO phases (48 MFMAs)
+      sched_phase(fa, fb, ga, gb, it);
+      sched_phase(ga, gb, fa, fb, it + 1);
+    }
+    if constexpr (ROLE >= PIPE_R && ROLE != SCHED_R) {                    // one iteration = ONE phase (24 MFMAs)
+      using all_t = std::integral_constant<bool, ROLE == PIPE_ALL>;
+      using rd_t = std::integral_constant<bool, ROLE == PIPE_R || ROLE == PIPE_ALL || ROLE == PIPE_RA>;
+      using ag_t = std::integral_constant<bool, ROLE == PIPE_MA || ROLE == PIPE_RA>;
+      if (it & 1) pipe_phase(ga, gb, fa, fb, it, all_t{}, rd_t{}, ag_t{});
+      else pipe_phase(fa, fb, ga, gb, it, all_t{}, rd_t{}, ag_t{});
+    }
     if constexpr (SYNC) { wait_lgkm0(); __builtin_amdgcn_s_barrier(); }
   };
 
@@ -107,11 +181,11 @@ __global__ __launch_bounds__(512) void k(const Args a) {
   t1 = __builtin_readcyclecounter();
   if (lane == 0) a.cyc[blockIdx.x * 8 + wave] = t1 - t0;
   float s = vacc + gacc[0] + gacc[1] + gacc[2] + gacc[3] + (float)(st & 1);
-  for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][7] + (float)fa[i][0];
+  for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][7] + (float)fa[i][0] + (float)ga[i][1] + (float)gb[i][2];
   a.sink[blockIdx.x * 512 + tid] = s;
 }
 
-static const char* kName[] = {"idle", "mfma24", "ldsr16", "gld2", "dsw2", "valu96", "barrier", "stamp", "phaseL", "phaseC"};
+static const char* kName[] = {"idle", "mfma24", "ldsr16", "gld2", "dsw2", "valu96", "barrier", "stamp", "phaseL", "phaseC", "pipeR", "pipeAll", "asmM(v)", "asmM(a)", "pipeR(a)", "schedR"};
 
 template <int RE, int RL, int SYNC>
 static void run(const Args& a, std::vector<unsigned long long>& h, int blocks) {
@@ -157,5 +231,19 @@ int main() {
   run<PHASE_L, IDLE, 0>(a, h, blocks);
   run<PHASE_L, PHASE_C, 0>(a, h, blocks);
   run<PHASE_L, PHASE_C, 1>(a, h, blocks);         // ping-pong: LOAD beside COMPUTE, one barrier per phase
+  // intra-wave pipelines: one wave per SIMD, two waves per SIMD, with a barrier per phase
+  run<SCHED_R, IDLE, 0>(a, h, blocks);            // 48 MFMAs + 16 ds_read_b128 per iteration, compiler-scheduled
+  run<SCHED_R, SCHED_R, 0>(a, h, blocks);
+  run<SCHED_R, IDLE, 1>(a, h, blocks);
+  run<PIPE_M, IDLE, 0>(a, h, blocks);             // the 24 MFMAs as raw instructions, VGPR / AccVGPR accumulators
+  run<PIPE_MA, IDLE, 0>(a, h, blocks);
+  run<PIPE_RA, IDLE, 0>(a, h, blocks);
+  run<PIPE_RA, PIPE_RA, 0>(a, h, blocks);
+  run<PIPE_R, IDLE, 0>(a, h, blocks);
+  run<PIPE_R, PIPE_R, 0>(a, h, blocks);
+  run<PIPE_ALL, IDLE, 0>(a, h, blocks);
+  run<PIPE_ALL, PIPE_ALL, 0>(a, h, blocks);
+  run<PIPE_ALL, IDLE, 1>(a, h, blocks);
+  run<PIPE_ALL, PIPE_ALL, 1>(a, h, blocks);
   return 0;
 }
