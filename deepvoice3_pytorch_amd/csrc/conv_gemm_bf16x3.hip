@@ -697,6 +697,10 @@ const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
 
 }  // namespace
 
+int g_x3_w1 = 0;   // dv3_debug_set(12, v)
+extern int g_w1_abl;
+int dv3_conv_gemm_w1_dispatch(const dv3_conv_desc* d, hipStream_t st);   // conv_gemm_w1.hip
+
 // called by dv3_conv_gemm_f32 (conv_gemm.hip) when d->a_split != NULL; returns 1 when the shape
 // is not eligible (caller falls back to the exact kernel), else a DV3_* code.
 int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
@@ -707,6 +711,12 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   if ((int64_t)d->B * d->Tout >= (1ll << 30) || (int64_t)d->B * d->x_bs >= (1ll << 30)) return 1;
   if (d->xmask && (int64_t)d->B * d->Cin * d->xmask_rs >= (1ll << 30)) return 1;
   if ((int64_t)d->J * ((d->Cin + 31) / 32 * 4) * d->lda >= (1ll << 27)) return 1;
+  // experimental one-wave-per-SIMD kernel (conv_gemm_w1.hip): dv3_debug_set(12, 1) or tile_hint 30
+  if (g_x3_w1 || d->tile_hint == 30) {
+    const int rc = dv3_conv_gemm_w1_dispatch(d, st);
+    if (rc != 1) return rc;
+    if (d->tile_hint == 30) return 1;
+  }
   // the flat column axis needs batch-strided tensors only through (b, t) addressing: fine for all
   const TileCfg* best = pick_tile_x3(d, gated, d->tile_hint > 20 ? d->tile_hint - 20 : 0);
   if (!best) return 1;
@@ -744,6 +754,8 @@ int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 extern "C" int dv3_debug_set(int what, int value) {
   if (what >= 4 && what <= 8) return dv3_planes_debug_set(what, value);
   if (what == 9) g_x3_rel2 = value;
+  if (what == 12) g_x3_w1 = value;
+  if (what == 13) g_w1_abl = value;
   if (what == 1) g_x3_ablate = value;
   if (what == 2) g_wgrad_tile = value;
   if (what == 3) g_x3_pingpong = value;
