@@ -1018,7 +1018,6 @@ class ConvLayerC8Fn(torch.autograd.Function):
                 gm, _, part = gate_bwd_c8(dy, saved if need_y else None, None, B=B, C=M, T=T, mode=mode, alpha=alpha,
                                           want_dpre=not plain)
                 g8 = dy if plain else gm
-                gmat = g8
             else:          # fp32 (B, M, T) gradient of a c8 -> fp32 layer: blocked once, for both gradient GEMMs
                 if mode == EPI_LINEAR and alpha == 1.0:
                     _, _, part = gate_bwd(dy, None, None, B=B, C=M, T=T, mode=EPI_LINEAR, want_dpre=False)
