@@ -561,3 +561,30 @@ def test_c8_storage_host_logic():
         assert not ops.storage_c8()
     finally:
         ops.set_gemm_precision(prev)
+
+
+def test_archived_bench_line_meets_the_contract():
+    """the last bench line kept under profiles/ carries every field the driver contract names (bench.py's output
+    format is exercised on the GPU; this guards the archived evidence and the field names)"""
+    import glob
+    import json
+    import os
+    from tests.util import ROOT
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_line.json")))
+    assert lines
+    d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["dtype"] in ("f16x3", "bf16x3", "f32", "bf16")
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] in ("reference", "port")
+    assert abs(d["value"] - d["config"]["global_batch"] * 800 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
