@@ -1,9 +1,10 @@
 # coding: utf-8
 """bench.py -- mel-frames/sec/node of the DeepVoice3 training step on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: spawns its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --dry-launch      rendezvous + bucketed all-reduce only (gloo on a CPU-only box)
 
 One "step" = one full optimisation step (forward + losses + backward + [all-reduce] + clip + Adam,
 train.py:604-785) of builder=deepvoice3 preset=deepvoice3_ljspeech (BASELINE.json configs[1]) on a synthetic
@@ -253,7 +254,7 @@ def wgrad_roofline(dev, iters=50, mode=None):
     variant = _lib.lib().dv3_debug_get(11)
     ops.set_gemm_precision(prev)
     flops = 2.0 * B * T * (2 * C) * (k * C)
-    byts = 4.0 * (B * 2 * C * T + B * C * T + S * k * 2 * C * C)     # g + x + slabs
+    byts = 4.0 * (B * 2 * C * T + B * C * T + k * 2 * C * C)         # g + x + dW (the split-K slabs are an artefact)
     tf = flops / (us * 1e-6) / 1e12
     fam = variant // 1000
     peak = {1: PEAK_F32_MFMA_TF, 4: PEAK_16BIT_MFMA_TF}.get(fam, PEAK_16BIT_MFMA_TF / 3.0)
@@ -313,51 +314,85 @@ def cpu_baseline_reference(B, Tt, n_frames, max_seconds=25.0):
                        "frames/item), %.2f s/step" % (n, B, Tt, n_frames, dt), host_cpus=os.cpu_count())
 
 
-def cpu_baseline_port(B, Tt, n_frames, max_seconds=25.0):
-    """The oracle port of the reference train step on the host cores (bounded sample)."""
-    from oracle import dv3_oracle as O
-    hp = dict(DV3_LJ)
-    spec = O.build_spec("deepvoice3", **hp)
-    from deepvoice3_pytorch_amd import builder
-    torch.manual_seed(0)
-    sd = {k: v.detach().clone() for k, v in builder.deepvoice3(**hp).state_dict().items()}
-    frozen = ("seq2seq.decoder.embed_query_positions.weight", "seq2seq.decoder.embed_keys_positions.weight")
-    names = [k for k in sd if k not in frozen]
-    for k in names:
-        sd[k].requires_grad_(True)
-    m = {k: torch.zeros_like(sd[k]) for k in names}
-    v = {k: torch.zeros_like(sd[k]) for k in names}
-    rng = np.random.RandomState(1234)
-    bt = synth_batch(rng, B, Tt, n_frames, hp)
-    mel = bt["mel"][:, 0::4, :].contiguous()
-    lhp = dict(outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5, binary_divergence_weight=0.1,
-               use_guided_attention=True, guided_attention_sigma=0.2)
+class _PortStep(object):
+    """the oracle port of one train step on the host (state for one batch size)"""
 
-    def drop(site, t, p, layout):     # F.dropout stand-in with the same cost profile (bernoulli_ + mul)
+    def __init__(self, B, Tt, n_frames):
+        from oracle import dv3_oracle as O
+        from deepvoice3_pytorch_amd import builder
+        self.O = O
+        hp = dict(DV3_LJ)
+        self.spec = O.build_spec("deepvoice3", **hp)
+        torch.manual_seed(0)
+        sd = {k: v.detach().clone() for k, v in builder.deepvoice3(**hp).state_dict().items()}
+        frozen = ("seq2seq.decoder.embed_query_positions.weight", "seq2seq.decoder.embed_keys_positions.weight")
+        self.names = [k for k in sd if k not in frozen]
+        for k in self.names:
+            sd[k].requires_grad_(True)
+        self.sd = sd
+        self.m = {k: torch.zeros_like(sd[k]) for k in self.names}
+        self.v = {k: torch.zeros_like(sd[k]) for k in self.names}
+        rng = np.random.RandomState(1234)
+        self.bt = synth_batch(rng, B, Tt, n_frames, hp)
+        self.mel = self.bt["mel"][:, 0::4, :].contiguous()
+        self.lhp = dict(outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5, binary_divergence_weight=0.1,
+                        use_guided_attention=True, guided_attention_sigma=0.2)
+        self.frames = float(self.bt["target_lengths"].sum())
+        self.it = 0
+
+    @staticmethod
+    def _drop(site, t, p, layout):     # F.dropout stand-in with the same cost profile (bernoulli_ + mul)
         return torch.nn.functional.dropout(t, p, True)
 
-    def one(it):
+    def one(self):
+        O, sd, bt, names = self.O, self.sd, self.bt, self.names
         for k in names:
             sd[k].grad = None
-        out = O.model_forward(sd, spec, bt["text"], mel, None, bt["text_positions"], bt["frame_positions"],
-                              bt["input_lengths"], drop=drop)
-        loss, _ = O.train_losses(spec, lhp, out, mel, bt["y"], bt["done"], bt["input_lengths"], bt["target_lengths"])
+        out = O.model_forward(sd, self.spec, bt["text"], self.mel, None, bt["text_positions"], bt["frame_positions"],
+                              bt["input_lengths"], drop=self._drop)
+        loss, _ = O.train_losses(self.spec, self.lhp, out, self.mel, bt["y"], bt["done"], bt["input_lengths"],
+                                 bt["target_lengths"])
         loss.backward()
+        self.it += 1
         with torch.no_grad():
-            O.clip_and_adam([sd[k] for k in names], [sd[k].grad for k in names], [m[k] for k in names],
-                            [v[k] for k in names], it + 1, 5e-4)
-    one(0)
-    t0 = time.time()
-    n = 0
-    while n < 20 and (time.time() - t0) < max_seconds:
-        one(n + 1)
-        n += 1
-    dt = (time.time() - t0) / n
-    frames = float(bt["target_lengths"].sum())
-    out = dict(value=round(frames / dt, 1), unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
+            O.clip_and_adam([sd[k] for k in names], [sd[k].grad for k in names], [self.m[k] for k in names],
+                            [self.v[k] for k in names], self.it, 5e-4)
+
+    def time(self, max_steps, max_seconds):
+        self.one()                      # warm-up at the current thread count (allocator, thread pool)
+        t0, n = time.time(), 0
+        while n < max_steps and (time.time() - t0) < max_seconds:
+            self.one()
+            n += 1
+        return (time.time() - t0) / n, n
+
+
+def cpu_baseline_port(B, Tt, n_frames, max_seconds=25.0):
+    """The oracle port of the reference train step on the host cores (bounded sample).  The intra-op thread count
+    is tuned first: a sweep over {8, 16, 32, 64, 128, all} on a batch-8 slice of the workload (one step each),
+    then the full-batch sample runs at the best count."""
+    ncpu = os.cpu_count() or 8
+    prev_threads = torch.get_num_threads()
+    sweep = {}
+    try:
+        small = _PortStep(min(B, 8), Tt, n_frames)
+        for nt in sorted(set(t for t in (8, 16, 32, 64, 128, prev_threads) if t <= ncpu)):
+            torch.set_num_threads(nt)
+            dt_s, _ = small.time(1, 6.0)
+            sweep[nt] = round(small.frames / dt_s, 1)
+        best = max(sweep, key=sweep.get)
+        del small
+        torch.set_num_threads(best)
+        full = _PortStep(B, Tt, n_frames)
+        dt, n = full.time(20, max_seconds)
+        frames = full.frames
+    finally:
+        torch.set_num_threads(prev_threads)
+    out = dict(value=round(frames / dt, 1), unit="mel-frames/s", cores=best, kind="port",
                sample="%d train steps of the same workload (B=%d, Tt=%d, %d frames/item) through "
-                      "oracle/dv3_oracle.py on the host, %.2f s/step" % (n, B, Tt, n_frames, dt),
-               host_cpus=os.cpu_count())
+                      "oracle/dv3_oracle.py on the host at the best of the swept thread counts, %.2f s/step"
+                      % (n, B, Tt, n_frames, dt),
+               host_cpus=ncpu, thread_sweep_frames_per_s_at_batch8=sweep)
     try:      # port / reference time ratio recorded once in the build container (scripts/cpu_baseline_calibration.py)
         cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_port_vs_reference.json")))
         out["port_over_reference_time"] = cal["port_over_reference_time"]
@@ -429,6 +464,64 @@ def synth_run(dev, batch=64, reps=3, warm=1, gl_iters=60, step_graph=True):
 # -------------------------------------------------------------------------------------------------
 # the train step
 # -------------------------------------------------------------------------------------------------
+class _PowerSampler(object):
+    """Shader clock and socket power of one GPU sampled from sysfs by a thread while the timed loop runs (the step
+    runs at the chip's power limit: profiles/r02c; the guide's "DVFS give-back").  Best effort: None when the
+    node does not expose the files."""
+
+    def __init__(self, index, period=0.02):
+        import glob
+        import threading
+        self.sclk, self.power = [], []
+        base = None
+        for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+            if os.path.exists(os.path.join(card, "pp_dpm_sclk")):
+                if index == 0:
+                    base = card
+                    break
+                index -= 1
+        self.f_sclk = os.path.join(base, "pp_dpm_sclk") if base else None
+        hw = sorted(glob.glob(os.path.join(base, "hwmon", "hwmon*"))) if base else []
+        self.f_pow = None
+        for h in hw:
+            for name in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(h, name)):
+                    self.f_pow = os.path.join(h, name)
+                    break
+        self.period, self._stop = period, False
+        self.th = None
+        if self.f_sclk or self.f_pow:
+            self.th = threading.Thread(target=self._run, daemon=True)
+            self.th.start()
+
+    def _run(self):
+        while not self._stop:
+            try:
+                if self.f_sclk:
+                    for line in open(self.f_sclk).read().splitlines():
+                        if line.rstrip().endswith("*"):
+                            self.sclk.append(float(line.split(":")[1].strip().split("M")[0]))
+                if self.f_pow:
+                    self.power.append(float(open(self.f_pow).read()) * 1e-6)
+            except (IOError, OSError, ValueError, IndexError):
+                pass
+            time.sleep(self.period)
+
+    def stop(self):
+        if self.th is None:
+            return None
+        self._stop = True
+        self.th.join(1.0)
+        out = dict(samples=max(len(self.sclk), len(self.power)), source="sysfs pp_dpm_sclk / hwmon power1_average")
+        if self.sclk:
+            out["avg_sclk_mhz"] = round(sum(self.sclk) / len(self.sclk), 1)
+            out["min_sclk_mhz"] = min(self.sclk)
+        if self.power:
+            out["avg_power_w"] = round(sum(self.power) / len(self.power), 1)
+            out["max_power_w"] = round(max(self.power), 1)
+        return out
+
+
 class TrainRun(object):
     """model + trainer + resident batch of one (preset, gemm mode); .measure() = the contract's timed loop"""
 
@@ -452,37 +545,66 @@ class TrainRun(object):
                                                    bt["text_positions"], bt["frame_positions"], bt["done"],
                                                    bt["target_lengths"], self.spk, downsample_step=4, device=dev)
         self.trainer.check_lengths(self.batch)
-        # Launch mode.  At the north-star batch (64) the GPU stays ahead of the host, eager launches are
-        # GPU-bound and the RCCL bucket all-reduces can be issued from autograd hooks on a side stream.  A
-        # whole-step hipGraph pays when the step is launch-bound: small per-GPU batches on one GPU.
-        self.use_graph = graph and world == 1
+        # Launch mode.  The step is ~390 kernel launches; through Python + ctypes the host needs 10-15 ms to enqueue
+        # them, about what the GPU needs to run them, so the default is ONE hipGraph per batch shape (forward, losses,
+        # backward, the bucketed RCCL all-reduces on their side stream, clip + Adam) replayed per step.  Eager
+        # launches (--no-graph) remain for shapes that change every step.
+        self.use_graph = bool(graph)
         self.runner = None
+        self.graph_error = None
         if self.use_graph:
+            ok = 1
             try:
                 self.runner = train_step.GraphedTrainer(self.trainer, self.batch, warmup=2)
             except Exception as e:      # capture not possible: say so, go eager
+                ok = 0
+                self.graph_error = "%s: %s" % (type(e).__name__, e)
                 if rank == 0:
                     import traceback
                     traceback.print_exc()
                     print("hipGraph capture failed (%s); running eager" % type(e).__name__, file=sys.stderr)
-                self.use_graph = False
                 torch.cuda.synchronize()
+            if pg is not None:          # replay only if EVERY rank captured (a mixed job would dead-lock its collectives)
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                if self.runner is not None:
+                    self.runner.close()
+                self.runner, self.use_graph = None, False
 
     def step(self, batch=None):
         if self.use_graph:
-            return self.runner.step()
+            return self.runner.step(batch)      # a fresh batch is copied into the captured one first
         return self.trainer.step(batch if batch is not None else self.batch)
 
-    def measure(self, steps, warmup, feed=None):
+    def measure(self, steps, warmup, feed=None, settle_s=0.0):
         """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks.
         feed: an iterator of device batches (data.Prefetcher) used instead of the resident batch."""
         pg, dev = self.pg, self.dev
         nxt = (lambda: next(feed)) if feed is not None else (lambda: None)
+        comm = self.trainer.comm
+        if settle_s > 0:
+            # the clock governor needs ~1 s of this load before the step time is stationary; a short --warmup
+            # would otherwise time the transient.  Same count on every rank (collectives inside the step).
+            t_s = time.perf_counter()
+            for _ in range(2):
+                scal = self.step(nxt())
+            torch.cuda.synchronize()
+            per = max((time.perf_counter() - t_s) / 2, 1e-4)
+            n_settle = torch.tensor([int(min(200, max(0, settle_s / per - 2)))], dtype=torch.int32, device=dev)
+            if pg is not None:
+                torch.distributed.all_reduce(n_settle, op=torch.distributed.ReduceOp.MAX)
+            for _ in range(int(n_settle.item())):
+                scal = self.step(nxt())
         for _ in range(warmup):
             scal = self.step(nxt())
+        if comm is not None:
+            comm.exposed_events = [] if not self.use_graph else None
         if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+        sampler = _PowerSampler(dev.index or 0) if self.rank == 0 else None
         t0 = time.perf_counter()
         for _ in range(steps):
             scal = self.step(nxt())
@@ -491,6 +613,10 @@ class TrainRun(object):
         if pg is not None:
             torch.distributed.barrier()
         dt = time.perf_counter() - t0
+        power = sampler.stop() if sampler is not None else None
+        exposed = comm.exposed_ms() if (comm is not None and comm.exposed_events is not None) else None
+        if comm is not None:
+            comm.exposed_events = None
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         frames = torch.tensor([float(self.batch.n_frames)], dtype=torch.float64, device=dev)
         if pg is not None:
@@ -504,7 +630,7 @@ class TrainRun(object):
         value = float(frames.item()) / (dt / steps)
         tf = MFLOP_PER_FRAME[self.preset] * 1e6 * value / 1e12
         return dict(value=round(value, 1), ms_per_step=round(ms, 3), steps=steps, warmup=warmup,
-                    host_enqueue_ms_per_step=round(t_host / steps * 1e3, 3),
+                    host_enqueue_ms_per_step=round(t_host / steps * 1e3, 3), allreduce_exposed_ms=exposed, power=power,
                     final_loss=round(loss, 5), frames_per_step=float(frames.item()),
                     step_flop_frac=dict(alg_mflop_per_frame=MFLOP_PER_FRAME[self.preset], achieved_tflops=round(tf, 1),
                                         peak=round(mfma_peak_tf(self.gemm), 1),
@@ -523,16 +649,92 @@ class TrainRun(object):
 
 def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup):
     run = TrainRun(dev, pg, rank, world, preset, gemm, args.batch, args.text_len, args.frames,
-                   graph=(args.graph or args.batch < 32) and not args.no_graph)
+                   graph=not args.no_graph)
     try:
         m = run.measure(steps, warmup)
+        used_graph = bool(run.use_graph)
     finally:
         run.close()
     return dict(metric="mel-frames/sec/node (train step, %s)" % preset, value=m["value"], unit="mel-frames/s",
                 n_gpus=world, steps=steps, warmup=warmup, ms_per_step=m["ms_per_step"], dtype=gemm,
                 dtype_note=dtype_note(gemm), step_flop_frac=m["step_flop_frac"],
                 config=dict(workload="builder=%s preset=%s train step" % (PRESETS[preset][0], preset),
-                            per_gpu_batch=args.batch, global_batch=args.batch * world, final_loss=m["final_loss"]))
+                            per_gpu_batch=args.batch, global_batch=args.batch * world, final_loss=m["final_loss"],
+                            hipgraph=used_graph, host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"],
+                            launch_bound=bool(m["host_enqueue_ms_per_step"] > 0.97 * m["ms_per_step"]),
+                            allreduce_exposed_ms=m["allreduce_exposed_ms"]))
+
+
+# -------------------------------------------------------------------------------------------------
+# multi-rank launch
+# -------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: re-execute this script under
+    torch.distributed.run with N ranks on this node (one per GPU, RCCL over xGMI; 127.0.0.1 rendezvous).
+    Rank 0 prints the JSON line; the launcher's exit code is returned."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    env["DV3_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(args):
+    """The multi-rank plumbing without the HIP path: N ranks rendezvous (RCCL when every rank has its own GPU, else
+    gloo on the host), exchange a flat gradient arena of the headline model's size through dist.BucketedAllReduce
+    exactly as Trainer.optimizer_step does, check the sum, and rank 0 prints a contract-shaped JSON line."""
+    from deepvoice3_pytorch_amd import dist as dv3dist
+    import torch.distributed as tdist
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= max(args.gpus, 1)
+    pg, rank, world, local_rank = dv3dist.init_from_env(backend=None if use_gpu else "gloo")
+    dev = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    n_par = 48
+    params = [torch.nn.Parameter(torch.zeros(256 * 1024 // 4 + 3 * i, device=dev)) for i in range(n_par)]   # ~12 MB
+    from deepvoice3_pytorch_amd.train_step import FlatArena
+    arena = FlatArena(params)
+    comm = dv3dist.BucketedAllReduce(arena, pg, bucket_mb=2.0) if pg is not None else None
+    t0 = time.perf_counter()
+    for it in range(3):
+        arena.grad.fill_(float(rank + 1))
+        if comm is not None:
+            comm.arm()
+            for i in range(n_par - 1, -1, -1):      # gradients become final tail-first, as backward produces them
+                comm._make_hook(i)(params[i])
+            comm.finish()
+        if use_gpu:
+            torch.cuda.synchronize()
+        want = world * (world + 1) / 2.0
+        if float(arena.grad.min()) != want or float(arena.grad.max()) != want:
+            raise RuntimeError("rank %d: all-reduced arena holds [%r, %r], expected %r"
+                               % (rank, float(arena.grad.min()), float(arena.grad.max()), want))
+    dt = (time.perf_counter() - t0) / 3
+    backend = tdist.get_backend(pg) if pg is not None else "none"
+    ranks = tdist.get_world_size(pg) if pg is not None else 1
+    if pg is not None:
+        tdist.barrier()
+    if rank == 0:
+        print(json.dumps(dict(metric="mel-frames/sec/node (train step, %s)" % args.preset, value=None, unit="mel-frames/s",
+                              n_gpus=world, steps=0, warmup=0, ms_per_step=None, higher_is_better=True, scaling="weak",
+                              vs_baseline=None, dtype=None, data="none (dry launch)", dry_launch=True,
+                              rccl_ranks=ranks, backend=backend, device=dev.type,
+                              allreduce_ms_per_arena=round(dt * 1e3, 3), arena_mb=round(arena.total * 4 / 2 ** 20, 1),
+                              buckets=len(comm.buckets) if comm is not None else 0,
+                              config=dict(workload="rank launch + bucketed gradient all-reduce only",
+                                          parallelism="dp%d" % world))))
+    if pg is not None:
+        tdist.destroy_process_group()
 
 
 def main():
@@ -550,21 +752,36 @@ def main():
     ap.add_argument("--text-len", type=int, default=150)
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph replay")
-    ap.add_argument("--graph", action="store_true", help="force the whole-step hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="(default) whole-step hipGraph replay; kept for old command lines")
+    ap.add_argument("--settle", type=float, default=1.0,
+                    help="seconds of untimed steps before --warmup (clock governor settle time; 0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip value_exact_f32 / configs / input_pipeline (headline + rooflines only)")
     ap.add_argument("--mode", default="train", choices=["train", "conv", "conv-ab", "synth"])
     ap.add_argument("--gl-iters", type=int, default=60, help="Griffin-Lim iterations (synth mode)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the N ranks, rendezvous and run the bucketed all-reduce only (no HIP compute; gloo "
+                         "on a CPU-only box)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        # no launcher around us: start the N ranks ourselves (the driver runs `python bench.py --gpus N`)
+        if not args.dry_launch and torch.cuda.device_count() < args.gpus:
+            sys.exit("bench.py --gpus %d: this node exposes %d GPU(s); one process per GPU is the only mode"
+                     % (args.gpus, torch.cuda.device_count()))
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.dry_launch:
+        return dry_launch(args)
 
     from deepvoice3_pytorch_amd import ops, dist as dv3dist
     if args.gemm:
         ops.set_gemm_precision(args.gemm)
     gemm = ops.gemm_precision()
     pg, rank, world, local_rank = dv3dist.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torchrun for --gpus > 1"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -591,9 +808,18 @@ def main():
                               roofline=rf, roofline_wgrad=wgrad_roofline(dev))))
         return
 
-    graph = (args.graph or args.batch < 32) and not args.no_graph
+    graph = not args.no_graph
     run = TrainRun(dev, pg, rank, world, args.preset, gemm, args.batch, args.text_len, args.frames, graph)
-    m = run.measure(args.steps, args.warmup)
+    m = run.measure(args.steps, args.warmup, settle_s=args.settle)
+    m_eager = None
+    if run.use_graph and not args.no_extras:
+        # the same step launched eagerly (what a run with per-step shapes pays): host enqueue time and the
+        # all-reduce time left exposed are only observable there
+        run.use_graph = False
+        try:
+            m_eager = run.measure(max(5, args.steps // 4), 3)
+        finally:
+            run.use_graph = True
     out = None
     if rank == 0:
         out = dict(metric="mel-frames/sec/node (train step, %s)" % args.preset, value=m["value"],
@@ -608,11 +834,30 @@ def main():
                                frames_per_item=args.frames, parallelism="dp%d" % world,
                                hipgraph=bool(run.use_graph), gemm=gemm, final_loss=m["final_loss"],
                                host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"],
-                               launch_bound=bool(m["host_enqueue_ms_per_step"] > 0.97 * m["ms_per_step"])),
+                               launch_bound=bool(m["host_enqueue_ms_per_step"] > 0.97 * m["ms_per_step"]),
+                               settle_s=args.settle),
                    step_flop_frac=m["step_flop_frac"])
+        if pg is not None:
+            import torch.distributed as tdist
+            out["rccl_ranks"] = tdist.get_world_size(pg)
+            out["backend"] = tdist.get_backend(pg)
+            out["allreduce_exposed_ms"] = m["allreduce_exposed_ms"]
+            out["gradient_buckets"] = len(run.trainer.comm.buckets)
+        if run.graph_error:
+            out["config"]["hipgraph_error"] = run.graph_error
+        if m["power"]:
+            out["avg_sclk_mhz"] = m["power"].get("avg_sclk_mhz")
+            out["avg_power_w"] = m["power"].get("avg_power_w")
+            out["power"] = m["power"]
+        if m_eager is not None:
+            out["eager"] = dict(value=m_eager["value"], ms_per_step=m_eager["ms_per_step"], steps=m_eager["steps"],
+                                host_enqueue_ms_per_step=m_eager["host_enqueue_ms_per_step"],
+                                launch_bound=bool(m_eager["host_enqueue_ms_per_step"] > 0.97 * m_eager["ms_per_step"]),
+                                allreduce_exposed_ms=m_eager["allreduce_exposed_ms"],
+                                note="the same step with per-kernel launches through Python + ctypes (--no-graph)")
     extras = not args.no_extras
     # ---- the same step fed through the input pipeline (sampler -> pinned staging -> side-stream H2D + device collate)
-    if extras and not run.use_graph:
+    if extras:
         try:
             from deepvoice3_pytorch_amd import data as dv3data
             rng = np.random.RandomState(99 + rank)

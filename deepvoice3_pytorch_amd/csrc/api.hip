@@ -12,6 +12,39 @@ void dv3_set_error(const char* fmt, ...) {
 }
 
 int g_dv3_last_conv = 0, g_dv3_last_wgrad = 0;
+
+// sticky fp16-range event counter of the f16x3 mode (include/dv3hip.h: dv3_f16_range_events)
+__device__ uint32_t g_dv3_range_events;
+uint32_t* dv3_range_ctr() {
+  static uint32_t* ptr = nullptr;
+  if (!ptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_dv3_range_events)) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, sizeof(uint32_t));
+    ptr = (uint32_t*)p;
+  }
+  return ptr;
+}
+extern "C" int dv3_f16_range_events(int32_t* dst, int32_t reset, void* stream) {
+  uint32_t* ctr = dv3_range_ctr();
+  DV3_REQUIRE(ctr != nullptr, "f16_range_events: no device");
+  hipStream_t st = (hipStream_t)stream;
+  if (dst) {
+    hipError_t e = hipMemcpyAsync(dst, ctr, sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+      dv3_set_error("f16_range_events: %s", hipGetErrorString(e));
+      return DV3_ELAUNCH;
+    }
+  }
+  if (reset) {
+    hipError_t e = hipMemsetAsync(ctr, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) {
+      dv3_set_error("f16_range_events: %s", hipGetErrorString(e));
+      return DV3_ELAUNCH;
+    }
+  }
+  return DV3_OK;
+}
 extern "C" int dv3_debug_get(int what) {
   if (what == 10) return g_dv3_last_conv;
   if (what == 11) return g_dv3_last_wgrad;

@@ -37,7 +37,48 @@ extern int g_dv3_last_conv, g_dv3_last_wgrad;
 static inline int dv3_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t dv3_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- fp16 range guard of the f16x3 mode ----------------------------------------------
+// Device address of the library's sticky range-event counter (api.hip: a __device__ word, no allocation): every kernel
+// that builds scaled fp16 operand pairs adds the number of 16-byte units in which some |v * 2^s| left the fp16 range.
+uint32_t* dv3_range_ctr();
+
 // ---- device helpers -----------------------------------------------------------------
+typedef __bf16 dv3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dv3_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dv3_f16x2 __attribute__((ext_vector_type(2)));
+typedef float dv3_f32x2 __attribute__((ext_vector_type(2)));
+
+// Scaled fp16 pair of 8 values a[i] = v * 2^s (include/dv3hip.h, "f16x3"): hi = fp16_rn(clamp(a, +-65504)),
+// lo = fp16_rn(a - hi).  The residual is taken from the UNCLAMPED a: inside the range nothing changes; up to
+// 2 x 65504 the pair still carries a to fp16 precision; beyond that lo becomes Inf, and a NaN / Inf input gives a
+// NaN / Inf lo -- the GEMM output turns non-finite exactly as the fp32 reference's would, instead of training on
+// saturated values.  Returns true when some |a| exceeded 65504 (the caller counts it: dv3_note_range).
+__device__ __forceinline__ bool dv3_split8_f16(const float (&a)[8], dv3_bf16x8& hi, dv3_bf16x8& lo) {
+  dv3_f16x8 h8, l8;
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const dv3_f32x2 f = {a[i], a[i + 1]};
+    const dv3_f32x2 c = {__builtin_amdgcn_fmed3f(a[i], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(a[i + 1], -65504.f, 65504.f)};
+    const dv3_f16x2 h = __builtin_convertvector(c, dv3_f16x2);
+    const dv3_f32x2 r = f - __builtin_convertvector(h, dv3_f32x2);
+    const dv3_f16x2 l = __builtin_convertvector(r, dv3_f16x2);
+    h8[i] = h[0]; h8[i + 1] = h[1];
+    l8[i] = l[0]; l8[i + 1] = l[1];
+  }
+  hi = __builtin_bit_cast(dv3_bf16x8, h8);
+  lo = __builtin_bit_cast(dv3_bf16x8, l8);
+  const float m0 = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fabsf(a[2]));
+  const float m1 = fmaxf(fmaxf(fabsf(a[3]), fabsf(a[4])), fabsf(a[5]));
+  const float m = fmaxf(fmaxf(m0, m1), fmaxf(fabsf(a[6]), fabsf(a[7])));
+  return !(m <= 65504.f);
+}
+// count the units of this wave whose scaled value left the fp16 range (rare path: one ballot per call)
+__device__ __forceinline__ void dv3_note_range(uint32_t* ctr, bool bad) {
+  if (__builtin_expect(__any(bad), 0)) {
+    if (ctr && bad) atomicAdd(ctr, 1u);
+  }
+}
+
 __device__ __forceinline__ float dv3_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // Bijective XCD-aware remap of a 1-D block id (MI355X: block b runs on XCD b % 8).  Gives each

@@ -11,6 +11,8 @@ struct ConvArgs {
   int a_scalar;  // packed operand not 16-byte aligned (per-batch A = an activation): scalar staging
   int kp;        // bf16x3: K extent of the split weight image (Cin rounded up to 32)
   int stagger;   // planes kernel: s_sleep(127) repeats before the second co-resident workgroup starts
+  uint32_t* range_ctr = nullptr;   // f16x3: sticky fp16-range event counter (common.h), NULL = do not count
+  int prio = 0;  // ping-pong tap-GEMM: wave priority scheme (dv3_debug_set(14, v); 0 = none)
 };
 
 template <typename T>

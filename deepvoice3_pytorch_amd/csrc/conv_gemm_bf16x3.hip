@@ -56,23 +56,6 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
   }
 }
 
-// Scaled fp16 split (include/dv3hip.h, "f16x3"): v arrives already multiplied by its power-of-two scale;
-// clamp to the fp16 range, hi = fp16_rn(a), lo = fp16_rn(a - hi).  The 16-byte units travel through the same
-// LDS images as the bf16 ones (raw bits in a bf16x8).
-__device__ __forceinline__ void split8_f16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-  f16x8 h8, l8;
-#pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    const f32x2 f = {__builtin_amdgcn_fmed3f(v[i], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[i + 1], -65504.f, 65504.f)};
-    const f16x2 h = __builtin_convertvector(f, f16x2);
-    const f32x2 r = f - __builtin_convertvector(h, f32x2);
-    const f16x2 l = __builtin_convertvector(r, f16x2);
-    h8[i] = h[0]; h8[i + 1] = h[1];
-    l8[i] = l[0]; l8[i + 1] = l[1];
-  }
-  hi = __builtin_bit_cast(bf16x8, h8);
-  lo = __builtin_bit_cast(bf16x8, l8);
-}
 // one 32x32x16 MFMA on raw 16-byte operand units, bf16 or fp16
 template <bool F16>
 __device__ __forceinline__ f32x16 mma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
@@ -281,7 +264,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
           else if (F16) v[e] *= xscale;
         }
         bf16x8 hi, lo;
-        if constexpr (F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
+        if constexpr (F16) dv3_note_range(args.range_ctr, dv3_split8_f16(v, hi, lo)); else split8(v, hi, lo);
         dst[idx] = hi;
         if (TERMS == 3) dst[KB * BNH + idx] = lo;
       }
@@ -343,6 +326,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
     load_A((1 < nsteps && J == 1) ? 1 : 0, (1 < nsteps && J > 1) ? 1 : 0);
     if (1 < nchunks) load_X(1);
     stamp();                       // slot 0: prologue done
+    // wave priority scheme (measurement knob, dv3_debug_set(14, v)): 1 = LOAD phases at priority 3, 2 = COMPUTE
+    // phases at priority 3, 3 / 4 = the late / early half at static priority 1
+    const int prio = args.prio;
+    if (prio == 3 && late) __builtin_amdgcn_s_setprio(1);
+    if (prio == 4 && !late) __builtin_amdgcn_s_setprio(1);
     if (late) __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
       const int cur = step & 1;
@@ -351,6 +339,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
       const bool has_next = step + 1 < nsteps;
       const bool new_chunk = has_next && jn == 0;
       stamp();                     // slot 1 + 6*step: LOAD begins
+      if (prio == 1) __builtin_amdgcn_s_setprio(3);
       // ---------------- LOAD ----------------
       bf16x8 ah[2][2], al[2][2], bh[2][NI], bl[2][NI];
       {
@@ -408,6 +397,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
       stamp();                     // LOAD issued (the SMEM read waits for the LDS queue)
       __syncthreads();
       stamp();                     // COMPUTE begins
+      if (prio == 1) __builtin_amdgcn_s_setprio(0);
+      if (prio == 2) __builtin_amdgcn_s_setprio(3);
       // ---------------- COMPUTE ----------------
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -430,6 +421,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         }
       }
       stamp();                     // MFMAs issued
+      if (prio == 2) __builtin_amdgcn_s_setprio(0);
       if (has_next || !late) __syncthreads();
       j = jn;
       c = cn;
@@ -570,7 +562,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
 // packed fp32 [J][K][lda] -> split image [plane][j][k8][m][8]
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ src,
                                                          bf16x8* __restrict__ dst, int J, int K,
-                                                         int lda, int k8_total, int dtype) {
+                                                         int lda, int k8_total, int dtype, uint32_t* range_ctr) {
   const int64_t n = (int64_t)J * k8_total * lda;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
@@ -585,7 +577,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
     if (dtype == DV3_SPLIT_DTYPE_F16) v[i] *= (float)(1 << DV3_F16_WEIGHT_SHIFT);
   }
   bf16x8 hi, lo;
-  if (dtype == DV3_SPLIT_DTYPE_F16) split8_f16(v, hi, lo); else split8(v, hi, lo);
+  if (dtype == DV3_SPLIT_DTYPE_F16) dv3_note_range(range_ctr, dv3_split8_f16(v, hi, lo)); else split8(v, hi, lo);
   dst[idx] = hi;
   dst[n + idx] = lo;
 }
@@ -697,9 +689,7 @@ const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
 
 }  // namespace
 
-int g_x3_w1 = 0;   // dv3_debug_set(12, v)
-extern int g_w1_abl;
-int dv3_conv_gemm_w1_dispatch(const dv3_conv_desc* d, hipStream_t st);   // conv_gemm_w1.hip
+int g_x3_prio = 0; // dv3_debug_set(14, v): wave priority scheme of the ping-pong main loop
 
 // called by dv3_conv_gemm_f32 (conv_gemm.hip) when d->a_split != NULL; returns 1 when the shape
 // is not eligible (caller falls back to the exact kernel), else a DV3_* code.
@@ -711,12 +701,6 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   if ((int64_t)d->B * d->Tout >= (1ll << 30) || (int64_t)d->B * d->x_bs >= (1ll << 30)) return 1;
   if (d->xmask && (int64_t)d->B * d->Cin * d->xmask_rs >= (1ll << 30)) return 1;
   if ((int64_t)d->J * ((d->Cin + 31) / 32 * 4) * d->lda >= (1ll << 27)) return 1;
-  // experimental one-wave-per-SIMD kernel (conv_gemm_w1.hip): dv3_debug_set(12, 1) or tile_hint 30
-  if (g_x3_w1 || d->tile_hint == 30) {
-    const int rc = dv3_conv_gemm_w1_dispatch(d, st);
-    if (rc != 1) return rc;
-    if (d->tile_hint == 30) return 1;
-  }
   // the flat column axis needs batch-strided tensors only through (b, t) addressing: fine for all
   const TileCfg* best = pick_tile_x3(d, gated, d->tile_hint > 20 ? d->tile_hint - 20 : 0);
   if (!best) return 1;
@@ -727,6 +711,8 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   ConvArgs a;
   a.d = *d;
   a.a_scalar = 0;
+  a.prio = g_x3_prio;
+  a.range_ctr = d->split_terms == DV3_SPLIT_F16X3 ? dv3_range_ctr() : nullptr;
   a.kp = (d->Cin + 31) / 32 * 32;
   a.m_tiles = gated ? dv3_cdiv(d->Cg, BMH) : dv3_cdiv(d->M, BM);
   a.n_tiles = (int)dv3_cdiv64((int64_t)d->B * d->Tout, BN);
@@ -749,13 +735,13 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   return 1;
 }
 
-extern int g_wgrad_tile;   // wgrad_gemm_bf16x3.hip
+extern int g_wgrad_tile, g_wgrad_prio;   // wgrad_gemm_bf16x3.hip
 int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 extern "C" int dv3_debug_set(int what, int value) {
   if (what >= 4 && what <= 8) return dv3_planes_debug_set(what, value);
   if (what == 9) g_x3_rel2 = value;
-  if (what == 12) g_x3_w1 = value;
-  if (what == 13) g_w1_abl = value;
+  if (what == 14) g_x3_prio = value;
+  if (what == 15) g_wgrad_prio = value;
   if (what == 1) g_x3_ablate = value;
   if (what == 2) g_wgrad_tile = value;
   if (what == 3) g_x3_pingpong = value;
@@ -781,6 +767,7 @@ extern "C" int dv3_split_pack_bf16(const float* packed, uint16_t* out, int32_t J
   const int k8_total = (K + 31) / 32 * 4;
   const int64_t n = (int64_t)J * k8_total * lda;
   hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)dv3_cdiv64(n, 256)), dim3(256), 0,
-                     (hipStream_t)stream, packed, reinterpret_cast<bf16x8*>(out), J, K, lda, k8_total, (int)dtype);
+                     (hipStream_t)stream, packed, reinterpret_cast<bf16x8*>(out), J, K, lda, k8_total, (int)dtype,
+                     dv3_range_ctr());
   return dv3_check_launch("split_pack_bf16");
 }

@@ -472,24 +472,9 @@ __device__ __forceinline__ void split8_bf16(const float (&v)[8], bf16x8& hi, bf1
     lo[i] = l[0]; lo[i + 1] = l[1];
   }
 }
-__device__ __forceinline__ void split8_f16(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-  f16x8 h8, l8;
-#pragma unroll
-  for (int i = 0; i < 8; i += 2) {
-    const f32x2 f = {__builtin_amdgcn_fmed3f(v[i], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[i + 1], -65504.f, 65504.f)};
-    const f16x2 h = __builtin_convertvector(f, f16x2);
-    const f32x2 r = f - __builtin_convertvector(h, f32x2);
-    const f16x2 l = __builtin_convertvector(r, f16x2);
-    h8[i] = h[0]; h8[i + 1] = h[1];
-    l8[i] = l[0]; l8[i + 1] = l[1];
-  }
-  hi = __builtin_bit_cast(bf16x8, h8);
-  lo = __builtin_bit_cast(bf16x8, l8);
-}
-
 // one thread per 16-byte unit (b, c8, t); t fastest: the 8 channel reads are row-coalesced, the two unit stores
 // are 16-byte coalesced
-__global__ __launch_bounds__(256) void split_planes_kernel(const dv3_planes_desc p, int c8p) {
+__global__ __launch_bounds__(256) void split_planes_kernel(const dv3_planes_desc p, int c8p, uint32_t* range_ctr) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int c8 = blockIdx.y, b = blockIdx.z;
   if (t >= p.T) return;
@@ -508,7 +493,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const dv3_planes_desc
     v[e] = x;
   }
   bf16x8 hi, lo;
-  if (p.dtype == DV3_SPLIT_DTYPE_F16) split8_f16(v, hi, lo); else split8_bf16(v, hi, lo);
+  if (p.dtype == DV3_SPLIT_DTYPE_F16) dv3_note_range(range_ctr, dv3_split8_f16(v, hi, lo)); else split8_bf16(v, hi, lo);
   bf16x8* out = reinterpret_cast<bf16x8*>(p.out);
   const int64_t u = ((int64_t)b * c8p + c8) * p.T + t;
   out[u] = hi;
@@ -661,7 +646,7 @@ extern "C" int dv3_split_planes_f32(const dv3_planes_desc* d, void* stream) {
   if (d->mask) DV3_REQUIRE(d->mask_rs * 32 >= d->T, "split_planes: mask row stride too small");
   const int c8p = (d->C + 31) / 32 * 4;
   DV3_REQUIRE(c8p <= 65535 && d->B <= 65535, "split_planes: grid too large");
-  hipLaunchKernelGGL(split_planes_kernel, dim3(dv3_cdiv(d->T, 256), c8p, d->B), dim3(256), 0, (hipStream_t)stream, *d, c8p);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(dv3_cdiv(d->T, 256), c8p, d->B), dim3(256), 0, (hipStream_t)stream, *d, c8p, dv3_range_ctr());
   return dv3_check_launch("split_planes");
 }
 

@@ -111,22 +111,16 @@ __device__ __forceinline__ void wn_split8(const float (&v)[8], wn_bf16x8& hi, wn
     lo[i] = (__bf16)(v[i] - (float)h);
   }
 }
-typedef _Float16 wn_f16x8 __attribute__((ext_vector_type(8)));
-// scaled fp16 split of the forward image (include/dv3hip.h "f16x3"): a = clamp(v * 2^8)
-__device__ __forceinline__ void wn_split8_f16(const float (&v)[8], wn_bf16x8& hi, wn_bf16x8& lo) {
-  wn_f16x8 h8, l8;
+// scaled fp16 split of the forward image (include/dv3hip.h "f16x3"): a = v * 2^8; true when a left the fp16 range
+__device__ __forceinline__ bool wn_split8_f16(const float (&v)[8], wn_bf16x8& hi, wn_bf16x8& lo) {
+  float a[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float a = __builtin_amdgcn_fmed3f(v[i] * (float)(1 << DV3_F16_WEIGHT_SHIFT), -65504.f, 65504.f);
-    const _Float16 h = (_Float16)a;
-    h8[i] = h;
-    l8[i] = (_Float16)(a - (float)h);
-  }
-  hi = __builtin_bit_cast(wn_bf16x8, h8);
-  lo = __builtin_bit_cast(wn_bf16x8, l8);
+  for (int i = 0; i < 8; ++i) a[i] = v[i] * (float)(1 << DV3_F16_WEIGHT_SHIFT);
+  return dv3_split8_f16(a, hi, lo);
 }
 __device__ __forceinline__ void wn_split_both_block(const dv3_wn_desc& p, wn_bf16x8* __restrict__ fs,
-                                                    wn_bf16x8* __restrict__ bs, int bx, int by, float* tile) {
+                                                    wn_bf16x8* __restrict__ bs, int bx, int by, float* tile,
+                                                    uint32_t* range_ctr) {
   const int O = p.O, I = p.I, J = p.J;
   const int o0 = bx * 32, i0 = by * 32;
   const int W = 32 * J, LD = W + 1;
@@ -154,7 +148,9 @@ __device__ __forceinline__ void wn_split_both_block(const dv3_wn_desc& p, wn_bf1
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[ol * LD + (q * 8 + e) * J + j];
     wn_bf16x8 hi, lo;
-    if (p.fwd_dtype == DV3_SPLIT_DTYPE_F16) wn_split8_f16(v, hi, lo); else wn_split8(v, hi, lo);
+    bool bad = false;
+    if (p.fwd_dtype == DV3_SPLIT_DTYPE_F16) bad = wn_split8_f16(v, hi, lo); else wn_split8(v, hi, lo);
+    if (bad && range_ctr) atomicAdd(range_ctr, 1u);     // divergent loop: no wave-wide ballot here
     const int64_t g = ((int64_t)j * k8f + (i0 >> 3) + q) * p.lda + col;
     fs[g] = hi;
     fs[plane_f + g] = lo;
@@ -177,9 +173,9 @@ __device__ __forceinline__ void wn_split_both_block(const dv3_wn_desc& p, wn_bf1
 }
 
 __global__ __launch_bounds__(256) void wn_split_both_kernel(const dv3_wn_desc p, wn_bf16x8* __restrict__ fs,
-                                                            wn_bf16x8* __restrict__ bs) {
+                                                            wn_bf16x8* __restrict__ bs, uint32_t* range_ctr) {
   extern __shared__ float tile[];  // [32][32*J+1]
-  wn_split_both_block(p, fs, bs, blockIdx.x, blockIdx.y, tile);
+  wn_split_both_block(p, fs, bs, blockIdx.x, blockIdx.y, tile, range_ctr);
 }
 
 // ---- every weight-normed Conv1d / Linear layer of a model in TWO launches (the per-layer form costs two small
@@ -202,14 +198,15 @@ __global__ __launch_bounds__(256) void wn_inv_norm_multi_kernel(const dv3_wn_mul
   wn_inv_norm_row(d.v, d.g, d.scale, d.I * d.J, blockIdx.x - first_row[l], red);
 }
 __global__ __launch_bounds__(256) void wn_split_both_multi_kernel(const dv3_wn_multi_entry* __restrict__ tab,
-                                                                  const int32_t* __restrict__ first_block, int n) {
+                                                                  const int32_t* __restrict__ first_block, int n,
+                                                                  uint32_t* range_ctr) {
   extern __shared__ float tile[];
   const int l = wn_find_layer(first_block, n, blockIdx.x);
   const dv3_wn_multi_entry e = tab[l];
   const int b = blockIdx.x - first_block[l];
   const int nbx = (e.d.O + 31) / 32;
   wn_split_both_block(e.d, reinterpret_cast<wn_bf16x8*>(e.fwd_split), reinterpret_cast<wn_bf16x8*>(e.bwd_split),
-                      b % nbx, b / nbx, tile);
+                      b % nbx, b / nbx, tile, range_ctr);
 }
 
 __global__ void zero_kernel(float* p, int64_t n) {
@@ -360,7 +357,7 @@ extern "C" int dv3_weight_norm_split_pack_bf16(const dv3_wn_desc* d, uint16_t* f
   const size_t lds = (size_t)32 * (32 * d->J + 1) * 4;
   DV3_REQUIRE(lds <= 64 * 1024, "wn_split_pack: too many taps");
   hipLaunchKernelGGL(wn_split_both_kernel, dim3(dv3_cdiv(d->O, 32), dv3_cdiv(d->I, 32)), dim3(256), lds, st,
-                     *d, reinterpret_cast<wn_bf16x8*>(fwd_split), reinterpret_cast<wn_bf16x8*>(bwd_split));
+                     *d, reinterpret_cast<wn_bf16x8*>(fwd_split), reinterpret_cast<wn_bf16x8*>(bwd_split), dv3_range_ctr());
   return dv3_check_launch("weight_norm_split_pack_bf16");
 }
 
@@ -373,7 +370,8 @@ extern "C" int dv3_weight_norm_split_pack_multi(const dv3_wn_multi_entry* table_
   DV3_REQUIRE(lds <= 64 * 1024, "wn_split_pack_multi: too many taps");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wn_inv_norm_multi_kernel, dim3(total_rows), dim3(256), 0, st, table_dev, first_row_dev, n_layers);
-  hipLaunchKernelGGL(wn_split_both_multi_kernel, dim3(total_blocks), dim3(256), lds, st, table_dev, first_block_dev, n_layers);
+  hipLaunchKernelGGL(wn_split_both_multi_kernel, dim3(total_blocks), dim3(256), lds, st, table_dev, first_block_dev, n_layers,
+                     dv3_range_ctr());
   return dv3_check_launch("weight_norm_split_pack_multi");
 }
 

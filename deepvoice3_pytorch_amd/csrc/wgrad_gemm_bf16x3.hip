@@ -29,6 +29,7 @@ namespace {
 struct WgradArgs {
   dv3_wgrad_desc d;
   int m_tiles, c_tiles;
+  int prio = 0;   // all-taps kernel: wave priority scheme (dv3_debug_set(15, v))
 };
 
 constexpr int BKT = 32;  // time steps per K step
@@ -455,10 +456,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_taps_kernel(const WgradArgs args
     write_step(0, S0{});
   }
   __syncthreads();
+  const int prio = args.prio;   // measurement knob: 1 = staging at priority 3, 2 = MFMAs at priority 3
   for (int step = 0; step < nsteps; ++step) {
+    if (prio == 1) __builtin_amdgcn_s_setprio(3);
     if (step + 1 < nsteps) load_step(step + 1, S0{});
+    if (prio == 1) __builtin_amdgcn_s_setprio(0);
+    if (prio == 2) __builtin_amdgcn_s_setprio(3);
     mfma_step(step & 1);
+    if (prio == 2) __builtin_amdgcn_s_setprio(0);
+    if (prio == 1) __builtin_amdgcn_s_setprio(3);
     if (step + 1 < nsteps) write_step((step + 1) & 1, S0{});
+    if (prio == 1) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
   }
 
@@ -482,6 +490,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_taps_kernel(const WgradArgs args
 }  // namespace
 
 int g_wgrad_taps_default = 1;   // the all-taps form measured 7-14 % faster at every model shape (scripts/wgrad_ab.py)
+int g_wgrad_prio = 0;   // debug (dv3_debug_set(15, v))
 int g_wgrad_tile = 0;   // debug (dv3_debug_set(2, v)): 0 auto, 1 force 128x128 per tap, 2 force 256x128 per tap, 3 force all-taps
 
 template <bool MASK, int TERMS>
@@ -535,6 +544,7 @@ int dv3_wgrad_gemm_bf16x3_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
     return 1;   // caller falls back to the exact kernel
   WgradArgs a;
   a.d = *d;
+  a.prio = g_wgrad_prio;
   // three taps, K split over contiguous ranges: one 8-wave workgroup per (m-tile, c-tile, slab) serves all taps
   if (d->J == 3 && d->k_split && (g_wgrad_tile == 3 || (g_wgrad_tile == 0 && g_wgrad_taps_default))) {
     a.m_tiles = dv3_cdiv(d->M, 128);

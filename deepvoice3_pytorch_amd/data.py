@@ -188,10 +188,12 @@ class LengthBucketedSampler(object):
     batches r, r + world, r + 2*world, ... (the reference sampler is not rank-aware).  Every
     rank draws the same permutation (numpy RandomState(seed + epoch)), so the shards are disjoint and cover
     the epoch; the batch list is truncated to a multiple of `world` so all ranks take the same number of
-    steps (a data-parallel step is collective)."""
+    steps (a data-parallel step is collective).  Under world > 1 a short tail batch would meet full batches in
+    one 1/world gradient average and over-weight its samples, so drop_last defaults to True there (None = that
+    rule); the batches cut off by the truncation rotate with the epoch, so no sample is skipped every epoch."""
 
     def __init__(self, lengths, batch_size=16, batch_group_size=None, permutate=True, rank=0, world=1, seed=0,
-                 drop_last=False):
+                 drop_last=None):
         lengths = np.asarray(lengths, dtype=np.int64)
         self.sorted_indices = np.argsort(lengths, kind="stable")
         self.batch_size = int(batch_size)
@@ -205,7 +207,7 @@ class LengthBucketedSampler(object):
         self.batch_group_size = batch_group_size
         self.permutate = permutate
         self.rank, self.world, self.seed, self.epoch = int(rank), int(world), int(seed), 0
-        self.drop_last = drop_last
+        self.drop_last = (int(world) > 1) if drop_last is None else bool(drop_last)
         if not 0 <= self.rank < self.world:
             raise ValueError("rank must be in [0, world)")
 
@@ -233,8 +235,12 @@ class LengthBucketedSampler(object):
 
     def __iter__(self):
         batches = self.epoch_batches()
-        usable = len(batches) - len(batches) % self.world
-        for b in batches[self.rank:usable:self.world]:
+        extra = len(batches) % self.world
+        if extra:      # drop `extra` batches at an epoch-dependent position (same on every rank; epoch 0: the last ones)
+            nb = len(batches)
+            gone = set((nb - extra * (self.epoch + 1) + k) % nb for k in range(extra))
+            batches = [b for i, b in enumerate(batches) if i not in gone]
+        for b in batches[self.rank::self.world]:
             yield [int(i) for i in b]
 
     def __len__(self):

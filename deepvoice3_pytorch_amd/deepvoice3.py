@@ -377,7 +377,7 @@ class Decoder(nn.Module):
         dev = keys.device
         if self.training:
             raise RuntimeError('incremental_forward only supports eval mode')
-        if getattr(self, "fast_decode", False) and keys.is_cuda:
+        if getattr(self, "fast_decode", False) and keys.is_cuda and self._fast_decode_eligible(keys.size(1)):
             return self._incremental_fast(encoder_out, text_positions, speaker_embed, initial_input, test_inputs)
         w = self._rate(self.key_position_rate, self.speaker_proj1, speaker_embed)
         keys_bct = self.embed_keys_positions.forward_bct(text_positions, w,
@@ -487,6 +487,34 @@ class Decoder(nn.Module):
         outputs = torch.stack(outputs).transpose(0, 1).contiguous()
         return outputs, alignments, dones, decoder_states
 
+    def _fast_decode_eligible(self, Tk):
+        """What the fused step program (csrc/decode_step.hip) takes; anything else runs the module-by-module
+        path below, which handles every configuration the reference does."""
+        def fits(conv):      # dv3_conv_step_f32 stages the k-tap window of 4 batch items in 64 KB of LDS
+            k = conv.kernel_size[0]
+            return (k * conv.in_channels * 4 + 16 * 16 * 2 * 4) * 4 <= 64 * 1024
+        mods, i = list(self.preattention), 0
+        while i < len(mods):
+            f = mods[i]
+            if isinstance(f, Conv1dGLU):
+                if not fits(f.conv):
+                    return False
+            elif isinstance(f, _conv.Conv1d):
+                if f.kernel_size[0] != 1 or not fits(f):
+                    return False
+                i += int(i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU))
+            else:
+                return False
+            i += 1
+        for f, att in zip(self.convolutions, self.attention):
+            if not isinstance(f, Conv1dGLU) or not fits(f.conv):
+                return False
+            if att is not None:
+                E = att.query_projection.out_features
+                if (E + Tk) * 4 > 64 * 1024:
+                    return False
+        return True
+
     # -- the same decode on the fused step kernels (csrc/decode_step.hip) -------------------------------
     def _incremental_fast(self, encoder_out, text_positions, speaker_embed=None, initial_input=None,
                           test_inputs=None):
@@ -595,9 +623,9 @@ class Decoder(nn.Module):
                 residual = x
                 st = states if idx == n_conv - 1 else None
                 if attention is None:
-                    x = glu_step(f, x, False, r2=residual, out_seq=st)       # (glu + residual) * sqrt(.5)
+                    x = glu_step(f, x, f.residual, r2=residual, out_seq=st)   # (glu + residual) * sqrt(.5)
                     continue
-                xq = glu_step(f, x, False, post_add=pe_all)                  # conv output + the step's position code
+                xq = glu_step(f, x, f.residual, post_add=pe_all)              # conv output + the step's position code
                 kp, vp = proj[idx]
                 q = conv_step(attention.query_projection, xq, ops.EPI_LINEAR, attention.query_projection.out_features)
                 ctx = torch.empty(B, kp.size(1), **f32)

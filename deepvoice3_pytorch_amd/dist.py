@@ -44,6 +44,10 @@ class BucketedAllReduce(object):
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self._armed = False
+        # measurement (bench.py): when a list, finish() appends an (event, event) pair bracketing the point where
+        # the step stream joins the collective stream -- their distance is the all-reduce time NOT hidden behind
+        # backward.  Timing events can not be recorded while a hipGraph is being captured.
+        self.exposed_events = None
         # a parameter reports its gradient final either through autograd (AccumulateGrad hook) or, for
         # the conv-layer parameters whose gradient is accumulated in place, through ops.grad_ready_hooks
         self._index_of = {id(p): i for i, p in enumerate(arena.params)}
@@ -111,17 +115,33 @@ class BucketedAllReduce(object):
             if not self.launched[b]:
                 self._launch(b)
         if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+            cur = torch.cuda.current_stream()
+            timed = self.exposed_events is not None and not torch.cuda.is_current_stream_capturing()
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+            cur.wait_stream(self.side)
+            if timed:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(cur)
+                self.exposed_events.append((e0, e1))
+
+    def exposed_ms(self):
+        """mean GPU time per step the step stream spent waiting for the collective stream (call after a
+        synchronize); clears the record"""
+        ev, self.exposed_events = self.exposed_events or [], []
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, allow_single=False):
     """torch.distributed init from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).
-    -> (process_group | None, rank, world, local_rank)"""
+    -> (process_group | None, rank, world, local_rank).  A single process gets no group unless `allow_single`
+    (a world-size-1 group exercises the collective path -- RCCL on a GPU box -- with one device)."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not (allow_single and "MASTER_PORT" in os.environ):
         return None, 0, 1, 0
-    rank = int(os.environ["RANK"])
+    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

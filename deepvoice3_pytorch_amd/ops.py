@@ -75,6 +75,42 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ----------------------------------------------------------------------------------------------
+# range guard of the f16x3 mode (include/dv3hip.h, dv3_f16_range_events): the forward operands are
+# v * 2^4 (activations) / v * 2^8 (weights) in fp16, so |x| > 4094 or |w| > 255.9 leaves the range.
+# The kernels never saturate silently (values stay fp16-accurate to twice the range, then turn
+# Inf / NaN like a diverged fp32 run) and count every 16-byte operand unit that left the range.
+# ----------------------------------------------------------------------------------------------
+def f16_range_events_tensor(device, reset=False):
+    """-> int32 device tensor [1]: the sticky counter as of this point of the current stream (no host sync)"""
+    out = torch.empty(1, dtype=torch.int32, device=device)
+    _lib.call("dv3_f16_range_events", out.data_ptr(), int(bool(reset)), _stream())
+    return out
+
+
+def f16_range_events(reset=False, device=None):
+    """-> int: operand units that left the fp16 range since the last reset (synchronises with the device)"""
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return int(f16_range_events_tensor(device, reset).item())
+
+
+def with_f16_range_fallback(fn, *args, **kwargs):
+    """Run fn(*args, **kwargs); when the f16x3 kernels report operands outside the fp16 range, run it again in
+    the bf16x3 mode (bf16 pairs have fp32's exponent range: ~5e-6 per GEMM instead of ~1e-6, never out of
+    range) and return that result.  -> (result, fell_back).  Synchronises once."""
+    if _gemm_mode != "f16x3":
+        return fn(*args, **kwargs), False
+    f16_range_events(reset=True)
+    out = fn(*args, **kwargs)
+    if f16_range_events(reset=True) == 0:
+        return out, False
+    prev = set_gemm_precision("bf16x3")
+    try:
+        return fn(*args, **kwargs), True
+    finally:
+        set_gemm_precision(prev)
+
+
 def _ptr(t):
     return t.data_ptr() if t is not None else None
 

@@ -29,7 +29,8 @@ class TrainConfig(object):
                  use_guided_attention=True,
                  guided_attention_sigma=0.2, clip_thresh=0.1, adam_beta1=0.5, adam_beta2=0.9,
                  adam_eps=1e-6, weight_decay=0.0, initial_learning_rate=5e-4,
-                 lr_schedule="noam_learning_rate_decay", lr_schedule_kwargs=None, max_positions=512):
+                 lr_schedule="noam_learning_rate_decay", lr_schedule_kwargs=None, max_positions=512,
+                 range_check_every=0):
         self.outputs_per_step = outputs_per_step
         self.downsample_step = downsample_step
         self.masked_loss_weight = masked_loss_weight
@@ -45,6 +46,10 @@ class TrainConfig(object):
         self.lr_schedule = lr_schedule
         self.lr_schedule_kwargs = lr_schedule_kwargs or {}
         self.max_positions = max_positions
+        # f16x3 range guard: every N steps read the device counter (one host sync) and move the run to the
+        # bf16x3 mode when operands left the fp16 range; 0 = never read it on the host (the counter is still in
+        # every step's scalars as a device tensor, "f16_range_events")
+        self.range_check_every = range_check_every
 
 
 def noam_learning_rate_decay(init_lr, global_step, warmup_steps=4000):
@@ -154,8 +159,10 @@ class Trainer(object):
         # freeze_embedding; reference __init__.py:48-63) take no gradient at all: a .grad outside the arena
         # would never be zeroed and only cost backward work
         owned = set(id(p) for p in params)
+        self._frozen = []                 # (parameter, its requires_grad before): restored by close()
         for p in model.parameters():
             if id(p) not in owned:
+                self._frozen.append((p, p.requires_grad))
                 p.requires_grad_(False)
         dev = self.arena.flat.device
         self.device = dev
@@ -184,6 +191,9 @@ class Trainer(object):
         if self.comm is not None:
             self.comm.close()
             self.comm = None
+        for p, flag in getattr(self, "_frozen", []):      # hand the un-owned parameters back as they were
+            p.requires_grad_(flag)
+        self._frozen = []
 
     # ------------------------------------------------------------------------------------
     def current_lr(self):
@@ -301,14 +311,40 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         self.optimizer_step()
         scal["grad_norm"] = self.norm_out[0] * (1.0 / self.world)
         scal["learning_rate"] = self.hyper[0].clone()
+        if ops.gemm_precision() == "f16x3" and self.device.type == "cuda":
+            scal["f16_range_events"] = ops.f16_range_events_tensor(self.device)
         self.global_step += 1
+        n = self.cfg.range_check_every
+        if n and self.global_step % n == 0:
+            self.check_range(scal)
         return scal
+
+    def check_range(self, scal=None):
+        """f16x3 range guard (ops.f16_range_events): when forward operands left the fp16 range since the last
+        check, warn and continue in the bf16x3 mode (full exponent range; the weight images are re-packed on the
+        next step).  One host synchronisation.  -> number of events"""
+        if ops.gemm_precision() != "f16x3" or self.device.type != "cuda":
+            return 0
+        n = ops.f16_range_events(reset=True, device=self.device)
+        if n:
+            import warnings
+            warnings.warn("%d operand units left the fp16 range of the f16x3 GEMM mode (|activation| > 4094 or "
+                          "|weight| > 255.9): continuing in the bf16x3 mode" % n)
+            ops.set_gemm_precision("bf16x3")
+        return n
 
 
 class GraphedTrainer(object):
-    """Whole-step hipGraph: forward + losses + backward + (all-reduce) + clip/Adam captured once per
-    batch shape and replayed -- removes the per-kernel host launch cost (~300 launches/step).
-    Dropout masks still change every replay: the Philox seed offset lives on the device."""
+    """Whole-step hipGraph: forward + losses + backward + (bucketed all-reduce) + clip/Adam captured once per
+    batch shape and replayed -- removes the per-kernel host launch cost (~390 launches/step: 10-15 ms of host
+    time against a 17 ms step at the north-star batch).  Dropout masks still change every replay: the Philox
+    seed offset lives on the device.  `step(batch)` copies a fresh batch of the captured shape into the static
+    one first (device-to-device, on the step stream); batches of another shape raise -- bucket the input
+    pipeline by shape (data.LengthBucketedSampler pads to the batch maximum) or run those eagerly.
+
+    Data parallel: the RCCL all-reduces issued on the collective stream are captured with the step (the side
+    stream forks from and joins the capturing stream through the events BucketedAllReduce records), so a replay
+    re-issues them in the same order on every rank."""
 
     def __init__(self, trainer, static_batch, warmup=3):
         self.t = trainer
@@ -328,7 +364,9 @@ class GraphedTrainer(object):
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
         site0 = ops.dropout_state.site
-        with torch.cuda.graph(self.graph):
+        # a process group brings its watchdog thread: its event queries must not invalidate this thread's capture
+        mode = dict(capture_error_mode="thread_local") if trainer.comm is not None else {}
+        with torch.cuda.graph(self.graph, **mode):
             self.scal = self._body()
         ops.dropout_state.site = site0
 
@@ -338,10 +376,35 @@ class GraphedTrainer(object):
         scal = t.forward_backward(self.batch)
         t.optimizer_step()
         scal["grad_norm"] = t.norm_out[0] * (1.0 / t.world)
+        if ops.gemm_precision() == "f16x3":
+            scal["f16_range_events"] = ops.f16_range_events_tensor(t.device)
         self.seed_offset.add_(1)
         return scal
 
-    def step(self):
+    _TENSORS = ("text", "text_positions", "frame_positions", "mel", "y", "done", "speaker_ids", "input_lengths",
+                "target_lengths", "decoder_lengths")
+
+    def load(self, batch):
+        """copy `batch` (same shapes as the captured one) into the static batch the graph reads"""
+        st = self.batch
+        if batch is st:
+            return
+        for name in self._TENSORS:
+            a, b = getattr(st, name), getattr(batch, name)
+            if (a is None) != (b is None) or (a is not None and (a.shape != b.shape or a.dtype != b.dtype)):
+                raise RuntimeError("GraphedTrainer: batch field %s %s does not fit the captured %s" % (
+                    name, None if b is None else tuple(b.shape), None if a is None else tuple(a.shape)))
+        self.t.check_lengths(batch)
+        for name in self._TENSORS:
+            a = getattr(st, name)
+            if a is not None:
+                a.copy_(getattr(batch, name), non_blocking=True)
+        st.input_lengths_host, st.target_lengths_host = batch.input_lengths_host, batch.target_lengths_host
+        st.decoder_lengths_host, st.n_frames = batch.decoder_lengths_host, batch.n_frames
+
+    def step(self, batch=None):
+        if batch is not None:
+            self.load(batch)
         self.t._set_hyper()
         self.graph.replay()
         ops.bump_param_epoch()           # the replayed clip/Adam wrote the parameters
@@ -388,11 +451,32 @@ def save_checkpoint(trainer, checkpoint_dir, global_epoch=0, save_optimizer_stat
     return path
 
 
-def load_checkpoint(path_or_dict, trainer, reset_optimizer=False):
+def _load_file(path, unsafe=False):
+    """torch.load restricted to tensors / containers / numbers (what train.save_checkpoint writes); the general
+    unpickler (arbitrary code execution from an untrusted file) only behind `unsafe=True`."""
+    # a reference run stores numpy scalars (global_step is incremented from numpy values): allow exactly those
+    safe = [np.core.multiarray.scalar if hasattr(np, "core") and hasattr(np.core, "multiarray") else None, np.dtype]
+    try:
+        import numpy._core.multiarray as _ncm
+        safe.append(_ncm.scalar)
+    except ImportError:
+        pass
+    safe += [type(np.dtype(t)) for t in (np.int64, np.int32, np.float64, np.float32, np.bool_)]
+    safe = [g for g in safe if g is not None]
+    try:
+        with torch.serialization.safe_globals(safe):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        if not unsafe:
+            raise
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
+def load_checkpoint(path_or_dict, trainer, reset_optimizer=False, unsafe=False):
     """train.load_checkpoint (train.py:852-867): model weights, (unless reset_optimizer) the Adam
     moments, and the two counters.  Returns global_epoch.  Accepts files written by the reference:
     its optimizer enumerates get_trainable_parameters() in the same order the arena does."""
-    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu", weights_only=False)
+    ck = path_or_dict if isinstance(path_or_dict, dict) else _load_file(path_or_dict, unsafe)
     a = trainer.arena
     with torch.no_grad():     # copy INTO the arena views (load_state_dict would keep them too; be explicit)
         own = trainer.model.state_dict()
@@ -421,8 +505,8 @@ def load_checkpoint(path_or_dict, trainer, reset_optimizer=False):
     return int(ck.get("global_epoch", 0))
 
 
-def _state_dict_of(path_or_dict):
-    ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location="cpu", weights_only=False)
+def _state_dict_of(path_or_dict, unsafe=False):
+    ck = path_or_dict if isinstance(path_or_dict, dict) else _load_file(path_or_dict, unsafe)
     return ck["state_dict"] if "state_dict" in ck else ck
 
 

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 28
+#define DV3_ABI_VERSION 29
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -185,7 +185,7 @@ int dv3_mask_bits_to_c8(const uint32_t* bits, int32_t bits_rs, uint8_t* out, int
  * `out` holds 2*J*Kp*lda uint16 elements.
  *
  * Scaled split-fp16 ("f16x3", dtype = DV3_SPLIT_DTYPE_F16): the same images with
- *   a = clamp(v * 2^s, +-65504), hi = fp16_rn(a), lo = fp16_rn(a - hi)      (|a - hi - lo| <= 2^-23 |a|
+ *   a = v * 2^s, hi = fp16_rn(clamp(a, +-65504)), lo = fp16_rn(a - hi)      (|a - hi - lo| <= 2^-23 |a|
  *   while |a| >= 2^-3; below that the error is absolute, <= 2^-25 in a-units)
  * s = DV3_F16_WEIGHT_SHIFT (8) for weights, DV3_F16_ACT_SHIFT (4) for activations (fixed powers of two:
  * exact, no amax pass; weight-normed |w| <= |g| and O(1..100) activations sit far inside the range);
@@ -194,6 +194,17 @@ int dv3_mask_bits_to_c8(const uint32_t* bits, int32_t bits_rs, uint8_t* out, int
  * the depth of the network, exceed the 1e-4 parity bar (tests/test_gpu_preset_scale.py measures both);
  * the gradient GEMMs keep the bf16 split, whose exponent range covers gradients without a scale search.
  */
+/* Range guard of the f16x3 mode.  The scale shifts are fixed, so |x| > 65504 / 2^4 = 4094 (activations) or
+ * |w| > 65504 / 2^8 = 255.9 (weights) leaves the fp16 range.  Nothing is saturated silently: lo is the fp16 of the
+ * UNCLAMPED residual, so the pair stays fp16-accurate up to twice the range and turns Inf / NaN beyond it (a NaN or
+ * Inf input propagates as in the fp32 reference); and every kernel that builds such pairs counts the 16-byte units
+ * that left the range in a sticky device counter.  dv3_f16_range_events copies the counter into dst (device int32,
+ * may be NULL) and optionally clears it, both asynchronously on `stream`; the host side (ops.f16_range_events,
+ * Trainer.step's scalars) uses it to move a model to the bf16x3 mode, whose operands have fp32's exponent range.
+ * Replaces: nothing in the reference (its fp32 kernels have the range of fp32); deepvoice3_pytorch/modules.py:145-164
+ * is the computation guarded. */
+int dv3_f16_range_events(int32_t* dst, int32_t reset, void* stream);
+
 #define DV3_SPLIT_DTYPE_BF16 0
 #define DV3_SPLIT_DTYPE_F16 1
 #define DV3_SPLIT_F16X3 19

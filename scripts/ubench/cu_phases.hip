@@ -28,7 +28,7 @@ struct Args {
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int RE, int RL, int SYNC>
+template <int RE, int RL, int SYNC, int PE = 0, int PL = 0>
 __global__ __launch_bounds__(512) void k(const Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // explicit LDS address space: a volatile generic pointer would compile to flat_load / flat_store
@@ -172,6 +172,8 @@ __global__ __launch_bounds__(512) void k(const Args a) {
   };
 
   __syncthreads();
+  // static wave priorities (round 3): PE for waves 0-3, PL for their SIMD partners
+  if (late) { if constexpr (PL) __builtin_amdgcn_s_setprio(PL); } else { if constexpr (PE) __builtin_amdgcn_s_setprio(PE); }
   t0 = __builtin_readcyclecounter();
   if (late) {
     for (int it = 0; it < ITER; ++it) body(std::integral_constant<int, RL>{}, it);
@@ -187,15 +189,15 @@ __global__ __launch_bounds__(512) void k(const Args a) {
 
 static const char* kName[] = {"idle", "mfma24", "ldsr16", "gld2", "dsw2", "valu96", "barrier", "stamp", "phaseL", "phaseC", "pipeR", "pipeAll", "asmM(v)", "asmM(a)", "pipeR(a)", "schedR"};
 
-template <int RE, int RL, int SYNC>
+template <int RE, int RL, int SYNC, int PE = 0, int PL = 0>
 static void run(const Args& a, std::vector<unsigned long long>& h, int blocks) {
-  (void)hipFuncSetAttribute((const void*)k<RE, RL, SYNC>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<RE, RL, SYNC>), dim3(blocks), dim3(512), 96 * 1024, 0, a);
+  (void)hipFuncSetAttribute((const void*)k<RE, RL, SYNC, PE, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k<RE, RL, SYNC, PE, PL>), dim3(blocks), dim3(512), 96 * 1024, 0, a);
   if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); exit(2); }
   (void)hipMemcpy(h.data(), a.cyc, h.size() * 8, hipMemcpyDeviceToHost);
   unsigned long long me = 0, ml = 0;
   for (int b = 0; b < blocks; ++b) { if (h[b * 8] > me) me = h[b * 8]; if (h[b * 8 + 4] > ml) ml = h[b * 8 + 4]; }
-  printf("%-8s %-8s %d    | %9.1f %9.1f | %9.1f %9.1f\n", kName[RE], kName[RL], SYNC, h[0] / (double)ITER,
+  printf("%-8s %-8s %d p%d%d | %9.1f %9.1f | %9.1f %9.1f\n", kName[RE], kName[RL], SYNC, PE, PL, h[0] / (double)ITER,
          h[4] / (double)ITER, me / (double)ITER, ml / (double)ITER);
 }
 
@@ -231,6 +233,15 @@ int main() {
   run<PHASE_L, IDLE, 0>(a, h, blocks);
   run<PHASE_L, PHASE_C, 0>(a, h, blocks);
   run<PHASE_L, PHASE_C, 1>(a, h, blocks);         // ping-pong: LOAD beside COMPUTE, one barrier per phase
+  // round 3: the same pairs with a static wave priority for the memory-issuing (early) or the computing (late) waves
+  run<GLD2, MFMA24, 0, 3, 0>(a, h, blocks);
+  run<GLD2, MFMA24, 0, 0, 3>(a, h, blocks);
+  run<VALU96, MFMA24, 0, 3, 0>(a, h, blocks);
+  run<LDSR16, MFMA24, 0, 3, 0>(a, h, blocks);
+  run<PHASE_L, PHASE_C, 0, 3, 0>(a, h, blocks);
+  run<PHASE_L, PHASE_C, 1, 3, 0>(a, h, blocks);
+  run<PHASE_L, PHASE_C, 1, 1, 0>(a, h, blocks);
+  run<PHASE_L, PHASE_C, 1, 0, 3>(a, h, blocks);
   // intra-wave pipelines: one wave per SIMD, two waves per SIMD, with a barrier per phase
   run<SCHED_R, IDLE, 0>(a, h, blocks);            // 48 MFMAs + 16 ds_read_b128 per iteration, compiler-scheduled
   run<SCHED_R, SCHED_R, 0>(a, h, blocks);

@@ -385,11 +385,18 @@ def test_length_bucketed_sampler_shards_are_disjoint_and_cover():
         assert len({len(b) for b in per_rank}) == 1
         flat = [i for b in per_rank for x in b for i in x]
         assert len(flat) == len(set(flat))
-        full = data.LengthBucketedSampler(lengths, 16, seed=7).epoch_batches()
+        full = data.LengthBucketedSampler(lengths, 16, seed=7, drop_last=world > 1).epoch_batches()
+        assert world == 1 or all(len(b) == 16 for b in full)      # no short tail batch in a 1/world average
         usable = len(full) - len(full) % world
         assert sorted(flat) == sorted(int(i) for b in full[:usable] for i in b)
         for r in range(world):      # rank r holds batches r, r+world, ...
             assert per_rank[r] == [[int(i) for i in b] for b in full[r:usable:world]]
+    # the batches cut off to equalise the step count rotate with the epoch
+    s8 = data.LengthBucketedSampler(lengths, 16, rank=0, world=8, seed=7)
+    nb = len(s8.epoch_batches())
+    assert nb % 8 and len(list(s8)) == nb // 8
+    s8.set_epoch(1)
+    assert len(list(s8)) == nb // 8
     s = data.LengthBucketedSampler(lengths, 16, seed=7)
     e0 = list(s)
     assert e0 == list(data.LengthBucketedSampler(lengths, 16, seed=7))
@@ -588,3 +595,23 @@ def test_archived_bench_line_meets_the_contract():
         assert k in cb, k
     assert cb["kind"] in ("reference", "port")
     assert abs(d["value"] - d["config"]["global_batch"] * 800 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+
+
+def test_bench_self_launches_its_ranks_dry():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (the driver's command
+    line); --dry-launch keeps it to the rendezvous + bucketed all-reduce so it runs on a CPU-only box (gloo)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, universal_newlines=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 alone prints, one line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["dry_launch"] is True and out["buckets"] >= 2
+    if not torch.cuda.is_available():
+        assert out["backend"] == "gloo"

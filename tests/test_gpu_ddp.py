@@ -64,7 +64,19 @@ def _spawn(world):
     procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = []
+    for _ in range(240):
+        try:
+            res.append(q.get(timeout=1.0))
+        except Exception:
+            if not all(p.is_alive() or p.exitcode == 0 for p in procs):
+                break
+        if len(res) == world:
+            break
+    if len(res) != world:
+        for p in procs:
+            p.kill()
+        raise RuntimeError("a rank ended without a result: exit codes %r" % ([p.exitcode for p in procs],))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -87,3 +99,94 @@ def test_two_rank_step_equals_single_process_step():
     assert rep <= 1e-6 * moved, msg                       # replicas stay identical (gloo may round per rank)
     assert diff < 2e-5 * moved, msg                       # == the single-process step on the whole batch
     assert abs(two[0][2] - one[0][2]) < 1e-4 * abs(one[0][2]), msg
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The RCCL path itself on the one GPU a test box has: a world-size-1 "nccl" group.  Proves that librccl loads next
+# to libdv3hip.so, that the side-stream hand-off in dist.BucketedAllReduce (event -> collective stream ->
+# wait_stream in finish()) and the bucket notification order are right under the real backend, and that the
+# collectives can be captured into the whole-step hipGraph.
+# ----------------------------------------------------------------------------------------------------------------
+def _run_nccl(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from deepvoice3_pytorch_amd import builder, train_step
+    from deepvoice3_pytorch_amd import dist as dv3dist
+    dev = torch.device("cuda:0")
+    bt = _make_batch(0, 4)
+
+    def batch():
+        return train_step.Batch.from_collate(bt["text"], bt["input_lengths"], bt["mel"], bt["y"], bt["text_positions"],
+                                             bt["frame_positions"], bt["done"], bt["target_lengths"], None,
+                                             downsample_step=4, device=dev)
+
+    def weights(pg, graphed, steps=3):
+        torch.manual_seed(0)
+        model = builder.deepvoice3(**HP).to(dev)
+        tr = train_step.Trainer(model, train_step.TrainConfig(max_positions=128), process_group=pg, bucket_mb=0.05)
+        info = {}
+        if graphed:
+            g = train_step.GraphedTrainer(tr, batch(), warmup=1)
+            for _ in range(steps - 1):
+                scal = g.step()
+            g.close()
+        else:
+            if tr.comm is not None:
+                tr.comm.exposed_events = []
+            b = batch()
+            for _ in range(steps):
+                scal = tr.step(b)
+        torch.cuda.synchronize()
+        if tr.comm is not None:
+            info["buckets"] = len(tr.comm.buckets)
+            if not graphed:
+                info["exposed_ms"] = tr.comm.exposed_ms()
+        w = tr.arena.flat.cpu().numpy().copy()
+        gn = float(scal["grad_norm"])
+        tr.close()
+        return w, gn, info
+
+    plain = weights(None, False)
+    pg, rank, world, local_rank = dv3dist.init_from_env(allow_single=True)   # backend "nccl" (= RCCL) on a GPU box
+    assert world == 1 and dist.get_backend(pg) == "nccl"
+    eager = weights(pg, False)
+    graphed = weights(pg, True)
+    graphed_plain = weights(None, True)
+    maps = open("/proc/self/maps").read()
+    q.put(dict(plain=plain, eager=eager, graphed=graphed, graphed_plain=graphed_plain,
+               rccl_loaded="librccl" in maps, dv3_loaded="libdv3hip.so" in maps, ranks=dist.get_world_size(pg)))
+    dist.destroy_process_group()
+
+
+def test_world1_nccl_group_step_is_the_plain_step_eager_and_captured():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_run_nccl, args=(29900 + os.getpid() % 500, q))
+    p.start()
+    res = None
+    for _ in range(180):           # poll: a crashed child must fail the test at once, not after a long queue timeout
+        try:
+            res = q.get(timeout=1.0)
+            break
+        except Exception:
+            if not p.is_alive():
+                break
+    if res is None:
+        p.kill()
+        pytest.fail("the RCCL child process ended without a result (exit code %r)" % (p.exitcode,))
+    p.join(60)
+    assert p.exitcode == 0
+    assert res["rccl_loaded"] and res["dv3_loaded"] and res["ranks"] == 1
+    w0, g0, _ = res["plain"]
+    w1, g1, info1 = res["eager"]
+    w2, g2, info2 = res["graphed"]
+    w3, g3, _ = res["graphed_plain"]
+    assert info1["buckets"] >= 2 and info1["exposed_ms"] is not None and info1["exposed_ms"] >= 0.0
+    assert np.array_equal(w0, w1) and g0 == g1, "RCCL world-1 eager step differs from the no-group step"
+    assert np.array_equal(w0, w3) and g0 == g3, "whole-step hipGraph differs from the eager step"
+    assert np.array_equal(w0, w2) and g0 == g2, "hipGraph with captured RCCL all-reduces differs from the eager step"

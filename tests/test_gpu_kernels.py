@@ -583,51 +583,3 @@ def test_fused_attention_forward_equals_unfused(dev, gemm_mode, B, E, Tq, Tk, p)
         Pw = torch.softmax(S.masked_fill(m, -float("inf")), dim=-1)
         want = torch.bmm(Pw, v.transpose(1, 2)).transpose(1, 2) * (Tk * math.sqrt(1.0 / Tk))
         assert rel_err(res[True][1], Pw) < 1e-5 and rel_err(res[True][0], want) < 1e-5
-
-
-@pytest.mark.parametrize("B,C,T,d,causal,masked", [(3, 64, 75, 2, False, True), (2, 256, 150, 27, False, False),
-                                                   (2, 128, 100, 1, True, True), (5, 96, 61, 9, False, True)])
-def test_one_wave_per_simd_tap_gemm_is_bit_identical(dev, B, C, T, d, causal, masked):
-    """csrc/conv_gemm_w1.hip (experimental, tile_hint 30): the 128x128-per-wave kernel performs the same MFMAs per
-    accumulator in the same order as the shipped split kernels -- forward (Conv1dGLU, modules.py:145-164, with the
-    pre-gate save) and input-gradient form must agree bit for bit in both split modes"""
-    from deepvoice3_pytorch_amd import ops, _lib
-    prev = ops.gemm_precision()
-    try:
-        for mode in ("f16x3", "bf16x3"):
-            ops.set_gemm_precision(mode)
-            k = 3
-            torch.manual_seed(0)
-            x = torch.randn(B, C, T, device=dev)
-            v = torch.randn(2 * C, C, k, device=dev) * math.sqrt(4.0 * 0.95 / (k * C))
-            g = v.reshape(2 * C, -1).norm(dim=1).view(-1, 1, 1).clone()
-            bias = torch.randn(2 * C, device=dev) * 0.1
-            pk = ops.pack_weights(v, g, glu_cg=C, need_bwd=True)
-            bits = rs = None
-            if masked:
-                ops.dropout_state.manual_seed(3)
-                bits, rs = ops.dropout_bits(B * C, T, 0.05, dev)
-            padL = (k - 1) * d if causal else d
-            kw = dict(B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d, padL=padL, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x,
-                      residual=1, a_split=pk.fwd_s, xmask=bits, xmask_rs=rs or 0, drop_scale=1 / 0.95 if masked else 1.0)
-            ys, abs_ = [], []
-            for hint in (0, 30):
-                y = torch.empty(B, C, T, device=dev)
-                ab = torch.empty(B, 2 * C, T, device=dev)
-                ops.conv_gemm(x, None, pk.lda, pk.a_half, y=y, ab=ab, tile_hint=hint, **kw)
-                ys.append(y)
-                abs_.append(ab)
-            assert _lib.lib().dv3_debug_get(10) % 1000 == 300
-            assert torch.equal(ys[0], ys[1]) and torch.equal(abs_[0], abs_[1])
-            gm = torch.randn(B, 2 * C, T, device=dev)
-            dres = torch.randn(B, C, T, device=dev)
-            dkw = dict(B=B, Cin=2 * C, Tin=T, M=C, Tout=T, J=k, dil=d, padL=(k - 1) * d - padL, mode=ops.EPI_DGRAD,
-                       r=dres, ymask=bits, ymask_rs=rs or 0, drop_scale=1 / 0.95 if masked else 1.0, a_split=pk.bwd_s)
-            dxs = []
-            for hint in (0, 30):
-                dx = torch.empty(B, C, T, device=dev)
-                ops.conv_gemm(gm, None, pk.ldb, 0, y=dx, tile_hint=hint, **dkw)
-                dxs.append(dx)
-            assert torch.equal(dxs[0], dxs[1])
-    finally:
-        ops.set_gemm_precision(prev)
