@@ -351,8 +351,11 @@ extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
     DV3_REQUIRE(!d->ymask_c8, "conv_gemm: ymask_c8 belongs to a c8 DGRAD output");
   }
   DV3_REQUIRE(!d->ymask_c8 || d->mode == DV3_EPI_DGRAD, "conv_gemm: ymask_c8 is a DGRAD input");
-  DV3_REQUIRE(!d->xmask_c8 || (d->x_planes && d->split_terms == 1 && d->mode != DV3_EPI_DGRAD),
-              "conv_gemm: xmask_c8 masks a c8 input (x_planes, split_terms == 1) of a forward layer");
+  // keep-bytes mask a c8 input (x_planes, split_terms == 1), or accompany the keep-bits of an fp32 input (the
+  // 256 x 256 split kernel stages the byte form, the others the bit form: both must describe the same decisions)
+  DV3_REQUIRE(!d->xmask_c8 || d->mode != DV3_EPI_DGRAD, "conv_gemm: xmask_c8 masks the input of a forward layer");
+  DV3_REQUIRE(!d->xmask_c8 || (d->x_planes && d->split_terms == 1) || (!d->x_planes && d->xmask && d->a_split),
+              "conv_gemm: xmask_c8 needs a c8 input, or an fp32 input with its keep-bits and a split weight image");
   // both operands pre-split: the persistent planes kernel.  No silent fallback: the planes carry the dropout
   // mask of the consuming layer, which the other kernels would have to be handed separately.
   if (d->x_planes) {

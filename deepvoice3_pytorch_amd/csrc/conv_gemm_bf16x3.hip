@@ -689,6 +689,9 @@ const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
 
 }  // namespace
 
+int g_x3_pp2 = 0;  // dv3_debug_set(12, v): 1 = the 256 x 256 k16 ping-pong kernel (conv_gemm_pp2.hip) wherever it is eligible
+extern int g_pp2_abl;
+int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st);   // conv_gemm_pp2.hip
 int g_x3_prio = 0; // dv3_debug_set(14, v): wave priority scheme of the ping-pong main loop
 
 // called by dv3_conv_gemm_f32 (conv_gemm.hip) when d->a_split != NULL; returns 1 when the shape
@@ -701,6 +704,12 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   if ((int64_t)d->B * d->Tout >= (1ll << 30) || (int64_t)d->B * d->x_bs >= (1ll << 30)) return 1;
   if (d->xmask && (int64_t)d->B * d->Cin * d->xmask_rs >= (1ll << 30)) return 1;
   if ((int64_t)d->J * ((d->Cin + 31) / 32 * 4) * d->lda >= (1ll << 27)) return 1;
+  // 256 x 256 tile, k16 ping-pong (conv_gemm_pp2.hip): tile_hint 30 forces it, dv3_debug_set(12, 1) prefers it
+  if (d->tile_hint == 30 || (g_x3_pp2 && d->tile_hint == 0)) {
+    const int rc = dv3_conv_gemm_pp2_dispatch(d, st);
+    if (rc != 1) return rc;
+    if (d->tile_hint == 30) return 1;
+  }
   // the flat column axis needs batch-strided tensors only through (b, t) addressing: fine for all
   const TileCfg* best = pick_tile_x3(d, gated, d->tile_hint > 20 ? d->tile_hint - 20 : 0);
   if (!best) return 1;
@@ -740,6 +749,8 @@ int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 extern "C" int dv3_debug_set(int what, int value) {
   if (what >= 4 && what <= 8) return dv3_planes_debug_set(what, value);
   if (what == 9) g_x3_rel2 = value;
+  if (what == 12) g_x3_pp2 = value;
+  if (what == 13) g_pp2_abl = value;
   if (what == 14) g_x3_prio = value;
   if (what == 15) g_wgrad_prio = value;
   if (what == 1) g_x3_ablate = value;
@@ -748,7 +759,9 @@ extern "C" int dv3_debug_set(int what, int value) {
   return DV3_OK;
 }
 
+int dv3_pp2_read_stamps(void* dst, int64_t bytes);   // conv_gemm_pp2.hip
 extern "C" int dv3_debug_read(int what, void* dst, int64_t bytes) {
+  if (what == 2 && dst) return dv3_pp2_read_stamps(dst, bytes);
   DV3_REQUIRE(what == 1 && dst && bytes > 0 && bytes <= (int64_t)sizeof(unsigned long long) * 8 * STAMP_SLOTS * 2,
               "debug_read: bad arguments");
   hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_x3_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost);

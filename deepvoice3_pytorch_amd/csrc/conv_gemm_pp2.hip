@@ -1,0 +1,484 @@
+// Split-operand tap-GEMM, 256 x 256 workgroup tile, 8 waves of 128 x 64, ping-pong at k16 granularity.
+//
+// Same contract, operand images, accumulation order and fused tail as conv_gemm_bf16x3.hip (reference semantics:
+// deepvoice3_pytorch/modules.py:145-164, 205-226; the input gradient of the same layers), so its results are
+// bit-identical to that kernel's.  What changes is the work per wave and the phase structure:
+//
+//   * a wave owns 128 rows (two 32-row sub-tiles of the `a` half + the matching gate rows) x 64 columns: 8 accumulator
+//     blocks, 12 operand fragments per k16 block feed 24 MFMAs (the 64 x 64 wave tile of the 128 x 256 kernel reads 8
+//     fragments per 12 MFMAs): a third fewer LDS fragment reads, half the weight-panel bytes and half the
+//     activation-tile conversions per MFMA.
+//   * the two waves of a SIMD alternate LOAD / COMPUTE phases of ONE k16 block (24 MFMAs = ~800 cycles): a LOAD phase
+//     reads its 12 fragments and does a fixed share of the staging -- one of the thread's two weight-panel units of the
+//     NEXT step (store + refetch for the step after), and the activation-tile items assigned to that phase of the chunk
+//     (convert + store for the next chunk, refetch for the one after) -- so every LOAD phase carries the same ~800 cycles
+//     of work as the COMPUTE phase it runs beside (round-2 stamps of the 128 x 256 kernel: LOAD 820 / 1700 cycles
+//     against COMPUTE 800, profiles/r01e_pingpong_phase_stamps.md).
+//
+// LDS: [2 buffers] x {A hi, A lo}[4 k8][256 rows] = 64 KB, [2 buffers] x {X hi, X lo}[4 k8][256 + halo] <= 80 KB.
+// Dropout (MASK): keep-BYTES [B][C8][T] (bit e of byte (b, g, t) = channel 8g+e; dv3_conv_desc.xmask_c8): one byte
+// load per staged item instead of eight keep-bit words, which is what lets the staging registers fit beside the
+// 128 accumulator registers.
+#include "conv_common.h"
+#include <math.h>
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BKC = 32, KB = 4, HALO_MAX = 64;
+constexpr int BM = 256, BMH = 128, BN = 256, NT = 512, MI = 2, NI = 2, WN = 4;
+constexpr int JT = 3;                                       // taps (the models' kernel size); other sizes: conv_gemm_bf16x3.hip
+constexpr int AU = KB * BM / NT;                            // weight-panel units per plane per thread per step (2)
+constexpr int XI = (KB * (BN + HALO_MAX) + NT - 1) / NT;    // activation items per thread per chunk (3)
+static_assert(AU == 2, "one panel unit per k16 phase");
+
+__device__ __forceinline__ void pp2_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const f32x2 f = {v[i], v[i + 1]};
+    const bf16x2 h = __builtin_convertvector(f, bf16x2);
+    const f32x2 r = f - __builtin_convertvector(h, f32x2);
+    const bf16x2 l = __builtin_convertvector(r, bf16x2);
+    hi[i] = h[0]; hi[i + 1] = h[1];
+    lo[i] = l[0]; lo[i + 1] = l[1];
+  }
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 pp2_mma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ T pp2_ldg(const void* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// ABL 4 (dv3_debug_set(13, 4)): phase timestamps of ONE workgroup, [wave][slot][0 = s_memrealtime (100 MHz),
+// 1 = s_memtime (shader clock)]; read back with dv3_debug_read(2, ...)
+constexpr int PP2_STAMPS = 320;
+__device__ unsigned long long g_pp2_stamps[8 * PP2_STAMPS * 2];
+
+template <bool MASK, bool F16, int ABL = 0>
+__global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) {
+  const dv3_conv_desc& p = args.d;
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if constexpr (ABL == 4) {
+      if (blockIdx.x == gridDim.x / 2 + 3 && n_stamp < PP2_STAMPS) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), t1 = __builtin_readcyclecounter();
+        if ((threadIdx.x & 63) == 0) {
+          g_pp2_stamps[((threadIdx.x >> 6) * PP2_STAMPS + n_stamp) * 2] = t0;
+          g_pp2_stamps[((threadIdx.x >> 6) * PP2_STAMPS + n_stamp) * 2 + 1] = t1;
+        }
+      }
+      ++n_stamp;
+    }
+  };
+  stamp();                               // slot 0: kernel entry
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int J = JT;
+  const int dil = p.dil;
+  const int BNH = BN + (J - 1) * dil;
+  bf16x8* const As = reinterpret_cast<bf16x8*>(smem_raw);   // [2 buffers][hi | lo][KB][BM]
+  bf16x8* const Xs = As + 2 * 2 * KB * BM;                  // [2 buffers][hi | lo][KB][BNH]
+  const int xbuf = 2 * KB * BNH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int pid = dv3_xcd_remap(blockIdx.x, args.n_blocks);
+  const int mt = pid % args.m_tiles;
+  const int nt = pid / args.m_tiles;
+  const int n0 = nt * BN;
+
+  const bool gated = (p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY);
+  int h0b, h1b;
+  if (gated) {
+    h0b = mt * BMH; h1b = p.a_half + mt * BMH;
+  } else {
+    h0b = mt * BM; h1b = mt * BM + BMH;
+  }
+
+  const int Cin = p.Cin, T = p.Tout, lda = p.lda, B = p.B;
+  const int Ntot = B * T;
+  const int k8_total = args.kp >> 3;
+  const bf16x8* __restrict__ Wh = reinterpret_cast<const bf16x8*>(p.a_split);
+  const int64_t plane = (int64_t)J * k8_total * lda;   // 16-byte units per plane
+  const float xscale = F16 ? (float)(1 << DV3_F16_ACT_SHIFT) : 1.0f;
+  const float dscale = p.drop_scale * xscale;
+
+  // ---- this lane's output columns: per-tap validity of the shifted read (as conv_gemm_bf16x3.hip) ----
+  uint32_t vbits = 0;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+    const int bc = n / T, tc = n - bc * T;
+    for (int j = 0; j < J; ++j) {
+      const int ts = tc + j * dil - p.padL;
+      if (n < Ntot && ts >= 0 && ts < T) vbits |= 1u << (j * NI + ni);
+    }
+  }
+  uint32_t need = 0;
+  for (int j = 0; j < J; ++j) {
+    const uint32_t all = ((1u << NI) - 1u) << (j * NI);
+    if (!__all((vbits & all) == all)) need |= 1u << j;
+  }
+  need = __builtin_amdgcn_readfirstlane(need);
+
+  // ---- this thread's activation staging items: flat column -> (batch, time), fixed over chunks ----
+  uint32_t xoff[XI];                // byte offset of (b, k8*8, t) from p.x
+  uint32_t xmo[MASK ? XI : 1];      // byte offset of keep-byte (b, k8, t) from p.xmask_c8 (chunk 0)
+  const int n_items = KB * BNH;
+  const uint32_t x_rsb = (uint32_t)p.x_rs * 4u;
+  const uint32_t c8p = (uint32_t)((Cin + 31) / 32 * 4);
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int idx = tid + i * NT;
+    const int k8 = idx / BNH, q = idx - k8 * BNH;
+    const int f = n0 - p.padL + q;
+    int bf = 0, tf = 0;
+    if (idx < n_items && f >= 0 && f < Ntot) {
+      bf = f / T;
+      tf = f - bf * T;
+    }
+    const int xk8 = k8 < KB ? k8 * 8 : 0;
+    xoff[i] = ((uint32_t)bf * (uint32_t)p.x_bs + (uint32_t)tf) * 4u + (uint32_t)xk8 * x_rsb;
+    if (MASK) xmo[i] = ((uint32_t)bf * c8p + (uint32_t)(xk8 >> 3)) * (uint32_t)T + (uint32_t)tf;
+  }
+  // weight panel: per-unit column offset inside a (tap, k8) row of the split image
+  uint32_t aoff[AU];
+#pragma unroll
+  for (int u = 0; u < AU; ++u) {
+    const int idx = tid + u * NT;  // k8 * BM + col
+    const int col = idx % BM, k8 = idx / BM;
+    const bool hi_half = col >= BMH;
+    const int gcol = (hi_half ? h1b : h0b) + (col - (hi_half ? BMH : 0));
+    aoff[u] = (uint32_t)(k8 * lda + (gcol < lda ? gcol : 0)) * 16u;
+  }
+
+  // ---- register staging ----
+  bf16x8 ra[AU][2];
+  float rx[XI][8];
+  uint32_t rk[MASK ? XI : 1];
+
+  const int nchunks = Cin / BKC;       // whole chunks only (dispatcher)
+
+  // Every load below is UNCONDITIONAL and every k16 phase of a chunk issues the same loads in the same order (the
+  // tail re-fetches the last panel / chunk and stores into buffers nobody reads any more): the compiler then counts
+  // its s_waitcnt vmcnt(N) exactly and a LOAD phase only ever waits for loads issued at least two LOAD phases (four
+  // barrier intervals) earlier.  With loads under `if`s it falls back to the smallest N over all paths, which made
+  // every phase wait for the activation fetches issued just before it (round-3 stamps: 1200 cycles of a 1500-cycle
+  // LOAD phase; profiles/r03_pp2_phase_stamps.md).
+  auto load_A_unit = [&](int chunk, int j, auto uc) {
+    constexpr int u = decltype(uc)::value;
+    const bf16x8* srch = Wh + (int64_t)(j * k8_total + chunk * KB) * lda;  // uniform
+    ra[u][0] = pp2_ldg<bf16x8>(srch, aoff[u]);
+    ra[u][1] = pp2_ldg<bf16x8>(srch + plane, aoff[u]);
+  };
+  auto write_A_unit = [&](int buf, auto uc) {
+    constexpr int u = decltype(uc)::value;
+    bf16x8* dst = As + buf * (2 * KB * BM);
+    dst[tid + u * NT] = ra[u][0];
+    dst[KB * BM + tid + u * NT] = ra[u][1];
+  };
+  // half an item (four of its eight channel rows): one uniform base per chunk + a 32-bit per-thread offset
+  auto load_X_half = [&](int chunk, auto ic, auto hc) {
+    constexpr int i = decltype(ic)::value, h = decltype(hc)::value;
+    const char* xb = reinterpret_cast<const char*>(p.x) + (int64_t)(chunk * BKC) * x_rsb;
+    uint32_t rs = x_rsb;
+    asm volatile("" : "+s"(rs));      // opaque per call site: the 24 row offsets are recomputed (one SALU + one VALU per
+                                      // load), not hoisted out of the loop into 24 live registers
+#pragma unroll
+    for (int e = 4 * h; e < 4 * h + 4; ++e) rx[i][e] = pp2_ldg<float>(xb, xoff[i] + (uint32_t)e * rs);
+    if constexpr (MASK && h == 1)
+      rk[i] = (uint32_t)pp2_ldg<uint8_t>(p.xmask_c8 + (int64_t)chunk * 4 * T, xmo[i]);
+  };
+  auto write_X_item = [&](int buf, auto ic) {
+    constexpr int i = decltype(ic)::value;
+    bf16x8* dst = Xs + buf * xbuf;
+    const int idx = tid + i * NT;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = rx[i][e];
+      if constexpr (MASK) v[e] *= ((rk[i] >> e) & 1u) ? dscale : 0.f;
+      else if (F16) v[e] *= xscale;
+    }
+    bf16x8 hi, lo;
+    if constexpr (F16) dv3_note_range(args.range_ctr, dv3_split8_f16(v, hi, lo)); else pp2_split8(v, hi, lo);
+    if (idx < n_items) {
+      dst[idx] = hi;
+      dst[KB * BNH + idx] = lo;
+    }
+  };
+  using U0 = std::integral_constant<int, 0>;
+  using U1 = std::integral_constant<int, 1>;
+  using U2 = std::integral_constant<int, 2>;
+  static_assert(XI == 3 && JT == 3, "three activation items per thread, one per tap's pair of k16 phases");
+
+  f32x16 acc[MI][2][NI];   // [row sub-tile][a rows | gate rows][column sub-tile]
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] = 0.f;
+
+  const int a_off = wm * (MI * 32) + l31;
+  const int x_off = wn * (NI * 32) + l31;
+
+  // ---- prologue: step 0's panel and chunk 0's tile into buffer 0; then the fetches that run a step / a chunk ahead,
+  //      issued in the order the loop issues them ----
+  load_A_unit(0, 0, U0{});
+  load_A_unit(0, 0, U1{});
+  load_X_half(0, U0{}, U0{}); load_X_half(0, U0{}, U1{});
+  load_X_half(0, U1{}, U0{}); load_X_half(0, U1{}, U1{});
+  load_X_half(0, U2{}, U0{}); load_X_half(0, U2{}, U1{});
+  write_A_unit(0, U0{});
+  write_A_unit(0, U1{});
+  write_X_item(0, U0{});
+  write_X_item(0, U1{});
+  write_X_item(0, U2{});
+  __syncthreads();
+  {
+    const int c1 = min(1, nchunks - 1);
+    load_A_unit(0, 1, U0{});
+    load_X_half(c1, U0{}, U0{});
+    load_A_unit(0, 1, U1{});
+    load_X_half(c1, U0{}, U1{});
+    load_X_half(c1, U1{}, U0{}); load_X_half(c1, U1{}, U1{});
+    load_X_half(c1, U2{}, U0{}); load_X_half(c1, U2{}, U1{});
+  }
+
+  // ---- ping-pong main loop: waves w and w+4 share a SIMD and run the same phase sequence one phase apart ----
+  //   interval:   I0        I1        I2        I3
+  //   waves 0-3:  L(0)      C(0)      L(1)      C(1) ...
+  //   waves 4-7:  -         L(0)      C(0)      L(1) ...
+  // Phase q = 2 * tap + s of a chunk (s = k16 block of the 32-channel chunk).  LDS hazards: the panel of step t+1 is
+  // stored during the four L phases of step t (two per half) into the buffer last read in the L phases of step t-1 and
+  // first read in L of step t+1; the tile of chunk c+1 during the L phases of chunk c into the buffer last read in
+  // chunk c-1.  Every interval ends with a workgroup barrier.
+  const int late = wave >> 2;
+  stamp();                               // slot 1: prologue done
+  if (late) __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const bf16x8* XsH = Xs + (c & 1) * xbuf;
+    const bf16x8* XsL = XsH + KB * BNH;
+    const int cx = min(c + 2, nchunks - 1);          // the chunk fetched during this one (the tail re-fetches the last)
+    const bool last_chunk = c + 1 == nchunks;
+#pragma unroll
+    for (int q = 0; q < 2 * JT; ++q) {
+      constexpr int dummy = 0; (void)dummy;
+      const int j = q >> 1, s = q & 1;
+      const int cur = (c * JT + j) & 1;
+      const bf16x8* AsH = As + cur * (2 * KB * BM);
+      const bf16x8* AsL = AsH + KB * BM;
+      const bool fix = (need >> j) & 1u;
+      stamp();                           // 2 + 5*phase: LOAD begins
+      // ---------------- LOAD ----------------
+      // Order inside the phase: staging first, fragment reads last (pinned with sched_barrier) -- the twelve fragments
+      // (48 registers) are dead until then, which keeps the conversion temporaries of the staging inside the
+      // 256-register budget next to the 128 accumulator registers.
+      if (ABL != 2) {
+        // panel unit s of the next step: store, then fetch the same unit of the step after (two steps ahead of its use)
+        int j2 = j + 2, c2 = c;
+        if (j2 >= JT) { j2 -= JT; c2 = c + 1; }
+        if (c2 >= nchunks) { c2 = c; j2 = j; }          // past the end: re-fetch the current panel
+        if (s == 0) {
+          if (ABL != 9) write_A_unit(cur ^ 1, U0{});
+          if (ABL != 7) load_A_unit(c2, j2, U0{});
+        } else {
+          if (ABL != 9) write_A_unit(cur ^ 1, U1{});
+          if (ABL != 7) load_A_unit(c2, j2, U1{});
+        }
+        // activation item j of the next chunk: convert + store in the tap's first phase, fetch its halves for the
+        // chunk after in the tap's two phases
+        constexpr bool WX = ABL != 8, LX = ABL != 6;      // timing-only ablations: no conversion + store / no fetch
+        if (q == 0) { if (WX) write_X_item((c + 1) & 1, U0{}); if (LX) load_X_half(cx, U0{}, U0{}); }
+        if (q == 1) { if (LX) load_X_half(cx, U0{}, U1{}); }
+        if (q == 2) { if (WX) write_X_item((c + 1) & 1, U1{}); if (LX) load_X_half(cx, U1{}, U0{}); }
+        if (q == 3) { if (LX) load_X_half(cx, U1{}, U1{}); }
+        if (q == 4) { if (WX) write_X_item((c + 1) & 1, U2{}); if (LX) load_X_half(cx, U2{}, U0{}); }
+        if (q == 5) { if (LX) load_X_half(cx, U2{}, U1{}); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      stamp();                           // +1: staging issued
+      bf16x8 ah[MI][2], al[MI][2], bh[NI], bl[NI];
+      {
+        const int k8 = 2 * s + lhi;
+        const int ai = k8 * BM + a_off;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          ah[mi][0] = AsH[ai + mi * 32];
+          ah[mi][1] = AsH[ai + mi * 32 + BMH];
+          al[mi][0] = AsL[ai + mi * 32];
+          al[mi][1] = AsL[ai + mi * 32 + BMH];
+        }
+        const int xi = k8 * BNH + x_off + j * dil;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          bh[ni] = XsH[xi + ni * 32];
+          bl[ni] = XsL[xi + ni * 32];
+        }
+        if (fix) {
+          const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const bool ok = (vbits >> (j * NI + ni)) & 1u;
+            bh[ni] = ok ? bh[ni] : zero8;
+            bl[ni] = ok ? bl[ni] : zero8;
+          }
+        }
+      }
+      if constexpr (ABL == 4) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp();                         // +2: fragments landed
+      }
+      __syncthreads();
+      // The MFMAs are register-only instructions: without the two scheduling fences the compiler sinks them below the
+      // second barrier into the next LOAD phase -- legal, but then both waves of a SIMD issue their MFMAs in the same
+      // barrier interval and stage in the same interval, i.e. the ping-pong degenerates into the in-phase loop.
+      if (ABL != 5) __builtin_amdgcn_sched_barrier(0);
+      stamp();                           // +3: COMPUTE begins
+      // ---------------- COMPUTE: 24 MFMAs of one k16 block ----------------
+      if (ABL != 1) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][0][ni] = pp2_mma<F16>(al[mi][0], bh[ni], acc[mi][0][ni]);
+            acc[mi][1][ni] = pp2_mma<F16>(al[mi][1], bh[ni], acc[mi][1][ni]);
+          }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][0][ni] = pp2_mma<F16>(ah[mi][0], bl[ni], acc[mi][0][ni]);
+            acc[mi][1][ni] = pp2_mma<F16>(ah[mi][1], bl[ni], acc[mi][1][ni]);
+          }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][0][ni] = pp2_mma<F16>(ah[mi][0], bh[ni], acc[mi][0][ni]);
+            acc[mi][1][ni] = pp2_mma<F16>(ah[mi][1], bh[ni], acc[mi][1][ni]);
+          }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(ah[mi][0]), "v"(ah[mi][1]), "v"(al[mi][0]), "v"(al[mi][1]));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(bh[ni]), "v"(bl[ni]));
+      }
+      stamp();                           // +4: MFMAs issued
+      if (ABL != 5) __builtin_amdgcn_sched_barrier(0);
+      if (!(last_chunk && q == 2 * JT - 1) || !late) __syncthreads();
+    }
+  }
+  stamp();                               // main loop left
+
+  // ---- fused tail (conv_common.h), one 32-row sub-tile at a time ----
+  if (ABL != 3 || acc[0][0][0][0] + acc[1][1][1][7] == 1.2345e30f) {
+    if constexpr (F16) {   // the accumulators carry 2^(weight shift + activation shift) x the result
+      constexpr float kInv = 1.0f / (float)(1 << (DV3_F16_WEIGHT_SHIFT + DV3_F16_ACT_SHIFT));
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] *= kInv;
+    }
+    int n0e = n0;
+    asm volatile("" : "+s"(n0e));
+    int bcol[NI], tcol[NI];
+    bool okc[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0e + wn * (NI * 32) + ni * 32 + l31;
+      okc[ni] = n < Ntot;
+      bcol[ni] = n / T;
+      tcol[ni] = n - bcol[ni] * T;
+    }
+    conv_epilogue<BM, BMH, NI, 0, false>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+    conv_epilogue<BM, BMH, NI, 0, false>(p, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+  }
+  stamp();                               // tail stores issued
+}
+
+template <bool MASK, bool F16, int ABL = 0>
+int launch_pp2(const ConvArgs& a, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_pp2_kernel<MASK, F16, ABL>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      dv3_set_error("conv_gemm_pp2: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DV3_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_pp2_kernel<MASK, F16, ABL>), dim3(a.n_blocks), dim3(NT), lds, st, a);
+  return dv3_check_launch("conv_gemm_pp2");
+}
+
+}  // namespace
+
+int dv3_pp2_read_stamps(void* dst, int64_t bytes) {
+  if (bytes <= 0 || bytes > (int64_t)sizeof(unsigned long long) * 8 * PP2_STAMPS * 2) return DV3_EINVAL;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pp2_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? DV3_OK : DV3_ELAUNCH;
+}
+int g_pp2_abl = 0;   // dv3_debug_set(13, v): timing-only ablations of the unmasked kernel (1 no MFMAs, 2 no staging, 3 no tail)
+
+// Shapes this kernel takes (called by dv3_conv_gemm_bf16x3_dispatch): three-term split operands, fp32 (B, C, T)
+// activations, dropout as keep-bytes.  Returns 1 when not eligible.
+int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
+  if (d->split_terms == 1 || !d->a_split) return 1;
+  if (d->xmask && !d->xmask_c8) return 1;            // keep-bits only: the 128 x 256 kernel stages those
+  if (d->J != JT || (d->J - 1) * d->dil > HALO_MAX || (d->Cin & 31)) return 1;
+  if (d->a_bs != 0 || (d->lda & 3) || d->Tin != d->Tout) return 1;
+  const bool gated = d->mode == DV3_EPI_GLU || d->mode == DV3_EPI_HIGHWAY;
+  const bool f16 = d->split_terms == DV3_SPLIT_F16X3;
+  const int BNH = BN + (d->J - 1) * d->dil;
+  const size_t lds = (size_t)(2 * 2 * KB * BM + 2 * 2 * KB * BNH) * 16;
+  if (lds > 160 * 1024) return 1;
+  ConvArgs a;
+  a.d = *d;
+  a.a_scalar = 0;
+  a.range_ctr = f16 ? dv3_range_ctr() : nullptr;
+  a.kp = (d->Cin + 31) / 32 * 32;
+  a.m_tiles = gated ? dv3_cdiv(d->Cg, BMH) : dv3_cdiv(d->M, BM);
+  a.n_tiles = (int)dv3_cdiv64((int64_t)d->B * d->Tout, BN);
+  const int64_t nb = (int64_t)a.m_tiles * a.n_tiles;
+  DV3_REQUIRE(nb < (1ll << 31), "conv_gemm: grid too large");
+  a.n_blocks = (int)nb;
+  g_dv3_last_conv = (f16 ? 5000 : 3000) + 100 + 1;     // tile id 10, ping-pong
+  const bool mask = d->xmask_c8 != nullptr;
+  if (g_pp2_abl && !mask && f16) {
+    switch (g_pp2_abl) {
+      case 1: return launch_pp2<false, true, 1>(a, lds, st);
+      case 2: return launch_pp2<false, true, 2>(a, lds, st);
+      case 3: return launch_pp2<false, true, 3>(a, lds, st);
+      case 4: return launch_pp2<false, true, 4>(a, lds, st);
+      case 5: return launch_pp2<false, true, 5>(a, lds, st);
+      case 6: return launch_pp2<false, true, 6>(a, lds, st);
+      case 7: return launch_pp2<false, true, 7>(a, lds, st);
+      case 8: return launch_pp2<false, true, 8>(a, lds, st);
+      case 9: return launch_pp2<false, true, 9>(a, lds, st);
+    }
+  }
+  if (f16) return mask ? launch_pp2<true, true>(a, lds, st) : launch_pp2<false, true>(a, lds, st);
+  return mask ? launch_pp2<true, false>(a, lds, st) : launch_pp2<false, false>(a, lds, st);
+}

@@ -537,6 +537,7 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
     d.y, d.y_bs, d.y_rs = y.data_ptr(), y_bs, y_rs_
     d.ab = _ptr(ab)
     d.xmask, d.xmask_rs = _ptr(xmask), xmask_rs
+    d.xmask_c8 = _ptr(xmask_c8)      # the same keep decisions as bytes [B][C8][T]: the 256 x 256 kernel stages those
     d.ymask, d.ymask_rs = _ptr(ymask), ymask_rs
     d.drop_scale = drop_scale
     d.r_scale = r_scale

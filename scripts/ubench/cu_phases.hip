@@ -17,7 +17,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ITER = 256;
-enum Role { IDLE = 0, MFMA24, LDSR16, GLD2, DSW2, VALU96, BARRIER, STAMP, PHASE_L, PHASE_C, PIPE_R, PIPE_ALL, PIPE_M, PIPE_MA, PIPE_RA, SCHED_R };
+enum Role { IDLE = 0, MFMA24, LDSR16, GLD2, DSW2, VALU96, BARRIER, STAMP, PHASE_L, PHASE_C, PIPE_R, PIPE_ALL, PIPE_M, PIPE_MA, PIPE_RA, SCHED_R,
+            GLD8S, GLDS2, LDSR16B, MFMA24G, GLD8NW };
 
 struct Args {
   const f32x4* gsrc;          // >= 256 * 16 KB, L2-resident after the first touch
@@ -75,6 +76,52 @@ __global__ __launch_bounds__(512) void k(const Args a) {
     const f32x4 x1 = g0[(tid + 512 + it * 64) & 1023];
     wait_vm0();
     gacc += x0 + x1;
+  };
+  // round 3: eight dword loads through ONE uniform base + 32-bit offsets (the tap-GEMM's activation fetch form)
+  float g8acc = 0.f;
+  auto gld8s = [&](int it, bool wait) {
+    const float* g0 = reinterpret_cast<const float*>(a.gsrc + (size_t)blockIdx.x * 1024);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = g0[((tid + it * 64) & 511) + e * 512];
+    if (wait) wait_vm0();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g8acc += v[e];
+  };
+  // two LDS-DMA pieces (global_load_lds_dwordx4: 1 KB per wave-instruction) + vmcnt(0)
+  auto glds2 = [&](int it) {
+    const f32x4* g0 = a.gsrc + (size_t)blockIdx.x * 1024;
+    __attribute__((address_space(3))) void* l0 = (__attribute__((address_space(3))) void*)(smem_raw + 65536 + wave * 2048);
+    __builtin_amdgcn_global_load_lds((const void*)(g0 + ((tid + it * 64) & 511)), l0, 16, 0, 0);
+    __attribute__((address_space(3))) void* l1 = (__attribute__((address_space(3))) void*)(smem_raw + 65536 + wave * 2048 + 1024);
+    __builtin_amdgcn_global_load_lds((const void*)(g0 + ((tid + 512 + it * 64) & 1023)), l1, 16, 0, 0);
+    wait_vm0();
+  };
+  // 16 fragment reads issued back to back (plain loads: one wait at the end), the kernel's real LOAD pattern
+  typedef __attribute__((address_space(3))) bf16x8 lds_plain0;
+  auto ldsr16b = [&](int it) {
+    lds_plain0* lp = (lds_plain0*)smem_raw;
+    const int base = ((it & 1) * 2048 + wave * 256 + (lane >> 5) * 128 + (lane & 31));
+    bf16x8 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = lp[base + (r * 64) % 1536 + (r >> 2) * 16];
+    wait_lgkm0();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(v[r]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fa[r] = v[4 * r];
+  };
+  // 24 MFMAs with one idle issue slot (s_nop 7 = 8 cycles) behind each
+  auto mfma24g = [&]() {
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[(i + q) & 3], fb[i], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7");
+        __builtin_amdgcn_sched_barrier(0);
+      }
   };
   auto dsw2 = [&](int it) {
     lds[4096 + (it & 1) * 1024 + tid] = fa[0];
@@ -154,6 +201,11 @@ __global__ __launch_bounds__(512) void k(const Args a) {
     if constexpr (ROLE == LDSR16) ldsr16(it);
     if constexpr (ROLE == GLD2) gld2(it);
     if constexpr (ROLE == DSW2) dsw2(it);
+    if constexpr (ROLE == GLD8S) gld8s(it, true);
+    if constexpr (ROLE == GLD8NW) gld8s(it, false);
+    if constexpr (ROLE == GLDS2) glds2(it);
+    if constexpr (ROLE == LDSR16B) ldsr16b(it);
+    if constexpr (ROLE == MFMA24G) mfma24g();
     if constexpr (ROLE == VALU96) valu96();
     if constexpr (ROLE == STAMP) st += __builtin_readcyclecounter() & 1;
     if constexpr (ROLE == PHASE_L) { ldsr16(it); dsw2(it); gld2(it); }   // a LOAD phase minus the activation tile
@@ -182,12 +234,13 @@ __global__ __launch_bounds__(512) void k(const Args a) {
   }
   t1 = __builtin_readcyclecounter();
   if (lane == 0) a.cyc[blockIdx.x * 8 + wave] = t1 - t0;
-  float s = vacc + gacc[0] + gacc[1] + gacc[2] + gacc[3] + (float)(st & 1);
+  float s = g8acc + vacc + gacc[0] + gacc[1] + gacc[2] + gacc[3] + (float)(st & 1);
   for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][7] + (float)fa[i][0] + (float)ga[i][1] + (float)gb[i][2];
   a.sink[blockIdx.x * 512 + tid] = s;
 }
 
-static const char* kName[] = {"idle", "mfma24", "ldsr16", "gld2", "dsw2", "valu96", "barrier", "stamp", "phaseL", "phaseC", "pipeR", "pipeAll", "asmM(v)", "asmM(a)", "pipeR(a)", "schedR"};
+static const char* kName[] = {"idle", "mfma24", "ldsr16", "gld2", "dsw2", "valu96", "barrier", "stamp", "phaseL", "phaseC", "pipeR", "pipeAll", "asmM(v)", "asmM(a)", "pipeR(a)", "schedR",
+                              "gld8s", "glds2", "ldsr16b", "mfma24g", "gld8nw"};
 
 template <int RE, int RL, int SYNC, int PE = 0, int PL = 0>
 static void run(const Args& a, std::vector<unsigned long long>& h, int blocks) {
@@ -242,6 +295,19 @@ int main() {
   run<PHASE_L, PHASE_C, 1, 3, 0>(a, h, blocks);
   run<PHASE_L, PHASE_C, 1, 1, 0>(a, h, blocks);
   run<PHASE_L, PHASE_C, 1, 0, 3>(a, h, blocks);
+  // round 3: what a memory-issuing wave pays beside a computing SIMD partner, by instruction kind
+  run<LDSR16B, IDLE, 0>(a, h, blocks);            // 16 ds_read_b128 back to back, ONE wait (the kernels' real pattern)
+  run<LDSR16B, LDSR16B, 0>(a, h, blocks);
+  run<LDSR16B, MFMA24, 0>(a, h, blocks);
+  run<GLD8S, IDLE, 0>(a, h, blocks);
+  run<GLD8S, MFMA24, 0>(a, h, blocks);
+  run<GLD8NW, IDLE, 0>(a, h, blocks);             // the same loads consumed late (the wait sits behind the adds' use)
+  run<GLD8NW, MFMA24, 0>(a, h, blocks);
+  run<GLDS2, IDLE, 0>(a, h, blocks);
+  run<GLDS2, MFMA24, 0>(a, h, blocks);
+  run<GLD2, MFMA24G, 0>(a, h, blocks);            // the MFMA partner leaves an idle slot behind each MFMA
+  run<GLD8S, MFMA24G, 0>(a, h, blocks);
+  run<MFMA24G, IDLE, 0>(a, h, blocks);
   // intra-wave pipelines: one wave per SIMD, two waves per SIMD, with a barrier per phase
   run<SCHED_R, IDLE, 0>(a, h, blocks);            // 48 MFMAs + 16 ds_read_b128 per iteration, compiler-scheduled
   run<SCHED_R, SCHED_R, 0>(a, h, blocks);
