@@ -689,7 +689,10 @@ const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
 
 }  // namespace
 
-int g_x3_pp2 = 0;  // dv3_debug_set(12, v): 1 = the 256 x 256 k16 ping-pong kernel (conv_gemm_pp2.hip) wherever it is eligible
+int g_x3_pp2 = 128;  // dv3_debug_set(12, v): the 256 x 256 k16 ping-pong kernel (conv_gemm_pp2.hip) serves eligible shapes
+                     // whose grid has at least v tiles (0 = never).  Measured at B=64 over the presets' conv shapes
+                     // (scripts/pp2_sweep.py, profiles/r03_pp2_sweep.txt): 0.73-0.88 of the 128 x 256 / 128 x 64 kernels'
+                     // time from 152 tiles up, 1.3-1.9 x at 50-100 tiles (half the chip idle).
 extern int g_pp2_abl;
 int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st);   // conv_gemm_pp2.hip
 int g_x3_prio = 0; // dv3_debug_set(14, v): wave priority scheme of the ping-pong main loop
@@ -705,7 +708,9 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   if (d->xmask && (int64_t)d->B * d->Cin * d->xmask_rs >= (1ll << 30)) return 1;
   if ((int64_t)d->J * ((d->Cin + 31) / 32 * 4) * d->lda >= (1ll << 27)) return 1;
   // 256 x 256 tile, k16 ping-pong (conv_gemm_pp2.hip): tile_hint 30 forces it, dv3_debug_set(12, 1) prefers it
-  if (d->tile_hint == 30 || (g_x3_pp2 && d->tile_hint == 0)) {
+  const bool gated0 = d->mode == DV3_EPI_GLU || d->mode == DV3_EPI_HIGHWAY;
+  const int64_t pp2_tiles = (int64_t)(gated0 ? dv3_cdiv(d->Cg, 128) : dv3_cdiv(d->M, 256)) * dv3_cdiv64((int64_t)d->B * d->Tout, 256);
+  if (d->tile_hint == 30 || (g_x3_pp2 > 0 && d->tile_hint == 0 && pp2_tiles >= g_x3_pp2)) {
     const int rc = dv3_conv_gemm_pp2_dispatch(d, st);
     if (rc != 1) return rc;
     if (d->tile_hint == 30) return 1;

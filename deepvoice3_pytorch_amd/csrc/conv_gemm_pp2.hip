@@ -137,7 +137,6 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
 
   // ---- this thread's activation staging items: flat column -> (batch, time), fixed over chunks ----
   uint32_t xoff[XI];                // byte offset of (b, k8*8, t) from p.x
-  uint32_t xmo[MASK ? XI : 1];      // byte offset of keep-byte (b, k8, t) from p.xmask_c8 (chunk 0)
   const int n_items = KB * BNH;
   const uint32_t x_rsb = (uint32_t)p.x_rs * 4u;
   const uint32_t c8p = (uint32_t)((Cin + 31) / 32 * 4);
@@ -153,21 +152,21 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
     }
     const int xk8 = k8 < KB ? k8 * 8 : 0;
     xoff[i] = ((uint32_t)bf * (uint32_t)p.x_bs + (uint32_t)tf) * 4u + (uint32_t)xk8 * x_rsb;
-    if (MASK) xmo[i] = ((uint32_t)bf * c8p + (uint32_t)(xk8 >> 3)) * (uint32_t)T + (uint32_t)tf;
   }
-  // weight panel: per-unit column offset inside a (tap, k8) row of the split image
-  uint32_t aoff[AU];
-#pragma unroll
-  for (int u = 0; u < AU; ++u) {
-    const int idx = tid + u * NT;  // k8 * BM + col
+  // weight panel: per-unit column offset inside a (tap, k8) row of the split image; recomputed at each use from an
+  // opaque copy of the thread index (a handful of VALU) instead of living in registers across the loop
+  auto aoff_of = [&](int u) -> uint32_t {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    const int idx = t_ + u * NT;  // k8 * BM + col
     const int col = idx % BM, k8 = idx / BM;
     const bool hi_half = col >= BMH;
     const int gcol = (hi_half ? h1b : h0b) + (col - (hi_half ? BMH : 0));
-    aoff[u] = (uint32_t)(k8 * lda + (gcol < lda ? gcol : 0)) * 16u;
-  }
+    return (uint32_t)(k8 * lda + (gcol < lda ? gcol : 0)) * 16u;
+  };
 
   // ---- register staging ----
-  bf16x8 ra[AU][2];
+  bf16x8 ra[2];            // ONE weight-panel unit (hi, lo) in flight: fetched in one LOAD phase, stored in the next
   float rx[XI][8];
   uint32_t rk[MASK ? XI : 1];
 
@@ -182,14 +181,15 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   auto load_A_unit = [&](int chunk, int j, auto uc) {
     constexpr int u = decltype(uc)::value;
     const bf16x8* srch = Wh + (int64_t)(j * k8_total + chunk * KB) * lda;  // uniform
-    ra[u][0] = pp2_ldg<bf16x8>(srch, aoff[u]);
-    ra[u][1] = pp2_ldg<bf16x8>(srch + plane, aoff[u]);
+    const uint32_t ao = aoff_of(u);
+    ra[0] = pp2_ldg<bf16x8>(srch, ao);
+    ra[1] = pp2_ldg<bf16x8>(srch + plane, ao);
   };
   auto write_A_unit = [&](int buf, auto uc) {
     constexpr int u = decltype(uc)::value;
     bf16x8* dst = As + buf * (2 * KB * BM);
-    dst[tid + u * NT] = ra[u][0];
-    dst[KB * BM + tid + u * NT] = ra[u][1];
+    dst[tid + u * NT] = ra[0];
+    dst[KB * BM + tid + u * NT] = ra[1];
   };
   // half an item (four of its eight channel rows): one uniform base per chunk + a 32-bit per-thread offset
   auto load_X_half = [&](int chunk, auto ic, auto hc) {
@@ -200,8 +200,22 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
                                       // load), not hoisted out of the loop into 24 live registers
 #pragma unroll
     for (int e = 4 * h; e < 4 * h + 4; ++e) rx[i][e] = pp2_ldg<float>(xb, xoff[i] + (uint32_t)e * rs);
-    if constexpr (MASK && h == 1)
-      rk[i] = (uint32_t)pp2_ldg<uint8_t>(p.xmask_c8 + (int64_t)chunk * 4 * T, xmo[i]);
+    if constexpr (MASK && h == 1) {
+      // keep-byte (b, chunk * 4 + k8, t) of this item: its offset is recomputed here (two integer divisions per item and
+      // chunk) rather than held in a register across the loop
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+      const int idx = t_ + i * NT;
+      const int k8 = idx / BNH, q = idx - k8 * BNH;
+      const int f = n0 - p.padL + q;
+      int bf = 0, tf = 0;
+      if (idx < n_items && f >= 0 && f < Ntot) {
+        bf = f / T;
+        tf = f - bf * T;
+      }
+      const uint32_t mo = ((uint32_t)bf * c8p + (uint32_t)(k8 < KB ? k8 : 0)) * (uint32_t)T + (uint32_t)tf;
+      rk[i] = (uint32_t)pp2_ldg<uint8_t>(p.xmask_c8 + (int64_t)chunk * 4 * T, mo);
+    }
   };
   auto write_X_item = [&](int buf, auto ic) {
     constexpr int i = decltype(ic)::value;
@@ -242,11 +256,11 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   // ---- prologue: step 0's panel and chunk 0's tile into buffer 0; then the fetches that run a step / a chunk ahead,
   //      issued in the order the loop issues them ----
   load_A_unit(0, 0, U0{});
+  write_A_unit(0, U0{});
   load_A_unit(0, 0, U1{});
   load_X_half(0, U0{}, U0{}); load_X_half(0, U0{}, U1{});
   load_X_half(0, U1{}, U0{}); load_X_half(0, U1{}, U1{});
   load_X_half(0, U2{}, U0{}); load_X_half(0, U2{}, U1{});
-  write_A_unit(0, U0{});
   write_A_unit(0, U1{});
   write_X_item(0, U0{});
   write_X_item(0, U1{});
@@ -254,9 +268,8 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   __syncthreads();
   {
     const int c1 = min(1, nchunks - 1);
-    load_A_unit(0, 1, U0{});
+    load_A_unit(0, 1, U0{});           // unit 0 of step 1's panel: stored by the first LOAD phase
     load_X_half(c1, U0{}, U0{});
-    load_A_unit(0, 1, U1{});
     load_X_half(c1, U0{}, U1{});
     load_X_half(c1, U1{}, U0{}); load_X_half(c1, U1{}, U1{});
     load_X_half(c1, U2{}, U0{}); load_X_half(c1, U2{}, U1{});
@@ -292,16 +305,20 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
       // (48 registers) are dead until then, which keeps the conversion temporaries of the staging inside the
       // 256-register budget next to the 128 accumulator registers.
       if (ABL != 2) {
-        // panel unit s of the next step: store, then fetch the same unit of the step after (two steps ahead of its use)
-        int j2 = j + 2, c2 = c;
-        if (j2 >= JT) { j2 -= JT; c2 = c + 1; }
-        if (c2 >= nchunks) { c2 = c; j2 = j; }          // past the end: re-fetch the current panel
+        // panel unit s of the next step: store (it was fetched in this wave's previous LOAD phase), then fetch the
+        // unit the NEXT LOAD phase stores: one unit (8 registers) in flight, two barrier intervals to land (an L2 hit)
+        int jn = j + 1, cn = c;
+        if (jn >= JT) { jn = 0; cn = c + 1; }
+        int j2 = jn + 1, c2 = cn;
+        if (j2 >= JT) { j2 = 0; c2 = cn + 1; }
+        if (cn >= nchunks) { cn = c; jn = j; }          // past the end: re-fetch the current panel
+        if (c2 >= nchunks) { c2 = c; j2 = j; }
         if (s == 0) {
           if (ABL != 9) write_A_unit(cur ^ 1, U0{});
-          if (ABL != 7) load_A_unit(c2, j2, U0{});
+          if (ABL != 7) load_A_unit(cn, jn, U1{});       // unit 1 of the next step's panel
         } else {
           if (ABL != 9) write_A_unit(cur ^ 1, U1{});
-          if (ABL != 7) load_A_unit(c2, j2, U1{});
+          if (ABL != 7) load_A_unit(c2, j2, U0{});       // unit 0 of the panel after
         }
         // activation item j of the next chunk: convert + store in the tap's first phase, fetch its halves for the
         // chunk after in the tap's two phases
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] *= kInv;
     }
-    int n0e = n0;
+    int n0e = __builtin_amdgcn_readfirstlane(n0);
     asm volatile("" : "+s"(n0e));
     int bcol[NI], tcol[NI];
     bool okc[NI];

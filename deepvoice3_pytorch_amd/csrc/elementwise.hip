@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict_
 // in one launch.  One thread per (b, group, 32-frame word): eight Philox words, an 8 x 32 bit transpose, 32 bytes.
 __global__ __launch_bounds__(256) void dropout_keep_c8_kernel(uint8_t* __restrict__ out, int B, int C, int T, int rs,
                                                               int c8p, uint32_t thr, uint64_t seed, uint64_t site,
-                                                              const uint64_t* __restrict__ dev_off) {
+                                                              const uint64_t* __restrict__ dev_off,
+                                                              uint32_t* __restrict__ bits_out) {
   // a workgroup = 32 entries (b, group, 32-frame word) x 8 channels: one Philox word per thread, the 8 x 32 bit
   // transpose through LDS, then thread (entry, q) writes bytes 4q .. 4q+3 of its entry (a wave covers 8 entries =
   // 256 contiguous bytes when T is a multiple of 32)
@@ -276,7 +277,10 @@ __global__ __launch_bounds__(256) void dropout_keep_c8_kernel(uint8_t* __restric
     bg = ent / (uint32_t)rs;
     const uint32_t g = bg % (uint32_t)c8p, b = bg / (uint32_t)c8p;
     const uint32_t ch = g * 8u + e;
-    words[threadIdx.x >> 3][e] = ch < (uint32_t)C ? philox_keep_word(((int64_t)b * C + ch) * rs + wi, thr, seed, site) : 0u;
+    const int64_t wrow = ((int64_t)b * C + ch) * rs + wi;
+    const uint32_t w = ch < (uint32_t)C ? philox_keep_word(wrow, thr, seed, site) : 0u;
+    words[threadIdx.x >> 3][e] = w;
+    if (bits_out && ch < (uint32_t)C) bits_out[wrow] = w;      // the same decisions in the keep-bit form [B*C][rs]
   }
   __syncthreads();
   if (ent >= n_ent) return;
@@ -664,8 +668,19 @@ extern "C" int dv3_dropout_bits(uint32_t* bits, int64_t n_words, float p, uint64
   return dv3_check_launch("dropout_bits");
 }
 
+static int dropout_keep_launch(uint8_t* out, uint32_t* bits, int32_t B, int32_t C, int32_t T, float p, uint64_t seed,
+                               uint64_t site, const uint64_t* dev_seed_offset, void* stream);
 extern "C" int dv3_dropout_keep_c8(uint8_t* out, int32_t B, int32_t C, int32_t T, float p, uint64_t seed, uint64_t site,
                                    const uint64_t* dev_seed_offset, void* stream) {
+  return dropout_keep_launch(out, nullptr, B, C, T, p, seed, site, dev_seed_offset, stream);
+}
+extern "C" int dv3_dropout_bits_keep(uint32_t* bits, uint8_t* keep, int32_t B, int32_t C, int32_t T, float p, uint64_t seed,
+                                     uint64_t site, const uint64_t* dev_seed_offset, void* stream) {
+  DV3_REQUIRE(bits, "dropout_bits_keep: null pointer");
+  return dropout_keep_launch(keep, bits, B, C, T, p, seed, site, dev_seed_offset, stream);
+}
+static int dropout_keep_launch(uint8_t* out, uint32_t* bits, int32_t B, int32_t C, int32_t T, float p, uint64_t seed,
+                               uint64_t site, const uint64_t* dev_seed_offset, void* stream) {
   DV3_REQUIRE(out && B > 0 && C > 0 && T > 0, "dropout_keep_c8: bad args");
   DV3_REQUIRE(p >= 0.f && p < 1.f, "dropout_keep_c8: p out of range");
   const uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
@@ -673,7 +688,7 @@ extern "C" int dv3_dropout_keep_c8(uint8_t* out, int32_t B, int32_t C, int32_t T
   const int64_t n = (int64_t)B * c8p * rs;
   DV3_REQUIRE((int64_t)B * c8p * T < (1ll << 31), "dropout_keep_c8: mask exceeds the 2 GB the kernel can address");
   hipLaunchKernelGGL(dropout_keep_c8_kernel, dim3((unsigned)dv3_cdiv64(n, 32)), dim3(256), 0, (hipStream_t)stream, out,
-                     B, C, T, rs, c8p, thr, seed, site, dev_seed_offset);
+                     B, C, T, rs, c8p, thr, seed, site, dev_seed_offset, bits);
   return dv3_check_launch("dropout_keep_c8");
 }
 

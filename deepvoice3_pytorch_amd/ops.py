@@ -470,6 +470,24 @@ def dropout_keep_c8(B, C, T, p, device, name=None):
     return out
 
 
+def dropout_bits_keep(B, C, T, p, device, name=None):
+    """one dropout site in both forms, one launch: -> (keep-bits int32 [B*C][rs], rs, keep-bytes uint8 [B][C8][T])"""
+    rs = (T + 31) // 32
+    bits = torch.empty(B * C * rs, dtype=torch.int32, device=device)
+    keep = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=device)
+    site = dropout_state.next_site()
+    _lib.call("dv3_dropout_bits_keep", bits.data_ptr(), keep.data_ptr(), B, C, T, float(p), dropout_state.seed, site,
+              _ptr(dropout_state.dev_offset), _stream())
+    if dropout_state.record is not None and name is not None:
+        dropout_state.record[name] = (bits, B * C, T)
+    return bits, rs, keep
+
+
+def pp2_wants_keep_bytes(Cin, J, dil, T, Tout):
+    """shapes the 256 x 256 k16 ping-pong tap-GEMM (csrc/conv_gemm_pp2.hip) takes: it stages dropout as keep-bytes"""
+    return _gemm_mode in ("f16x3", "bf16x3") and J == 3 and Cin % 32 == 0 and T == Tout and (J - 1) * dil <= 64
+
+
 def mask_bits_to_c8(bits, bits_rs, B, C, T):
     """dropout keep-bits [B*C][rs] -> keep-bytes [B][C8][T] for the c8 consumers"""
     out = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=bits.device)
@@ -795,9 +813,13 @@ class ConvLayerFn(torch.autograd.Function):
             pk = prepacked.lookup(v, Cg)          # packed for the whole model at the top of the step
         if pk is None:
             pk = pack_weights(v, g, glu_cg=Cg, transposed=cfg.transposed, need_bwd=need_grad, split_only=split_only)
-        bits, bits_rs, dscale = None, 0, 1.0
+        bits, bits_rs, dscale, keep8 = None, 0, 1.0, None
         if cfg.training and cfg.p > 0:
-            bits, bits_rs = dropout_bits(B * Cin, T, cfg.p, x.device, cfg.site)
+            J_ = 1 if cfg.transposed else (v.shape[2] if v.dim() == 3 else 1)
+            if not cfg.transposed and pp2_wants_keep_bytes(Cin, J_, cfg.dil, T, cfg.t_out if cfg.t_out is not None else T):
+                bits, bits_rs, keep8 = dropout_bits_keep(B, Cin, T, cfg.p, x.device, cfg.site)
+            else:
+                bits, bits_rs = dropout_bits(B * Cin, T, cfg.p, x.device, cfg.site)
             dscale = 1.0 / (1.0 - cfg.p)
         padL = _pad_left(J, cfg.dil, cfg.causal) if not cfg.transposed else 0
         if cfg.pad_left is not None:
@@ -826,7 +848,7 @@ class ConvLayerFn(torch.autograd.Function):
                       bias=bias, spk=spk, spk_strides=spk_strides,
                       r=res_in if (mode == EPI_HIGHWAY or cfg.residual or not gated) else None,
                       r2=r2c, residual=int(cfg.residual), ab=ab, xmask=bits if xp is None else None,
-                      xmask_rs=bits_rs if xp is None else 0, x_planes=xp,
+                      xmask_rs=bits_rs if xp is None else 0, x_planes=xp, xmask_c8=keep8 if xp is None else None,
                       drop_scale=dscale, a_split=pk.fwd_s if _gemm_mode != "f32" else None,
                       store_mode=STORE_INTERLEAVE2 if cfg.transposed else STORE_BCT)
         if need_grad:

@@ -352,6 +352,12 @@ int dv3_dropout_bits(uint32_t* bits, int64_t n_words, float p, uint64_t seed,
 
 /* The same keep decisions as dv3_dropout_bits over rows [B*C] (same seed / site / offset), written as the keep-BYTES
  * [B][round_up(C,32)/8][T] the c8 consumers read (= dv3_dropout_bits + dv3_mask_bits_to_c8 in one launch).      */
+/* Both forms of one dropout site in ONE launch: keep-bits [B*C][ceil(T/32)] (what the weight-gradient and
+ * input-gradient kernels read) and keep-bytes [B][round_up(C,32)/8][T] (what the 256 x 256 split tap-GEMM and the c8
+ * kernels stage: one byte load per 8-channel item instead of eight keep-bit words).  Same decisions as
+ * dv3_dropout_bits for the same seed / site / offset.  Replaces F.dropout's bernoulli_ (modules.py:147,210). */
+int dv3_dropout_bits_keep(uint32_t* bits, uint8_t* keep, int32_t B, int32_t C, int32_t T, float p, uint64_t seed,
+                          uint64_t site, const uint64_t* dev_seed_offset, void* stream);
 int dv3_dropout_keep_c8(uint8_t* out, int32_t B, int32_t C, int32_t T, float p, uint64_t seed, uint64_t site,
                         const uint64_t* dev_seed_offset, void* stream);
 

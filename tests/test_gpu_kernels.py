@@ -583,3 +583,57 @@ def test_fused_attention_forward_equals_unfused(dev, gemm_mode, B, E, Tq, Tk, p)
         Pw = torch.softmax(S.masked_fill(m, -float("inf")), dim=-1)
         want = torch.bmm(Pw, v.transpose(1, 2)).transpose(1, 2) * (Tk * math.sqrt(1.0 / Tk))
         assert rel_err(res[True][1], Pw) < 1e-5 and rel_err(res[True][0], want) < 1e-5
+
+
+@pytest.mark.parametrize("B,C,T,d,causal,masked", [(3, 64, 75, 2, False, True), (2, 256, 150, 27, False, False),
+                                                   (2, 128, 100, 1, True, True), (5, 96, 61, 9, False, True),
+                                                   (4, 256, 800, 3, False, True), (7, 32, 33, 1, False, False)])
+def test_256x256_k16_pingpong_tap_gemm_equals_the_128_wide_kernels(dev, gemm_mode, B, C, T, d, causal, masked):
+    """csrc/conv_gemm_pp2.hip (tile_hint 30; the picker's choice from 128 tiles up): same MFMAs per accumulator in the
+    same order as the 128-row kernels -- forward (Conv1dGLU, modules.py:145-164, with the pre-gate save, dropout as
+    keep-bytes of the same decisions) and input-gradient form agree bit for bit in the default mode; in bf16x3 the
+    masked forward differs in the last bit of some lo operands (the mask multiply is contracted into the residual in
+    one kernel and not the other) and is held to the kernel tolerance."""
+    if gemm_mode == "f32":
+        pytest.skip("split-operand kernel test")
+    from deepvoice3_pytorch_amd import ops, _lib
+    k = 3
+    torch.manual_seed(0)
+    x = torch.randn(B, C, T, device=dev)
+    v = torch.randn(2 * C, C, k, device=dev) * math.sqrt(4.0 * 0.95 / (k * C))
+    g = v.reshape(2 * C, -1).norm(dim=1).view(-1, 1, 1).clone()
+    bias = torch.randn(2 * C, device=dev) * 0.1
+    pk = ops.pack_weights(v, g, glu_cg=C, need_bwd=True)
+    bits = rs = kb = None
+    if masked:
+        ops.dropout_state.manual_seed(3)
+        bits, rs, kb = ops.dropout_bits_keep(B, C, T, 0.05, dev)
+        ops.dropout_state.manual_seed(3)
+        bits2, _ = ops.dropout_bits(B * C, T, 0.05, dev)
+        assert torch.equal(bits, bits2) and torch.equal(kb, ops.mask_bits_to_c8(bits2, rs, B, C, T))
+    padL = (k - 1) * d if causal else d
+    kw = dict(B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d, padL=padL, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x,
+              residual=1, a_split=pk.fwd_s, xmask=bits, xmask_rs=rs or 0, xmask_c8=kb,
+              drop_scale=1 / 0.95 if masked else 1.0)
+    ys, abs_ = [], []
+    for hint in (21 if C >= 64 else 0, 30):
+        y = torch.empty(B, C, T, device=dev)
+        ab = torch.empty(B, 2 * C, T, device=dev)
+        ops.conv_gemm(x, None, pk.lda, pk.a_half, y=y, ab=ab, tile_hint=hint, **kw)
+        ys.append(y)
+        abs_.append(ab)
+    assert _lib.lib().dv3_debug_get(10) % 1000 == 101
+    if gemm_mode == "f16x3" or not masked:
+        assert torch.equal(ys[0], ys[1]) and torch.equal(abs_[0], abs_[1])
+    else:
+        assert rel_err(ys[1].cpu(), ys[0].cpu()) < KTOL and rel_err(abs_[1].cpu(), abs_[0].cpu()) < KTOL
+    gm = torch.randn(B, 2 * C, T, device=dev)
+    dres = torch.randn(B, C, T, device=dev)
+    dkw = dict(B=B, Cin=2 * C, Tin=T, M=C, Tout=T, J=k, dil=d, padL=(k - 1) * d - padL, mode=ops.EPI_DGRAD,
+               r=dres, ymask=bits, ymask_rs=rs or 0, drop_scale=1 / 0.95 if masked else 1.0, a_split=pk.bwd_s)
+    dxs = []
+    for hint in (0, 30):
+        dx = torch.empty(B, C, T, device=dev)
+        ops.conv_gemm(gm, None, pk.ldb, 0, y=dx, tile_hint=hint, **dkw)
+        dxs.append(dx)
+    assert torch.equal(dxs[0], dxs[1])
