@@ -545,10 +545,12 @@ class TrainRun(object):
                                                    bt["text_positions"], bt["frame_positions"], bt["done"],
                                                    bt["target_lengths"], self.spk, downsample_step=4, device=dev)
         self.trainer.check_lengths(self.batch)
-        # Launch mode.  The step is ~390 kernel launches; through Python + ctypes the host needs 10-15 ms to enqueue
-        # them, about what the GPU needs to run them, so the default is ONE hipGraph per batch shape (forward, losses,
-        # backward, the bucketed RCCL all-reduces on their side stream, clip + Adam) replayed per step.  Eager
-        # launches (--no-graph) remain for shapes that change every step.
+        # Launch mode.  The step is ~390 kernel launches.  Eager launches are the default: the host enqueues them in
+        # less time than the GPU needs, and only eager launches let the weight-gradient branch of backward
+        # (ops.SideStream) and the RCCL buckets overlap the input-gradient chain on their own streams -- a replayed
+        # hipGraph measured 3-5 % SLOWER than eager launches at the north-star batch (its branches are not run
+        # concurrently and a replay costs the host as much as the launches; profiles/r03_side_stream_ab.txt).
+        # --graph captures the whole step (forward, losses, backward, RCCL buckets, clip + Adam) as ONE hipGraph.
         self.use_graph = bool(graph)
         self.runner = None
         self.graph_error = None
@@ -649,7 +651,7 @@ class TrainRun(object):
 
 def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup):
     run = TrainRun(dev, pg, rank, world, preset, gemm, args.batch, args.text_len, args.frames,
-                   graph=not args.no_graph)
+                   graph=bool(args.graph) and not args.no_graph)
     try:
         m = run.measure(steps, warmup)
         used_graph = bool(run.use_graph)
@@ -751,8 +753,8 @@ def main():
                     help="GEMM arithmetic (default: DV3_GEMM or f16x3)")
     ap.add_argument("--text-len", type=int, default=150)
     ap.add_argument("--frames", type=int, default=800)
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a hipGraph replay")
-    ap.add_argument("--graph", action="store_true", help="(default) whole-step hipGraph replay; kept for old command lines")
+    ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph")
     ap.add_argument("--settle", type=float, default=1.0,
                     help="seconds of untimed steps before --warmup (clock governor settle time; 0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -808,13 +810,12 @@ def main():
                               roofline=rf, roofline_wgrad=wgrad_roofline(dev))))
         return
 
-    graph = not args.no_graph
+    graph = bool(args.graph) and not args.no_graph
     run = TrainRun(dev, pg, rank, world, args.preset, gemm, args.batch, args.text_len, args.frames, graph)
     m = run.measure(args.steps, args.warmup, settle_s=args.settle)
     m_eager = None
     if run.use_graph and not args.no_extras:
-        # the same step launched eagerly (what a run with per-step shapes pays): host enqueue time and the
-        # all-reduce time left exposed are only observable there
+        # the same step launched eagerly: host enqueue time and the all-reduce time left exposed are only observable there
         run.use_graph = False
         try:
             m_eager = run.measure(max(5, args.steps // 4), 3)

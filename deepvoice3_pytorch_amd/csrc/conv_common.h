@@ -2,6 +2,7 @@
 // split-bf16 MFMA): launch arguments, the fused epilogue and the tile table.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -11,6 +12,7 @@ struct ConvArgs {
   int a_scalar;  // packed operand not 16-byte aligned (per-batch A = an activation): scalar staging
   int kp;        // bf16x3: K extent of the split weight image (Cin rounded up to 32)
   int stagger;   // planes kernel: s_sleep(127) repeats before the second co-resident workgroup starts
+  int wide = 1;                    // 16-byte input-gradient epilogue through LDS (0 = off)
   uint32_t* range_ctr = nullptr;   // f16x3: sticky fp16-range event counter (common.h), NULL = do not count
   int prio = 0;  // ping-pong tap-GEMM: wave priority scheme (dv3_debug_set(14, v); 0 = none)
 };
@@ -202,6 +204,81 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wide form of the fp32 (B, C, T) epilogue of the INPUT GRADIENT (keep-mask, dropout scale, skip-path addend).  The MFMA
+// accumulator gives a lane ONE column (frame) and 16 rows, so the narrow epilogue above moves every element with its
+// own 4-byte access and loads one keep-mask word per element.  Here each 32 x 64 block is transposed through LDS (free
+// once the main loop has left: every wave owns DV3_WIDE_LDS bytes): values go in with ds_write_b32 in accumulator
+// order and come back with ds_read_b128 as FOUR CONSECUTIVE FRAMES of one row per lane, so the addend load, the
+// keep-mask word (one per four outputs) and the store are 16-byte accesses: 4 x fewer global instructions.  Needs
+// T % 4 == 0 (a group of four frames must not straddle two batch items of the flattened (b, t) axis) and 16-byte
+// aligned tensors.  Same operations per element as the narrow form.  Measured at the north-star shape, same run:
+// DGRAD 145.7 -> 136.9 us (256 x 256 kernel), 161.7 -> 153.0 us (128 x 256 kernel).  The Conv1dGLU forward tail was
+// built the same way and measured SLOWER (eval 155 -> 166 us, with the pre-gate save 173 -> 211 us): that tail is one
+// chip-wide HBM burst (all 256 workgroups reach it together: 134 MB in ~25 us = 5.4 TB/s), not an instruction-issue
+// problem, and the extra LDS round trips only lengthen it (profiles/r03_pp2_check_ablations.txt); removed.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int DV3_WIDE_LD = 68;                                   // floats per staged row (64 + 4: rows land on shifted banks)
+constexpr int DV3_WIDE_LDS = 32 * DV3_WIDE_LD * 4;                // bytes per wave
+
+__device__ __forceinline__ bool dv3_wide_epilogue_ok(const dv3_conv_desc& p, int enable) {
+  if (enable == 0 || p.mode != DV3_EPI_DGRAD) return false;
+  if (p.store_mode != DV3_STORE_BCT || (p.Tout & 3) || (p.io_bf16 != 0)) return false;
+  auto al = [](const void* q, int64_t rs, int64_t bs) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && (rs & 3) == 0 && (bs & 3) == 0); };
+  if (!al(p.y, p.y_rs, p.y_bs) || !al(p.r, p.r_rs, p.r_bs)) return false;
+  if (p.ymask && p.ymask_rs * 32 < p.Tout) return false;
+  return true;
+}
+
+// One 32-row block of a wave (rows row0 + [0, 32) of half `half` of the tile), 64 columns starting at flat column nw0:
+// y = keep ? acc * dscale : 0, + r_scale * r
+template <int BM, int BMH>
+__device__ __forceinline__ void conv_epilogue_wide_block(const dv3_conv_desc& p, const f32x16 (&acc0)[2], int mt, int row0,
+                                                         int half, int lane, int nw0, int Ntot, float* __restrict__ lds) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const uint32_t T = (uint32_t)p.Tout, M = (uint32_t)p.M;
+  // wide-side coordinates of this lane: row rr + 4 * i of the block (i = 0..7), frames n4 .. n4 + 3
+  const int rr = lane >> 4, c4 = lane & 15;
+  const int n4 = nw0 + c4 * 4;
+  const bool okw = n4 < Ntot;
+  const uint32_t b4 = okw ? (uint32_t)n4 / T : 0u, t4 = okw ? (uint32_t)n4 - b4 * T : 0u;
+  const uint32_t rowb = (uint32_t)(mt * BM + half * BMH + row0);
+  const float dscale = p.drop_scale;
+  const float rsc = p.r_scale != 0.f ? p.r_scale : 1.0f;
+  f32x4 rv[8];
+  uint32_t mw[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {        // addend rows and keep words in the wide layout, issued before the LDS round trip
+    const uint32_t m = rowb + (uint32_t)(rr + 4 * i);
+    const uint32_t mc = m < M ? m : M - 1;
+    rv[i] = (p.r && okw) ? *reinterpret_cast<const f32x4*>(p.r + (size_t)b4 * p.r_bs + (size_t)mc * p.r_rs + t4)
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
+    mw[i] = (p.ymask && okw) ? p.ymask[((size_t)b4 * M + mc) * (size_t)p.ymask_rs + (t4 >> 5)] : 0xffffffffu;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {       // accumulator order -> LDS [row][column]
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) lds[row * DV3_WIDE_LD + ni * 32 + l31] = acc0[ni][r];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t m = rowb + (uint32_t)(rr + 4 * i);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(lds + (rr + 4 * i) * DV3_WIDE_LD + c4 * 4);
+    if (!okw || m >= M) continue;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = w[e];
+      if (p.ymask) a = ((mw[i] >> ((t4 & 31) + e)) & 1u) ? a * dscale : 0.f;
+      o[e] = a + rsc * rv[i][e];
+    }
+    *reinterpret_cast<f32x4*>(p.y + (size_t)b4 * p.y_bs + (size_t)m * p.y_rs + t4) = o;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done before the next block overwrites the rows
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -550,6 +550,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
     if (TERMS == 1 && (p.io_bf16 & DV3_IO_OUT_C8)) {   // bf16 storage: channel-blocked y / ab / residuals
       conv_epilogue_c8<BM, BMH, NI>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
       if (MI == 2) conv_epilogue_c8<BM, BMH, NI>(p, acc[MI - 1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+    } else if (NI == 2 && TERMS == 3 && ABL == 0 && dv3_wide_epilogue_ok(p, args.wide) &&
+               (size_t)(WM * WN) * DV3_WIDE_LDS <= (size_t)(2 * 2 * KB * BM + 2 * xbuf) * 16) {
+      // 16-byte epilogue through LDS (conv_common.h): the main loop's last barrier is behind every LDS read
+      if constexpr (NI == 2) {
+        float* wl = reinterpret_cast<float*>(smem_raw) + wave * (DV3_WIDE_LDS / 4);
+        const int nw0 = n0e + wn * (NI * 32);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int row0 = wm * (MI * 32) + mi * 32;
+          conv_epilogue_wide_block<BM, BMH>(p, acc[mi][0], mt, row0, 0, lane, nw0, Ntot, wl);
+          conv_epilogue_wide_block<BM, BMH>(p, acc[mi][1], mt, row0, 1, lane, nw0, Ntot, wl);
+        }
+      }
     } else {
       conv_epilogue<BM, BMH, NI, ABL, TERMS == 1>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
       if (MI == 2)
@@ -695,6 +708,7 @@ int g_x3_pp2 = 128;  // dv3_debug_set(12, v): the 256 x 256 k16 ping-pong kernel
                      // time from 152 tiles up, 1.3-1.9 x at 50-100 tiles (half the chip idle).
 extern int g_pp2_abl;
 int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st);   // conv_gemm_pp2.hip
+int g_x3_wide = 1;  // dv3_debug_set(18, v): 16-byte epilogue through LDS (conv_common.h): 0 off, 1 DGRAD, 
 int g_x3_prio = 0; // dv3_debug_set(14, v): wave priority scheme of the ping-pong main loop
 
 // called by dv3_conv_gemm_f32 (conv_gemm.hip) when d->a_split != NULL; returns 1 when the shape
@@ -725,6 +739,7 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   ConvArgs a;
   a.d = *d;
   a.a_scalar = 0;
+  a.wide = g_x3_wide;
   a.prio = g_x3_prio;
   a.range_ctr = d->split_terms == DV3_SPLIT_F16X3 ? dv3_range_ctr() : nullptr;
   a.kp = (d->Cin + 31) / 32 * 32;
@@ -757,6 +772,7 @@ extern "C" int dv3_debug_set(int what, int value) {
   if (what == 12) g_x3_pp2 = value;
   if (what == 13) g_pp2_abl = value;
   if (what == 14) g_x3_prio = value;
+  if (what == 18) g_x3_wide = value;
   if (what == 15) g_wgrad_prio = value;
   if (what == 1) g_x3_ablate = value;
   if (what == 2) g_wgrad_tile = value;

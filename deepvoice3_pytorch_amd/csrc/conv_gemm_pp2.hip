@@ -429,8 +429,21 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
       bcol[ni] = n / T;
       tcol[ni] = n - bcol[ni] * T;
     }
-    conv_epilogue<BM, BMH, NI, 0, false>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
-    conv_epilogue<BM, BMH, NI, 0, false>(p, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+    if (ABL != 10 && dv3_wide_epilogue_ok(p, args.wide)) {
+      // 16-byte epilogue through LDS (conv_common.h): every LDS read of the main loop is behind the last barrier this
+      // wave passed, so the whole allocation is free; each wave transposes in its own 8.5 KB
+      float* wl = reinterpret_cast<float*>(smem_raw) + wave * (DV3_WIDE_LDS / 4);
+      const int nw0 = n0e + wn * (NI * 32);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row0 = wm * (MI * 32) + mi * 32;
+        conv_epilogue_wide_block<BM, BMH>(p, acc[mi][0], mt, row0, 0, lane, nw0, Ntot, wl);
+        conv_epilogue_wide_block<BM, BMH>(p, acc[mi][1], mt, row0, 1, lane, nw0, Ntot, wl);
+      }
+    } else {
+      conv_epilogue<BM, BMH, NI, 0, false>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+      conv_epilogue<BM, BMH, NI, 0, false>(p, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+    }
   }
   stamp();                               // tail stores issued
 }
@@ -457,6 +470,7 @@ int dv3_pp2_read_stamps(void* dst, int64_t bytes) {
   if (bytes <= 0 || bytes > (int64_t)sizeof(unsigned long long) * 8 * PP2_STAMPS * 2) return DV3_EINVAL;
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pp2_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? DV3_OK : DV3_ELAUNCH;
 }
+extern int g_x3_wide;
 int g_pp2_abl = 0;   // dv3_debug_set(13, v): timing-only ablations of the unmasked kernel (1 no MFMAs, 2 no staging, 3 no tail)
 
 // Shapes this kernel takes (called by dv3_conv_gemm_bf16x3_dispatch): three-term split operands, fp32 (B, C, T)
@@ -474,6 +488,7 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   ConvArgs a;
   a.d = *d;
   a.a_scalar = 0;
+  a.wide = g_x3_wide;
   a.range_ctr = f16 ? dv3_range_ctr() : nullptr;
   a.kp = (d->Cin + 31) / 32 * 32;
   a.m_tiles = gated ? dv3_cdiv(d->Cg, BMH) : dv3_cdiv(d->M, BM);
@@ -494,6 +509,7 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
       case 7: return launch_pp2<false, true, 7>(a, lds, st);
       case 8: return launch_pp2<false, true, 8>(a, lds, st);
       case 9: return launch_pp2<false, true, 9>(a, lds, st);
+      case 10: return launch_pp2<false, true, 10>(a, lds, st);
     }
   }
   if (f16) return mask ? launch_pp2<true, true>(a, lds, st) : launch_pp2<false, true>(a, lds, st);

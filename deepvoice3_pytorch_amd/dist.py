@@ -102,9 +102,17 @@ class BucketedAllReduce(object):
         if self.side is None:   # CPU / gloo (tests): synchronous
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
             return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.side.wait_event(ev)
+        # the bucket's gradients were written on the step stream (autograd) and, for the conv layers, on the
+        # weight-gradient stream (ops.SideStream): the collective waits for both
+        from . import ops as _ops
+        streams = {torch.cuda.current_stream()}
+        for st in (_ops.SideStream.stream, _ops.SideStream.main):
+            if st is not None:
+                streams.add(st)
+        for st in streams:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.side.wait_event(ev)
         with torch.cuda.stream(self.side):
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
 

@@ -178,6 +178,9 @@ class Trainer(object):
         self._hyper_slot = 0
         self.norm_partial = torch.empty(1024, dtype=torch.float32, device=dev)
         self.norm_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        # second stream for the weight-gradient branch of backward (ops.SideStream); DV3_WGRAD_STREAM=0 keeps one stream
+        self.side_stream = torch.cuda.Stream() if (dev.type == "cuda" and os.environ.get("DV3_WGRAD_STREAM", "1")
+                                                   not in ("0", "")) else None
         self.pg = process_group
         self.world = 1
         self.comm = None
@@ -288,7 +291,13 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         scal["loss"] = loss
         if self.comm is not None:
             self.comm.arm()
-        loss.backward()
+        ops.SideStream.stream = self.side_stream
+        ops.SideStream.main = torch.cuda.current_stream() if self.side_stream is not None else None
+        try:
+            loss.backward()
+        finally:
+            ops.SideStream.join()          # the step stream waits for the weight-gradient branch; its operands may go
+            ops.SideStream.stream = ops.SideStream.main = None
         return {k: v.detach() for k, v in scal.items()}
 
     def optimizer_step(self):
@@ -455,12 +464,13 @@ def _load_file(path, unsafe=False):
     """torch.load restricted to tensors / containers / numbers (what train.save_checkpoint writes); the general
     unpickler (arbitrary code execution from an untrusted file) only behind `unsafe=True`."""
     # a reference run stores numpy scalars (global_step is incremented from numpy values): allow exactly those
-    safe = [np.core.multiarray.scalar if hasattr(np, "core") and hasattr(np.core, "multiarray") else None, np.dtype]
+    safe = [np.dtype]
     try:
-        import numpy._core.multiarray as _ncm
+        import numpy._core.multiarray as _ncm        # numpy >= 2
         safe.append(_ncm.scalar)
     except ImportError:
-        pass
+        import numpy.core.multiarray as _ncm         # numpy 1.x
+        safe.append(_ncm.scalar)
     safe += [type(np.dtype(t)) for t in (np.int64, np.int32, np.float64, np.float32, np.bool_)]
     safe = [g for g in safe if g is not None]
     try:

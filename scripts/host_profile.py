@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
+torch.autograd.set_multithreading_enabled(False)      # backward in this thread, so that cProfile sees it
 run = bench.TrainRun(dev, None, 0, 1, "deepvoice3_ljspeech", "f16x3", 64, 150, 800, graph=False)
 for _ in range(5):
     run.step()
@@ -23,4 +24,5 @@ for _ in range(5):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr, stream=sys.stdout)
-st.sort_stats("tottime").print_stats(35)
+st.sort_stats("tottime").print_stats(45)
+st.sort_stats("cumtime").print_stats(30)

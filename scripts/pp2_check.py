@@ -105,11 +105,19 @@ for dil in (1, 27):
             tm = timeit(lambda: ops.conv_gemm(x, None, pk.lda, pk.a_half, tile_hint=hint, **mkw))
             td = timeit(lambda: ops.conv_gemm(gm, None, pk.ldb, 0, tile_hint=hint, **dkw))
             print("dil %2d hint %2d: eval fwd %.1f us   train fwd (masked, pre-gate save) %.1f us   dgrad %.1f us" % (dil, hint, te, tm, td))
+for wide in (0, 1, 0, 1):
+    L.dv3_debug_set(18, wide)
+    for hint in (29, 30):
+        te = timeit(lambda: ops.conv_gemm(x, None, pk.lda, pk.a_half, tile_hint=hint, **kw))
+        tm = timeit(lambda: ops.conv_gemm(x, None, pk.lda, pk.a_half, tile_hint=hint, **mkw))
+        td = timeit(lambda: ops.conv_gemm(gm, None, pk.ldb, 0, tile_hint=hint, **dkw))
+        print("wide epilogue %d hint %2d: eval fwd %.1f us   train fwd %.1f us   dgrad %.1f us" % (wide, hint, te, tm, td))
+L.dv3_debug_set(18, 1)
 kw = dict(B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=1, padL=1, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x,
           residual=1, a_split=pk.fwd_s, y=y, tile_hint=30)
 for abl, name in ((0, "full"), (5, "MFMAs not pinned between the barriers"), (1, "no MFMAs"), (2, "no staging"), (3, "no tail"),
                   (6, "no activation fetches"), (7, "no panel fetches"), (8, "no activation conversion / stores"),
-                  (9, "no panel stores")):
+                  (9, "no panel stores"), (10, "narrow (4-byte) tail")):
     L.dv3_debug_set(13, abl)
     print("ablation %-38s: %.1f us" % (name, timeit(lambda: ops.conv_gemm(x, None, pk.lda, pk.a_half, **kw))))
 L.dv3_debug_set(13, 0)
