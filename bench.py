@@ -163,12 +163,14 @@ def _traffic(kernel_key):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, calibrated as MI355X_MICROARCH.md
     prescribes), collected offline with rocprofv3 (scripts/pmc_hbm.sh; a counter pass can not run inside this
     process) and committed under profiles/ -- used only when the file was collected for THIS kernel."""
-    try:
-        hb = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
-        ent = hb[kernel_key]
-        return ent["hbm_bytes_per_launch"], "profiles/r02_hbm_traffic.json (%s)" % ent["source"]
-    except (IOError, OSError, KeyError, ValueError):
-        return None, None
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):      # newest collection that holds THIS variant
+        try:
+            hb = json.load(open(os.path.join(ROOT, "profiles", name)))
+            ent = hb[kernel_key]
+            return ent["hbm_bytes_per_launch"], "profiles/%s (%s)" % (name, ent["source"])
+        except (IOError, OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None, c8=False):
@@ -213,6 +215,8 @@ def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None, c8=False):
              6: "conv_planes_kernel<fp16 hi/lo>", 7: "conv_planes_kernel<bf16>",
              8: "conv_planes_kernel<bf16 x1, c8 storage>"}.get(fam, "?")
     key = "conv_fwd:%d" % variant
+    if variant % 1000 == 101:
+        kname = "conv_gemm_pp2_kernel<%s>" % ("fp16 hi/lo" if fam == 5 else "bf16 hi/lo")
     out = dict(bound="mfma", kernel="%s variant %d (Conv1dGLU fwd B=64 C=256 T=1024 k=3)" % (kname, variant),
                achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
                traffic=None, us_per_launch=round(us, 2), alg_flops=flops, alg_bytes=byts,
