@@ -148,8 +148,10 @@ def griffin_lim(mag, hop, n_iter, init_phasor=None):
 
 
 def inv_preemphasis_(y, coef):
-    _lib.call("dv3_deemphasis_f32", y.data_ptr(), y.shape[0], y.shape[1], float(coef), _stream())
-    return y
+    """de-emphasis filter (audio.py:26-28) of (B, L) waveforms -> a new tensor"""
+    out = torch.empty_like(y)
+    _lib.call("dv3_deemphasis_f32", y.data_ptr(), out.data_ptr(), y.shape[0], y.shape[1], float(coef), _stream())
+    return out
 
 
 def inv_spectrogram_batch(linear_outputs, cfg=None, init_phasor=None):

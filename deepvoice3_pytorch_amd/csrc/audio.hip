@@ -381,8 +381,90 @@ extern "C" int dv3_gl_project_f32(const float* y, const float* mag, float* frame
   return dv3_check_launch("gl_project");
 }
 
-extern "C" int dv3_deemphasis_f32(float* y, int32_t B, int32_t L, float coef, void* stream) {
-  DV3_REQUIRE(y && B > 0 && L > 0, "deemphasis: bad arguments");
+// The same filter in parallel over the row.  |coef| < 1, so the response to a sample dies off geometrically: a chunk of
+// DEEMPH_CH outputs is exact to fp32 rounding when its recursion starts DEEMPH_W samples earlier from zero state (what is
+// dropped is bounded by coef^W / (1 - coef) * max|x|: 1e-12 * max|x| at the presets' 0.97) -- no carry crosses a
+// workgroup.  One workgroup = one chunk of one row: every thread scans 16 contiguous samples in registers (four 16-byte
+// loads), the 256 segment carries are chained through LDS, outputs leave as 16-byte stores.  64 rows x 206 k samples:
+// 4288 workgroups instead of the 64 of the serial form (938 us, round 2).
+constexpr int DEEMPH_W = 1024, DEEMPH_CH = 3072, DEEMPH_E = (DEEMPH_W + DEEMPH_CH) / 256;
+static_assert(DEEMPH_E == 16, "sixteen samples per thread");
+__global__ __launch_bounds__(256) void deemphasis_chunk_kernel(const float* __restrict__ x, float* __restrict__ y, int L,
+                                                               float coef) {
+  __shared__ float seg_end[256];
+  __shared__ float carry[256];
+  const int tid = threadIdx.x;
+  const float* xr = x + (int64_t)blockIdx.y * L;
+  float* yr = y + (int64_t)blockIdx.y * L;
+  const int out0 = blockIdx.x * DEEMPH_CH;                    // first output of the chunk
+  const int i0 = out0 - DEEMPH_W + tid * DEEMPH_E;            // this thread's first sample (may lie before the row)
+  float v[DEEMPH_E];
+  const bool vec = i0 >= 0 && i0 + DEEMPH_E <= L && ((((uintptr_t)(xr + i0)) & 15) == 0);
+  if (vec) {
+#pragma unroll
+    for (int q = 0; q < DEEMPH_E / 4; ++q) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(xr + i0 + 4 * q);
+      v[4 * q] = t4[0]; v[4 * q + 1] = t4[1]; v[4 * q + 2] = t4[2]; v[4 * q + 3] = t4[3];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < DEEMPH_E; ++j) v[j] = (i0 + j >= 0 && i0 + j < L) ? xr[i0 + j] : 0.f;
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < DEEMPH_E; ++j) {
+    acc = v[j] + coef * acc;
+    v[j] = acc;
+  }
+  seg_end[tid] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float cE = coef;
+#pragma unroll
+    for (int j = 1; j < DEEMPH_E; ++j) cE *= coef;            // coef^16
+    float c = 0.f;                                            // filter state just before segment s
+    for (int s = 0; s < 256; ++s) {
+      carry[s] = c;
+      c = seg_end[s] + cE * c;
+    }
+  }
+  __syncthreads();
+  if (i0 + DEEMPH_E <= out0 || i0 >= L) return;               // warm-up segments and segments past the row write nothing
+  const float c = carry[tid];
+  float g = coef;
+#pragma unroll
+  for (int j = 0; j < DEEMPH_E; ++j) {
+    v[j] += g * c;
+    g *= coef;
+  }
+  if (vec && i0 >= out0 && ((((uintptr_t)(yr + i0)) & 15) == 0)) {
+#pragma unroll
+    for (int q = 0; q < DEEMPH_E / 4; ++q)
+      *reinterpret_cast<f32x4*>(yr + i0 + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  } else {
+#pragma unroll
+    for (int j = 0; j < DEEMPH_E; ++j)
+      if (i0 + j >= out0 && i0 + j < L) yr[i0 + j] = v[j];
+  }
+}
+
+extern "C" int dv3_deemphasis_f32(const float* x, float* y, int32_t B, int32_t L, float coef, void* stream) {
+  DV3_REQUIRE(x && y && B > 0 && L > 0, "deemphasis: bad arguments");
+  // the chunked form needs the warm-up to swallow the filter's memory; a coefficient too close to 1 (or >= 1) runs
+  // the serial-per-row form, which is in place
+  const float a = fabsf(coef);
+  const bool chunked = a < 1.f && (a == 0.f || DEEMPH_W * logf(a) <= logf(1e-9f * (1.f - a))) && x != y;
+  if (chunked) {
+    hipLaunchKernelGGL(deemphasis_chunk_kernel, dim3(dv3_cdiv(L, DEEMPH_CH), B), dim3(256), 0, (hipStream_t)stream, x, y, L, coef);
+    return dv3_check_launch("deemphasis");
+  }
+  if (x != y) {
+    hipError_t e = hipMemcpyAsync(y, x, (size_t)B * L * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) {
+      dv3_set_error("deemphasis: %s", hipGetErrorString(e));
+      return DV3_ELAUNCH;
+    }
+  }
   hipLaunchKernelGGL(deemphasis_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, y, L, coef);
   return dv3_check_launch("deemphasis");
 }

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void conv_step_kernel(const dv3_conv_step_desc
       if (p.r2) v = (v + p.r2[(int64_t)b * p.r2_bs + m]) * rs2;
       y = v;
     }
+    if (p.y_pre) p.y_pre[(int64_t)b * p.y_pre_bs + m] = y;
     if (p.post_add) y += p.post_add[(int64_t)t * p.post_add_ts + (int64_t)b * p.post_add_bs + m];
     p.y[(int64_t)b * p.y_bs + m] = y;
     float o = y;

@@ -189,9 +189,99 @@ class Decoder(nn.Module):
         done = self.fc.forward_bct(self.last_conv(x), ops.EPI_SIGMOID).transpose(1, 2)
         return outputs, alignments.unsqueeze(0), done, decoder_states
 
+    def _fast_decode_eligible(self, Tk):
+        """what the fused step program below takes (csrc/decode_step.hip stages a layer's k-tap window of 4 batch items
+        and the attention scores in 64 KB of LDS); anything else runs the module-by-module path"""
+        def fits(conv):
+            return (conv.kernel_size[0] * conv.in_channels * 4 + 16 * 16 * 2 * 4) * 4 <= 64 * 1024
+        for mods in (self.audio_encoder_modules, self.audio_decoder_modules):
+            for f in mods:
+                if isinstance(f, HighwayConv1d):
+                    if f.glu or not fits(f.conv):
+                        return False
+                elif isinstance(f, _conv.Conv1d):
+                    if f.kernel_size[0] != 1 or not fits(f):
+                        return False
+                elif not isinstance(f, nn.ReLU):
+                    return False
+        E = self.attention.query_projection.out_features
+        return (E + Tk) * 4 <= 64 * 1024 and fits(self.last_conv)
+
+    def _incremental_fast(self, encoder_out, text_positions, initial_input=None, test_inputs=None):
+        """incremental_forward (nyanko.py:250-338) as a flat per-step launch program (decode_program.StepProgram):
+        28 conv-step launches + one attention-step launch per decoder step instead of ~150 module calls; the
+        concat [R, Q] (nyanko.py:308) is one (B, 2D) buffer both producers write into."""
+        from .decode_program import StepProgram
+        keys, values = encoder_out
+        B, dev = keys.size(0), keys.device
+        with torch.no_grad():
+            keys_bct = keys.transpose(1, 2).contiguous()
+            if text_positions is not None:
+                keys_bct = ops.add_position_encoding(keys_bct, text_positions, self.embed_keys_positions.weight,
+                                                     None, False)
+            values_bct = values.transpose(1, 2).contiguous()
+            att = self.attention
+            k = (att.key_projection.forward_bct(keys_bct) if att.key_projection is not None else keys_bct).contiguous()
+            v = (att.value_projection.forward_bct(values_bct) if att.value_projection is not None else values_bct).contiguous()
+            Tk = k.size(-1)
+            F = self.in_dim * self.r
+            n_max = test_inputs.size(1) if test_inputs is not None else self.max_decoder_steps + 1
+            P = StepProgram(B, dev)
+            # position code of step t = row t + 1 of the frozen table (nyanko.py:162-166), the same for every item
+            pe_all = self.embed_query_positions.weight[1:n_max + 1].detach().contiguous()      # (n_max, D)
+            if pe_all.size(0) < n_max:
+                raise RuntimeError("decoder steps exceed max_positions")
+            pe_all = pe_all[:, None, :].expand(n_max, B, pe_all.size(1))                          # batch stride 0
+            cur_in = (initial_input.reshape(B, F).clone().float() if initial_input is not None else P.buffer(B, F))
+            free_running = test_inputs is None
+            nxt_in = cur_in if free_running else P.buffer(B, F)
+            D = self.last_conv.in_channels
+            outs, dones_seq = P.buffer(n_max, B, F), P.buffer(n_max, B, 1)
+            states, aligns = P.buffer(n_max, B, D), P.buffer(n_max, B, Tk)
+            cat = P.buffer(B, 2 * D)                       # [R | Q]
+            xq = P.buffer(B, D)
+            P.keep.extend([k, v, pe_all, cur_in, nxt_in])
+
+            def run(mods, x, last_kw=None):
+                """a Conv1d(+ReLU) / HighwayConv1d stack, one launch per layer; last_kw: extra outputs of the last layer"""
+                mods = list(mods)
+                i = 0
+                while i < len(mods):
+                    f = mods[i]
+                    relu = isinstance(f, _conv.Conv1d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                    last = (i + int(relu)) == len(mods) - 1
+                    kw = dict(last_kw) if (last and last_kw) else {}
+                    if isinstance(f, HighwayConv1d):
+                        x = P.conv_step(f.conv, x, ops.EPI_HIGHWAY, f.conv.out_channels // 2, k=f.conv.kernel_size[0],
+                                        dil=f.conv.dilation[0], gated=True, **kw)
+                    else:
+                        x = P.conv_step(f, x, ops.EPI_RELU if relu else ops.EPI_LINEAR, f.out_channels, **kw)
+                        i += int(relu)
+                    i += 1
+                return x
+
+            # audio encoder: Q (into the concat buffer) and Q + position code (the attention query input)
+            run(self.audio_encoder_modules, cur_in, dict(y=xq, post_add=pe_all, y_pre=cat[:, D:]))
+            q = P.conv_step(att.query_projection, xq, ops.EPI_LINEAR, att.query_projection.out_features)
+            ctx = P.attn_step(q, k, v, att.window_backward, att.window_ahead, self.force_monotonic_attention,
+                              attn_seq=aligns)
+            P.conv_step(att.out_projection, ctx, ops.EPI_LINEAR, att.out_projection.out_features, r=xq, y=cat[:, :D])
+            x = run(self.audio_decoder_modules, cat, dict(out_seq=states))
+            pre = P.conv_step(self.last_conv, x, ops.EPI_LINEAR, F, y_act=nxt_in, out_seq=outs)
+            P.conv_step(self.fc, pre, ops.EPI_SIGMOID, 1, out_seq=dones_seq)
+            t = P.decode(cur_in, test_inputs, dones_seq, self.min_decoder_steps, self.max_decoder_steps,
+                         getattr(self, "use_step_graph", False))
+            alignments = aligns[:t].transpose(0, 1)
+            decoder_states = states[:t].transpose(0, 1).contiguous()
+            outputs = outs[:t].transpose(0, 1).contiguous()
+            dones = [dones_seq[i].view(B, 1, 1) for i in range(t)]
+        return outputs, alignments, dones, decoder_states
+
     def incremental_forward(self, encoder_out, text_positions, initial_input=None, test_inputs=None):
         """nyanko.py:250-338."""
         keys, values = encoder_out
+        if getattr(self, "fast_decode", True) and keys.is_cuda and self._fast_decode_eligible(keys.size(1)):
+            return self._incremental_fast(encoder_out, text_positions, initial_input, test_inputs)
         B = keys.size(0)
         dev = keys.device
         keys_bct = keys.transpose(1, 2).contiguous()

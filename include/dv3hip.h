@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 29
+#define DV3_ABI_VERSION 30
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -533,6 +533,8 @@ typedef struct dv3_conv_step_desc {
   float* y_act; int64_t y_act_bs;
   float* out_seq; int64_t out_seq_ts, out_seq_bs;
   int32_t B, Cin, M, Cg, J, dil, mode, residual;
+  float* y_pre; int64_t y_pre_bs;            /* optional: the layer output BEFORE post_add (nyanko.py:297-300: Q feeds the
+                                                concat while Q + position code feeds the attention query)            */
 } dv3_conv_step_desc;
 int dv3_conv_step_f32(const dv3_conv_step_desc* d, void* stream);
 
@@ -582,8 +584,10 @@ int dv3_stft_phase_f32(const float* y, float* phasor, float* spec, float* mag_bc
 int dv3_preemphasis_f32(const float* x, float* y, int32_t B, int32_t L, float coef, void* stream);
 int dv3_amp_to_db_norm_f32(const float* x, float* out, int64_t n, float min_level_db,
                            float ref_level_db, void* stream);
-/* in place y[n] = x[n] + coef*y[n-1] per row: inv_preemphasis, audio.py:26-28 */
-int dv3_deemphasis_f32(float* y, int32_t B, int32_t L, float coef, void* stream);
+/* y[n] = x[n] + coef*y[n-1] per row: inv_preemphasis, audio.py:26-28 (nnmnkwii's lfilter([1], [1, -coef])).  x != y
+ * runs chunked in parallel over the row (exact to fp32 rounding for |coef| well below 1: each 3072-sample chunk restarts
+ * 1024 samples early); x == y, or a coefficient whose memory outlasts the warm-up, runs one workgroup per row. */
+int dv3_deemphasis_f32(const float* x, float* y, int32_t B, int32_t L, float coef, void* stream);
 
 #ifdef __cplusplus
 }

@@ -134,6 +134,13 @@ def test_hip_deemphasis_and_inv_spectrogram(dev):
     y = torch.from_numpy(rng.randn(3, 7000).astype(np.float32))
     got = audio.inv_preemphasis_(y.clone().to(dev), 0.97).cpu().numpy()
     assert _rel(got, A.inv_preemphasis(y.numpy(), 0.97)) < 2e-5
+    # the chunked parallel form over many chunks (rows 16-byte aligned or not), a constant offset (the filter's DC gain
+    # of 33 must survive the chunk restarts), and a coefficient whose memory outlasts the warm-up (serial form)
+    for L, coef, dc in ((50000, 0.97, 0.0), (20481, 0.97, 0.5), (9000, 0.9995, 0.0), (4097, 0.5, 1.0)):
+        y = torch.from_numpy((rng.randn(2, L) + dc).astype(np.float32))
+        got = audio.inv_preemphasis_(y.to(dev), coef).cpu().numpy()
+        # (a pole at 0.9995 amplifies fp32 rounding ~2000 x: the serial form is held to 1e-4 there)
+        assert _rel(got, A.inv_preemphasis(y.numpy(), coef)) < (1e-4 if coef > 0.99 else 2e-5), (L, coef)
     # end to end, reference calling convention: (513, T) numpy in, waveform numpy out
     spec = np.clip(0.5 + 0.2 * rng.randn(513, 30), 0, 1).astype(np.float32)
     wav = audio.inv_spectrogram(spec, audio.AudioConfig(griffin_lim_iters=3))

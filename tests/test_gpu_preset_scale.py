@@ -473,3 +473,55 @@ def test_preset_forward_matches_reference_golden(dev, preset, gemm_mode):
     _record(test="reference_golden_preset", preset=preset, gemm=gemm_mode, **errs)
     for n, e in errs.items():
         assert e < tol, (n, e)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Incremental (autoregressive) decode AT THE BENCHMARKED SIZE: bench.py's synth_rtf times the fused step program
+# (csrc/decode_step.hip: 16 channels x 16 K-slices per workgroup) on the 256 / 512-channel presets; the toy fixtures of
+# tests/test_gpu_model.py never reach that work split.  Teacher-forced incremental_forward(test_inputs=mel)
+# (deepvoice3.py:405-408, nyanko.py:283-286) of the three presets at preset channel counts against the oracle's
+# restatement of Decoder.incremental_forward (deepvoice3.py:367-485 / nyanko.py:250-338), both decode paths.
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fast", [True, False])
+@pytest.mark.parametrize("preset", PRESET_NAMES)
+def test_preset_incremental_decode_matches_oracle(dev, preset, fast):
+    from deepvoice3_pytorch_amd import builder, ops
+    prev = ops.set_gemm_precision("f16x3")
+    try:
+        bname, hp, _ = _preset(preset)
+        torch.manual_seed(13)
+        model = getattr(builder, bname)(**hp).to(dev).eval()
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        spec = O.build_spec(bname, **hp)
+        B, Tt, steps = 5, 60, 24
+        rng = np.random.RandomState(3)
+        text = torch.from_numpy(rng.randint(2, hp["n_vocab"], (B, Tt)))
+        tpos = torch.arange(1, Tt + 1).repeat(B, 1)
+        mel = torch.from_numpy(rng.rand(B, steps, hp["mel_dim"] * hp["r"]).astype(np.float32))
+        spk = torch.from_numpy(rng.randint(0, hp["n_speakers"], B)) if hp["n_speakers"] > 1 else None
+        dec = model.seq2seq.decoder
+        dec.fast_decode = fast
+        with torch.no_grad():
+            se = model.embed_speakers(spk.to(dev)) if spk is not None else None
+            enc = model.seq2seq.encoder(text.to(dev), lengths=None, speaker_embed=se)
+            dec.start_fresh_sequence()
+            if bname == "nyanko":
+                got = dec.incremental_forward(enc, tpos.to(dev), test_inputs=mel.to(dev))
+            else:
+                got = dec.incremental_forward(enc, tpos.to(dev), speaker_embed=se, test_inputs=mel.to(dev))
+            se_c = torch.nn.functional.embedding(spk, sd["embed_speakers.weight"]) if spk is not None else None
+            if bname == "nyanko":
+                enc_c = O.ny_encoder(sd, spec, text)
+                want = O.ny_incremental_decode(sd, spec, enc_c, tpos, test_inputs=mel)
+            else:
+                enc_c = O.dv3_encoder(sd, spec, text, se_c)
+                want = O.dv3_incremental_decode(sd, spec, enc_c, tpos, se_c, test_inputs=mel)
+        errs = dict(mel=rel_err(got[0].cpu(), want[0]), alignments=rel_err(got[1].cpu(), want[1]),
+                    states=rel_err(got[3].cpu(), want[3]),
+                    done=rel_err(torch.cat([d.reshape(B, -1) for d in got[2]], 1).cpu(),
+                                 torch.cat([d.reshape(B, -1) for d in want[2]], 1)))
+        _record(test="incremental_decode", preset=preset, fast=fast, **errs)
+        for n, e in errs.items():
+            assert e < TOL_OUT, (n, e)
+    finally:
+        ops.set_gemm_precision(prev)
