@@ -764,7 +764,7 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   return 1;
 }
 
-extern int g_wgrad_tile, g_wgrad_prio;   // wgrad_gemm_bf16x3.hip
+extern int g_wgrad_tile, g_wgrad_prio, g_wgrad_t2_abl, g_wgrad_taps2_default;   // wgrad_gemm_bf16x3.hip, wgrad_taps2.hip
 int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 extern "C" int dv3_debug_set(int what, int value) {
   if (what >= 4 && what <= 8) return dv3_planes_debug_set(what, value);
@@ -774,6 +774,8 @@ extern "C" int dv3_debug_set(int what, int value) {
   if (what == 14) g_x3_prio = value;
   if (what == 18) g_x3_wide = value;
   if (what == 15) g_wgrad_prio = value;
+  if (what == 16) g_wgrad_t2_abl = value;
+  if (what == 17) g_wgrad_taps2_default = value;
   if (what == 1) g_x3_ablate = value;
   if (what == 2) g_wgrad_tile = value;
   if (what == 3) g_x3_pingpong = value;

@@ -489,6 +489,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_taps_kernel(const WgradArgs args
 
 }  // namespace
 
+int g_wgrad_taps2_default = 1;   // the two-steps-ahead form of the all-taps kernel (wgrad_taps2.hip; masked 205 -> 173 us, unmasked
+                                 // 164 -> 150 us at the north-star shape, bit-identical slabs); dv3_debug_set(17, 0) = the one-step form
+int dv3_wgrad_taps2_dispatch(const dv3_wgrad_desc* d, hipStream_t st);
 int g_wgrad_taps_default = 1;   // the all-taps form measured 7-14 % faster at every model shape (scripts/wgrad_ab.py)
 int g_wgrad_prio = 0;   // debug (dv3_debug_set(15, v))
 int g_wgrad_tile = 0;   // debug (dv3_debug_set(2, v)): 0 auto, 1 force 128x128 per tap, 2 force 256x128 per tap, 3 force all-taps
@@ -545,6 +548,10 @@ int dv3_wgrad_gemm_bf16x3_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
   WgradArgs a;
   a.d = *d;
   a.prio = g_wgrad_prio;
+  if (d->J == 3 && d->k_split && d->split_bf16 != 2 && (g_wgrad_tile == 4 || (g_wgrad_tile == 0 && g_wgrad_taps2_default)) &&
+      (int64_t)(d->B - 1) * d->g_bs + (int64_t)(d->M - 1) * d->g_rs + d->T >= 8 &&
+      (int64_t)(d->B - 1) * d->x_bs + (int64_t)(d->Cin - 1) * d->x_rs + d->Tin >= 8)
+    return dv3_wgrad_taps2_dispatch(d, st);
   // three taps, K split over contiguous ranges: one 8-wave workgroup per (m-tile, c-tile, slab) serves all taps
   if (d->J == 3 && d->k_split && (g_wgrad_tile == 3 || (g_wgrad_tile == 0 && g_wgrad_taps_default))) {
     a.m_tiles = dv3_cdiv(d->M, 128);

@@ -49,7 +49,7 @@ log = open("gpurun_out/pmc_r3_FETCH_SIZE.log").read()
 var = dict(re.findall(r"VARIANT (\w+) (\d+)", log))
 res, busy = {}, {}
 names = (("conv_fwd:%s" % var.get("conv"), "conv_gemm_pp2_kernel" if var.get("conv", "").endswith("101") else "conv_gemm_bf16x3_kernel", 135792640),
-         ("wgrad:%s" % var.get("wgrad"), "wgrad_taps_kernel", 202899456), ("conv_fwd:%s" % var.get("convc8"), "conv_planes_kernel", 67897344))
+         ("wgrad:%s" % var.get("wgrad"), "wgrad_taps2_kernel" if var.get("wgrad", "").endswith("40") else "wgrad_taps_kernel", 202899456), ("conv_fwd:%s" % var.get("convc8"), "conv_planes_kernel", 67897344))
 D = durs("SQ_VALU_MFMA_BUSY_CYCLES")
 for key, name, alg in names:
     kn, f = pick(F, name); _, w = pick(W, name)
