@@ -23,6 +23,21 @@ __device__ __forceinline__ void block_reduce4(float v[4], float* out /* [4] per 
                                           red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// binary divergence of one element and its derivative (train.py:537-556):
+//   L = logit(y_hat) = log(y_hat + eps) - log(1 - y_hat + eps),  z = -y L + log1p(exp(L)),  dz/dy_hat = (sigmoid(L) - y) L'
+// With a = y_hat + eps, b = 1 - y_hat + eps:  exp(L) = a / b,  log1p(exp(L)) = log(a + b) - log(b),
+// sigmoid(L) = a / (a + b): two logarithms and two reciprocals instead of four transcendental calls -- the loss kernels
+// were VALU-bound on them (round 2: 145 us per launch whatever the access pattern).  a + b = 1 + 2 eps.
+__device__ __forceinline__ void spec_bd(float yh, float y, float& z, float& dz) {
+  const float eps = 1e-8f;
+  const float a = yh + eps, b = 1.f - yh + eps;
+  const float la = logf(a), lb = logf(b);
+  const float ab = a + b;
+  z = -y * (la - lb) + (logf(ab) - lb);
+  const float ra = __builtin_amdgcn_rcpf(a), rb = __builtin_amdgcn_rcpf(b);
+  dz = (a * __builtin_amdgcn_rcpf(ab) - y) * (ra + rb);
+}
+
 // mask_sum as train.py:286-290 computes it: sum over the expanded (B, T-r, D) mask
 __device__ __forceinline__ float spec_mask_sum(const dv3_spec_loss_desc& p) {
   float ms = 0.f;
@@ -43,7 +58,6 @@ __global__ __launch_bounds__(kLossBlock) void spec_loss_kernel(const dv3_spec_lo
   const float inv_n = 1.0f / (float)n;
   const float wm = use_mask ? p.w_masked : 0.f;
   const float c_all = (1.f - wm) * inv_n, c_msk = use_mask ? wm / msum : 0.f;
-  const float eps = 1e-8f;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};  // l1, l1 masked, z, z masked
   const int64_t stride = (int64_t)gridDim.x * kLossBlock;
   // iterate with the faster-varying axis of y_hat innermost so its accesses coalesce
@@ -71,17 +85,74 @@ __global__ __launch_bounds__(kLossBlock) void spec_loss_kernel(const dv3_spec_lo
     acc[1] += m * ad;
     float dz = 0.f;
     if (p.w_bd > 0.f) {
-      const float L = logf(yh + eps) - logf(1.f - yh + eps);
-      const float z = -y * L + log1pf(expf(L));
+      float z;
+      spec_bd(yh, y, z, dz);
       acc[2] += z;
       acc[3] += m * z;
-      const float sig = 1.0f / (1.0f + expf(-L));
-      dz = (sig - y) * (1.0f / (yh + eps) + 1.0f / (1.f - yh + eps));
     }
     if (p.dyh) {
       const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
       const float coef = c_all + c_msk * m;
       p.dyh[ih] = p.gscale * coef * ((1.f - p.w_bd) * sgn + p.w_bd * dz);
+    }
+  }
+  block_reduce4(acc, p.scratch + (int64_t)blockIdx.x * 4);
+}
+
+// The same loss when the prediction is time-fastest (the model's (B, T, D) outputs are transposed views of its BCT
+// tensors) and the target is bin-fastest (collate_fn's (B, T, D) arrays): either thread order leaves one of the two
+// tensors read with a D- or T-element stride (round 2: ~1 TB/s, 300 us for the linear-spectrogram loss).  A workgroup
+// takes 64 frames x 64 bins at a time: the target tile is read bin-fastest into LDS, then every thread works
+// frame-fastest -- prediction read, gradient write and the LDS reads (row stride 65) are all unit-stride.  Persistent
+// grid (tiles are walked with a grid stride) so that the block partial sums fit the caller's scratch.
+__global__ __launch_bounds__(kLossBlock) void spec_loss_tiled_kernel(const dv3_spec_loss_desc p, int t_tiles, int d_tiles,
+                                                                     int n_tiles) {
+  __shared__ float ys[64 * 65];
+  const int Tr = p.T - p.r, D = p.D;
+  const int64_t n = (int64_t)p.B * Tr * D;
+  const bool use_mask = p.w_masked > 0.f && p.lengths;
+  const float msum = use_mask ? spec_mask_sum(p) : 1.f;
+  const float inv_n = 1.0f / (float)n;
+  const float wm = use_mask ? p.w_masked : 0.f;
+  const float c_all = (1.f - wm) * inv_n, c_msk = use_mask ? wm / msum : 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int tid = threadIdx.x;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int dt = tile % d_tiles, tt_ = (tile / d_tiles) % t_tiles, b = tile / (d_tiles * t_tiles);
+    const int t0 = tt_ * 64, d0 = dt * 64;
+    __syncthreads();                                   // the previous tile's LDS reads are done
+#pragma unroll 4
+    for (int q = tid; q < 64 * 64; q += kLossBlock) {  // target tile, bin-fastest: y[b][t0 + tl + r][d0 + dl]
+      const int tl = q >> 6, dl = q & 63;
+      const int t = t0 + tl, dd = d0 + dl;
+      ys[tl * 65 + dl] = (t < Tr && dd < D) ? p.y[b * p.y_bs + (int64_t)(t + p.r) * p.y_ts + dd] : 0.f;
+    }
+    __syncthreads();
+    const int len_b = use_mask ? p.lengths[b] : 0;
+#pragma unroll 4
+    for (int q = tid; q < 64 * 64; q += kLossBlock) {  // frame-fastest
+      const int dl = q >> 6, tl = q & 63;
+      const int t = t0 + tl, dd = d0 + dl;
+      if (t >= Tr || dd >= D) continue;
+      const int64_t ih = b * p.yh_bs + t + (int64_t)dd * p.yh_ds;
+      const float yh = p.y_hat[ih], y = ys[tl * 65 + dl];
+      const float m = (use_mask && (t + p.r) < len_b) ? 1.f : 0.f;
+      const float diff = yh - y;
+      const float ad = fabsf(diff);
+      acc[0] += ad;
+      acc[1] += m * ad;
+      float dz = 0.f;
+      if (p.w_bd > 0.f) {
+        float z;
+        spec_bd(yh, y, z, dz);
+        acc[2] += z;
+        acc[3] += m * z;
+      }
+      if (p.dyh) {
+        const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+        const float coef = c_all + c_msk * m;
+        p.dyh[ih] = p.gscale * coef * ((1.f - p.w_bd) * sgn + p.w_bd * dz);
+      }
     }
   }
   block_reduce4(acc, p.scratch + (int64_t)blockIdx.x * 4);
@@ -191,7 +262,11 @@ inline int loss_blocks(int64_t n) {
 }  // namespace
 
 extern "C" int dv3_spec_loss_scratch_floats(int32_t B, int32_t T, int32_t D) {
-  return 4 * loss_blocks((int64_t)B * T * D) + 16;
+  // block partial sums of either form: the flat grid, or one block per 64 x 64 tile (at most 1024)
+  int64_t tiles = (int64_t)B * dv3_cdiv(T, 64) * dv3_cdiv(D, 64);
+  if (tiles > 1024) tiles = 1024;
+  const int64_t flat = loss_blocks((int64_t)B * T * D);
+  return (int)(4 * (tiles > flat ? tiles : flat) + 16);
 }
 
 extern "C" int dv3_spec_loss_f32(const dv3_spec_loss_desc* d, void* stream) {
@@ -200,8 +275,16 @@ extern "C" int dv3_spec_loss_f32(const dv3_spec_loss_desc* d, void* stream) {
   DV3_REQUIRE(d->w_masked <= 0.f || d->lengths, "spec_loss: masked weight needs lengths");
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = (int64_t)d->B * (d->T - d->r) * d->D;
-  const int nb = loss_blocks(n);
-  hipLaunchKernelGGL(spec_loss_kernel, dim3(nb), dim3(kLossBlock), 0, st, *d);
+  int nb = loss_blocks(n);
+  if (d->yh_ts == 1 && d->y_ds == 1 && d->yh_ds > 1 && d->y_ts > 1 && (int64_t)d->B * d->yh_bs < (1ll << 40)) {
+    // time-fastest prediction against a bin-fastest target: the tiled form
+    const int t_tiles = dv3_cdiv(d->T - d->r, 64), d_tiles = dv3_cdiv(d->D, 64);
+    const int64_t nt = (int64_t)d->B * t_tiles * d_tiles;
+    nb = (int)(nt < 1024 ? nt : 1024);
+    hipLaunchKernelGGL(spec_loss_tiled_kernel, dim3(nb), dim3(kLossBlock), 0, st, *d, t_tiles, d_tiles, (int)nt);
+  } else {
+    hipLaunchKernelGGL(spec_loss_kernel, dim3(nb), dim3(kLossBlock), 0, st, *d);
+  }
   if (d->dyh && d->r > 0) {
     const int64_t nt = (int64_t)d->B * d->r * d->D;
     hipLaunchKernelGGL(spec_loss_tail_zero_kernel, dim3((unsigned)dv3_cdiv64(nt, 256)), dim3(256), 0,
