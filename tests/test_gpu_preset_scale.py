@@ -53,12 +53,19 @@ pytestmark = pytest.mark.gpu
 TOL_OUT = 1e-4
 TOL_GRAD = 5e-4
 GRAD_K = {"f32": 4.0, "f16x3": 16.0, "bf16x3": 16.0}
-BF16_OUT, BF16_LOSS, BF16_COS = 2e-1, 2e-2, 0.995
-BF16_OUT_SAME_ROUNDING = 2e-1
+BF16_LOSS, BF16_COS = 2e-2, 0.995
+# The bf16 mode's parity gates are test_preset_bf16_every_layer_pins_to_the_same_rounding_reference (every conv /
+# linear launch of a forward against the same arithmetic on the CPU, to the storage format's half ulp) and
+# test_preset_bf16_stacks_sit_at_the_storage_noise (each stack against the oracle with bf16 operands and bf16 stored
+# activations).  The end-to-end numbers against the fp32 oracle are recorded and only held to a sanity bound: a
+# randomly initialised attention decoder amplifies ANY 2^-9 perturbation of its inputs to several 1e-2 of the
+# outputs (the bf16-operand oracle against the fp32 oracle shows the same distance, no kernel involved -- recorded
+# as "*_oracle_bf16_vs_fp32").
+BF16_E2E_SANITY = 2e-1
 
 
 def out_tol(mode):
-    return {"bf16": BF16_OUT, "bf16x3": 5e-4}.get(mode, TOL_OUT)
+    return {"bf16": BF16_E2E_SANITY, "bf16x3": 5e-4}.get(mode, TOL_OUT)
 
 
 def _record(**kw):
@@ -227,11 +234,222 @@ def test_preset_eval_forward_matches_oracle(dev, preset, gemm_mode):
                                           bt["frame_positions"], bt["input_lengths"])
         finally:
             O.set_operand_rounding(None)
-        for g, w, n in zip(got, want_bf, ("mel", "linear", "alignments", "done")):
+        for g, w, w32, n in zip(got, want_bf, want, ("mel", "linear", "alignments", "done")):
             errs[n + "_vs_bf16_oracle"] = rel_err(g.cpu(), w)
+            errs[n + "_oracle_bf16_vs_fp32"] = rel_err(w, w32)
     _record(test="eval_forward", preset=preset, gemm=gemm_mode, **errs)
     for n, e in errs.items():
-        assert e < (BF16_OUT_SAME_ROUNDING if n.endswith("_vs_bf16_oracle") else tol), (n, e)
+        assert e < tol, (n, e)
+
+
+def _bf16_ulp(t):
+    """spacing of bf16 numbers at |t| (8 significand bits): 2^(floor(log2|t|) - 7)"""
+    a = t.abs().double().clamp_min(2.0 ** -120)
+    return torch.pow(2.0, torch.floor(torch.log2(a)) - 7.0)
+
+
+def _hip_bf16_weight(ops, v, g, Cg):
+    """the bf16 weights the HIP layer multiplies with, read back from the operand image dv3_weight_norm_split_pack_bf16
+    writes: [plane hi][tap][k/8][column][8 k], gate rows' columns from a_half (include/dv3hip.h).  (O, I, k) fp32."""
+    O_, I = v.shape[0], v.shape[1]
+    k = v.shape[2] if v.dim() == 3 else 1
+    pk = ops.pack_weights(v.detach(), g.detach(), glu_cg=Cg, need_bwd=False, split_only=True)
+    kp = (I + 31) // 32 * 32
+    img = pk.fwd_s.view(torch.bfloat16)[: k * kp * pk.lda].view(k, kp // 8, pk.lda, 8).float().cpu()
+    cols = torch.tensor([o if (Cg == 0 or o < Cg) else pk.a_half + (o - Cg) for o in range(O_)])
+    w = img[:, :, cols, :]                                  # (k, kp/8, O, 8)
+    return w.permute(2, 1, 3, 0).reshape(O_, kp, k)[:, :I, :].contiguous()
+
+
+def _layer_reference(ops, x, w, bias, spk, r, r2, cfg):
+    """One conv layer of the model in the bf16 mode's arithmetic, on the CPU: bf16 operands (x arrives as stored, w is
+    the HIP path's own), fp32 accumulate, fp32 tail, no final rounding.  The tails are the reference's:
+    Conv1dGLU._forward (modules.py:145-164), HighwayConv1d._forward (modules.py:197-226), Conv1d + ReLU / sigmoid,
+    AttentionLayer's and the decoder's `(x + residual) * sqrt(0.5)` (deepvoice3.py:175, 348-349)."""
+    import torch.nn.functional as F
+    h = float(np.sqrt(np.float32(0.5)))
+    k, d, T = cfg.k, cfg.dil, x.size(2)
+    padL = cfg.pad_left if cfg.pad_left is not None else ((k - 1) * d if cfg.causal else (k - 1) // 2 * d)
+    Tout = cfg.t_out if cfg.t_out is not None else T
+    padR = (Tout - 1) + d * (k - 1) - padL - (T - 1)
+    xr = x.to(torch.bfloat16).float()
+    y = F.conv1d(F.pad(xr, (padL, padR)), w, bias, dilation=d)
+    m = cfg.mode
+    if m in (ops.EPI_GLU, ops.EPI_HIGHWAY):
+        a, b = y.split(y.size(1) // 2, dim=1)
+        if m == ops.EPI_GLU:
+            if spk is not None:
+                a = a + (spk.unsqueeze(-1) if spk.dim() == 2 else spk)
+            y = a * torch.sigmoid(b)
+            return (y + x) * h if cfg.residual else y
+        t = torch.sigmoid(b)
+        return t * a + (1 - t) * x
+    if m == ops.EPI_RELU:
+        y = F.relu(y)
+    elif m == ops.EPI_SIGMOID:
+        y = torch.sigmoid(y)
+    elif m == ops.EPI_SOFTSIGN:
+        y = F.softsign(y)
+    if r is not None:
+        y = (y + r) * h
+    if r2 is not None:
+        y = (y + r2) * h
+    return y
+
+
+@pytest.mark.parametrize("preset", PRESET_NAMES)
+def test_preset_bf16_every_layer_pins_to_the_same_rounding_reference(dev, preset):
+    """The bf16 mode's parity gate.  A whole eval forward of the preset runs in the bf16 mode; EVERY conv / linear layer
+    launch of it (ops.conv_layer: all stacks, the projections, the speaker terms) is then re-evaluated on the CPU from
+    the tensors the HIP layer actually read -- its stored bf16 input, its own bf16 weights, its residual inputs -- in
+    the same arithmetic (bf16 operands, fp32 accumulate and tail), and the HIP output must be
+      * for a bf16-stored output: inside (1/2 + 1/16) ulp_bf16 of the reference value, i.e. the correct rounding of
+        it except where the fp32 values straddle a rounding boundary (counted: < 2 % of a layer, each by one ulp);
+      * for an fp32 output: within 2e-5 of the layer's output range (fp32 summation order).
+    Layer by layer with the HIP path's own inputs, because two bf16 evaluations of a DEEP stack cannot be compared
+    end to end: one stored value that rounds the other way moves ~3 % of the next layer's outputs across their own
+    boundaries (measured: 1.7 % of the values differ after the first gated layer, 70 % after ten), so every
+    whole-stack distance sits at the storage noise itself -- see test_preset_bf16_stacks_sit_at_the_storage_noise."""
+    from deepvoice3_pytorch_amd import builder, ops
+    bname, hp, _ = _preset(preset)
+    prev = ops.set_gemm_precision("bf16")
+    calls = []
+    orig = ops.conv_layer
+
+    def conv_layer(x, v, g, bias, cfg, spk=None, r=None, r2=None, packed=None):
+        y = orig(x, v, g, bias, cfg, spk=spk, r=r, r2=r2, packed=packed)
+        calls.append((x, v, g, bias, cfg, spk, r, r2, y))
+        return y
+    try:
+        torch.manual_seed(11)
+        model = getattr(builder, bname)(**hp).to(dev).eval()
+        bt, spk_ids = _batch(hp)
+        mel_ds = bt["mel"][:, 0::4, :].contiguous()
+        ops.conv_layer = conv_layer
+        try:
+            with torch.no_grad():
+                model(bt["text"].to(dev), mel_ds.to(dev), spk_ids.to(dev) if spk_ids is not None else None,
+                      bt["text_positions"].to(dev), bt["frame_positions"].to(dev), bt["input_lengths"])
+        finally:
+            ops.conv_layer = orig
+
+        def f32(t, C=None):
+            if t is None:
+                return None
+            return (ops.from_c8(t, C) if ops.is_c8(t) else t).detach().float().cpu()
+        n8 = n32 = tot = nflip = 0
+        worst8, worst32, skipped = 0.0, 0.0, 0
+        for (x, v, g, bias, cfg, spk, r, r2, y) in calls:
+            if cfg.transposed:          # ConvTranspose1d: fp32 layer between two conversions (2 per converter)
+                skipped += 1
+                continue
+            gated = cfg.mode in (ops.EPI_GLU, ops.EPI_HIGHWAY)
+            O_, I = v.shape[0], v.shape[1]
+            Co = O_ // 2 if gated else O_
+            w = _hip_bf16_weight(ops, v, g, O_ // 2 if gated else 0)
+            want = _layer_reference(ops, f32(x, I), w, f32(bias), f32(spk), f32(r, Co), f32(r2, Co), cfg).double()
+            got = f32(y, Co).double()
+            assert got.shape == want.shape, (tuple(got.shape), tuple(want.shape))
+            scale = float(want.abs().max())
+            if ops.is_c8(y):
+                ulp = _bf16_ulp(want)
+                slack = 2e-6 * scale
+                excess = float(((got - want).abs() - (0.5 + 1.0 / 16) * ulp - slack).max())
+                assert excess <= 0.0, ("layer %d leaves the half-ulp band by %.3e" % (n8 + n32, excess), tuple(v.shape))
+                flips = got != want.float().to(torch.bfloat16).double()
+                frac = float(flips.double().mean())
+                assert frac < 2e-2, (frac, tuple(v.shape), cfg.mode)
+                tot += flips.numel()
+                nflip += int(flips.sum())
+                big = want.abs() > 1e-2 * scale              # (near zero the 2e-6 * range slack is many ulps)
+                worst8 = max(worst8, float(((got - want).abs() / ulp)[big].max()))
+                n8 += 1
+            else:
+                e = float((got - want).abs().max()) / max(scale, 1e-30)
+                worst32 = max(worst32, e)
+                assert e < 2e-5, (e, tuple(v.shape), cfg.mode)
+                n32 += 1
+        _record(test="bf16_layer_pins", preset=preset, gemm="bf16", layers_bf16_out=n8, layers_fp32_out=n32,
+                transposed_skipped=skipped, stored_values=tot, boundary_flips=nflip,
+                worst_bf16_out_in_ulps=worst8, worst_fp32_out_rel=worst32)
+        assert n8 >= 10 and n32 >= 3, (n8, n32)
+    finally:
+        ops.set_gemm_precision(prev)
+
+
+def _rms(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("preset", PRESET_NAMES)
+def test_preset_bf16_stacks_sit_at_the_storage_noise(dev, preset):
+    """Whole stacks in the bf16 mode: encoder, decoder and converter each get the fp32 oracle's tensors as input (no
+    stack inherits another's error) and are compared, in rms, with the oracle run with bf16 operands AND bf16 stored
+    activations (O.set_operand_rounding("bf16", store=True): the same arithmetic layer for layer).  Bit-level
+    agreement is not available here (see the per-layer test), so the yardstick is the storage rounding's own
+    footprint: rms(HIP - storage oracle) must not exceed 1.5 x rms(storage oracle - fp32 oracle) for every output --
+    the HIP path is one more bf16 evaluation of the stack, not a worse one."""
+    import torch.nn.functional as F
+    from deepvoice3_pytorch_amd import builder, ops
+    bname, hp, _ = _preset(preset)
+    prev = ops.set_gemm_precision("bf16")
+    try:
+        torch.manual_seed(11)
+        model = getattr(builder, bname)(**hp).to(dev).eval()
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        spec = O.build_spec(bname, **hp)
+        bt, spk = _batch(hp)
+        mel_ds = bt["mel"][:, 0::4, :].contiguous()
+        B = mel_ds.size(0)
+        dv3 = spec.kind == "deepvoice3"
+        se = F.embedding(spk, sd["embed_speakers.weight"]) if spk is not None else None
+
+        def enc_f():
+            return O.dv3_encoder(sd, spec, bt["text"], se) if dv3 else O.ny_encoder(sd, spec, bt["text"])
+
+        def dec_f(enc):
+            if dv3:
+                return O.dv3_decoder(sd, spec, enc, mel_ds, bt["text_positions"], bt["frame_positions"], se,
+                                     bt["input_lengths"])
+            return O.ny_decoder(sd, spec, enc, mel_ds, bt["text_positions"], bt["frame_positions"],
+                                bt["input_lengths"])
+
+        def post_f(x):
+            return O.dv3_converter(sd, spec, x, se) if dv3 else O.ny_converter(sd, spec, x)
+        with torch.no_grad():
+            enc32 = enc_f()
+            dec32 = dec_f(enc32)
+            Tm = dec32[0].reshape(B, -1, spec.mel_dim).size(1)
+            post32 = dec32[3].reshape(B, Tm, -1) if spec.use_decoder_state_for_postnet_input else \
+                dec32[0].reshape(B, Tm, spec.mel_dim)
+            lin32 = post_f(post32)
+            O.set_operand_rounding("bf16", store=True)
+            try:
+                enc_w = enc_f()
+                dec_w = dec_f(enc32)
+                post_w = post_f(post32)
+            finally:
+                O.set_operand_rounding(None)
+            sed = se.to(dev) if se is not None else None
+            enc_g = model.seq2seq.encoder(bt["text"].to(dev), lengths=bt["input_lengths"], speaker_embed=sed)
+            dec_g = model.seq2seq.decoder(tuple(e.to(dev) for e in enc32), mel_ds.to(dev),
+                                          text_positions=bt["text_positions"].to(dev),
+                                          frame_positions=bt["frame_positions"].to(dev), speaker_embed=sed,
+                                          lengths=bt["input_lengths"])
+            post_g = model.postnet(post32.to(dev), sed)
+        trip = {"encoder_keys": (enc_g[0], enc_w[0], enc32[0]), "encoder_values": (enc_g[1], enc_w[1], enc32[1]),
+                "decoder_mel": (dec_g[0], dec_w[0], dec32[0]), "alignments": (dec_g[1], dec_w[1], dec32[1]),
+                "decoder_done": (dec_g[2], dec_w[2], dec32[2]), "decoder_states": (dec_g[3], dec_w[3], dec32[3]),
+                "converter_linear": (post_g, post_w, lin32)}
+        errs = {n: _rms(g.cpu(), w) for n, (g, w, _) in trip.items()}
+        noise = {n: _rms(w, w32) for n, (_, w, w32) in trip.items()}
+        _record(test="bf16_stacks", preset=preset, gemm="bf16", rms_hip_vs_storage_oracle=errs,
+                rms_storage_oracle_vs_fp32=noise)
+        for n in errs:
+            assert errs[n] <= 1.5 * noise[n] + 1e-6, (n, errs[n], noise[n])
+    finally:
+        ops.set_gemm_precision(prev)
 
 
 @pytest.mark.parametrize("preset", PRESET_NAMES)
