@@ -549,15 +549,21 @@ class TrainRun(object):
                                                    bt["text_positions"], bt["frame_positions"], bt["done"],
                                                    bt["target_lengths"], self.spk, downsample_step=4, device=dev)
         self.trainer.check_lengths(self.batch)
-        # Launch mode.  The step is ~390 kernel launches.  Eager launches are the default: the host enqueues them in
-        # less time than the GPU needs, and only eager launches let the weight-gradient branch of backward
-        # (ops.SideStream) and the RCCL buckets overlap the input-gradient chain on their own streams -- a replayed
-        # hipGraph measured 3-5 % SLOWER than eager launches at the north-star batch (its branches are not run
-        # concurrently and a replay costs the host as much as the launches; profiles/r03_side_stream_ab.txt).
-        # --graph captures the whole step (forward, losses, backward, RCCL buckets, clip + Adam) as ONE hipGraph.
-        self.use_graph = bool(graph)
+        # Launch mode.  The step is ~300-390 kernel launches.  A replayed whole-step hipGraph (forward, losses,
+        # backward, RCCL buckets, clip + Adam captured once) costs the host 1.5-3 ms per step against 7-10 ms of
+        # Python + ctypes for eager launches, but the graph executor overlaps the weight-gradient branch of backward
+        # (ops.SideStream) with the input-gradient chain less well than two real streams do.  Which one wins depends
+        # on the configuration (measured: eager 15.5 vs graph 16.3 ms at the north-star f16x3 step, graph 12.3 vs
+        # eager 13.1 ms for nyanko bf16; scripts/graph_host_cost.py), so the default PROBES both for a few steps and
+        # keeps the faster; --graph / --no-graph force one.  All ranks take the same decision (MAX over ranks).
         self.runner = None
+        self.use_graph = False
         self.graph_error = None
+        self.launch_probe = None
+        t_eager = None
+        if graph == "auto":
+            t_eager = self._probe(4)
+        self.use_graph = bool(graph)
         if self.use_graph:
             ok = 1
             try:
@@ -578,6 +584,28 @@ class TrainRun(object):
                 if self.runner is not None:
                     self.runner.close()
                 self.runner, self.use_graph = None, False
+        if graph == "auto" and self.use_graph:
+            t_graph = self._probe(4)
+            self.launch_probe = dict(eager_ms_per_step=round(t_eager, 3), hipgraph_ms_per_step=round(t_graph, 3), steps=4)
+            if t_graph > 0.995 * t_eager:       # no gain: keep the two real streams
+                self.runner.close()
+                self.runner, self.use_graph = None, False
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+
+    def _probe(self, n):
+        """ms per step of the current launch mode over n steps (after 2 untimed ones), MAX over ranks"""
+        for _ in range(2):
+            self.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            self.step()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / n * 1e3], dtype=torch.float64, device=self.dev)
+        if self.pg is not None:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
 
     def step(self, batch=None):
         if self.use_graph:
@@ -620,6 +648,19 @@ class TrainRun(object):
             torch.distributed.barrier()
         dt = time.perf_counter() - t0
         power = sampler.stop() if sampler is not None else None
+        # Host time to issue ONE step into an idle queue.  (t_host above also contains back-pressure: once the host
+        # is a few steps ahead the runtime makes it wait -- a replayed hipGraph cannot be launched again while it is
+        # in flight, and eager launches block when the queue's kernarg ring is full -- so over a long loop it
+        # converges to the GPU's step time whatever the host really costs.)
+        t_issue = 0.0
+        for _ in range(3):
+            torch.cuda.synchronize()
+            if pg is not None:
+                torch.distributed.barrier()
+            h0 = time.perf_counter()
+            scal = self.step(nxt())
+            t_issue += time.perf_counter() - h0
+        torch.cuda.synchronize()
         exposed = comm.exposed_ms() if (comm is not None and comm.exposed_events is not None) else None
         if comm is not None:
             comm.exposed_events = None
@@ -636,7 +677,8 @@ class TrainRun(object):
         value = float(frames.item()) / (dt / steps)
         tf = MFLOP_PER_FRAME[self.preset] * 1e6 * value / 1e12
         return dict(value=round(value, 1), ms_per_step=round(ms, 3), steps=steps, warmup=warmup,
-                    host_enqueue_ms_per_step=round(t_host / steps * 1e3, 3), allreduce_exposed_ms=exposed, power=power,
+                    host_enqueue_ms_per_step=round(t_issue / 3 * 1e3, 3),
+                    host_loop_ms_per_step=round(t_host / steps * 1e3, 3), allreduce_exposed_ms=exposed, power=power,
                     final_loss=round(loss, 5), frames_per_step=float(frames.item()),
                     step_flop_frac=dict(alg_mflop_per_frame=MFLOP_PER_FRAME[self.preset], achieved_tflops=round(tf, 1),
                                         peak=round(mfma_peak_tf(self.gemm), 1),
@@ -653,12 +695,19 @@ class TrainRun(object):
         torch.cuda.empty_cache()
 
 
+def launch_mode(args):
+    """--graph / --no-graph force the launch mode; the default probes both (TrainRun)"""
+    if args.no_graph:
+        return False
+    return True if args.graph else "auto"
+
+
 def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup):
     run = TrainRun(dev, pg, rank, world, preset, gemm, args.batch, args.text_len, args.frames,
-                   graph=bool(args.graph) and not args.no_graph)
+                   graph=launch_mode(args))
     try:
         m = run.measure(steps, warmup)
-        used_graph = bool(run.use_graph)
+        used_graph, probe = bool(run.use_graph), run.launch_probe
     finally:
         run.close()
     return dict(metric="mel-frames/sec/node (train step, %s)" % preset, value=m["value"], unit="mel-frames/s",
@@ -666,7 +715,9 @@ def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup):
                 dtype_note=dtype_note(gemm), step_flop_frac=m["step_flop_frac"],
                 config=dict(workload="builder=%s preset=%s train step" % (PRESETS[preset][0], preset),
                             per_gpu_batch=args.batch, global_batch=args.batch * world, final_loss=m["final_loss"],
-                            hipgraph=used_graph, host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"],
+                            hipgraph=used_graph, launch_probe=probe,
+                            host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"],
+                            host_loop_ms_per_step=m["host_loop_ms_per_step"],
                             launch_bound=bool(m["host_enqueue_ms_per_step"] > 0.97 * m["ms_per_step"]),
                             allreduce_exposed_ms=m["allreduce_exposed_ms"]))
 
@@ -757,7 +808,7 @@ def main():
                     help="GEMM arithmetic (default: DV3_GEMM or f16x3)")
     ap.add_argument("--text-len", type=int, default=150)
     ap.add_argument("--frames", type=int, default=800)
-    ap.add_argument("--no-graph", action="store_true", help="(default) eager launches")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches (default: probe both, keep the faster)")
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one hipGraph")
     ap.add_argument("--settle", type=float, default=1.0,
                     help="seconds of untimed steps before --warmup (clock governor settle time; 0 = none)")
@@ -814,8 +865,7 @@ def main():
                               roofline=rf, roofline_wgrad=wgrad_roofline(dev))))
         return
 
-    graph = bool(args.graph) and not args.no_graph
-    run = TrainRun(dev, pg, rank, world, args.preset, gemm, args.batch, args.text_len, args.frames, graph)
+    run = TrainRun(dev, pg, rank, world, args.preset, gemm, args.batch, args.text_len, args.frames, launch_mode(args))
     m = run.measure(args.steps, args.warmup, settle_s=args.settle)
     m_eager = None
     if run.use_graph and not args.no_extras:
@@ -837,8 +887,13 @@ def main():
                                         "(fwd+losses+bwd+clip+Adam), synthetic LJSpeech-shaped batches" % (run.bname, args.preset),
                                per_gpu_batch=args.batch, global_batch=args.batch * world, text_len=args.text_len,
                                frames_per_item=args.frames, parallelism="dp%d" % world,
-                               hipgraph=bool(run.use_graph), gemm=gemm, final_loss=m["final_loss"],
+                               hipgraph=bool(run.use_graph), launch_probe=run.launch_probe, gemm=gemm,
+                               final_loss=m["final_loss"],
                                host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"],
+                               host_loop_ms_per_step=m["host_loop_ms_per_step"],
+                               host_enqueue_note="time to issue one step into an idle queue (synchronize, then time the "
+                                                 "issue); host_loop = host time per step inside the timed loop, which "
+                                                 "includes the runtime's back-pressure once the host runs ahead",
                                launch_bound=bool(m["host_enqueue_ms_per_step"] > 0.97 * m["ms_per_step"]),
                                settle_s=args.settle),
                    step_flop_frac=m["step_flop_frac"])

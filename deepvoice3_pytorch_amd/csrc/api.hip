@@ -45,6 +45,26 @@ extern "C" int dv3_f16_range_events(int32_t* dst, int32_t reset, void* stream) {
   }
   return DV3_OK;
 }
+extern "C" int dv3_stream_fork(void* from, void* to) {
+  static hipEvent_t ring[256];
+  static unsigned next = 0, made = 0;
+  const unsigned i = next++ % 256u;
+  if (i >= made) {
+    hipError_t e = hipEventCreateWithFlags(&ring[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+      dv3_set_error("stream_fork: hipEventCreate: %s", hipGetErrorString(e));
+      return DV3_ELAUNCH;
+    }
+    made = i + 1;
+  }
+  hipError_t e = hipEventRecord(ring[i], (hipStream_t)from);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)to, ring[i], 0);
+  if (e != hipSuccess) {
+    dv3_set_error("stream_fork: %s", hipGetErrorString(e));
+    return DV3_ELAUNCH;
+  }
+  return DV3_OK;
+}
 extern "C" int dv3_debug_get(int what) {
   if (what == 10) return g_dv3_last_conv;
   if (what == 11) return g_dv3_last_wgrad;
@@ -84,6 +104,8 @@ extern "C" int dv3_sizeof(const char* name) {
   DV3_SZ(dv3_wn_multi_entry);
   DV3_SZ(dv3_conv_step_desc);
   DV3_SZ(dv3_attn_step_desc);
+  DV3_SZ(dv3_decode_entry);
+  DV3_SZ(dv3_decode_program);
   DV3_SZ(dv3_attn_fwd_desc);
 #undef DV3_SZ
   return -1;

@@ -4,9 +4,12 @@
 A decoder step of the reference (deepvoice3.py:397-461, nyanko.py:283-321) is ~100 tiny module calls; here it is a
 flat list of descriptors built ONCE per utterance batch -- one dv3_conv_step_f32 per conv / projection layer (ring
 buffer on a device step counter, k-tap GEMV, the whole layer tail) and one dv3_attn_step_f32 per attention read --
-that the host replays per step (optionally as one hipGraph).  `StepProgram` owns the buffers the descriptors point at.
+that is either walked by ONE persistent launch for the whole utterance (dv3_decode_program_run: the loop, the ring
+buffers, the stop rule and the layer-to-layer hand-over all stay on the device) or replayed by the host launch by
+launch (optionally as one hipGraph per step).  `StepProgram` owns the buffers the descriptors point at.
 """
 import ctypes
+import os
 
 import torch
 
@@ -89,10 +92,64 @@ class StepProgram(object):
             ops._lib.call(name, ctypes.byref(d), s)
         self.t_dev.add_(1)
 
-    def decode(self, cur_in, test_inputs, dones_seq, min_steps, max_steps, use_graph):
+    def decode_persistent(self, cur_in, test_inputs, dones_seq, min_steps, max_steps):
+        """the whole loop as one launch of the persistent program kernel (include/dv3hip.h: dv3_decode_program_run)
+        -> number of steps taken"""
+        B, dev = self.B, self.dev
+        free_running = test_inputs is None
+        Entry, Prog = STRUCTS["dv3_decode_entry"], STRUCTS["dv3_decode_program"]
+        arr = (Entry * len(self.prog))()
+        ti = None
+        if not free_running:
+            ti = test_inputs.to(torch.float32).reshape(B, test_inputs.size(1), -1).contiguous()
+            if ti.size(2) != cur_in.size(1):
+                raise RuntimeError("decode program: test_inputs frames carry %d values, the decoder input %d" % (
+                    ti.size(2), cur_in.size(1)))
+            self.keep.append(ti)
+        fed = 0
+        for i, (name, d) in enumerate(self.prog):
+            if name == "dv3_conv_step_f32":
+                arr[i].kind = 0
+                arr[i].conv = d
+                if ti is not None and d.x == cur_in.data_ptr():     # teacher forcing: frame t of test_inputs
+                    arr[i].conv.x, arr[i].conv.x_bs, arr[i].conv.x_ts = ti.data_ptr(), ti.stride(0), ti.stride(1)
+                    fed += 1
+            else:
+                arr[i].kind = 1
+                arr[i].attn = d
+        if ti is not None and fed == 0:
+            raise RuntimeError("decode program: no entry reads the decoder input buffer")
+        host = bytearray(bytes(arr))
+        entries = torch.frombuffer(host, dtype=torch.uint8).to(dev)
+        n_sync = ops._lib.lib().dv3_decode_program_sync_ints(B)
+        sync = torch.empty(n_sync, dtype=torch.int32, device=dev)
+        steps_out = torch.zeros(1, dtype=torch.int32, device=dev)
+        p = Prog()
+        p.entries = entries.data_ptr()
+        p.entries_host = ctypes.addressof(arr)
+        p.n_entries, p.B = len(self.prog), B
+        p.t0 = 0
+        p.n_steps = ti.size(1) if ti is not None else max_steps + 1
+        if free_running:
+            p.done_seq, p.done_ts = dones_seq.data_ptr(), dones_seq.stride(0)
+        p.min_steps, p.max_steps = min_steps, max_steps
+        p.sync, p.steps_out = sync.data_ptr(), steps_out.data_ptr()
+        ops._lib.call("dv3_decode_program_run", ctypes.byref(p), ops._stream())
+        t = int(steps_out.item())
+        if t < 0:
+            raise RuntimeError("decode program: a device barrier timed out (the persistent grid was not co-resident?)")
+        self.t_dev.fill_(t)
+        return t
+
+    def decode(self, cur_in, test_inputs, dones_seq, min_steps, max_steps, use_graph, persistent=None):
         """the decoder loop (deepvoice3.py:397-473 / nyanko.py:277-331): teacher-forced over test_inputs (B, n, D), or
         free running until every item's done flag passed 0.5 after min_steps, at most max_steps + 1 steps.
-        -> number of steps taken"""
+        -> number of steps taken.  persistent (default; DV3_DECODE_PERSISTENT=0 turns it off): one launch for the
+        whole loop; else one launch per program entry per step, optionally replayed as a per-step hipGraph."""
+        if persistent is None:
+            persistent = os.environ.get("DV3_DECODE_PERSISTENT", "1") != "0"
+        if persistent:
+            return self.decode_persistent(cur_in, test_inputs, dones_seq, min_steps, max_steps)
         free_running = test_inputs is None
         B = self.B
         graphed = bool(use_graph) and free_running

@@ -518,17 +518,15 @@ class Decoder(nn.Module):
     # -- the same decode on the fused step kernels (csrc/decode_step.hip) -------------------------------
     def _incremental_fast(self, encoder_out, text_positions, speaker_embed=None, initial_input=None,
                           test_inputs=None):
-        """incremental_forward with one dv3_conv_step_f32 launch per conv / projection layer and one
-        dv3_attn_step_f32 per attention read (17 launches per step for the ljspeech preset instead of ~100):
-        ring buffers indexed by a device step counter (no window shifting), every layer tail fused, the per-step
+        """incremental_forward as a flat per-step program (decode_program.StepProgram): one conv-step entry per conv /
+        projection layer and one attention-step entry per attention read (17 per step for the ljspeech preset instead
+        of ~100 module calls), walked by ONE persistent launch for the whole utterance (or launch by launch):
+        ring buffers indexed by the step counter (no window shifting), every layer tail fused, the per-step
         outputs written straight into the stacked result tensors.  Same quirks as the module-by-module path
         (last_attended from batch item 0, no padding mask, `ave_alignment + ave_alignment`)."""
-        import ctypes
-        from ._lib import STRUCTS
-        cdesc, adesc = STRUCTS["dv3_conv_step_desc"], STRUCTS["dv3_attn_step_desc"]
+        from .decode_program import StepProgram
         keys, values = encoder_out
         B, dev = keys.size(0), keys.device
-        f32 = dict(dtype=torch.float32, device=dev)
         with torch.no_grad():
             w = self._rate(self.key_position_rate, self.speaker_proj1, speaker_embed)
             keys_bct = self.embed_keys_positions.forward_bct(text_positions, w, base=keys.transpose(1, 2).contiguous())
@@ -547,59 +545,23 @@ class Decoder(nn.Module):
             wq = self._rate(self.query_position_rate, self.speaker_proj2, speaker_embed)
             pos = torch.arange(1, n_max + 1, device=dev, dtype=torch.long)[None].expand(B, n_max).contiguous()
             pe_all = self.embed_query_positions.forward_bct(pos, wq).permute(2, 0, 1).contiguous()   # (n_max, B, C)
-            t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-            cur_in = (initial_input.reshape(B, D).clone().float() if initial_input is not None
-                      else torch.zeros(B, D, **f32))
+            P = StepProgram(B, dev)
+            cur_in = (initial_input.reshape(B, D).clone().float() if initial_input is not None else P.buffer(B, D))
             free_running = test_inputs is None
-            nxt_in = cur_in if free_running else torch.empty(B, D, **f32)
+            nxt_in = cur_in if free_running else P.buffer(B, D)
             n_att = sum(1 for a in self.attention if a is not None)
             Cs = self.convolutions[-1].conv.out_channels // 2
-            outs = torch.zeros(n_max, B, D, **f32)
-            dones_seq = torch.zeros(n_max, B, 1, **f32)
-            states = torch.zeros(n_max, B, Cs, **f32)
-            aligns = torch.zeros(n_max, B, Tk, **f32)
-            keep, prog = [keys_bct, values_bct, proj, pe_all, t_dev, cur_in, nxt_in, outs, dones_seq, states, aligns], []
-
-            def conv_step(layer, x, mode, Cout, k=1, dil=1, gated=False, residual=False, spk=None, r=None, r2=None,
-                          post_add=None, y_act=None, out_seq=None):
-                pk = layer.packed(glu_cg=Cout if gated else 0)
-                y = torch.empty(B, Cout, **f32)
-                d = cdesc()
-                d.x, d.x_bs = x.data_ptr(), x.stride(0)
-                if k > 1:
-                    L = (k - 1) * dil + 1
-                    ring = torch.zeros(L, B, x.size(1), **f32)
-                    keep.append(ring)
-                    d.ring, d.L = ring.data_ptr(), L
-                d.t = t_dev.data_ptr()
-                d.a, d.lda, d.a_half = pk.fwd.data_ptr(), pk.lda, pk.a_half
-                d.bias = layer.bias.data_ptr() if layer.bias is not None else None
-                if spk is not None:
-                    d.spk, d.spk_bs = spk.data_ptr(), spk.stride(0)
-                if r is not None:
-                    d.r, d.r_bs = r.data_ptr(), r.stride(0)
-                if r2 is not None:
-                    d.r2, d.r2_bs = r2.data_ptr(), r2.stride(0)
-                if post_add is not None:
-                    d.post_add, d.post_add_ts, d.post_add_bs = post_add.data_ptr(), post_add.stride(0), post_add.stride(1)
-                d.y, d.y_bs = y.data_ptr(), y.stride(0)
-                if y_act is not None:
-                    d.y_act, d.y_act_bs = y_act.data_ptr(), y_act.stride(0)
-                if out_seq is not None:
-                    d.out_seq, d.out_seq_ts, d.out_seq_bs = out_seq.data_ptr(), out_seq.stride(0), out_seq.stride(1)
-                d.B, d.Cin, d.M = B, x.size(1), (2 * Cout if gated else Cout)
-                d.Cg, d.J, d.dil, d.mode, d.residual = (Cout if gated else 0), k, dil, mode, int(residual)
-                keep.extend([pk, y, spk])
-                prog.append(("dv3_conv_step_f32", d))
-                return y
+            outs, dones_seq = P.buffer(n_max, B, D), P.buffer(n_max, B, 1)
+            states, aligns = P.buffer(n_max, B, Cs), P.buffer(n_max, B, Tk)
+            P.keep.extend([keys_bct, values_bct, proj, pe_all, cur_in, nxt_in])
 
             def glu_step(f, x, residual, **kw):
                 spk = None
                 if f.speaker_proj is not None:
                     se = speaker_embed if speaker_embed.dim() == 2 else speaker_embed[:, 0, :]
                     spk = f.speaker_bias(se).contiguous()
-                return conv_step(f.conv, x, ops.EPI_GLU, f.conv.out_channels // 2, k=f.conv.kernel_size[0],
-                                 dil=f.conv.dilation[0], gated=True, residual=residual, spk=spk, **kw)
+                return P.conv_step(f.conv, x, ops.EPI_GLU, f.conv.out_channels // 2, k=f.conv.kernel_size[0],
+                                   dil=f.conv.dilation[0], gated=True, residual=residual, spk=spk, **kw)
 
             # ---- the step program (deepvoice3.py:397-461) ----
             x = cur_in
@@ -612,12 +574,12 @@ class Decoder(nn.Module):
                     relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                     if f.kernel_size[0] != 1:
                         raise RuntimeError("fast decode: only 1x1 plain convolutions in the pre-attention stack")
-                    x = conv_step(f, x, ops.EPI_RELU if relu else ops.EPI_LINEAR, f.out_channels)
+                    x = P.conv_step(f, x, ops.EPI_RELU if relu else ops.EPI_LINEAR, f.out_channels)
                     i += int(relu)
                 else:
                     raise RuntimeError("fast decode: unsupported pre-attention module %r" % type(f))
                 i += 1
-            last_att, first_att = [], True
+            first_att = True
             n_conv = len(self.convolutions)
             for idx, (f, attention) in enumerate(zip(self.convolutions, self.attention)):
                 residual = x
@@ -627,55 +589,17 @@ class Decoder(nn.Module):
                     continue
                 xq = glu_step(f, x, f.residual, post_add=pe_all)              # conv output + the step's position code
                 kp, vp = proj[idx]
-                q = conv_step(attention.query_projection, xq, ops.EPI_LINEAR, attention.query_projection.out_features)
-                ctx = torch.empty(B, kp.size(1), **f32)
-                la = None
-                if self.force_monotonic_attention[idx]:
-                    la = torch.zeros(2, dtype=torch.int32, device=dev)
-                    last_att.append(la)
-                a = adesc()
-                a.q, a.q_bs, a.k, a.v = q.data_ptr(), q.stride(0), kp.data_ptr(), vp.data_ptr()
-                a.last_attended = la.data_ptr() if la is not None else None
-                a.win_back, a.win_ahead, a.t = attention.window_backward, attention.window_ahead, t_dev.data_ptr()
-                a.ctx, a.ctx_bs = ctx.data_ptr(), ctx.stride(0)
-                if first_att:      # ave_alignment = the FIRST layer's alignment * 2^(n-1)/n (the reference's `ave + ave`)
-                    a.attn_seq, a.attn_seq_ts = aligns.data_ptr(), aligns.stride(0)
-                    first_att = False
-                a.B, a.E, a.Tk = B, kp.size(1), Tk
-                keep.extend([ctx, la])
-                prog.append(("dv3_attn_step_f32", a))
-                x = conv_step(attention.out_projection, ctx, ops.EPI_LINEAR, attention.out_projection.out_features,
-                              r=xq, r2=residual, out_seq=st)
-            pre = conv_step(self.last_conv, x, ops.EPI_LINEAR, D, y_act=nxt_in, out_seq=outs)
-            conv_step(self.fc, pre, ops.EPI_SIGMOID, 1, out_seq=dones_seq)
-
-            def run_step():
-                s = ops._stream()
-                for name, d in prog:
-                    ops._lib.call(name, ctypes.byref(d), s)
-                t_dev.add_(1)
-
-            graphed = bool(getattr(self, "use_step_graph", False)) and free_running
-            graph, t = None, 0
-            while True:
-                if not free_running:
-                    if t >= test_inputs.size(1):
-                        break
-                    cur_in.copy_(test_inputs[:, t, :].reshape(B, D))
-                if graphed and t >= 1:
-                    if graph is None:
-                        graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(graph):
-                            run_step()
-                    graph.replay()
-                else:
-                    run_step()
-                t += 1
-                if free_running:
-                    if t > self.min_decoder_steps and bool((dones_seq[t - 1] > 0.5).all()):
-                        break
-                    elif t > self.max_decoder_steps:
-                        break
+                q = P.conv_step(attention.query_projection, xq, ops.EPI_LINEAR, attention.query_projection.out_features)
+                # ave_alignment = the FIRST layer's alignment * 2^(n-1)/n (the reference's `ave + ave`)
+                ctx = P.attn_step(q, kp, vp, attention.window_backward, attention.window_ahead,
+                                  self.force_monotonic_attention[idx], attn_seq=aligns if first_att else None)
+                first_att = False
+                x = P.conv_step(attention.out_projection, ctx, ops.EPI_LINEAR, attention.out_projection.out_features,
+                                r=xq, r2=residual, out_seq=st)
+            pre = P.conv_step(self.last_conv, x, ops.EPI_LINEAR, D, y_act=nxt_in, out_seq=outs)
+            P.conv_step(self.fc, pre, ops.EPI_SIGMOID, 1, out_seq=dones_seq)
+            t = P.decode(cur_in, test_inputs, dones_seq, self.min_decoder_steps, self.max_decoder_steps,
+                         getattr(self, "use_step_graph", False), getattr(self, "persistent_decode", None))
             scale = float(2 ** (n_att - 1)) / n_att if n_att else 1.0
             alignments = aligns[:t].transpose(0, 1)
             if scale != 1.0:

@@ -10,6 +10,7 @@ contiguous -- the layout of the reference conv stacks (deepvoice3_pytorch/module
 """
 import contextlib
 import ctypes
+import functools
 import math
 
 import torch
@@ -747,6 +748,7 @@ def axpby(a, b, alpha):
     return out
 
 
+@functools.lru_cache(maxsize=None)
 def _ksplit_count(total_steps, tiles, slots=512, min_steps=8):
     """Split-K factor for the bf16x3 wgrad: the grid (tiles x S workgroups) should fill the chip's
     2 x 256 workgroup slots a whole number of times, with at least `min_steps` K steps each."""
@@ -764,6 +766,7 @@ def _ksplit_count(total_steps, tiles, slots=512, min_steps=8):
     return best
 
 
+@functools.lru_cache(maxsize=None)
 def _slab_count(B, tiles):
     """Split-K factor for wgrad: enough blocks to fill 256 CUs ~2x, at most B."""
     want = max(1, (512 + tiles - 1) // tiles)
@@ -809,7 +812,6 @@ class SideStream(object):
     stream = None          # torch.cuda.Stream while a trainer runs a step, else None (everything on one stream)
     main = None            # the step stream while `stream` is set
     keep = []
-    _events, _next = [], 0
 
     class _Section(object):
         """`with` body = launches on the side stream.  Only this package's launches are redirected (ops._stream());
@@ -828,14 +830,10 @@ class SideStream(object):
 
     @classmethod
     def fork(cls, *tensors):
-        if len(cls._events) < 64:
-            cls._events.append(torch.cuda.Event())
-        ev = cls._events[cls._next % len(cls._events)]
-        cls._next += 1
-        ev.record()                                  # on the step stream: the section's inputs are complete
-        cls.stream.wait_event(ev)
+        # the section's inputs are complete on the step stream: the side stream waits for exactly that point
+        _lib.call("dv3_stream_fork", cls.main.cuda_stream, cls.stream.cuda_stream)
         cls.keep.append(tensors)
-        return cls._Section()
+        return cls._section
 
     @classmethod
     def retain(cls, *tensors):
@@ -844,8 +842,11 @@ class SideStream(object):
     @classmethod
     def join(cls):
         if cls.stream is not None:
-            torch.cuda.current_stream().wait_stream(cls.stream)
+            _lib.call("dv3_stream_fork", cls.stream.cuda_stream, cls.main.cuda_stream)
         cls.keep = []
+
+
+SideStream._section = SideStream._Section()
 
 
 class ConvLayerFn(torch.autograd.Function):

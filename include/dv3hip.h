@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 30
+#define DV3_ABI_VERSION 31
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -204,6 +204,13 @@ int dv3_mask_bits_to_c8(const uint32_t* bits, int32_t bits_rs, uint8_t* out, int
  * Replaces: nothing in the reference (its fp32 kernels have the range of fp32); deepvoice3_pytorch/modules.py:145-164
  * is the computation guarded. */
 int dv3_f16_range_events(int32_t* dst, int32_t reset, void* stream);
+
+/* Order two HIP streams: everything enqueued on `to` after this call waits for everything enqueued on `from` before
+ * it (hipEventRecord on `from` + hipStreamWaitEvent on `to`, with an event from a ring the library owns; inside a
+ * stream capture the pair becomes a graph dependency).  The host-side step uses it to fork the weight-gradient
+ * branch of backward onto its own stream and to join it again (ops.SideStream) in one call instead of two torch
+ * event calls per layer.  Replaces: nothing in the reference (single stream; train.py:755 loss.backward()). */
+int dv3_stream_fork(void* from, void* to);
 
 #define DV3_SPLIT_DTYPE_BF16 0
 #define DV3_SPLIT_DTYPE_F16 1
@@ -535,6 +542,8 @@ typedef struct dv3_conv_step_desc {
   int32_t B, Cin, M, Cg, J, dil, mode, residual;
   float* y_pre; int64_t y_pre_bs;            /* optional: the layer output BEFORE post_add (nyanko.py:297-300: Q feeds the
                                                 concat while Q + position code feeds the attention query)            */
+  int64_t x_ts;                              /* the new frame of step t is x + t*x_ts (teacher forcing: x = test_inputs,
+                                                deepvoice3.py:411-415); 0 = the same buffer every step               */
 } dv3_conv_step_desc;
 int dv3_conv_step_f32(const dv3_conv_step_desc* d, void* stream);
 
@@ -550,6 +559,39 @@ typedef struct dv3_attn_step_desc {
   int32_t B, E, Tk;
 } dv3_attn_step_desc;
 int dv3_attn_step_f32(const dv3_attn_step_desc* d, void* stream);
+
+/* The whole decoder loop in ONE launch (Decoder.incremental_forward's `while True`, deepvoice3.py:397-473;
+ * nyanko.py:277-331).  `entries` is the per-step launch program -- the same descriptors dv3_conv_step_f32 /
+ * dv3_attn_step_f32 take, in execution order, in DEVICE memory; their `t` pointers are ignored (the step index is the
+ * kernel's loop variable).  A persistent grid of ceil(B/4) batch groups x wg_per_group workgroups walks the program:
+ * the workgroups of one batch group share an entry's output-channel blocks and meet at a group barrier after every
+ * entry (the activations of 4 batch items never leave their group); all groups meet once per step, where the stop
+ * rule of the reference is evaluated on the device:
+ *     steps = t + 1;  stop if (done_seq != NULL and steps > min_steps and done_seq[t][b] > 0.5 for all b)
+ *                     or steps > max_steps                       (deepvoice3.py:463-470; without done_seq: n_steps)
+ * The number of steps executed is stored in steps_out.  `sync` is device scratch of dv3_decode_program_sync_ints(B)
+ * int32 that the call zeroes first.  The grid must be co-resident (it is at most 256 workgroups of 256 threads).
+ * A barrier that does not complete in ~2 s of spinning sets steps_out to -1 and the kernel exits. */
+typedef struct dv3_decode_entry {
+  int32_t kind;                              /* 0: conv step, 1: attention step */
+  int32_t reserved;
+  dv3_conv_step_desc conv;
+  dv3_attn_step_desc attn;
+} dv3_decode_entry;
+typedef struct dv3_decode_program {
+  const dv3_decode_entry* entries;           /* device */
+  const dv3_decode_entry* entries_host;      /* the host copy `entries` was uploaded from: validated by the call */
+  int32_t n_entries, B;
+  int32_t t0, n_steps;                       /* steps t0 .. t0 + n_steps - 1 at most */
+  const float* done_seq; int64_t done_ts;    /* [t][b] done flags the program writes, or NULL */
+  int32_t min_steps, max_steps;
+  int32_t* sync;
+  int32_t* steps_out;                        /* device int: steps executed in this call */
+  int32_t wg_per_group;                      /* 0 = library default */
+  int32_t reserved;
+} dv3_decode_program;
+int dv3_decode_program_sync_ints(int32_t B);
+int dv3_decode_program_run(const dv3_decode_program* prog, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Audio inverse (audio.py:37-43, synthesis.py:64-71): linear spectrogram -> waveform on the

@@ -561,6 +561,7 @@ def test_fast_decode_equals_module_by_module_decode(dev, name, gemm_mode):
     r = hp.get("r", 4)
     mel_r = mel.view(B, mel.size(1) // r, -1)
     res = {}
+    dec.persistent_decode = False          # launch by launch here; the persistent program has its own test below
     for fast in (False, True):
         dec.fast_decode = fast
         with torch.no_grad():
@@ -578,6 +579,7 @@ def test_fast_decode_equals_module_by_module_decode(dev, name, gemm_mode):
             dec.use_step_graph = False
         res[fast] = (tf, fr, fg)
     dec.fast_decode = True
+    dec.persistent_decode = None
     for which, tag in ((0, "teacher-forced"), (1, "free-running"), (2, "free-running, step graph")):
         slow, fast = res[False][which], res[True][which]
         for a, bb, nm in zip(slow, fast, ("outputs", "alignments", "dones", "states")):
@@ -590,6 +592,56 @@ def test_fast_decode_equals_module_by_module_decode(dev, name, gemm_mode):
         a = torch.stack(a) if isinstance(a, (list, tuple)) else a
         bb = torch.stack(bb) if isinstance(bb, (list, tuple)) else bb
         assert torch.equal(a, bb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dv3_tiny", "dv3_preset_like", "dv3_multispeaker", "nyanko_tiny"])
+@pytest.mark.parametrize("batch", [1, 3, None])
+def test_persistent_decode_program_equals_launch_by_launch(dev, name, batch):
+    """dv3_decode_program_run -- the whole decoder loop as ONE persistent launch (device-side step loop, group
+    barriers between the layers, the reference's stop rule evaluated on the device) -- against the same step program
+    launched entry by entry from the host: bit-identical stacked outputs and the same number of steps, teacher-forced,
+    free-running to the step limit, and free-running with the done rule firing early; batch sizes that fill a batch
+    group partially, exactly and several groups."""
+    fx, b, hp, sd, x, model = _build(name, dev)
+    model.eval()
+    dec = model.seq2seq.decoder
+    xg = _to(x, dev)
+    B = int(xg["text"].size(0)) if batch is None else min(batch, int(xg["text"].size(0)))
+    text, tp, mel = xg["text"][:B], xg["text_positions"][:B], xg["mel"][:B]
+    spk = xg["speaker_ids"][:B] if "speaker_ids" in xg else None
+    r = hp.get("r", 4)
+    mel_r = mel.view(B, mel.size(1) // r, -1)
+    dec.fast_decode = True
+    dec.use_step_graph = False
+    res, bias0 = {}, dec.fc.bias.detach().clone()
+    try:
+        for persistent in (False, True):
+            dec.persistent_decode = persistent
+            with torch.no_grad():
+                se = model.embed_speakers(spk) if spk is not None else None
+                kw = dict(speaker_embed=se) if b.startswith("deepvoice3") else {}
+                enc = model.seq2seq.encoder(text, lengths=None, speaker_embed=se)
+                dec.start_fresh_sequence() if hasattr(dec, "start_fresh_sequence") else None
+                tf = dec.incremental_forward(enc, tp, test_inputs=mel_r, **kw)
+                dec.min_decoder_steps, dec.max_decoder_steps = 5, 14
+                fr = dec.incremental_forward(enc, tp, **kw)
+                dec.fc.bias.fill_(30.0)             # every done flag saturates: the stop rule fires at min_steps + 1
+                early = dec.incremental_forward(enc, tp, **kw)
+                dec.fc.bias.copy_(bias0)
+            res[persistent] = (tf, fr, early)
+    finally:
+        with torch.no_grad():
+            dec.fc.bias.copy_(bias0)
+        dec.persistent_decode = None
+    assert len(res[True][2][2]) == 6, len(res[True][2][2])          # min_decoder_steps + 1 steps, like the reference loop
+    assert len(res[True][1][2]) in range(6, 16)
+    for which, tag in ((0, "teacher-forced"), (1, "free-running"), (2, "early stop")):
+        for a, bb, nm in zip(res[False][which], res[True][which], ("outputs", "alignments", "dones", "states")):
+            a = torch.stack(a) if isinstance(a, (list, tuple)) else a
+            bb = torch.stack(bb) if isinstance(bb, (list, tuple)) else bb
+            assert a.shape == bb.shape, (tag, nm, tuple(a.shape), tuple(bb.shape))
+            assert torch.equal(a, bb), (tag, nm, float((a - bb).abs().max()))
 
 
 @pytest.mark.gpu
