@@ -783,8 +783,10 @@ extern "C" int dv3_debug_set(int what, int value) {
 }
 
 int dv3_pp2_read_stamps(void* dst, int64_t bytes);   // conv_gemm_pp2.hip
+int dv3_decode_read_stamps(void* dst, int64_t bytes);  // decode_step.hip
 extern "C" int dv3_debug_read(int what, void* dst, int64_t bytes) {
   if (what == 2 && dst) return dv3_pp2_read_stamps(dst, bytes);
+  if (what == 3 && dst) return dv3_decode_read_stamps(dst, bytes);
   DV3_REQUIRE(what == 1 && dst && bytes > 0 && bytes <= (int64_t)sizeof(unsigned long long) * 8 * STAMP_SLOTS * 2,
               "debug_read: bad arguments");
   hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_x3_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost);

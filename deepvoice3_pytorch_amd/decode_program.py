@@ -4,9 +4,9 @@
 A decoder step of the reference (deepvoice3.py:397-461, nyanko.py:283-321) is ~100 tiny module calls; here it is a
 flat list of descriptors built ONCE per utterance batch -- one dv3_conv_step_f32 per conv / projection layer (ring
 buffer on a device step counter, k-tap GEMV, the whole layer tail) and one dv3_attn_step_f32 per attention read --
-that is either walked by ONE persistent launch for the whole utterance (dv3_decode_program_run: the loop, the ring
-buffers, the stop rule and the layer-to-layer hand-over all stay on the device) or replayed by the host launch by
-launch (optionally as one hipGraph per step).  `StepProgram` owns the buffers the descriptors point at.
+that the host replays launch by launch (optionally as one hipGraph per step), or that ONE persistent launch walks for
+the whole utterance (dv3_decode_program_run: the loop, the ring buffers, the stop rule and the layer-to-layer
+hand-over all stay on the device; opt-in, see StepProgram.decode).  `StepProgram` owns the buffers the descriptors point at.
 """
 import ctypes
 import os
@@ -44,7 +44,15 @@ class StepProgram(object):
             ring = self.buffer(L, B, Cin)
             d.ring, d.L = ring.data_ptr(), L
         d.t = self.t_dev.data_ptr()
-        d.a, d.lda, d.a_half = pk.fwd.data_ptr(), pk.lda, pk.a_half
+        tiles = getattr(pk, "step_tiles", None)         # the weights in step-tile order, built once per packed image
+        if tiles is None:
+            Cg, M = (Cout if gated else 0), (2 * Cout if gated else Cout)
+            n = ops._lib.lib().dv3_conv_step_pack_floats(k * Cin, M, Cg)
+            tiles = torch.empty(n, **self.f32)
+            ops._lib.call("dv3_conv_step_pack_f32", pk.fwd.data_ptr(), pk.lda, pk.a_half, k * Cin, M, Cg,
+                          tiles.data_ptr(), ops._stream())
+            pk.step_tiles = tiles
+        d.a, d.lda, d.a_half = tiles.data_ptr(), pk.lda, pk.a_half
         d.bias = layer.bias.data_ptr() if layer.bias is not None else None
         if spk is not None:
             d.spk, d.spk_bs = spk.data_ptr(), spk.stride(0)
@@ -92,15 +100,14 @@ class StepProgram(object):
             ops._lib.call(name, ctypes.byref(d), s)
         self.t_dev.add_(1)
 
-    def decode_persistent(self, cur_in, test_inputs, dones_seq, min_steps, max_steps):
-        """the whole loop as one launch of the persistent program kernel (include/dv3hip.h: dv3_decode_program_run)
-        -> number of steps taken"""
-        B, dev = self.B, self.dev
-        free_running = test_inputs is None
-        Entry, Prog = STRUCTS["dv3_decode_entry"], STRUCTS["dv3_decode_program"]
+    def _entries(self, cur_in, test_inputs):
+        """the program as a host array of dv3_decode_entry (teacher forcing: the entries that read the decoder input
+        buffer read frame t of test_inputs instead, deepvoice3.py:411-415)"""
+        B = self.B
+        Entry = STRUCTS["dv3_decode_entry"]
         arr = (Entry * len(self.prog))()
         ti = None
-        if not free_running:
+        if test_inputs is not None:
             ti = test_inputs.to(torch.float32).reshape(B, test_inputs.size(1), -1).contiguous()
             if ti.size(2) != cur_in.size(1):
                 raise RuntimeError("decode program: test_inputs frames carry %d values, the decoder input %d" % (
@@ -111,7 +118,7 @@ class StepProgram(object):
             if name == "dv3_conv_step_f32":
                 arr[i].kind = 0
                 arr[i].conv = d
-                if ti is not None and d.x == cur_in.data_ptr():     # teacher forcing: frame t of test_inputs
+                if ti is not None and d.x == cur_in.data_ptr():
                     arr[i].conv.x, arr[i].conv.x_bs, arr[i].conv.x_ts = ti.data_ptr(), ti.stride(0), ti.stride(1)
                     fed += 1
             else:
@@ -119,6 +126,15 @@ class StepProgram(object):
                 arr[i].attn = d
         if ti is not None and fed == 0:
             raise RuntimeError("decode program: no entry reads the decoder input buffer")
+        return arr, ti
+
+    def decode_persistent(self, cur_in, test_inputs, dones_seq, min_steps, max_steps):
+        """the whole loop as one launch of the persistent program kernel (include/dv3hip.h: dv3_decode_program_run)
+        -> number of steps taken"""
+        B, dev = self.B, self.dev
+        free_running = test_inputs is None
+        Prog = STRUCTS["dv3_decode_program"]
+        arr, ti = self._entries(cur_in, test_inputs)
         host = bytearray(bytes(arr))
         entries = torch.frombuffer(host, dtype=torch.uint8).to(dev)
         n_sync = ops._lib.lib().dv3_decode_program_sync_ints(B)
@@ -133,6 +149,8 @@ class StepProgram(object):
         if free_running:
             p.done_seq, p.done_ts = dones_seq.data_ptr(), dones_seq.stride(0)
         p.min_steps, p.max_steps = min_steps, max_steps
+        p.reserved = int(os.environ.get("DV3_DECODE_ABLATE", "0"))      # developer knob: timing ablations of the barriers
+        p.wg_per_group = int(os.environ.get("DV3_DECODE_WG", "0"))
         p.sync, p.steps_out = sync.data_ptr(), steps_out.data_ptr()
         ops._lib.call("dv3_decode_program_run", ctypes.byref(p), ops._stream())
         t = int(steps_out.item())
@@ -141,15 +159,52 @@ class StepProgram(object):
         self.t_dev.fill_(t)
         return t
 
-    def decode(self, cur_in, test_inputs, dones_seq, min_steps, max_steps, use_graph, persistent=None):
+    def decode_launched(self, cur_in, test_inputs, dones_seq, min_steps, max_steps, chunk=8):
+        """the loop with the launches issued by the library (dv3_decode_program_launch: one call per chunk of steps, the
+        step index in the descriptors).  Free running, the done flags are read once per chunk and the steps after the
+        stopping one are dropped -- later steps never change earlier outputs.  -> number of steps taken"""
+        Prog = STRUCTS["dv3_decode_program"]
+        arr, ti = self._entries(cur_in, test_inputs)
+        p = Prog()
+        p.entries_host = ctypes.addressof(arr)
+        p.n_entries, p.B = len(self.prog), self.B
+        stream = ops._stream()
+        if ti is not None:
+            p.t0, p.n_steps = 0, ti.size(1)
+            if p.n_steps > 0:
+                ops._lib.call("dv3_decode_program_launch", ctypes.byref(p), stream)
+            return int(ti.size(1))
+        limit, t = max_steps + 1, 0
+        while True:
+            n = min(min_steps + 1 if t == 0 else chunk, limit - t)
+            p.t0, p.n_steps = t, n
+            ops._lib.call("dv3_decode_program_launch", ctypes.byref(p), stream)
+            done = (dones_seq[t:t + n].reshape(n, -1) > 0.5).all(dim=1).tolist()
+            for k in range(n):
+                if t + k + 1 > min_steps and done[k]:
+                    return t + k + 1
+            t += n
+            if t >= limit:
+                return t
+
+    def decode(self, cur_in, test_inputs, dones_seq, min_steps, max_steps, use_graph, persistent=None, launched=None):
         """the decoder loop (deepvoice3.py:397-473 / nyanko.py:277-331): teacher-forced over test_inputs (B, n, D), or
         free running until every item's done flag passed 0.5 after min_steps, at most max_steps + 1 steps.
-        -> number of steps taken.  persistent (default; DV3_DECODE_PERSISTENT=0 turns it off): one launch for the
-        whole loop; else one launch per program entry per step, optionally replayed as a per-step hipGraph."""
+        -> number of steps taken.  Default (launched): one launch per program entry per step, issued by the library in
+        chunks of steps (decode_launched).  launched=False: the same launches from Python, optionally replayed as a
+        per-step hipGraph (~110 us of host time per step either way: slower than the GPU).  persistent=True (or
+        DV3_DECODE_PERSISTENT=1): ONE launch for the whole loop -- bit-identical, and the host drops out entirely,
+        but on MI355X the device-wide barrier between layers (agent-scope release + acquire: L2 write-back /
+        invalidate across the 8 XCDs, ~3.5 us) costs more than a kernel boundary does (scripts/decode_time.py), so
+        it is opt-in."""
         if persistent is None:
-            persistent = os.environ.get("DV3_DECODE_PERSISTENT", "1") != "0"
+            persistent = os.environ.get("DV3_DECODE_PERSISTENT", "0") == "1"
         if persistent:
             return self.decode_persistent(cur_in, test_inputs, dones_seq, min_steps, max_steps)
+        if launched is None:
+            launched = os.environ.get("DV3_DECODE_LAUNCHED", "1") != "0"
+        if launched:
+            return self.decode_launched(cur_in, test_inputs, dones_seq, min_steps, max_steps)
         free_running = test_inputs is None
         B = self.B
         graphed = bool(use_graph) and free_running

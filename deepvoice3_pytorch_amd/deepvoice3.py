@@ -599,7 +599,8 @@ class Decoder(nn.Module):
             pre = P.conv_step(self.last_conv, x, ops.EPI_LINEAR, D, y_act=nxt_in, out_seq=outs)
             P.conv_step(self.fc, pre, ops.EPI_SIGMOID, 1, out_seq=dones_seq)
             t = P.decode(cur_in, test_inputs, dones_seq, self.min_decoder_steps, self.max_decoder_steps,
-                         getattr(self, "use_step_graph", False), getattr(self, "persistent_decode", None))
+                         getattr(self, "use_step_graph", False), getattr(self, "persistent_decode", None),
+                         getattr(self, "launched_decode", None))
             scale = float(2 ** (n_att - 1)) / n_att if n_att else 1.0
             alignments = aligns[:t].transpose(0, 1)
             if scale != 1.0:

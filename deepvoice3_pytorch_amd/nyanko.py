@@ -270,7 +270,8 @@ class Decoder(nn.Module):
             pre = P.conv_step(self.last_conv, x, ops.EPI_LINEAR, F, y_act=nxt_in, out_seq=outs)
             P.conv_step(self.fc, pre, ops.EPI_SIGMOID, 1, out_seq=dones_seq)
             t = P.decode(cur_in, test_inputs, dones_seq, self.min_decoder_steps, self.max_decoder_steps,
-                         getattr(self, "use_step_graph", False), getattr(self, "persistent_decode", None))
+                         getattr(self, "use_step_graph", False), getattr(self, "persistent_decode", None),
+                         getattr(self, "launched_decode", None))
             alignments = aligns[:t].transpose(0, 1)
             decoder_states = states[:t].transpose(0, 1).contiguous()
             outputs = outs[:t].transpose(0, 1).contiguous()

@@ -193,7 +193,7 @@ def dropout_bits(rows, T, p, device, name=None):
 # ----------------------------------------------------------------------------------------------
 class Packed(object):
     __slots__ = ("fwd", "bwd", "scale", "lda", "a_half", "ldb", "O", "I", "J", "transposed", "glu_cg",
-                 "fwd_s", "bwd_s", "fwd_f16")
+                 "fwd_s", "bwd_s", "fwd_f16", "step_tiles")
 
 
 SPLIT_BF16, SPLIT_F16 = CONSTS["DV3_SPLIT_DTYPE_BF16"], CONSTS["DV3_SPLIT_DTYPE_F16"]

@@ -515,7 +515,9 @@ int dv3_clip_adam_f32(float* p, const float* g, float* m, float* v, int64_t n,
  *   window: tap J-1 = the new frame x (B, Cin); tap j = the frame (J-1-j)*dil steps back, kept in `ring`
  *   [L][B][Cin] (slot t mod L holds step t; the call stores x there; L >= (J-1)*dil + 1; zero the ring to
  *   start a sequence = conv.py clear_buffer);  acc[b][m] = sum_{j,c} a[j][c][m] * window[b][j][c]
- *   (a = dv3_weight_norm_pack_f32's fwd_pack);  then, by mode:
+ *   (a = the layer's weights in STEP-TILE order, written by dv3_conv_step_pack_f32 from dv3_weight_norm_pack_f32's
+ *   fwd_pack: [row block of 16][window element j*Cin + c][16 rows], gated layers [..][16 `a` rows | 16 gate rows] --
+ *   the 100 KB a workgroup streams per layer are one dense block; lda / a_half are ignored);  then, by mode:
  *     GLU / HIGHWAY  (+bias, +spk[b][m] on the `a` half) gate with the new frame as residual / highway carry
  *                    (modules.py:157-164, 224-226), then r2: y = (y + r2) * sqrt(.5)
  *     LINEAR / RELU / SIGMOID / SOFTSIGN  activation, then r and r2 residuals, each (y + r) * sqrt(.5)
@@ -544,8 +546,14 @@ typedef struct dv3_conv_step_desc {
                                                 concat while Q + position code feeds the attention query)            */
   int64_t x_ts;                              /* the new frame of step t is x + t*x_ts (teacher forcing: x = test_inputs,
                                                 deepvoice3.py:411-415); 0 = the same buffer every step               */
+  int32_t t_value, reserved;                 /* the step index when `t` is NULL (host-driven loops: dv3_decode_program_launch) */
 } dv3_conv_step_desc;
 int dv3_conv_step_f32(const dv3_conv_step_desc* d, void* stream);
+/* fwd_pack ([J*Cin][lda] fp32; gated: `a` rows at column 0, gate rows at column a_half) -> the step-tile image
+ * dv3_conv_step_f32 reads.  Cg = gated ? rows per half : 0.  out holds dv3_conv_step_pack_floats(...) floats. */
+int dv3_conv_step_pack_floats(int32_t Ktot, int32_t M, int32_t Cg);
+int dv3_conv_step_pack_f32(const float* fwd_pack, int32_t lda, int32_t a_half, int32_t Ktot, int32_t M, int32_t Cg,
+                           float* out, void* stream);
 
 typedef struct dv3_attn_step_desc {
   const float* q; int64_t q_bs;              /* (B, E)                                       */
@@ -557,6 +565,7 @@ typedef struct dv3_attn_step_desc {
   float* attn;                               /* (B, Tk) or NULL                              */
   float* attn_seq; int64_t attn_seq_ts;      /* [t][B][Tk] or NULL                           */
   int32_t B, E, Tk;
+  int32_t t_value;                           /* the step index when `t` is NULL             */
 } dv3_attn_step_desc;
 int dv3_attn_step_f32(const dv3_attn_step_desc* d, void* stream);
 
@@ -592,6 +601,13 @@ typedef struct dv3_decode_program {
 } dv3_decode_program;
 int dv3_decode_program_sync_ints(int32_t B);
 int dv3_decode_program_run(const dv3_decode_program* prog, void* stream);
+/* The same program, host driven: steps t0 .. t0 + n_steps - 1 as one kernel launch per entry per step, issued by ONE
+ * call (a step of the ljspeech decoder is 17 launches: issued from Python + ctypes or as a replayed per-step hipGraph
+ * they cost the host ~110 us per step, more than the GPU needs; from this loop ~3 us each).  Uses entries_host; the
+ * step index travels in the descriptors (t_value), no device counter.  No stop rule here: the caller runs a chunk of
+ * steps, reads the done flags of the chunk, and discards the steps after the stopping one (later steps never change
+ * earlier outputs, so the kept prefix is what a step-by-step loop produces). */
+int dv3_decode_program_launch(const dv3_decode_program* prog, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Audio inverse (audio.py:37-43, synthesis.py:64-71): linear spectrogram -> waveform on the

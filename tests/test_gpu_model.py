@@ -561,7 +561,8 @@ def test_fast_decode_equals_module_by_module_decode(dev, name, gemm_mode):
     r = hp.get("r", 4)
     mel_r = mel.view(B, mel.size(1) // r, -1)
     res = {}
-    dec.persistent_decode = False          # launch by launch here; the persistent program has its own test below
+    dec.persistent_decode = dec.launched_decode = False    # launch by launch from Python here; the library-driven loops
+                                                           # have their own test below
     for fast in (False, True):
         dec.fast_decode = fast
         with torch.no_grad():
@@ -579,7 +580,7 @@ def test_fast_decode_equals_module_by_module_decode(dev, name, gemm_mode):
             dec.use_step_graph = False
         res[fast] = (tf, fr, fg)
     dec.fast_decode = True
-    dec.persistent_decode = None
+    dec.persistent_decode = dec.launched_decode = None
     for which, tag in ((0, "teacher-forced"), (1, "free-running"), (2, "free-running, step graph")):
         slow, fast = res[False][which], res[True][which]
         for a, bb, nm in zip(slow, fast, ("outputs", "alignments", "dones", "states")):
@@ -597,12 +598,13 @@ def test_fast_decode_equals_module_by_module_decode(dev, name, gemm_mode):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["dv3_tiny", "dv3_preset_like", "dv3_multispeaker", "nyanko_tiny"])
 @pytest.mark.parametrize("batch", [1, 3, None])
-def test_persistent_decode_program_equals_launch_by_launch(dev, name, batch):
-    """dv3_decode_program_run -- the whole decoder loop as ONE persistent launch (device-side step loop, group
-    barriers between the layers, the reference's stop rule evaluated on the device) -- against the same step program
-    launched entry by entry from the host: bit-identical stacked outputs and the same number of steps, teacher-forced,
-    free-running to the step limit, and free-running with the done rule firing early; batch sizes that fill a batch
-    group partially, exactly and several groups."""
+def test_library_driven_decode_loops_equal_launch_by_launch(dev, name, batch):
+    """dv3_decode_program_launch (the default: the library issues the launches of a chunk of steps, the done flags are
+    read per chunk and the surplus steps dropped) and dv3_decode_program_run (the whole loop as ONE persistent launch:
+    device-side step loop, group barriers between the layers, the reference's stop rule evaluated on the device)
+    against the same step program launched entry by entry from Python: bit-identical stacked outputs and the same
+    number of steps, teacher-forced, free-running to the step limit, and free-running with the done rule firing
+    early; batch sizes that fill a batch group partially, exactly and several groups."""
     fx, b, hp, sd, x, model = _build(name, dev)
     model.eval()
     dec = model.seq2seq.decoder
@@ -616,8 +618,9 @@ def test_persistent_decode_program_equals_launch_by_launch(dev, name, batch):
     dec.use_step_graph = False
     res, bias0 = {}, dec.fc.bias.detach().clone()
     try:
-        for persistent in (False, True):
-            dec.persistent_decode = persistent
+        for persistent in (False, True, "launched"):
+            dec.persistent_decode = persistent is True
+            dec.launched_decode = persistent == "launched"
             with torch.no_grad():
                 se = model.embed_speakers(spk) if spk is not None else None
                 kw = dict(speaker_embed=se) if b.startswith("deepvoice3") else {}
@@ -633,15 +636,16 @@ def test_persistent_decode_program_equals_launch_by_launch(dev, name, batch):
     finally:
         with torch.no_grad():
             dec.fc.bias.copy_(bias0)
-        dec.persistent_decode = None
-    assert len(res[True][2][2]) == 6, len(res[True][2][2])          # min_decoder_steps + 1 steps, like the reference loop
-    assert len(res[True][1][2]) in range(6, 16)
-    for which, tag in ((0, "teacher-forced"), (1, "free-running"), (2, "early stop")):
-        for a, bb, nm in zip(res[False][which], res[True][which], ("outputs", "alignments", "dones", "states")):
-            a = torch.stack(a) if isinstance(a, (list, tuple)) else a
-            bb = torch.stack(bb) if isinstance(bb, (list, tuple)) else bb
-            assert a.shape == bb.shape, (tag, nm, tuple(a.shape), tuple(bb.shape))
-            assert torch.equal(a, bb), (tag, nm, float((a - bb).abs().max()))
+        dec.persistent_decode = dec.launched_decode = None
+    for mode in (True, "launched"):
+        assert len(res[mode][2][2]) == 6, len(res[mode][2][2])      # min_decoder_steps + 1 steps, like the reference loop
+        assert len(res[mode][1][2]) in range(6, 16)
+        for which, tag in ((0, "teacher-forced"), (1, "free-running"), (2, "early stop")):
+            for a, bb, nm in zip(res[False][which], res[mode][which], ("outputs", "alignments", "dones", "states")):
+                a = torch.stack(a) if isinstance(a, (list, tuple)) else a
+                bb = torch.stack(bb) if isinstance(bb, (list, tuple)) else bb
+                assert a.shape == bb.shape, (mode, tag, nm, tuple(a.shape), tuple(bb.shape))
+                assert torch.equal(a, bb), (mode, tag, nm, float((a - bb).abs().max()))
 
 
 @pytest.mark.gpu
