@@ -23,16 +23,18 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_
   timeout 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_r3_$T -- python /tmp/pmc_run.py > $R/gpurun_out/pmc_r3_$T.log 2>&1; echo "$T rc=$?"
 done
 cd $R; python - <<'PY'
-import csv, glob, json, re
+import csv, glob, json, os, re
+def newest(pat):
+    return sorted(glob.glob(pat), key=os.path.getmtime)[-1]
 def vals(tag, counter):
-    f = glob.glob("gpurun_out/pmc_r3_%s/*/*counter_collection.csv" % tag)[0]
+    f = newest("gpurun_out/pmc_r3_%s/*/*counter_collection.csv" % tag)
     out = {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter: continue
         out.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
     return out
 def durs(tag):
-    f = glob.glob("gpurun_out/pmc_r3_%s/*/*kernel_trace.csv" % tag)[0]
+    f = newest("gpurun_out/pmc_r3_%s/*/*kernel_trace.csv" % tag)
     out = {}
     for r in csv.DictReader(open(f)):
         out.setdefault(r["Kernel_Name"], []).append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
@@ -68,10 +70,14 @@ for key, name, alg in names:
     except Exception:
         b["GRBM_GUI_ACTIVE"] = None
     b["duration_us_in_pmc_pass"] = pick(D, name)[1] / 1e3
-    # matrix-pipe busy: MFMA busy cycles are summed over the 1024 SIMDs; GRBM_GUI_ACTIVE counts chip cycles of the launch
-    if b.get("SQ_VALU_MFMA_BUSY_CYCLES") and b.get("GRBM_GUI_ACTIVE"):
-        b["mfma_busy_frac_of_launch"] = round(b["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / b["GRBM_GUI_ACTIVE"], 4)
-        b["implied_clock_ghz"] = round(b["GRBM_GUI_ACTIVE"] / (b["duration_us_in_pmc_pass"] * 1e3), 3)
+    # matrix-pipe busy: MFMA busy cycles are summed over the 1024 SIMDs (= 32 cycles x MFMAs issued), SQ_BUSY_CYCLES
+    # over the 32 shader engines; GRBM_GUI_ACTIVE is not a usable cycle base on this stack (it implies > 2.4 GHz)
+    if b.get("SQ_VALU_MFMA_BUSY_CYCLES") and b.get("SQ_BUSY_CYCLES"):
+        cyc = b["SQ_BUSY_CYCLES"] / 32.0
+        b["launch_cycles_from_SQ_BUSY_CYCLES_over_32_SEs"] = int(cyc)
+        b["implied_clock_ghz"] = round(cyc / (b["duration_us_in_pmc_pass"] * 1e3), 3)
+        b["mfma_busy_cycles_per_simd"] = int(b["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0)
+        b["mfma_busy_frac_of_launch_cycles"] = round(b["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc, 4)
     busy[key] = b
 json.dump(res, open("gpurun_out/r03_hbm_traffic.json", "w"), indent=1)
 json.dump(busy, open("gpurun_out/r03_mfma_busy.json", "w"), indent=1)
