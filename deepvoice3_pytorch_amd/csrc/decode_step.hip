@@ -306,25 +306,27 @@ __device__ __forceinline__ void attn_step_item(const dv3_attn_step_desc& p, cons
   }
   for (int e = tid; e < E; e += 256) q[e] = p.q[(int64_t)b * p.q_bs + e];
   __syncthreads();
+  // scores: a wave takes 4 consecutive keys at a time, its lanes split the E axis (16 independent loads per lane in
+  // flight, one round trip for a 4-key monotonic window); with (B, Tk, E) keys a row is 4 contiguous 256-byte reads
+  const int es = p.kv_tke ? 1 : Tk, ns = p.kv_tke ? E : 1;
   const float* __restrict__ kb = p.k + (int64_t)b * E * Tk;
-  float mx = -INFINITY;
-  for (int n = tid; n < Tk; n += 256) {
-    float s = -INFINITY;
-    if (n >= lo && n < hi) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      int e = 0;
-      for (; e + 4 <= E; e += 4) {
-        a0 = fmaf(q[e], kb[(int64_t)e * Tk + n], a0);
-        a1 = fmaf(q[e + 1], kb[(int64_t)(e + 1) * Tk + n], a1);
-        a2 = fmaf(q[e + 2], kb[(int64_t)(e + 2) * Tk + n], a2);
-        a3 = fmaf(q[e + 3], kb[(int64_t)(e + 3) * Tk + n], a3);
-      }
-      for (; e < E; ++e) a0 = fmaf(q[e], kb[(int64_t)e * Tk + n], a0);
-      s = (a0 + a1) + (a2 + a3);
+  for (int n0 = lo + 4 * wave; n0 < hi; n0 += 16) {
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int e = lane; e < E; e += 64) {
+      const float qe = q[e];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[i] = fmaf(qe, kb[(int64_t)min(n0 + i, hi - 1) * ns + (int64_t)e * es], part[i]);
     }
-    sc[n] = s;
-    mx = fmaxf(mx, s);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float s = dv3_wave_sum(part[i]);
+      if (lane == 0 && n0 + i < hi) sc[n0 + i] = s;
+    }
   }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int n = tid; n < Tk; n += 256)
+    if (n >= lo && n < hi) mx = fmaxf(mx, sc[n]);
   mx = dv3_wave_max(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
@@ -356,7 +358,15 @@ __device__ __forceinline__ void attn_step_item(const dv3_attn_step_desc& p, cons
   const float* __restrict__ vb = p.v + (int64_t)b * E * Tk;
   for (int e = tid; e < E; e += 256) {
     float c = 0.f;
-    for (int n = lo; n < hi; ++n) c = fmaf(sc[n], vb[(int64_t)e * Tk + n], c);
+    int n = lo;
+    for (; n + 4 <= hi; n += 4) {         // loads first: one round trip per 4 keys
+      float vv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vv[i] = vb[(int64_t)(n + i) * ns + (int64_t)e * es];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c = fmaf(sc[n + i], vv[i], c);
+    }
+    for (; n < hi; ++n) c = fmaf(sc[n], vb[(int64_t)n * ns + (int64_t)e * es], c);
     p.ctx[(int64_t)b * p.ctx_bs + e] = c * scale;
   }
   // next step's window: argmax of batch item 0 (deepvoice3.py:445), first maximum

@@ -78,18 +78,22 @@ class StepProgram(object):
     def attn_step(self, q, k, v, window_backward, window_ahead, monotonic, attn_seq=None):
         """one attention read over (B, E, Tk) keys / values (deepvoice3.py:143-171 at Tq = 1, no padding mask)"""
         B = self.B
-        ctx = torch.empty(B, k.size(1), **self.f32)
+        E, Tk = k.size(1), k.size(2)
+        ctx = torch.empty(B, E, **self.f32)
         la = self.buffer(2).to(torch.int32) if monotonic else None
         if la is not None:
             self.keep.append(la)
+        # one-frame reads want a key / value ROW contiguous: (B, Tk, E), transposed once per utterance batch
+        kt, vt = ops.transpose(k.contiguous()), ops.transpose(v.contiguous())
+        self.keep.extend([kt, vt])
         a = STRUCTS["dv3_attn_step_desc"]()
-        a.q, a.q_bs, a.k, a.v = q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr()
+        a.q, a.q_bs, a.k, a.v, a.kv_tke = q.data_ptr(), q.stride(0), kt.data_ptr(), vt.data_ptr(), 1
         a.last_attended = la.data_ptr() if la is not None else None
         a.win_back, a.win_ahead, a.t = window_backward, window_ahead, self.t_dev.data_ptr()
         a.ctx, a.ctx_bs = ctx.data_ptr(), ctx.stride(0)
         if attn_seq is not None:
             a.attn_seq, a.attn_seq_ts = attn_seq.data_ptr(), attn_seq.stride(0)
-        a.B, a.E, a.Tk = B, k.size(1), k.size(2)
+        a.B, a.E, a.Tk = B, E, Tk
         self.keep.extend([q, k, v, ctx, attn_seq])
         self.prog.append(("dv3_attn_step_f32", a))
         return ctx

@@ -557,7 +557,7 @@ int dv3_conv_step_pack_f32(const float* fwd_pack, int32_t lda, int32_t a_half, i
 
 typedef struct dv3_attn_step_desc {
   const float* q; int64_t q_bs;              /* (B, E)                                       */
-  const float* k; const float* v;            /* (B, E, Tk) each, BCT                         */
+  const float* k; const float* v;            /* (B, E, Tk) each, BCT (or (B, Tk, E): kv_tke)  */
   int32_t* last_attended;                    /* [2] device ints or NULL                      */
   int32_t win_back, win_ahead;
   const int32_t* t;
@@ -566,6 +566,8 @@ typedef struct dv3_attn_step_desc {
   float* attn_seq; int64_t attn_seq_ts;      /* [t][B][Tk] or NULL                           */
   int32_t B, E, Tk;
   int32_t t_value;                           /* the step index when `t` is NULL             */
+  int32_t kv_tke, reserved;                  /* 1: k and v are (B, Tk, E) -- the reference's own layout (deepvoice3.py:
+                                                132-141), a key / value row is contiguous: coalesced for a one-frame read */
 } dv3_attn_step_desc;
 int dv3_attn_step_f32(const dv3_attn_step_desc* d, void* stream);
 

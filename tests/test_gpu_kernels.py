@@ -585,6 +585,39 @@ def test_fused_attention_forward_equals_unfused(dev, gemm_mode, B, E, Tq, Tk, p)
         assert rel_err(res[True][1], Pw) < 1e-5 and rel_err(res[True][0], want) < 1e-5
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x3"])
+@pytest.mark.parametrize("B,M,C,T,d,masked,S", [(3, 128, 64, 75, 2, False, 2), (2, 512, 256, 150, 27, True, 3),
+                                               (4, 96, 200, 61, 9, True, 5), (5, 256, 128, 800, 1, True, 7),
+                                               (2, 130, 130, 33, 3, True, 2), (6, 72, 64, 100, 1, False, 19)])
+def test_two_steps_ahead_wgrad_equals_the_all_taps_wgrad(dev, mode, B, M, C, T, d, masked, S):
+    """wgrad_taps2_kernel (csrc/wgrad_taps2.hip, the default weight-gradient kernel: operand units of the NEXT two steps
+    in flight as raw registers) against wgrad_taps_kernel: the K-slab partial sums are bit-identical (same tile, slab
+    and accumulation order), ragged channel counts, dilations up to 27 and masked operands included; the variant each
+    call served is read back (dv3_debug_get(11))."""
+    from deepvoice3_pytorch_amd import ops, _lib
+    L = _lib.lib()
+    prev = ops.set_gemm_precision(mode)
+    try:
+        torch.manual_seed(1)
+        x = torch.randn(B, C, T, device=dev)
+        g = torch.randn(B, M, T, device=dev)
+        bits = rs = None
+        if masked:
+            ops.dropout_state.manual_seed(3)
+            bits, rs = ops.dropout_bits(B * C, T, 0.05, dev)
+        outs = []
+        for tile in (3, 4):         # dv3_debug_set(2, .): 3 = all-taps kernel, 4 = two-steps-ahead kernel
+            L.dv3_debug_set(2, tile)
+            o = ops.wgrad_gemm(g, x, B=B, M=M, Cin=C, T=T, Tin=T, J=3, dil=d, padL=d, n_slabs=S, xmask=bits,
+                               xmask_rs=rs or 0, drop_scale=1 / 0.95 if masked else 1.0, split_bf16=True, k_split=True)
+            outs.append((o.clone(), L.dv3_debug_get(11)))
+    finally:
+        L.dv3_debug_set(2, 0)
+        ops.set_gemm_precision(prev)
+    assert outs[0][1] % 1000 == 30 and outs[1][1] % 1000 == 40, (outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[1][0]), float((outs[0][0] - outs[1][0]).abs().max())
+
+
 @pytest.mark.parametrize("B,C,T,d,causal,masked", [(3, 64, 75, 2, False, True), (2, 256, 150, 27, False, False),
                                                    (2, 128, 100, 1, True, True), (5, 96, 61, 9, False, True),
                                                    (4, 256, 800, 3, False, True), (7, 32, 33, 1, False, False)])
