@@ -366,6 +366,25 @@ __global__ __launch_bounds__(256) void deinterleave2_kernel(const float* __restr
   }
 }
 
+// the same with wide accesses: a thread takes 4 consecutive samples of a row (one 16-byte load) and writes 2 even + 2
+// odd ones (two 8-byte stores); T % 2 == 0 (rows of 2T floats stay 16-byte aligned, rows of T floats 8-byte aligned)
+// and 16-byte aligned bases.  i over [B*O][T/2]
+typedef float dl_f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void deinterleave2_vec_kernel(const float* __restrict__ dy, float* __restrict__ out,
+                                                                int O, int T, int64_t n2) {
+  const int T2 = T >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+    const int q = (int)(i % T2);
+    const int64_t bo = i / T2;
+    const int o = (int)(bo % O);
+    const int64_t b = bo / O;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(dy + bo * 2 * (int64_t)T + 4 * (int64_t)q);
+    const dl_f32x2 ev = {v[0], v[2]}, od = {v[1], v[3]};
+    *reinterpret_cast<dl_f32x2*>(out + ((b * 2 + 0) * O + o) * (int64_t)T + 2 * q) = ev;
+    *reinterpret_cast<dl_f32x2*>(out + ((b * 2 + 1) * O + o) * (int64_t)T + 2 * q) = od;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Embedding gather straight into BCT (+dropout): deepvoice3.py:74-75, nyanko.py:63.
 // block = 32 time steps x 32 channels through an LDS tile so both sides are coalesced.
@@ -722,6 +741,13 @@ extern "C" int dv3_deinterleave2_f32(const float* dy, float* out, int32_t B, int
                                      void* stream) {
   DV3_REQUIRE(dy && out && B > 0 && O > 0 && T > 0, "deinterleave2: bad args");
   const int64_t n = (int64_t)B * O * 2 * T;
+  if ((T & 1) == 0 && (((uintptr_t)dy | (uintptr_t)out) & 15) == 0) {
+    const int64_t n2 = n / 4;
+    int64_t blocks = dv3_cdiv64(n2, 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(deinterleave2_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, out, O, T, n2);
+    return dv3_check_launch("deinterleave2_f32");
+  }
   int64_t blocks = dv3_cdiv64(n, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(deinterleave2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
