@@ -459,7 +459,11 @@ def synth_run(dev, batch=64, reps=3, warm=1, gl_iters=60, step_graph=True):
                 ms_per_step=round(wall * 1e3, 2), reps=reps, dtype=ops.gemm_precision(),
                 config=dict(workload="builder=deepvoice3 preset=deepvoice3_ljspeech synthesis, Tt=100, 201 decoder steps "
                                      "= 804 frames per utterance", utterances=B, griffin_lim_iters=gl_iters,
-                            step_hipgraph=bool(dec.use_step_graph), audio_seconds=round(audio_s, 1),
+                            decode_loop=("persistent program (one launch)" if os.environ.get("DV3_DECODE_PERSISTENT") == "1"
+                                         else "python launches" + (", per-step hipGraph" if dec.use_step_graph else "")
+                                         if os.environ.get("DV3_DECODE_LAUNCHED") == "0"
+                                         else "library-launched chunks of steps (dv3_decode_program_launch)"),
+                            audio_seconds=round(audio_s, 1),
                             model_ms=round(float(np.mean(tm)) * 1e3, 1), vocoder_ms=round(float(np.mean(tv)) * 1e3, 1),
                             rtf_model_only=round(float(np.mean(tm)) / audio_s, 6),
                             ms_per_decoder_step=round(float(np.mean(tm)) * 1e3 / 201, 3)))

@@ -218,10 +218,7 @@ __global__ void zero_kernel(float* p, int64_t n) {
 // ---- backward ------------------------------------------------------------------------
 // one block per normalised row r (o, or i when transposed).  dW row gathered from the slabs
 // into LDS, dot with v, then dv / dg.
-__global__ __launch_bounds__(256) void wn_bwd_kernel(const dv3_wn_bwd_desc p) {
-  extern __shared__ float dw[];  // [len]
-  __shared__ float red[4];
-  const int r = blockIdx.x;
+__device__ __forceinline__ void wn_bwd_row(const dv3_wn_bwd_desc& p, const int r, const int nrows, float* dw, float* red) {
   const int O = p.O, I = p.I, J = p.J;
   const int len = p.transposed ? O * J : I * J;
   const float* vrow = p.v + (int64_t)r * len;
@@ -259,7 +256,7 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const dv3_wn_bwd_desc p) {
   dot = red[0] + red[1] + red[2] + red[3];
   // bias gradient (sum of the per-batch partials) rides along: block k reduces bias channel k
   if (p.bias_part && p.dbias) {
-    for (int o = r; o < O; o += gridDim.x) {
+    for (int o = r; o < O; o += nrows) {
       float bs = 0.f;
       for (int k = threadIdx.x; k < p.n_part; k += 256) bs += p.bias_part[(int64_t)k * O + o];
       bs = dv3_wave_sum(bs);
@@ -286,6 +283,30 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const dv3_wn_bwd_desc p) {
   } else {
     for (int idx = threadIdx.x; idx < len; idx += 256) dvrow[idx] = p.accumulate ? dvrow[idx] + dw[idx] : dw[idx];
   }
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const dv3_wn_bwd_desc p) {
+  extern __shared__ float dw[];  // [len]
+  __shared__ float red[4];
+  wn_bwd_row(p, blockIdx.x, gridDim.x, dw, red);
+}
+
+// several layers in one launch: block -> (layer, row); the descriptors are kernel arguments (include/dv3hip.h)
+struct WnBwdMultiArgs {
+  dv3_wn_bwd_desc d[DV3_WN_BWD_MULTI_MAX];
+  int32_t first_row[DV3_WN_BWD_MULTI_MAX + 1];
+  int32_t n;
+};
+__global__ __launch_bounds__(256) void wn_bwd_multi_kernel(const WnBwdMultiArgs a) {
+  extern __shared__ float dw[];
+  __shared__ float red[4];
+  const int blk = blockIdx.x;
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < DV3_WN_BWD_MULTI_MAX; ++k)
+    if (k < a.n && a.first_row[k] <= blk) l = k;
+  // (uniform per workgroup: the descriptor is read from the argument segment with scalar loads)
+  wn_bwd_row(a.d[l], blk - a.first_row[l], a.first_row[l + 1] - a.first_row[l], dw, red);
 }
 
 // dbias[o] = sum_p part[p][o]
@@ -375,15 +396,46 @@ extern "C" int dv3_weight_norm_split_pack_multi(const dv3_wn_multi_entry* table_
   return dv3_check_launch("weight_norm_split_pack_multi");
 }
 
-extern "C" int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream) {
+static int wn_bwd_check(const dv3_wn_bwd_desc* d, int* rows, size_t* lds) {
   DV3_REQUIRE(d && d->slabs && d->v && d->dv, "wn_bwd: null pointer");
   DV3_REQUIRE(!d->g || (d->scale && d->dg), "wn_bwd: g given without scale/dg");
   DV3_REQUIRE(d->O > 0 && d->I > 0 && d->J > 0 && d->n_slabs > 0, "wn_bwd: bad dims");
-  hipStream_t st = (hipStream_t)stream;
-  const int rows = d->transposed ? d->I : d->O;
+  *rows = d->transposed ? d->I : d->O;
   const int len = d->transposed ? d->O * d->J : d->I * d->J;
-  const size_t lds = (size_t)len * 4;
-  DV3_REQUIRE(lds <= 64 * 1024, "wn_bwd: row too long (%d)", len);
-  hipLaunchKernelGGL(wn_bwd_kernel, dim3(rows), dim3(256), lds, st, *d);
+  *lds = (size_t)len * 4;
+  DV3_REQUIRE(*lds <= 64 * 1024, "wn_bwd: row too long (%d)", len);
+  return DV3_OK;
+}
+
+extern "C" int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream) {
+  int rows = 0;
+  size_t lds = 0;
+  const int rc = wn_bwd_check(d, &rows, &lds);
+  if (rc != DV3_OK) return rc;
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, *d);
   return dv3_check_launch("weight_norm_bwd_f32");
+}
+
+extern "C" int dv3_weight_norm_bwd_multi(const dv3_wn_bwd_desc* descs, int32_t n, void* stream) {
+  DV3_REQUIRE(descs && n > 0 && n <= DV3_WN_BWD_MULTI_MAX, "wn_bwd_multi: 1..%d descriptors", DV3_WN_BWD_MULTI_MAX);
+  WnBwdMultiArgs a;
+  size_t lds_max = 0;
+  int total = 0;
+  for (int l = 0; l < n; ++l) {
+    int rows = 0;
+    size_t lds = 0;
+    const int rc = wn_bwd_check(&descs[l], &rows, &lds);
+    if (rc != DV3_OK) return rc;
+    for (int k = 0; k < l; ++k)
+      DV3_REQUIRE(descs[k].dv != descs[l].dv, "wn_bwd_multi: entries %d and %d write the same gradient", k, l);
+    if (lds > lds_max) lds_max = lds;
+    a.d[l] = descs[l];
+    a.first_row[l] = total;
+    total += rows;
+  }
+  for (int l = n; l <= DV3_WN_BWD_MULTI_MAX; ++l) a.first_row[l] = total;
+  for (int l = n; l < DV3_WN_BWD_MULTI_MAX; ++l) a.d[l] = descs[0];
+  a.n = n;
+  hipLaunchKernelGGL(wn_bwd_multi_kernel, dim3((unsigned)total), dim3(256), lds_max, (hipStream_t)stream, a);
+  return dv3_check_launch("weight_norm_bwd_multi");
 }

@@ -727,8 +727,52 @@ def weight_norm_bwd(slabs, n_slabs, ldo, v, g, scale, bias_part, n_part, O, I, J
     d.bias_part, d.n_part, d.dbias = _ptr(bias_part) if dbias is not None else None, n_part, _ptr(dbias)
     d.O, d.I, d.J, d.transposed = O, I, J, int(transposed)
     d.accumulate = int(into is not None)
+    if into is not None and WnBwdBatch.active:
+        WnBwdBatch.add(d, I if transposed else O, (slabs, v, g, scale, bias_part, dv, dg, dbias))
+        return dv, dg, dbias
     _lib.call("dv3_weight_norm_bwd_f32", ctypes.byref(d), _stream())
     return dv, dg, dbias
+
+
+class WnBwdBatch(object):
+    """The weight-norm backward of several layers in ONE launch (dv3_weight_norm_bwd_multi).  A single layer's launch
+    is a chain of ~24 memory round trips on two workgroups per CU (36 us whatever the layer); a trainer with in-place
+    gradients queues the descriptors during backward and flushes every `group` layers (on the stream the layers'
+    weight-gradient GEMMs run on, so the order with them is kept) and once at the end.  Off while gradient-ready hooks
+    are registered (data parallel: the buckets want each parameter's gradient as early as possible)."""
+    active = False
+    group = CONSTS["DV3_WN_BWD_MULTI_MAX"]
+    _q, _keep, _dv = [], [], set()
+
+    @classmethod
+    def add(cls, d, rows, keep):
+        if d.dv in cls._dv:             # a parameter used twice (the decoder's last_conv): keep the two updates ordered
+            cls.flush()
+        c = type(d)()
+        ctypes.memmove(ctypes.byref(c), ctypes.byref(d), ctypes.sizeof(d))
+        cls._q.append(c)
+        cls._keep.append(keep)
+        cls._dv.add(d.dv)
+        if len(cls._q) >= cls.group:
+            cls.flush()
+
+    @classmethod
+    def flush(cls):
+        """launch what is queued on ops._stream() (the side stream inside a SideStream section: the order with the
+        queued layers' weight-gradient GEMMs, which ran there, is the stream order)"""
+        if not cls._q:
+            return
+        q, keep = cls._q, cls._keep
+        cls._q, cls._keep, cls._dv = [], [], set()
+        arr = (type(q[0]) * len(q))(*q)
+        _lib.call("dv3_weight_norm_bwd_multi", ctypes.byref(arr), len(q), _stream())
+        if SideStream.stream is not None:
+            SideStream.retain(keep)
+
+    @classmethod
+    def discard(cls):
+        """drop what an aborted backward left queued"""
+        cls._q, cls._keep, cls._dv = [], [], set()
 
 
 def transpose(x, add=None, alpha=1.0):

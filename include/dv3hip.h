@@ -327,6 +327,13 @@ typedef struct dv3_wn_bwd_desc {
                                                 0: overwrite                                          */
 } dv3_wn_bwd_desc;
 int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream);
+/* The same for n <= DV3_WN_BWD_MULTI_MAX layers in ONE launch: one workgroup per normalised row of every layer.  A
+ * layer's launch is a chain of ~24 memory round trips on 2 workgroups per CU (36 us whatever the layer size); several
+ * layers together fill the chip and overlap those chains.  The descriptors (HOST memory) travel by value as kernel
+ * arguments: no table upload.  Two entries must not write the same gradient buffers.  Bit-identical to n single calls.
+ * Replaces: autograd of nn.utils.weight_norm for the layers of loss.backward() (train.py:755). */
+#define DV3_WN_BWD_MULTI_MAX 8
+int dv3_weight_norm_bwd_multi(const dv3_wn_bwd_desc* descs, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Gate / activation backward (autograd of modules.py:157-164, 224-226 and of ReLU/sigmoid).

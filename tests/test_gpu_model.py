@@ -544,6 +544,41 @@ def test_save_load_step_equals_uninterrupted_step(dev, gemm_mode, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dv3_preset_like", "nyanko_tiny", "dv3_multispeaker"])
+def test_batched_weight_norm_backward_equals_per_layer_launches(dev, gemm_mode, name):
+    """ops.WnBwdBatch / dv3_weight_norm_bwd_multi (the weight-norm backward of 8 layers per launch, descriptors as kernel
+    arguments, flushed on the stream their weight-gradient GEMMs ran on) against one launch per layer: three
+    optimisation steps with dropout end in bit-identical parameters and Adam moments (a parameter used twice in the
+    graph -- the decoder's last_conv -- keeps its two updates ordered)."""
+    from deepvoice3_pytorch_amd import builder, ops, train_step
+    fx, b, hp, sd, x, _ = _build(name, dev)
+    xg = _to(x, dev)
+    B, Td = x["mel"].shape[0], x["mel"].shape[1]
+    rng = np.random.RandomState(1)
+    ds = 4 if b != "nyanko" else hp.get("downsample_step", 4)
+    y = torch.from_numpy(rng.rand(B, Td * ds, hp["linear_dim"]).astype(np.float32)).to(dev)
+    batch = train_step.Batch(xg["text"], xg["text_positions"], xg["frame_positions"], xg["mel"], y,
+                             torch.zeros(B, Td, 1, device=dev), x["input_lengths"].numpy(),
+                             np.full(B, Td * ds - ds), xg.get("speaker_ids"), 1, ds, dev)
+    cfg = train_step.TrainConfig(max_positions=hp.get("max_positions", 512), initial_learning_rate=2e-3)
+    res = {}
+    for batched in (False, True):
+        m = getattr(builder, b)(**hp)
+        m.load_state_dict(sd)
+        tr = train_step.Trainer(m.to(dev), cfg)
+        tr.batch_wn_bwd = batched
+        for _ in range(3):
+            ops.dropout_state.manual_seed(7000 + tr.global_step)
+            tr.step(batch)
+        res[batched] = ({k: v.clone() for k, v in tr.model.state_dict().items()}, tr.arena.exp_avg.clone(),
+                        tr.arena.exp_avg_sq.clone())
+        tr.close()
+    for k in res[False][0]:
+        assert torch.equal(res[False][0][k], res[True][0][k]), k
+    assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["dv3_tiny", "dv3_preset_like", "dv3_multispeaker"])
 def test_fast_decode_equals_module_by_module_decode(dev, name, gemm_mode):
     """Decoder.incremental_forward on the fused decode-step kernels (decoder.fast_decode, 17 launches per step:
