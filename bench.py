@@ -699,16 +699,21 @@ class TrainRun(object):
         torch.cuda.empty_cache()
 
 
-def launch_mode(args):
-    """--graph / --no-graph force the launch mode; the default probes both (TrainRun)"""
+def launch_mode(args, world=1):
+    """--graph / --no-graph force the launch mode; the default probes both (TrainRun).  Under a process group the
+    default is eager: the bucketed all-reduces overlap backward from their own stream there (dist.py), and a capture
+    that contains RCCL collectives has only been exercised at world size 1 on this project's hardware -- opt in
+    with --graph."""
     if args.no_graph:
         return False
-    return True if args.graph else "auto"
+    if args.graph:
+        return True
+    return "auto" if world == 1 else False
 
 
 def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup):
     run = TrainRun(dev, pg, rank, world, preset, gemm, args.batch, args.text_len, args.frames,
-                   graph=launch_mode(args))
+                   graph=launch_mode(args, world))
     try:
         m = run.measure(steps, warmup)
         used_graph, probe = bool(run.use_graph), run.launch_probe
@@ -869,7 +874,7 @@ def main():
                               roofline=rf, roofline_wgrad=wgrad_roofline(dev))))
         return
 
-    run = TrainRun(dev, pg, rank, world, args.preset, gemm, args.batch, args.text_len, args.frames, launch_mode(args))
+    run = TrainRun(dev, pg, rank, world, args.preset, gemm, args.batch, args.text_len, args.frames, launch_mode(args, world))
     m = run.measure(args.steps, args.warmup, settle_s=args.settle)
     m_eager = None
     if run.use_graph and not args.no_extras:
