@@ -76,6 +76,7 @@ PRESETS = {"deepvoice3_ljspeech": ("deepvoice3", DV3_LJ, 0.2), "nyanko_ljspeech"
            "deepvoice3_vctk": ("deepvoice3_multispeaker", DV3_VCTK, 0.4)}
 # algorithmic forward+backward FLOPs per un-padded mel-frame at the bench shapes (FlopCounterMode)
 MFLOP_PER_FRAME = {"deepvoice3_ljspeech": 57.1, "nyanko_ljspeech": 64.8, "deepvoice3_vctk": 52.9}
+MFMA_RANDOM_OPERANDS_TF = 1681.0      # measured, profiles/r03_mfma_power.txt (zero operands: 2463)
 PEAK_F32_MFMA_TF = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak (= vector peak)
 PEAK_16BIT_MFMA_TF = 2500.0  # same guide: dense bf16 / fp16 MFMA peak
 PEAK_HBM_GBS = 8000.0
@@ -231,6 +232,11 @@ def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None, c8=False):
                             "kernels issue 3 MFMAs per product block; executed MFMA rate = 3 x achieved")
         out["mfma_executed_tflops"] = round(3 * tf, 1)
         out["x_fp32_matrix_peak"] = round(tf / PEAK_F32_MFMA_TF, 3)
+        # informational: what the matrix pipes alone sustain on RANDOM operands on this part (they reach the nominal
+        # 2.46 PF only on zeros: scripts/ubench/mfma_power.hip, profiles/r03_mfma_power.txt) -- `frac` above stays
+        # priced against the nominal dense peak
+        out["frac_of_mfma_rate_on_random_operands"] = round(3 * tf / MFMA_RANDOM_OPERANDS_TF, 3)
+        out["mfma_rate_on_random_operands_tflops"] = MFMA_RANDOM_OPERANDS_TF
     return out
 
 
