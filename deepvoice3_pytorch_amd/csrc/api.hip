@@ -1,5 +1,7 @@
 // Error plumbing + library identity for libdv3hip.so.
 #include "common.h"
+#include <atomic>
+#include <mutex>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -46,17 +48,19 @@ extern "C" int dv3_f16_range_events(int32_t* dst, int32_t reset, void* stream) {
   return DV3_OK;
 }
 extern "C" int dv3_stream_fork(void* from, void* to) {
+  // a ring of events created once (backward runs on autograd's device thread, join() on the caller's: thread-safe)
   static hipEvent_t ring[256];
-  static unsigned next = 0, made = 0;
-  const unsigned i = next++ % 256u;
-  if (i >= made) {
-    hipError_t e = hipEventCreateWithFlags(&ring[i], hipEventDisableTiming);
-    if (e != hipSuccess) {
-      dv3_set_error("stream_fork: hipEventCreate: %s", hipGetErrorString(e));
-      return DV3_ELAUNCH;
-    }
-    made = i + 1;
+  static std::once_flag made;
+  static std::atomic<unsigned> next{0};
+  static hipError_t create_err = hipSuccess;
+  std::call_once(made, [] {
+    for (int i = 0; i < 256 && create_err == hipSuccess; ++i) create_err = hipEventCreateWithFlags(&ring[i], hipEventDisableTiming);
+  });
+  if (create_err != hipSuccess) {
+    dv3_set_error("stream_fork: hipEventCreate: %s", hipGetErrorString(create_err));
+    return DV3_ELAUNCH;
   }
+  const unsigned i = next.fetch_add(1, std::memory_order_relaxed) % 256u;
   hipError_t e = hipEventRecord(ring[i], (hipStream_t)from);
   if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)to, ring[i], 0);
   if (e != hipSuccess) {
