@@ -595,6 +595,11 @@ def test_archived_bench_line_meets_the_contract():
         assert k in cb, k
     assert cb["kind"] in ("reference", "port")
     assert abs(d["value"] - d["config"]["global_batch"] * 800 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    # round 3: the host's issue time and the launch-mode probe are reported for the headline and for every side config
+    for cfg in [d["config"]] + [c["config"] for k, c in d["configs"].items() if k != "synth_rtf"]:
+        assert cfg["host_enqueue_ms_per_step"] > 0 and "hipgraph" in cfg and "launch_bound" in cfg
+        assert cfg["launch_probe"] is None or {"eager_ms_per_step", "hipgraph_ms_per_step"} <= set(cfg["launch_probe"])
+    assert "roofline_wgrad" in d and d["roofline_wgrad"]["alg_bytes"] > 2e8       # g + x + dW
 
 
 def test_bench_self_launches_its_ranks_dry():
