@@ -993,6 +993,7 @@ def main():
         if rank == 0:
             out["configs"] = cfgs
     if rank != 0:
+        _shutdown(pg)
         return
     if not args.no_roofline:
         rmode = "f16x3" if gemm == "bf16" else gemm
@@ -1010,7 +1011,21 @@ def main():
                                                            "hbm_frac", "variant")}
     if not args.no_cpu_baseline and world == 1 and args.preset == "deepvoice3_ljspeech":
         out["cpu_baseline"] = cpu_baseline(args.batch, args.text_len, args.frames)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    _shutdown(pg)
+
+
+def _shutdown(pg):
+    """leave the job together: rank 0 still times the single-GPU rooflines after the other ranks are done, and a rank
+    that exits while a peer's communicator is alive makes RCCL's watchdog noisy"""
+    if pg is None:
+        return
+    import torch.distributed as tdist
+    try:
+        tdist.barrier()
+        tdist.destroy_process_group()
+    except Exception as e:       # the measurement is printed already: never turn a teardown problem into a failed run
+        print("process group teardown: %s: %s" % (type(e).__name__, e), file=sys.stderr)
 
 
 if __name__ == "__main__":
