@@ -195,8 +195,9 @@ class StepProgram(object):
         """the decoder loop (deepvoice3.py:397-473 / nyanko.py:277-331): teacher-forced over test_inputs (B, n, D), or
         free running until every item's done flag passed 0.5 after min_steps, at most max_steps + 1 steps.
         -> number of steps taken.  Default (launched): one launch per program entry per step, issued by the library in
-        chunks of steps (decode_launched).  launched=False: the same launches from Python, optionally replayed as a
-        per-step hipGraph (~110 us of host time per step either way: slower than the GPU).  persistent=True (or
+        chunks of steps (decode_launched: ~3 us of host time per launch).  launched=False: the same launches from
+        Python + ctypes, optionally replayed as a per-step hipGraph (~100 us of host time per step either way: about
+        what the GPU needs for the step, so the host is on the critical path).  persistent=True (or
         DV3_DECODE_PERSISTENT=1): ONE launch for the whole loop -- bit-identical, and the host drops out entirely,
         but on MI355X the device-wide barrier between layers (agent-scope release + acquire: L2 write-back /
         invalidate across the 8 XCDs, ~3.5 us) costs more than a kernel boundary does (scripts/decode_time.py), so
