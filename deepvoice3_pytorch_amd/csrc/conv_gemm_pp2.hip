@@ -191,6 +191,26 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
     dst[tid + u * NT] = ra[0];
     dst[KB * BM + tid + u * NT] = ra[1];
   };
+  // EXPERIMENT (ABL == 11, dv3_debug_set(13, 11); compiled and inspected, NOT yet run on hardware -- round 4's first
+  // measurement): the same unit straight from global memory into its LDS slot with global_load_lds_dwordx4 -- no
+  // register round trip, no ds_write.  The panel image As[buf][plane][k8][BM] is indexed tid + u * NT, i.e. the 64
+  // lanes of a wave own 64 CONSECUTIVE 16-byte units: exactly the layout the LDS-DMA instruction writes (M0 = the
+  // wave's base, lane i lands at base + 16 i).  What the ISA of this first form shows (24 global_load_lds_dwordx4, 24
+  // fewer ds_write_b128 and 7 fewer registers than the shipped loop): the workgroup-scope fence inside __syncthreads()
+  // makes the compiler wait vmcnt(0) before the barrier that ends the issuing phase -- the whole memory latency once per
+  // step.  The form to measure next therefore replaces that one barrier by a raw s_barrier with a COUNTED wait
+  // (the 20 activation loads issued after the DMA may stay in flight: vmcnt is in order), as the uniform load schedule
+  // already allows for the register path.
+  auto dma_A_unit = [&](int buf, int chunk, int j, auto uc) {
+    constexpr int u = decltype(uc)::value;
+    const bf16x8* srch = Wh + (int64_t)(j * k8_total + chunk * KB) * lda;  // uniform
+    const uint32_t ao = aoff_of(u);
+    bf16x8* dst = As + buf * (2 * KB * BM) + u * NT + wave * 64;           // uniform per wave
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const char*>(srch) + ao), (lptr)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const char*>(srch + plane) + ao), (lptr)(dst + KB * BM), 16, 0, 0);
+  };
   // half an item (four of its eight channel rows): one uniform base per chunk + a 32-bit per-thread offset
   auto load_X_half = [&](int chunk, auto ic, auto hc) {
     constexpr int i = decltype(ic)::value, h = decltype(hc)::value;
@@ -268,7 +288,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   __syncthreads();
   {
     const int c1 = min(1, nchunks - 1);
-    load_A_unit(0, 1, U0{});           // unit 0 of step 1's panel: stored by the first LOAD phase
+    if (ABL != 11) load_A_unit(0, 1, U0{});           // unit 0 of step 1's panel: stored by the first LOAD phase
     load_X_half(c1, U0{}, U0{});
     load_X_half(c1, U0{}, U1{});
     load_X_half(c1, U1{}, U0{}); load_X_half(c1, U1{}, U1{});
@@ -313,7 +333,16 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
         if (j2 >= JT) { j2 = 0; c2 = cn + 1; }
         if (cn >= nchunks) { cn = c; jn = j; }          // past the end: re-fetch the current panel
         if (c2 >= nchunks) { c2 = c; j2 = j; }
-        if (s == 0) {
+        if constexpr (ABL == 11) {
+          // both units of the NEXT step's panel by LDS-DMA in the step's first phase: their buffer (cur ^ 1) was last
+          // read in the previous step and is first read two LOAD phases from now (the buffer of the step after is
+          // still being read during this one, so nothing can be sent there yet)
+          if (s == 0) {
+            dma_A_unit(cur ^ 1, cn, jn, U0{});
+            dma_A_unit(cur ^ 1, cn, jn, U1{});
+          }
+          (void)c2; (void)j2;
+        } else if (s == 0) {
           if (ABL != 9) write_A_unit(cur ^ 1, U0{});
           if (ABL != 7) load_A_unit(cn, jn, U1{});       // unit 1 of the next step's panel
         } else {
@@ -510,6 +539,7 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
       case 8: return launch_pp2<false, true, 8>(a, lds, st);
       case 9: return launch_pp2<false, true, 9>(a, lds, st);
       case 10: return launch_pp2<false, true, 10>(a, lds, st);
+      case 11: return launch_pp2<false, true, 11>(a, lds, st);   // EXPERIMENT: weight panels by LDS-DMA (see dma_A_unit)
     }
   }
   if (f16) return mask ? launch_pp2<true, true>(a, lds, st) : launch_pp2<false, true>(a, lds, st);
