@@ -164,7 +164,7 @@ def _traffic(kernel_key):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, calibrated as MI355X_MICROARCH.md
     prescribes), collected offline with rocprofv3 (scripts/pmc_hbm.sh; a counter pass can not run inside this
     process) and committed under profiles/ -- used only when the file was collected for THIS kernel."""
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json"):      # newest collection that holds THIS variant
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):      # newest collection that holds THIS variant
         try:
             hb = json.load(open(os.path.join(ROOT, "profiles", name)))
             ent = hb[kernel_key]
@@ -210,13 +210,14 @@ def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None, c8=False):
     tf = flops / (us * 1e-6) / 1e12
     fam = variant // 1000
     peak = {1: PEAK_F32_MFMA_TF, 2: PEAK_F32_MFMA_TF, 4: PEAK_16BIT_MFMA_TF,
-            8: PEAK_16BIT_MFMA_TF}.get(fam, PEAK_16BIT_MFMA_TF / 3.0)
+            8: PEAK_16BIT_MFMA_TF, 9: PEAK_16BIT_MFMA_TF}.get(fam, PEAK_16BIT_MFMA_TF / 3.0)
     kname = {1: "conv_gemm_f32_stream_kernel", 2: "conv_gemm_f32_kernel", 3: "conv_gemm_bf16x3_kernel<bf16 hi/lo>",
              4: "conv_gemm_bf16x3_kernel<bf16 x1>", 5: "conv_gemm_bf16x3_kernel<fp16 hi/lo>",
              6: "conv_planes_kernel<fp16 hi/lo>", 7: "conv_planes_kernel<bf16>",
-             8: "conv_planes_kernel<bf16 x1, c8 storage>"}.get(fam, "?")
+             8: "conv_planes_kernel<bf16 x1, c8 storage>",
+             9: "conv_c8pp_kernel<bf16 x1, c8 storage, 256 x 256 k32 ping-pong>"}.get(fam, "?")
     key = "conv_fwd:%d" % variant
-    if variant % 1000 == 101:
+    if variant % 1000 == 101 and fam in (3, 5):
         kname = "conv_gemm_pp2_kernel<%s>" % ("fp16 hi/lo" if fam == 5 else "bf16 hi/lo")
     out = dict(bound="mfma", kernel="%s variant %d (Conv1dGLU fwd B=64 C=256 T=1024 k=3)" % (kname, variant),
                achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
@@ -539,7 +540,7 @@ class _PowerSampler(object):
 class TrainRun(object):
     """model + trainer + resident batch of one (preset, gemm mode); .measure() = the contract's timed loop"""
 
-    def __init__(self, dev, pg, rank, world, preset, gemm, batch, text_len, frames, graph):
+    def __init__(self, dev, pg, rank, world, preset, gemm, batch, text_len, frames, graph, ragged=False):
         from deepvoice3_pytorch_amd import builder, train_step, ops
         self.ops, self.train_step = ops, train_step
         self.prev_mode = ops.set_gemm_precision(gemm)
@@ -552,7 +553,7 @@ class TrainRun(object):
         cfg = train_step.TrainConfig(max_positions=self.hp["max_positions"], guided_attention_sigma=ga_sigma)
         self.trainer = train_step.Trainer(self.model, cfg, process_group=pg)
         rng = np.random.RandomState(1234 + rank)
-        self.bt = synth_batch(rng, batch, text_len, frames, self.hp)
+        self.bt = synth_batch(rng, batch, text_len, frames, self.hp, fixed=not ragged)
         self.spk = torch.from_numpy(rng.randint(0, self.hp["n_speakers"], batch)) if self.hp["n_speakers"] > 1 else None
         bt = self.bt
         self.batch = train_step.Batch.from_collate(bt["text"], bt["input_lengths"], bt["mel"], bt["y"],
@@ -706,35 +707,94 @@ class TrainRun(object):
 
 
 def launch_mode(args, world=1):
-    """--graph / --no-graph force the launch mode; the default probes both (TrainRun).  Under a process group the
-    default is eager: the bucketed all-reduces overlap backward from their own stream there (dist.py), and a capture
-    that contains RCCL collectives has only been exercised at world size 1 on this project's hardware -- opt in
-    with --graph."""
+    """--graph / --no-graph force the launch mode; the default PROBES both (TrainRun) and keeps the faster step --
+    also under a world-size-1 process group (--force-group: RCCL collectives captured into the whole-step hipGraph,
+    tests/test_gpu_ddp.py).  With more than one rank the default stays eager: a capture that contains RCCL collectives
+    has only ever run at world size 1 on this project's hardware (no multi-GPU node was available to any round), and a
+    capture that hangs would void the scaling run; DV3_BENCH_DDP_GRAPH=auto (or --graph) opts in."""
     if args.no_graph:
         return False
     if args.graph:
         return True
-    return "auto" if world == 1 else False
+    if world > 1 and os.environ.get("DV3_BENCH_DDP_GRAPH", "") != "auto":
+        return False
+    return "auto"
 
 
-def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup):
-    run = TrainRun(dev, pg, rank, world, preset, gemm, args.batch, args.text_len, args.frames,
-                   graph=launch_mode(args, world))
+def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup, batch=None, ragged=False):
+    batch = batch or args.batch
+    run = TrainRun(dev, pg, rank, world, preset, gemm, batch, args.text_len, args.frames,
+                   graph=launch_mode(args, world), ragged=ragged)
     try:
         m = run.measure(steps, warmup)
         used_graph, probe = bool(run.use_graph), run.launch_probe
+        shape = dict(text_len=int(run.bt["text"].shape[1]), padded_frames=int(run.bt["mel"].shape[1]),
+                     frames_per_step=m["frames_per_step"])
     finally:
         run.close()
     return dict(metric="mel-frames/sec/node (train step, %s)" % preset, value=m["value"], unit="mel-frames/s",
                 n_gpus=world, steps=steps, warmup=warmup, ms_per_step=m["ms_per_step"], dtype=gemm,
                 dtype_note=dtype_note(gemm), step_flop_frac=m["step_flop_frac"],
                 config=dict(workload="builder=%s preset=%s train step" % (PRESETS[preset][0], preset),
-                            per_gpu_batch=args.batch, global_batch=args.batch * world, final_loss=m["final_loss"],
+                            per_gpu_batch=batch, global_batch=batch * world, final_loss=m["final_loss"],
+                            lengths=("ragged LJSpeech-shaped (SURVEY 8d cfg2: frames ~ clip(N(566,180),120,870), text ~ "
+                                     "clip(N(100,30),20,187)), padded to the batch maximum as train.collate_fn does"
+                                     if ragged else "fixed"), shape=shape,
                             hipgraph=used_graph, launch_probe=probe,
                             host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"],
                             host_loop_ms_per_step=m["host_loop_ms_per_step"],
                             launch_bound=bool(m["host_enqueue_ms_per_step"] > 0.97 * m["ms_per_step"]),
+                            host_below_half_step=bool(m["host_enqueue_ms_per_step"] < 0.5 * m["ms_per_step"]),
                             allreduce_exposed_ms=m["allreduce_exposed_ms"]))
+
+
+def ddp_world1_config(dev, preset, gemm, args, no_group_ms, steps=12, warmup=4):
+    """The data-parallel step with its gradient exchange ARMED, on the one GPU a bench box has: a world-size-1 "nccl"
+    (RCCL) group, dist.BucketedAllReduce's notifications, bucketed all-reduces on the collective stream, clip with
+    the 1/world prescale.  Measured in both launch modes: eager (two real backward streams + the collective stream)
+    and the replayed whole-step hipGraph with the RCCL collectives captured.  What it shows: the host cost of a step
+    with the group armed, and the step time against the same step without a group."""
+    import torch.distributed as tdist
+    pg = tdist.group.WORLD
+    out = dict(no_group_ms_per_step=no_group_ms)
+    for mode in ("eager", "hipgraph"):
+        try:
+            run = TrainRun(dev, pg, 0, 1, preset, gemm, args.batch, args.text_len, args.frames, graph=(mode == "hipgraph"))
+        except Exception as e:
+            out[mode] = dict(error="%s: %s" % (type(e).__name__, e))
+            continue
+        try:
+            if mode == "hipgraph" and not run.use_graph:
+                out[mode] = dict(error=run.graph_error or "capture failed")
+                continue
+            m = run.measure(steps, warmup)
+            comm = run.trainer.comm
+            out.setdefault("gradient_buckets", len(comm.buckets))
+            out.setdefault("bucket_mb", [round((hi - lo) * 4 / 2 ** 20, 2) for lo, hi, _ in comm.buckets])
+            out["autograd_hooks_after_first_step"] = len(comm._handles)
+            out["parameters"] = len(run.trainer.arena.params)
+            out[mode] = dict(ms_per_step=m["ms_per_step"], value=m["value"],
+                             host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"],
+                             allreduce_exposed_ms=m["allreduce_exposed_ms"],
+                             vs_no_group=round(m["ms_per_step"] / no_group_ms, 4) if no_group_ms else None)
+        except Exception as e:
+            out[mode] = dict(error="%s: %s" % (type(e).__name__, e))
+        finally:
+            run.close()
+    ok = [k for k in ("eager", "hipgraph") if "ms_per_step" in out.get(k, {})]
+    if ok:
+        out["faster"] = min(ok, key=lambda k: out[k]["ms_per_step"])
+    return out
+
+
+def _world1_group():
+    """a world-size-1 "nccl" group in this process (no launcher): RCCL loads and runs its collectives on one device"""
+    import torch.distributed as tdist
+    if tdist.is_initialized():
+        return False
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    return True
 
 
 # -------------------------------------------------------------------------------------------------
@@ -833,6 +893,9 @@ def main():
                     help="skip value_exact_f32 / configs / input_pipeline (headline + rooflines only)")
     ap.add_argument("--mode", default="train", choices=["train", "conv", "conv-ab", "synth"])
     ap.add_argument("--gl-iters", type=int, default=60, help="Griffin-Lim iterations (synth mode)")
+    ap.add_argument("--force-group", action="store_true",
+                    help="--gpus 1 only: run the headline step itself under a world-size-1 nccl (RCCL) process group "
+                         "(gradient buckets armed); without it the same measurement appears under configs.ddp_world1")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the N ranks, rendezvous and run the bucketed all-reduce only (no HIP compute; gloo "
                          "on a CPU-only box)")
@@ -852,6 +915,11 @@ def main():
         ops.set_gemm_precision(args.gemm)
     gemm = ops.gemm_precision()
     pg, rank, world, local_rank = dv3dist.init_from_env()
+    if args.force_group and pg is None and args.gpus == 1:
+        torch.cuda.set_device(0)
+        _world1_group()
+        import torch.distributed as tdist
+        pg = tdist.group.WORLD
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
@@ -990,6 +1058,30 @@ def main():
                 cfgs["synth_rtf"] = s
             except Exception as e:
                 cfgs["synth_rtf"] = dict(error="%s: %s" % (type(e).__name__, e))
+        if world == 1 and pg is None:
+            # the reference's own operating points (presets/deepvoice3_ljspeech.json:48 batch_size 16; SURVEY 8d cfg2's
+            # ragged LJSpeech-shaped lengths) and the data-parallel step armed on one GPU
+            for key, kw in (("dv3lj_b16", dict(batch=16)), ("dv3lj_b64_ragged", dict(batch=args.batch, ragged=True)),
+                            ("dv3lj_b16_ragged", dict(batch=16, ragged=True))):
+                try:
+                    cfgs[key] = side_config(dev, pg, rank, world, args.preset, gemm, args, 20, 8, **kw)
+                except Exception as e:
+                    cfgs[key] = dict(error="%s: %s" % (type(e).__name__, e))
+            try:
+                made = _world1_group()
+                import torch.distributed as tdist
+                d1 = dict(backend=tdist.get_backend(), rccl_ranks=tdist.get_world_size(),
+                          note="world-size-1 nccl group in the bench process: gradient buckets armed, all-reduces on the "
+                               "collective stream; eager = per-kernel launches on three streams, hipgraph = the whole "
+                               "step incl. the RCCL collectives captured and replayed")
+                d1["dv3lj_" + gemm] = ddp_world1_config(dev, args.preset, gemm, args, m["ms_per_step"])
+                d1["nyanko_bf16"] = ddp_world1_config(dev, "nyanko_ljspeech", "bf16", args, cfgs["nyanko_bf16"]["ms_per_step"])
+                d1["vctk_bf16"] = ddp_world1_config(dev, "deepvoice3_vctk", "bf16", args, cfgs["vctk_bf16"]["ms_per_step"])
+                cfgs["ddp_world1"] = d1
+                if made:
+                    tdist.destroy_process_group()
+            except Exception as e:
+                cfgs["ddp_world1"] = dict(error="%s: %s" % (type(e).__name__, e))
         if rank == 0:
             out["configs"] = cfgs
     if rank != 0:

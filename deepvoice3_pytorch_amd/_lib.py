@@ -13,7 +13,10 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "dv3hip.h")
-_LIBPATH = os.path.join(_HERE, "libdv3hip.so")
+# DV3_LIBPATH: developer scripts load the experiment build (csrc: `make EXP=1` -> libdv3hip_exp.so) instead
+_LIBPATH = os.environ.get("DV3_LIBPATH") or os.path.join(_HERE, "libdv3hip.so")
+if not os.path.isabs(_LIBPATH):
+    _LIBPATH = os.path.join(_HERE, _LIBPATH)
 
 _CTYPES = {
     "float": ctypes.c_float,

@@ -18,13 +18,14 @@ int g_dv3_last_conv = 0, g_dv3_last_wgrad = 0;
 // sticky fp16-range event counter of the f16x3 mode (include/dv3hip.h: dv3_f16_range_events)
 __device__ uint32_t g_dv3_range_events;
 uint32_t* dv3_range_ctr() {
+  // resolved once (backward runs on autograd's thread: call_once, not an unsynchronised static); the __device__ word is
+  // zero-initialised by the loader, so nothing is issued on any stream here (a first call may land inside a capture)
   static uint32_t* ptr = nullptr;
-  if (!ptr) {
+  static std::once_flag once;
+  std::call_once(once, [] {
     void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_dv3_range_events)) != hipSuccess) return nullptr;
-    (void)hipMemset(p, 0, sizeof(uint32_t));
-    ptr = (uint32_t*)p;
-  }
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_dv3_range_events)) == hipSuccess) ptr = (uint32_t*)p;
+  });
   return ptr;
 }
 extern "C" int dv3_f16_range_events(int32_t* dst, int32_t reset, void* stream) {

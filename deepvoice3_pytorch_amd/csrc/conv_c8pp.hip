@@ -1,0 +1,371 @@
+// Single-term bf16 tap-GEMM on channel-blocked bf16 ("c8") activations, 256 x 256 workgroup tile, 8 waves of 128 x 64,
+// ping-pong at k32 granularity -- the forward / input-gradient kernel of the bf16 configurations (BASELINE configs 3/4:
+// nyanko_ljspeech, deepvoice3_vctk; reference semantics deepvoice3_pytorch/modules.py:145-164, 205-226 and their
+// autograd; layer shapes nyanko.py:28-58,364-399, deepvoice3.py:39-67,213-264).
+//
+// Same contract, operand images, accumulation order and fused tails as the single-term instantiation of
+// conv_planes_kernel (conv_planes.hip), so its results are bit-identical to that kernel's.  What changes:
+//
+//   * a wave owns 128 rows (two 32-row sub-tiles of the `a` half + the matching gate rows) x 64 columns: 8 accumulator
+//     blocks; per k16 block 6 operand fragments feed 8 MFMAs (the 64 x 64 wave tile of the 128 x 256 kernel reads 4
+//     fragments per 4 MFMAs).  Round 3's PMC pass of that kernel: matrix pipe busy 24 % of the launch, half the wave
+//     cycles parked in s_waitcnt -- at one MFMA per fragment the LDS pipe (256 B/clk) is as busy as the matrix pipe.
+//   * the two waves of a SIMD alternate LOAD / COMPUTE phases of one (32-channel chunk, tap) step: a LOAD phase stores
+//     the thread's share of the NEXT step's weight panel and of the NEXT chunk's activation tile (fetched one step / one
+//     chunk earlier: plain 16-byte copies, c8 IS the operand layout), re-issues those fetches for the step / chunk
+//     after, and reads the 12 fragments of its step; the COMPUTE phase is 16 MFMAs (512 matrix-pipe cycles) on registers
+//     only.  While one wave of a SIMD computes, its partner loads.
+//   * every global load is unconditional and issued in one fixed order per step (the tail re-fetches the last panel /
+//     chunk into buffers nobody reads), so each s_waitcnt vmcnt is exact (conv_gemm_pp2.hip measured why).
+//
+// LDS: weight panels [2][4 k8][256 rows] = 32 KB, activation tiles [2][XI * 512 units] <= 48 KB.
+// Dropout: keep-BYTES of the c8 input (dv3_conv_desc.xmask_c8), applied to the staged units; 1/(1-p) on the accumulators.
+#include "conv_common.h"
+#include <math.h>
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int KB = 4, HALO_MAX = 64;
+constexpr int BM = 256, BMH = 128, BN = 256, NT = 512, MI = 2, NI = 2, WN = 4;
+constexpr int AU = KB * BM / NT;                            // weight-panel units per thread per step (2)
+static_assert(AU == 2, "two panel units per thread and step");
+
+template <typename T>
+__device__ __forceinline__ T c8pp_ldg(const void* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+// zero the dropped channels of one unit (bit e of the keep-byte = channel e)
+__device__ __forceinline__ bf16x8 c8pp_keep8(const bf16x8& v, uint32_t m) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 d = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_sbfe((int)m, 2 * i, 1) & 0xffffu;
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_sbfe((int)m, 2 * i + 1, 1) << 16;
+    d[i] &= (lo | hi);
+  }
+  return __builtin_bit_cast(bf16x8, d);
+}
+
+template <int JT, bool MASK>
+__global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
+  constexpr int XI = (KB * (BN + (JT > 1 ? HALO_MAX : 0)) + NT - 1) / NT;   // activation units per thread per chunk
+  constexpr int XPS = XI * NT;                                              // units per tile buffer (padded: no store is predicated)
+  static_assert(JT == 1 || JT == 3, "tap counts of the models' layers");
+  static_assert(JT == 1 || XI == JT, "three-tap layers: one activation item per tap phase");
+  const dv3_conv_desc& p = args.d;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int dil = p.dil;
+  const int BNH = BN + (JT - 1) * dil;
+  bf16x8* const As = reinterpret_cast<bf16x8*>(smem_raw);   // [2 buffers][KB][BM]
+  bf16x8* const Xs = As + 2 * KB * BM;                      // [2 buffers][XPS]  ([KB][BNH] + padding)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  const int pid = dv3_xcd_remap(blockIdx.x, args.n_blocks);
+  const int mt = pid % args.m_tiles;
+  const int nt = pid / args.m_tiles;
+  const int n0 = nt * BN;
+
+  const bool gated = (p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY);
+  int h0b, h1b;
+  if (gated) {
+    h0b = mt * BMH; h1b = p.a_half + mt * BMH;
+  } else {
+    h0b = mt * BM; h1b = mt * BM + BMH;
+  }
+
+  const int T = p.Tout, lda = p.lda, B = p.B;
+  const int Ntot = B * T;
+  const int k8_total = args.kp >> 3;                        // == p.x_c8p
+  const int nchunks = args.kp >> 5;
+  const bf16x8* __restrict__ Wh = reinterpret_cast<const bf16x8*>(p.a_split);
+  const bf16x8* __restrict__ XP = reinterpret_cast<const bf16x8*>(p.x_planes);
+  const uint8_t* __restrict__ const xkeep = p.xmask_c8;
+  const int n_items = KB * BNH;
+
+  // ---- this lane's output columns: per-tap validity of the shifted read (the conv's zero padding at sequence edges) ----
+  uint32_t vbits = 0;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * (NI * 32) + ni * 32 + l31;
+    const int bc = n / T, tc = n - bc * T;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const int ts = tc + j * dil - p.padL;
+      if (n < Ntot && ts >= 0 && ts < T) vbits |= 1u << (j * NI + ni);
+    }
+  }
+  uint32_t need = 0;
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    const uint32_t all = ((1u << NI) - 1u) << (j * NI);
+    if (!__all((vbits & all) == all)) need |= 1u << j;
+  }
+  need = __builtin_amdgcn_readfirstlane(need);
+
+  // ---- this thread's staging units, fixed over the K loop ----
+  uint32_t xoff[XI];                // byte offset of unit (b, k8, t) inside the c8 tensor, chunk 0
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int idx = tid + i * NT;
+    const int k8 = idx / BNH, q = idx - k8 * BNH;
+    const int f = n0 - p.padL + q;
+    int bf = 0, tf = 0;
+    if (idx < n_items && f >= 0 && f < Ntot) {
+      bf = f / T;
+      tf = f - bf * T;
+    }
+    const int k8c = k8 < KB ? k8 : 0;
+    xoff[i] = (((uint32_t)bf * (uint32_t)k8_total + (uint32_t)k8c) * (uint32_t)T + (uint32_t)tf) * 16u;
+  }
+  uint32_t aoff[AU];                // byte offset of this thread's panel units inside a (tap, chunk) panel row block
+#pragma unroll
+  for (int u = 0; u < AU; ++u) {
+    const int idx = tid + u * NT;   // k8 * BM + col
+    const int col = idx % BM, k8 = idx / BM;
+    const bool hi_half = col >= BMH;
+    const int gcol = (hi_half ? h1b : h0b) + (col - (hi_half ? BMH : 0));
+    aoff[u] = (uint32_t)(k8 * lda + (gcol < lda ? gcol : 0)) * 16u;
+  }
+
+  bf16x8 ra[AU], rx[XI];
+  uint32_t rk[MASK ? XI : 1];
+
+  auto load_A = [&](int chunk, int j) {
+    const bf16x8* src = Wh + (int64_t)(j * k8_total + chunk * KB) * lda;   // uniform
+#pragma unroll
+    for (int u = 0; u < AU; ++u) ra[u] = c8pp_ldg<bf16x8>(src, aoff[u]);
+  };
+  auto write_A = [&](int buf) {
+    bf16x8* dst = As + buf * (KB * BM);
+#pragma unroll
+    for (int u = 0; u < AU; ++u) dst[tid + u * NT] = ra[u];
+  };
+  auto load_X_item = [&](int chunk, auto ic) {
+    constexpr int i = decltype(ic)::value;
+    const bf16x8* src = XP + (int64_t)chunk * KB * T;                       // uniform: chunk c = 4 k8 blocks further
+    rx[i] = c8pp_ldg<bf16x8>(src, xoff[i]);
+    if constexpr (MASK) rk[i] = (uint32_t)c8pp_ldg<uint8_t>(xkeep + (int64_t)chunk * KB * T, xoff[i] >> 4);
+  };
+  auto write_X_item = [&](int buf, auto ic) {
+    constexpr int i = decltype(ic)::value;
+    bf16x8 v = rx[i];
+    if constexpr (MASK) v = c8pp_keep8(v, rk[i]);
+    Xs[buf * XPS + tid + i * NT] = v;
+  };
+  using U0 = std::integral_constant<int, 0>;
+  using U1 = std::integral_constant<int, 1>;
+  using U2 = std::integral_constant<int, 2>;
+  auto load_X_all = [&](int chunk) {
+    load_X_item(chunk, U0{});
+    load_X_item(chunk, U1{});
+    if constexpr (XI == 3) load_X_item(chunk, U2{});
+  };
+  auto write_X_all = [&](int buf) {
+    write_X_item(buf, U0{});
+    write_X_item(buf, U1{});
+    if constexpr (XI == 3) write_X_item(buf, U2{});
+  };
+
+  f32x16 acc[MI][2][NI];   // [row sub-tile][a rows | gate rows][column sub-tile]
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] = 0.f;
+
+  const int a_off = wm * (MI * 32) + l31;
+  const int x_off = wn * (NI * 32) + l31;
+
+  // ---- prologue: step 0's panel and chunk 0's tile into buffer 0; then the fetches that run a step / a chunk ahead ----
+  load_A(0, 0);
+  load_X_all(0);
+  write_A(0);
+  write_X_all(0);
+  __syncthreads();
+  {
+    // step 1 = (chunk 0, tap 1) for three-tap layers, (chunk 1, tap 0) for 1 x 1 layers; past the end: re-fetch step 0
+    int c1 = JT == 1 ? 1 : 0, j1 = JT == 1 ? 0 : 1;
+    if (c1 >= nchunks) { c1 = 0; j1 = 0; }
+    load_A(c1, j1);
+    load_X_all(min(1, nchunks - 1));
+  }
+
+  // ---- ping-pong main loop: waves w and w + 4 share a SIMD and run the same phase sequence one phase apart ----
+  //   interval:   I0        I1        I2        I3
+  //   waves 0-3:  L(0)      C(0)      L(1)      C(1) ...
+  //   waves 4-7:  -         L(0)      C(0)      L(1) ...
+  // LDS hazards: the panel of step s+1 is stored during the L phases of step s (intervals 2s, 2s+1) into the buffer last
+  // read in the L phases of step s-1 (intervals 2s-2, 2s-1) and first read in L(s+1) (interval 2s+2); the tile of chunk
+  // c+1 during the L phases of chunk c into the buffer last read in chunk c-1.  Every interval ends with a barrier.
+  const int late = wave >> 2;
+  if (late) __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const bf16x8* XsC = Xs + (c & 1) * XPS;
+    const int cx = min(c + 2, nchunks - 1);          // the chunk fetched during this one (the tail re-fetches the last)
+    const bool last_chunk = c + 1 == nchunks;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const int cur = (c * JT + j) & 1;
+      const bf16x8* AsC = As + cur * (KB * BM);
+      const bool fix = (need >> j) & 1u;
+      // ---------------- LOAD ----------------
+      {
+        // the next step's panel: store (fetched in this wave's previous LOAD phase), then fetch the panel after
+        int j2 = j + 2, c2 = c;
+        if (JT == 1) { j2 = 0; c2 = c + 2; }
+        else if (j2 >= JT) { j2 -= JT; c2 = c + 1; }
+        if (c2 >= nchunks) { c2 = c; j2 = j; }            // past the end: re-fetch the current panel
+        write_A(cur ^ 1);
+        load_A(c2, j2);
+        // the next chunk's tile: one item per tap phase (three-tap layers) or all of it (1 x 1 layers)
+        if constexpr (JT == 1) {
+          write_X_all((c + 1) & 1);
+          load_X_all(cx);
+        } else {
+          if (j == 0) { write_X_item((c + 1) & 1, U0{}); load_X_item(cx, U0{}); }
+          if (j == 1) { write_X_item((c + 1) & 1, U1{}); load_X_item(cx, U1{}); }
+          if (j == 2) { write_X_item((c + 1) & 1, U2{}); load_X_item(cx, U2{}); }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 fa[2][MI][2], fb[2][NI];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int k8 = 2 * ks + lhi;
+        const int ai = k8 * BM + a_off;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          fa[ks][mi][0] = AsC[ai + mi * 32];
+          fa[ks][mi][1] = AsC[ai + mi * 32 + BMH];
+        }
+        const int xi = k8 * BNH + x_off + j * dil;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fb[ks][ni] = XsC[xi + ni * 32];
+      }
+      if (fix) {
+        const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const bool ok = (vbits >> (j * NI + ni)) & 1u;
+            fb[ks][ni] = ok ? fb[ks][ni] : zero8;
+          }
+      }
+      __syncthreads();
+      // the MFMAs are register-only: without the fences the compiler sinks them below the second barrier into the next
+      // LOAD phase and the ping-pong degenerates into the in-phase loop (conv_gemm_pp2.hip)
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- COMPUTE: 16 MFMAs of one (chunk, tap) step ----------------
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mi][0], fb[ks][ni], acc[mi][0][ni], 0, 0, 0);
+            acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mi][1], fb[ks][ni], acc[mi][1][ni], 0, 0, 0);
+          }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(last_chunk && j == JT - 1) || !late) __syncthreads();
+    }
+  }
+
+  // ---- fused tail (conv_common.h), one 32-row sub-tile at a time ----
+  int n0e = __builtin_amdgcn_readfirstlane(n0);
+  asm volatile("" : "+s"(n0e));
+  int bcol[NI], tcol[NI];
+  bool okc[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0e + wn * (NI * 32) + ni * 32 + l31;
+    okc[ni] = n < Ntot;
+    bcol[ni] = n / T;
+    tcol[ni] = n - bcol[ni] * T;
+  }
+  if constexpr (MASK) {      // x * keep / (1-p): the 1/(1-p) of a masked c8 input, exact on the accumulators
+    const float ds = p.drop_scale;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] *= ds;
+  }
+  if (p.io_bf16 & DV3_IO_OUT_C8) {
+    conv_epilogue_c8<BM, BMH, NI>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+    conv_epilogue_c8<BM, BMH, NI>(p, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+  } else {
+    conv_epilogue<BM, BMH, NI, 0, true>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+    conv_epilogue<BM, BMH, NI, 0, true>(p, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+  }
+}
+
+template <int JT, bool MASK>
+int launch_c8pp(const ConvArgs& a, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_c8pp_kernel<JT, MASK>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      dv3_set_error("conv_c8pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DV3_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_c8pp_kernel<JT, MASK>), dim3(a.n_blocks), dim3(NT), lds, st, a);
+  return dv3_check_launch("conv_c8pp");
+}
+
+}  // namespace
+
+int g_c8pp_min_tiles = 128;   // dv3_debug_set(19, v): the 256 x 256 c8 kernel serves eligible shapes whose grid has at
+                              // least v tiles (0 = never; 1 = always)
+
+// Called by dv3_conv_planes_dispatch (conv_planes.hip) for single-term bf16 layers on c8 input.  Returns 1 when the
+// shape is not eligible (the caller continues with the 128-row planes kernel), else a DV3_* code.
+int dv3_conv_c8pp_dispatch(const dv3_conv_desc* d, hipStream_t st) {
+  if (g_c8pp_min_tiles <= 0 || d->split_terms != 1 || !d->a_split || !d->x_planes) return 1;
+  if ((d->J != 1 && d->J != 3) || (d->J - 1) * d->dil > HALO_MAX) return 1;
+  if (d->a_bs != 0 || (d->lda & 3) || d->Tin != d->Tout) return 1;
+  const bool gated = d->mode == DV3_EPI_GLU || d->mode == DV3_EPI_HIGHWAY;
+  const int kp = (d->Cin + 31) / 32 * 32;
+  if (d->x_c8p != kp / 8) return 1;
+  const int64_t ntot = (int64_t)d->B * d->Tout;
+  const int64_t m_tiles = gated ? dv3_cdiv(d->Cg, BMH) : dv3_cdiv(d->M, BM);
+  const int64_t nb = m_tiles * dv3_cdiv64(ntot, BN);
+  if (d->tile_hint != 40 && nb < g_c8pp_min_tiles) return 1;
+  const int XI = (KB * (BN + (d->J > 1 ? HALO_MAX : 0)) + NT - 1) / NT;
+  const size_t lds = (size_t)(2 * KB * BM + 2 * XI * NT) * 16;
+  ConvArgs a;
+  a.d = *d;
+  a.a_scalar = 0;
+  a.kp = kp;
+  a.m_tiles = (int)m_tiles;
+  a.n_tiles = (int)dv3_cdiv64(ntot, BN);
+  DV3_REQUIRE(nb < (1ll << 31), "conv_c8pp: grid too large");
+  a.n_blocks = (int)nb;
+  g_dv3_last_conv = 9000 + 100 + 1;     // single-term c8, 256 x 256 tile, ping-pong
+  const bool mask = d->xmask_c8 != nullptr;
+  if (d->J == 3) return mask ? launch_c8pp<3, true>(a, lds, st) : launch_c8pp<3, false>(a, lds, st);
+  return mask ? launch_c8pp<1, true>(a, lds, st) : launch_c8pp<1, false>(a, lds, st);
+}
+
+int dv3_c8pp_debug_set(int what, int value) {
+  if (what == 19) g_c8pp_min_tiles = value;
+  return DV3_OK;
+}

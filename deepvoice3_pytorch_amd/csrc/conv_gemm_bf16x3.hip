@@ -612,6 +612,7 @@ int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
   return dv3_check_launch("conv_gemm_bf16x3");
 }
 int g_x3_ablate = 0;   // debug: dv3_debug_set(); ablation variants of the 128x128 unmasked tile
+#ifdef DV3_EXPERIMENTS   // timing-only ablations / phase stamps: `make EXP=1` (not in the shipped library)
 template <int ABL>
 int launch_x3_abl(const ConvArgs& a, size_t lds, hipStream_t st) {
   (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<2, 2, 2, false, ABL>,
@@ -619,6 +620,7 @@ int launch_x3_abl(const ConvArgs& a, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<2, 2, 2, false, ABL>), dim3(a.n_blocks), dim3(256), lds, st, a);
   return dv3_check_launch("conv_gemm_bf16x3(abl)");
 }
+#endif
 // main loop of the 8-wave tiles, dv3_debug_set(3, v): 0 = in-phase, 1 = ping-pong (default)
 int g_x3_pingpong = 1;
 template <int WM, int WN, int NI, int MI, bool PP>
@@ -631,6 +633,7 @@ int launch_x3_big_pp(const ConvArgs& a, size_t lds, hipStream_t st) {
 }
 template <int WM, int WN, int NI, int MI>
 int launch_x3_big(const ConvArgs& a, size_t lds, hipStream_t st) {
+#ifdef DV3_EXPERIMENTS
   if constexpr (WM == 2 && WN == 4 && MI == 1) {
     if (g_x3_ablate == 10 && g_x3_pingpong && !a.d.xmask && (a.d.split_terms == 0 || a.d.split_terms == 3)) {
       (void)hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<2, 4, 2, false, 10, 3, 1, true>,
@@ -639,6 +642,7 @@ int launch_x3_big(const ConvArgs& a, size_t lds, hipStream_t st) {
       return dv3_check_launch("conv_gemm_bf16x3(stamps)");
     }
   }
+#endif
   if constexpr (WM * WN == 8 && MI == 1) {
     if (g_x3_pingpong) return launch_x3_big_pp<WM, WN, NI, MI, true>(a, lds, st);
   }
@@ -646,6 +650,7 @@ int launch_x3_big(const ConvArgs& a, size_t lds, hipStream_t st) {
 }
 template <int WM, int WN, int NI>
 int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
+#ifdef DV3_EXPERIMENTS
   if (g_x3_ablate && WM == 2 && WN == 2 && NI == 2 && !a.d.xmask && (a.d.split_terms == 0 || a.d.split_terms == 3)) {
     switch (g_x3_ablate) {
       case 1: return launch_x3_abl<1>(a, lds, st);
@@ -659,6 +664,7 @@ int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
       case 9: return launch_x3_abl<9>(a, lds, st);
     }
   }
+#endif
   if (a.d.split_terms == DV3_SPLIT_F16X3)
     return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3, 1, false, true>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3, 1, false, true>(a, lds, st);
   if (a.d.split_terms == 1)
@@ -766,8 +772,16 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
 
 extern int g_wgrad_tile, g_wgrad_prio, g_wgrad_t2_abl, g_wgrad_taps2_default;   // wgrad_gemm_bf16x3.hip, wgrad_taps2.hip
 int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
+int dv3_c8pp_debug_set(int what, int value);     // conv_c8pp.hip
 extern "C" int dv3_debug_set(int what, int value) {
+#ifndef DV3_EXPERIMENTS
+  // the timing-only ablation / stamp instantiations are compiled with `make EXP=1` only: say so instead of silently
+  // timing the production kernel
+  DV3_REQUIRE(!(value != 0 && (what == 1 || what == 6 || what == 13 || what == 16)),
+              "debug_set(%d, %d): ablation variants are not in this build (make EXP=1)", what, value);
+#endif
   if (what >= 4 && what <= 8) return dv3_planes_debug_set(what, value);
+  if (what == 19) return dv3_c8pp_debug_set(what, value);
   if (what == 9) g_x3_rel2 = value;
   if (what == 12) g_x3_pp2 = value;
   if (what == 13) g_pp2_abl = value;

@@ -527,6 +527,7 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   a.n_blocks = (int)nb;
   g_dv3_last_conv = (f16 ? 5000 : 3000) + 100 + 1;     // tile id 10, ping-pong
   const bool mask = d->xmask_c8 != nullptr;
+#ifdef DV3_EXPERIMENTS
   if (g_pp2_abl && !mask && f16) {
     switch (g_pp2_abl) {
       case 1: return launch_pp2<false, true, 1>(a, lds, st);
@@ -542,6 +543,7 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
       case 11: return launch_pp2<false, true, 11>(a, lds, st);   // EXPERIMENT: weight panels by LDS-DMA (see dma_A_unit)
     }
   }
+#endif
   if (f16) return mask ? launch_pp2<true, true>(a, lds, st) : launch_pp2<false, true>(a, lds, st);
   return mask ? launch_pp2<true, false>(a, lds, st) : launch_pp2<false, false>(a, lds, st);
 }

@@ -34,6 +34,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+int dv3_conv_c8pp_dispatch(const dv3_conv_desc* d, hipStream_t st);   // conv_c8pp.hip
+
 namespace {
 
 constexpr int KB = 4;          // k8 blocks per 32-channel chunk
@@ -549,6 +551,7 @@ int g_planes_mid_thr = 1;   // dv3_debug_set(8, v): 128x128 tiles once they numb
 int g_planes_stagger = -1;  // dv3_debug_set(5, v)
 int g_planes_abl = 0;       // dv3_debug_set(6, v)
 
+#ifdef DV3_EXPERIMENTS
 template <int WM, int WN, int NI, int ABL>
 int launch_planes_abl(const ConvArgs& a, size_t lds, int grid, hipStream_t st) {
   (void)hipFuncSetAttribute((const void*)conv_planes_kernel<WM, WN, NI, 3, true, ABL>,
@@ -564,6 +567,7 @@ int launch_planes_abl1(const ConvArgs& a, size_t lds, int grid, hipStream_t st) 
   hipLaunchKernelGGL((conv_planes_kernel<WM, WN, NI, 1, false, ABL>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
   return dv3_check_launch("conv_planes(abl)");
 }
+#endif
 
 template <int WM, int WN, int NI, int TERMS, bool F16, int JT>
 int launch_planes_j(const ConvArgs& a, size_t lds, int grid, hipStream_t st) {
@@ -594,6 +598,7 @@ int launch_planes_t(const ConvArgs& a, size_t lds, int grid, hipStream_t st) {
 }
 template <int WM, int WN, int NI>
 int launch_planes(const ConvArgs& a, size_t lds, int grid, hipStream_t st) {
+#ifdef DV3_EXPERIMENTS
   if (g_planes_abl && a.d.split_terms == DV3_SPLIT_F16X3 && NI == 2) {
     switch (g_planes_abl) {
       case 1: return launch_planes_abl<WM, WN, NI, 1>(a, lds, grid, st);
@@ -618,6 +623,7 @@ int launch_planes(const ConvArgs& a, size_t lds, int grid, hipStream_t st) {
       case 8: return launch_planes_abl1<WM, WN, NI, 8>(a, lds, grid, st);
     }
   }
+#endif
   if (a.d.split_terms == DV3_SPLIT_F16X3) return launch_planes_t<WM, WN, NI, 3, true>(a, lds, grid, st);
   if (a.d.split_terms == 1) return launch_planes_t<WM, WN, NI, 1, false>(a, lds, grid, st);
   return launch_planes_t<WM, WN, NI, 3, false>(a, lds, grid, st);
@@ -698,6 +704,13 @@ int dv3_conv_planes_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   if ((int64_t)d->J * (kp / 8) * d->lda >= (1ll << 27)) return 1;
   const int64_t ntot = (int64_t)d->B * d->Tout;
   if (ntot >= (1ll << 30)) return 1;
+  // single-term bf16 on c8 input: the 256 x 256 k32 ping-pong kernel (conv_c8pp.hip) where its grid fills the chip
+  // (tile_hint 40 forces it, dv3_debug_set(19, v) moves the threshold)
+  if (d->split_terms == 1 && (d->tile_hint == 40 || (d->tile_hint == 0 && g_planes_tile == 0))) {
+    const int rc = dv3_conv_c8pp_dispatch(d, st);
+    if (rc != 1) return rc;
+    if (d->tile_hint == 40) return 1;
+  }
   // tile: 1 = 128x128 (4 waves, two workgroups per CU), 2 = 128x64 (4 waves), 9 = 128x256 (8 waves, one per CU)
   int id = g_planes_tile;
   if (id != 1 && id != 2 && id != 9) {

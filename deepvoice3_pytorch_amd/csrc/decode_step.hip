@@ -554,11 +554,16 @@ static int conv_step_check(const dv3_conv_step_desc* d, bool need_t, size_t* lds
   if (d->J > 1) DV3_REQUIRE(d->ring && (d->t || !need_t) && d->L >= (d->J - 1) * d->dil + 1,
                             "conv_step: k > 1 needs ring, t and L >= (k-1)*d+1");
   if (d->post_add || d->out_seq || d->x_ts) DV3_REQUIRE(d->t || !need_t, "conv_step: post_add / out_seq / x_ts need the step counter");
-  const size_t lds = ((size_t)dv3_cdiv(d->J * d->Cin, KPAD_Q) * KPAD_Q * NB + RED_A + RED_B) * sizeof(float);
+  const size_t lds = (size_t)dv3_conv_step_lds_bytes(d->J, d->Cin);
   DV3_REQUIRE(((uintptr_t)d->a & 15) == 0, "conv_step: the step-tile weight image must be 16-byte aligned");
-  DV3_REQUIRE(lds <= 64 * 1024, "conv_step: window too large for LDS (%zu bytes)", lds);
+  DV3_REQUIRE(lds <= DV3_CONV_STEP_LDS_MAX, "conv_step: window too large for LDS (%zu bytes)", lds);
   *lds_out = lds;
   return DV3_OK;
+}
+
+extern "C" int dv3_conv_step_lds_bytes(int32_t J, int32_t Cin) {
+  if (J <= 0 || Cin <= 0 || (int64_t)J * Cin > (1 << 24)) return 1 << 30;
+  return (int)(((size_t)dv3_cdiv(J * Cin, KPAD_Q) * KPAD_Q * NB + RED_A + RED_B) * sizeof(float));
 }
 
 extern "C" int dv3_conv_step_pack_floats(int32_t Ktot, int32_t M, int32_t Cg) {

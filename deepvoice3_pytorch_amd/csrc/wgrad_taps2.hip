@@ -298,6 +298,7 @@ int dv3_wgrad_taps2_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
   const int64_t nb = (int64_t)a.m_tiles * a.c_tiles * d->n_slabs;
   DV3_REQUIRE(nb < (1ll << 31), "wgrad_gemm: grid too large");
   g_dv3_last_wgrad = 3000 + 40;
+#ifdef DV3_EXPERIMENTS
   if (g_wgrad_t2_abl && !d->xmask) {
     switch (g_wgrad_t2_abl) {
       case 1: return launch_wgrad_taps2<false, 1>(a, nb, st);
@@ -305,5 +306,6 @@ int dv3_wgrad_taps2_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
       case 6: return launch_wgrad_taps2<false, 6>(a, nb, st);
     }
   }
+#endif
   return d->xmask ? launch_wgrad_taps2<true>(a, nb, st) : launch_wgrad_taps2<false>(a, nb, st);
 }

@@ -490,9 +490,8 @@ class Decoder(nn.Module):
     def _fast_decode_eligible(self, Tk):
         """What the fused step program (csrc/decode_step.hip) takes; anything else runs the module-by-module
         path below, which handles every configuration the reference does."""
-        def fits(conv):      # dv3_conv_step_f32 stages the k-tap window of 4 batch items in 64 KB of LDS
-            k = conv.kernel_size[0]
-            return (k * conv.in_channels * 4 + 16 * 16 * 2 * 4) * 4 <= 64 * 1024
+        def fits(conv):      # dv3_conv_step_f32 stages the k-tap window of a batch group + its reduction stages in LDS
+            return ops.conv_step_fits(conv.kernel_size[0], conv.in_channels)
         mods, i = list(self.preattention), 0
         while i < len(mods):
             f = mods[i]

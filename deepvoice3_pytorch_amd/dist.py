@@ -17,11 +17,20 @@ import torch.distributed as dist
 
 
 class BucketedAllReduce(object):
-    def __init__(self, arena, process_group=None, bucket_mb=25.0):
+    """bucket_mb: size of the buckets cut from the arena's tail (the converter / decoder gradients, final early in
+    backward).  The gradients that become final LAST -- the head of the arena: the encoder, 54-63 % of the parameters
+     -- sit in smaller buckets of `last_bucket_mb` over the first `last_span_mb` of the arena:
+    clip + Adam need the whole reduced arena, so the all-reduce of the bucket that closes last is never hidden behind
+    backward and its size is the exposed time (one encoder layer is 6.3 MB; an 8 MB ring all-reduce over xGMI is
+    still bandwidth- rather than latency-bound).  last_bucket_mb=None: one size everywhere."""
+
+    def __init__(self, arena, process_group=None, bucket_mb=25.0, last_bucket_mb=8.0, last_span_mb=40.0):
         self.arena = arena
         self.pg = process_group
         self.side = torch.cuda.Stream() if arena.grad.is_cuda else None
         cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        cap_last = cap if last_bucket_mb is None else max(1, min(cap, int(last_bucket_mb * (1 << 20) / 4)))
+        span_last = 0 if last_bucket_mb is None else int(last_span_mb * (1 << 20) / 4)
         # cut buckets from the tail of the arena
         self.buckets = []   # (lo, hi, [param indices])
         hi = arena.total
@@ -29,7 +38,8 @@ class BucketedAllReduce(object):
         cur = []
         for i in range(len(arena.params) - 1, -1, -1):
             o = arena.offsets[i]
-            if hi - o > cap and cur:
+            c = cap_last if hi <= span_last else cap
+            if hi - o > c and cur:
                 self.buckets.append((lo, hi, cur))
                 hi, cur = lo, []
             lo = o
@@ -48,11 +58,18 @@ class BucketedAllReduce(object):
         # the step stream joins the collective stream -- their distance is the all-reduce time NOT hidden behind
         # backward.  Timing events can not be recorded while a hipGraph is being captured.
         self.exposed_events = None
-        # a parameter reports its gradient final either through autograd (AccumulateGrad hook) or, for
-        # the conv-layer parameters whose gradient is accumulated in place, through ops.grad_ready_hooks
+        # A parameter reports its gradient final either through autograd (AccumulateGrad hook) or, for the
+        # conv-layer parameters whose gradient is accumulated in place, through ops.grad_ready_hooks -- ONE call per
+        # layer from the layer's own backward.  Autograd fires its hook for the in-place parameters as well (measured
+        # on torch 2.10, although the Function returns no gradient for them): 130-190 Python callbacks per step that
+        # report nothing new.  After the first armed backward the autograd hooks of the parameters that reported in
+        # place are therefore removed (`prune_hooks`); what stays is one call per conv layer + one autograd hook per
+        # remaining parameter (embedding tables, speaker embedding: 3-6 per model).
         self._index_of = {id(p): i for i, p in enumerate(arena.params)}
-        self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i))
-                         for i, p in enumerate(arena.params)]
+        self._handles = {i: p.register_post_accumulate_grad_hook(self._make_hook(i))
+                         for i, p in enumerate(arena.params)}
+        self._inplace_seen = set()
+        self._pruned = False
         from . import ops as _ops
         self._ops_hook = self._on_inplace_grad
         _ops.grad_ready_hooks.append(self._ops_hook)
@@ -63,29 +80,48 @@ class BucketedAllReduce(object):
         from . import ops as _ops
         if self._ops_hook in _ops.grad_ready_hooks:
             _ops.grad_ready_hooks.remove(self._ops_hook)
-        for h in self._handles:
+        for h in self._handles.values():
             h.remove()
-        self._handles = []
+        self._handles = {}
         self._armed = False
 
     def _make_hook(self, i):
         def hook(param):
             # idempotent per step: a conv-layer parameter reports through ops.grad_ready_hooks when its
             # in-place gradient is final, and autograd's AccumulateGrad hook may fire for it as well
-            # (measured on torch 2.10: it does, even though the Function returns no gradient for it)
-            if not self._armed or self.notified[i]:
-                return
-            self.notified[i] = True
-            b = self.bucket_of[i]
-            self.pending[b] -= 1
-            if self.pending[b] == 0:
-                self._launch(b)
+            self._report(i)
         return hook
 
-    def _on_inplace_grad(self, param):
-        i = self._index_of.get(id(param))
-        if i is not None:
-            self._make_hook(i)(param)
+    def _report(self, i):
+        if not self._armed or self.notified[i]:
+            return
+        self.notified[i] = True
+        b = self.bucket_of[i]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
+
+    def _on_inplace_grad(self, *params):
+        """one call per conv layer (ops.ConvLayerFn.backward) with the layer's parameters (v, g, bias; None skipped)"""
+        for p in params:
+            if p is None:
+                continue
+            i = self._index_of.get(id(p))
+            if i is not None:
+                if not self._pruned:
+                    self._inplace_seen.add(i)
+                self._report(i)
+
+    def prune_hooks(self):
+        """drop the autograd hooks of the parameters that report in place (see __init__); called by finish() after
+        the first armed backward.  -> number of autograd hooks left"""
+        if not self._pruned:
+            for i in self._inplace_seen:
+                h = self._handles.pop(i, None)
+                if h is not None:
+                    h.remove()
+            self._pruned = True
+        return len(self._handles)
 
     def arm(self):
         """Call right before backward."""
@@ -118,7 +154,9 @@ class BucketedAllReduce(object):
 
     def finish(self):
         """Launch whatever is left (parameters that received no gradient) and join the side stream."""
-        self._armed = False
+        was_armed, self._armed = self._armed, False
+        if was_armed and not self._pruned and self._inplace_seen:
+            self.prune_hooks()
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)

@@ -193,7 +193,7 @@ class Decoder(nn.Module):
         """what the fused step program below takes (csrc/decode_step.hip stages a layer's k-tap window of 4 batch items
         and the attention scores in 64 KB of LDS); anything else runs the module-by-module path"""
         def fits(conv):
-            return (conv.kernel_size[0] * conv.in_channels * 4 + 16 * 16 * 2 * 4) * 4 <= 64 * 1024
+            return ops.conv_step_fits(conv.kernel_size[0], conv.in_channels)
         for mods in (self.audio_encoder_modules, self.audio_decoder_modules):
             for f in mods:
                 if isinstance(f, HighwayConv1d):

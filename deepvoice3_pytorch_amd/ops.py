@@ -74,22 +74,30 @@ def gemm_precision():
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-_dev_index = None
-_stream_override = None      # raw handle of ops.SideStream's stream while a side-stream section runs
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+import threading as _threading
+
+
+class _StreamOverride(_threading.local):
+    """raw handle of ops.SideStream's stream while a side-stream section runs ON THIS THREAD (backward runs on
+    autograd's thread; another thread launching ops meanwhile keeps its own current stream)"""
+    handle = None
+
+
+_stream_override = _StreamOverride()
 
 
 def _stream():
-    """the current HIP stream of this process' device as a raw handle.  torch.cuda.current_stream() costs ~8 us of
-    Python per call (measured: 0.8 ms per train-step forward); the C accessor costs ~0.2 us.  One process drives
-    one device (one process per GPU), so the device index is resolved once."""
-    global _dev_index
-    if _stream_override is not None:
-        return _stream_override
-    if _raw_stream is None:
+    """the current HIP stream of the calling thread's current device as a raw handle.  torch.cuda.current_stream()
+    costs ~8 us of Python per call (measured: 0.8 ms per train-step forward); the two C accessors cost ~0.3 us.  The
+    device is read on every call (torch.cuda.set_device after the first op, or a second model on another device, must
+    not be served the first device's stream)."""
+    h = _stream_override.handle
+    if h is not None:
+        return h
+    if _raw_stream is None or _cur_device is None:
         return torch.cuda.current_stream().cuda_stream
-    if _dev_index is None:
-        _dev_index = torch.cuda.current_device()
-    return _raw_stream(_dev_index)
+    return _raw_stream(_cur_device())
 
 
 # ----------------------------------------------------------------------------------------------
@@ -636,13 +644,18 @@ def _conv_gemm_c8(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J, dil, padL, mode
     return y
 
 
-def wgrad_gemm_c8(g8, x8, *, B, M, Cin, T, J, dil, padL, n_slabs, xmask_c8=None, drop_scale=1.0):
-    """dv3_wgrad_gemm_f32, c8 form: g8 (B, M/8.., T, 8), x8 (B, Cin/8.., T, 8) -> out [S][J][M][Cin]"""
-    out = torch.empty((n_slabs, J, M, Cin), dtype=torch.float32, device=g8.device)
+def wgrad_gemm_c8(g8, x8, *, B, M, Cin, T, J, dil, padL, n_slabs, xmask_c8=None, drop_scale=1.0, rows_of_slabs=False):
+    """dv3_wgrad_gemm_f32, c8 form: g8 (B, M/8.., T, 8), x8 (B, Cin/8.., T, 8) -> out [S][J][M][Cin]
+    (rows_of_slabs: [J][M][S][Cin], see wgrad_gemm)"""
     d = _wgrad_desc()
     d.g, d.x = g8.data_ptr(), x8.data_ptr()
     d.xmask_c8, d.drop_scale = _ptr(xmask_c8), drop_scale
-    d.out, d.out_ss, d.ldo = out.data_ptr(), J * M * Cin, Cin
+    if rows_of_slabs:
+        out = torch.empty((J, M, n_slabs, Cin), dtype=torch.float32, device=g8.device)
+        d.out, d.out_ss, d.ldo = out.data_ptr(), Cin, n_slabs * Cin
+    else:
+        out = torch.empty((n_slabs, J, M, Cin), dtype=torch.float32, device=g8.device)
+        d.out, d.out_ss, d.ldo = out.data_ptr(), J * M * Cin, Cin
     d.B, d.M, d.Cin, d.T, d.Tin, d.J, d.dil, d.padL, d.n_slabs = B, M, Cin, T, T, J, dil, padL, n_slabs
     d.split_bf16, d.k_split, d.c8 = 2, 1, 1
     _lib.call("dv3_wgrad_gemm_f32", ctypes.byref(d), _stream())
@@ -668,19 +681,29 @@ def gate_bwd_c8(dy, ab_or_y, x, *, B, C, T, mode, residual=0, alpha=1.0, want_dr
 
 def wgrad_gemm(g, x, *, B, M, Cin, T, Tin, J=1, dil=1, padL=0, n_slabs=1, xmask=None, xmask_rs=0,
                drop_scale=1.0, out=None, ldo=None, g_bs=None, g_rs=None, x_bs=None, x_rs=None,
-               split_bf16=False, k_split=False):
-    """dv3_wgrad_gemm_f32 -> out [S][J][M][ldo]."""
+               split_bf16=False, k_split=False, rows_of_slabs=False):
+    """dv3_wgrad_gemm_f32 -> out [S][J][M][ldo].
+    rows_of_slabs: the K-split partial sums as [J][M][S][ldo] instead -- the S partial rows of one weight row lie back
+    to back (S * ldo contiguous floats), which is how the weight-norm backward reads them (round 3 read S slabs
+    1.5 MB apart per element: 36 us per layer at 1.4 TB/s).  Same kernels: only the descriptor's slab stride (ldo) and
+    row stride (S * ldo) change."""
     if ldo is None:
         ldo = Cin
-    if out is None:
-        out = torch.empty((n_slabs, J, M, ldo), dtype=torch.float32, device=g.device)
+    if rows_of_slabs:
+        if out is None:
+            out = torch.empty((J, M, n_slabs, ldo), dtype=torch.float32, device=g.device)
+        out_ss, ldo_k = ldo, n_slabs * ldo
+    else:
+        if out is None:
+            out = torch.empty((n_slabs, J, M, ldo), dtype=torch.float32, device=g.device)
+        out_ss, ldo_k = J * M * ldo, ldo
     d = _wgrad_desc()
     d.g, d.g_bs, d.g_rs = g.data_ptr(), (g_bs if g_bs is not None else g.stride(0)), \
         (g_rs if g_rs is not None else g.stride(1))
     d.x, d.x_bs, d.x_rs = x.data_ptr(), (x_bs if x_bs is not None else x.stride(0)), \
         (x_rs if x_rs is not None else x.stride(1))
     d.xmask, d.xmask_rs, d.drop_scale = _ptr(xmask), xmask_rs, drop_scale
-    d.out, d.out_ss, d.ldo = out.data_ptr(), J * M * ldo, ldo
+    d.out, d.out_ss, d.ldo = out.data_ptr(), out_ss, ldo_k
     d.B, d.M, d.Cin, d.T, d.Tin, d.J, d.dil, d.padL, d.n_slabs = B, M, Cin, T, Tin, J, dil, padL, n_slabs
     d.split_bf16 = (2 if _gemm_mode == "bf16" else 1) if split_bf16 else 0
     d.k_split = int(bool(k_split))
@@ -708,9 +731,10 @@ def gate_bwd(dy, ab_or_y, x, *, B, C, T, mode, residual=0, alpha=1.0, want_dres=
 
 
 def weight_norm_bwd(slabs, n_slabs, ldo, v, g, scale, bias_part, n_part, O, I, J, transposed=False,
-                    want_bias=True, into=None):
+                    want_bias=True, into=None, rows_of_slabs=False):
     """into = (dv, dg, dbias) gradient buffers to ACCUMULATE into (the parameters' own .grad views in
-    the trainer's flat arena) instead of fresh tensors."""
+    the trainer's flat arena) instead of fresh tensors.  rows_of_slabs: the layout wgrad_gemm(rows_of_slabs=True)
+    wrote."""
     dev = v.device
     if into is not None:
         dv, dg, dbias = into
@@ -721,7 +745,10 @@ def weight_norm_bwd(slabs, n_slabs, ldo, v, g, scale, bias_part, n_part, O, I, J
     d = _wn_bwd_desc()
     M = J * O if transposed else O
     Jk = 1 if transposed else J
-    d.slabs, d.slab_ss, d.ldo, d.n_slabs = slabs.data_ptr(), Jk * M * ldo, ldo, n_slabs
+    if rows_of_slabs:
+        d.slabs, d.slab_ss, d.ldo, d.n_slabs = slabs.data_ptr(), ldo, n_slabs * ldo, n_slabs
+    else:
+        d.slabs, d.slab_ss, d.ldo, d.n_slabs = slabs.data_ptr(), Jk * M * ldo, ldo, n_slabs
     d.v, d.g, d.scale = v.data_ptr(), _ptr(g), _ptr(scale)
     d.dv, d.dg = dv.data_ptr(), _ptr(dg)
     d.bias_part, d.n_part, d.dbias = _ptr(bias_part) if dbias is not None else None, n_part, _ptr(dbias)
@@ -842,7 +869,12 @@ def _pad_left(k, dil, causal):
     return (k - 1) * dil if causal else (k - 1) // 2 * dil
 
 
-# called with a Parameter once its in-place gradient (see ConvLayerFn.backward) is final for this step
+# K-split partial sums of the weight gradient as [J][M][S][Cin] (wgrad_gemm(rows_of_slabs=True)); DV3_SLAB_ROWS=0 = the
+# round-3 layout [S][J][M][Cin], for A/B runs
+slab_rows_default = _os.environ.get("DV3_SLAB_ROWS", "1") not in ("0", "")
+
+# called as hook(v, g, bias) (entries may be None) once a conv layer's in-place gradients (see ConvLayerFn.backward)
+# are final for this step: one call per layer
 grad_ready_hooks = []
 
 
@@ -855,39 +887,73 @@ class SideStream(object):
     `join()` (the caching allocator would otherwise hand their memory to the next allocation of the main stream)."""
     stream = None          # torch.cuda.Stream while a trainer runs a step, else None (everything on one stream)
     main = None            # the step stream while `stream` is set
-    keep = []
+    keep = []              # [event | None, [tensors...]] per section, oldest first
+    capturing = False      # set by the trainer: no event queries while a hipGraph is being captured
+    release_every = 4      # sections between two release points (an event on the side stream + a poll of the oldest)
+    _n = 0
+    _events = []           # recycled torch.cuda.Event objects
 
     class _Section(object):
         """`with` body = launches on the side stream.  Only this package's launches are redirected (ops._stream());
         torch's current stream stays the step stream, so tensors allocated inside belong to the step stream's pool
-        and are kept alive until join() like the section's inputs (a torch.cuda.stream() context costs ~25 us of
-        Python per layer)."""
+        and are kept alive until the side stream is known to be past them, like the section's inputs (a
+        torch.cuda.stream() context costs ~25 us of Python per layer)."""
 
         def __enter__(self):
-            global _stream_override
-            _stream_override = SideStream.stream.cuda_stream
+            _stream_override.handle = SideStream.stream.cuda_stream
 
         def __exit__(self, *exc):
-            global _stream_override
-            _stream_override = None
+            _stream_override.handle = None
+            SideStream._release_point()
             return False
 
     @classmethod
     def fork(cls, *tensors):
         # the section's inputs are complete on the step stream: the side stream waits for exactly that point
         _lib.call("dv3_stream_fork", cls.main.cuda_stream, cls.stream.cuda_stream)
-        cls.keep.append(tensors)
+        cls.keep.append([None, [tensors]])
         return cls._section
 
     @classmethod
     def retain(cls, *tensors):
-        cls.keep.append(tensors)
+        if cls.keep:
+            cls.keep[-1][1].append(tensors)
+        else:
+            cls.keep.append([None, [tensors]])
+
+    @classmethod
+    def _release_point(cls):
+        """Every few sections: mark the side stream's position with an event, and drop the operands of the sections an
+        earlier, completed event covers -- the memory goes back to the caching allocator layer by layer, as autograd
+        frees it on one stream, instead of accumulating until join() (hundreds of MB per layer at B = 64)."""
+        cls._n += 1
+        if cls.capturing or cls.stream is None or cls._n % cls.release_every:
+            return
+        done = -1
+        for i, (ev, _) in enumerate(cls.keep):
+            if ev is not None:
+                if not ev.query():
+                    break
+                done = i
+        if done >= 0:
+            for ev, _ in cls.keep[:done + 1]:
+                if ev is not None:
+                    cls._events.append(ev)
+            del cls.keep[:done + 1]
+        if cls.keep and cls.keep[-1][0] is None:
+            ev = cls._events.pop() if cls._events else torch.cuda.Event()
+            ev.record(cls.stream)
+            cls.keep[-1][0] = ev
 
     @classmethod
     def join(cls):
         if cls.stream is not None:
             _lib.call("dv3_stream_fork", cls.stream.cuda_stream, cls.main.cuda_stream)
+        for ev, _ in cls.keep:
+            if ev is not None:
+                cls._events.append(ev)
         cls.keep = []
+        cls._n = 0
 
 
 SideStream._section = SideStream._Section()
@@ -1052,32 +1118,31 @@ class ConvLayerFn(torch.autograd.Function):
             else:
                 S = _slab_count(B, tiles)
             v3 = v if v.dim() == 3 else v.unsqueeze(-1)
+            slab_rows = slab_rows_default and S > 1
             side = SideStream.fork(gmat, x, ctx.bits, part, dy) if (ctx.inplace and SideStream.stream is not None) \
                 else contextlib.nullcontext()
             with side:
                 slabs = wgrad_gemm(gmat, x, B=B, M=Mg, Cin=Cin, T=Tg, Tin=T, J=Jd, dil=cfg.dil, padL=padL,
                                    n_slabs=S, xmask=ctx.bits, xmask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
-                                   split_bf16=x3, k_split=x3)
+                                   split_bf16=x3, k_split=x3, rows_of_slabs=slab_rows)
                 if ctx.inplace:
                     pv, pg, pb = ctx.leaves
                     weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None, pk.scale, part, B,
                                     pk.O, pk.I, pk.J, cfg.transposed, want_bias=ctx.has_bias,
                                     into=(pv.grad, pg.grad if pg is not None else None,
-                                          pb.grad if pb is not None else None))
+                                          pb.grad if pb is not None else None), rows_of_slabs=slab_rows)
                     if SideStream.stream is not None:
                         SideStream.retain(slabs)
                     pv._dv3_pending -= 1
                     if pv._dv3_pending == 0:
                         for hook in grad_ready_hooks:
-                            for t in (pv, pg, pb):
-                                if t is not None:
-                                    hook(t)
+                            hook(pv, pg, pb)
             if ctx.inplace:
                 dv = dg = dbias = None
             else:
                 dv, dg, dbias = weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None,
                                                 pk.scale, part, B, pk.O, pk.I, pk.J, cfg.transposed,
-                                                want_bias=ctx.has_bias)
+                                                want_bias=ctx.has_bias, rows_of_slabs=slab_rows)
                 dv = dv.view_as(v)
         return dx, dv, dg, dbias, dspk, dr, dr2, None, None
 
@@ -1215,6 +1280,7 @@ class ConvLayerC8Fn(torch.autograd.Function):
             tiles = ((M + 127) // 128) * ((Cin + 127) // 128)
             v3 = v if v.dim() == 3 else v.unsqueeze(-1)
             S = _ksplit_count(B * ((T + 31) // 32), tiles, slots=256)
+            slab_rows = slab_rows_default and S > 1
             side = SideStream.fork(g8, x, ctx.bits, ctx.keep8, part, dy) if (ctx.inplace and SideStream.stream is not None) \
                 else contextlib.nullcontext()
             with side:
@@ -1224,24 +1290,23 @@ class ConvLayerC8Fn(torch.autograd.Function):
                     x8t = _ToC8Fn.apply(x)
                     keep8 = mask_bits_to_c8(ctx.bits, ctx.bits_rs, B, Cin, T) if ctx.bits is not None else None
                 slabs = wgrad_gemm_c8(g8, x8t, B=B, M=M, Cin=Cin, T=T, J=J, dil=cfg.dil, padL=padL, n_slabs=S,
-                                      xmask_c8=keep8, drop_scale=ctx.dscale)
+                                      xmask_c8=keep8, drop_scale=ctx.dscale, rows_of_slabs=slab_rows)
                 if ctx.inplace:
                     pv, pg, pb = ctx.leaves
                     weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None, pk.scale, part, B,
                                     pk.O, pk.I, pk.J, False, want_bias=ctx.has_bias,
                                     into=(pv.grad, pg.grad if pg is not None else None,
-                                          pb.grad if pb is not None else None))
+                                          pb.grad if pb is not None else None), rows_of_slabs=slab_rows)
                     if SideStream.stream is not None:
                         SideStream.retain(slabs, x8t, keep8)
                     pv._dv3_pending -= 1
                     if pv._dv3_pending == 0:
                         for hook in grad_ready_hooks:
-                            for t in (pv, pg, pb):
-                                if t is not None:
-                                    hook(t)
+                            hook(pv, pg, pb)
             if not ctx.inplace:
                 dv, dg, dbias = weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None,
-                                                pk.scale, part, B, pk.O, pk.I, pk.J, False, want_bias=ctx.has_bias)
+                                                pk.scale, part, B, pk.O, pk.I, pk.J, False, want_bias=ctx.has_bias,
+                                                rows_of_slabs=slab_rows)
                 dv = dv.view_as(v)
         return dx, dv, dg, dbias, dspk, dr, dr2, None, None
 
@@ -1628,6 +1693,13 @@ def clip_adam(p, g, m, v, grad_norm, clip, hyper, beta1, beta2, eps, weight_deca
     _lib.call("dv3_clip_adam_f32", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
               _ptr(grad_norm), float(clip), hyper.data_ptr(), float(beta1), float(beta2), float(eps),
               float(weight_decay), float(grad_prescale), _stream())
+
+
+def conv_step_fits(k, cin):
+    """does dv3_conv_step_f32 (the fused decode step, csrc/decode_step.hip) take a k-tap layer with `cin` input
+    channels?  Asked of the library itself (dv3_conv_step_lds_bytes), so the Python predicate can not drift from the
+    kernel's LDS layout."""
+    return _lib.lib().dv3_conv_step_lds_bytes(int(k), int(cin)) <= CONSTS["DV3_CONV_STEP_LDS_MAX"]
 
 
 def ragged_pad_rows(src, row_off, B, T_out, lead=0, t_stride=1):

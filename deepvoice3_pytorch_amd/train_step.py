@@ -149,7 +149,7 @@ class FlatArena(object):
 class Trainer(object):
     HYPER_SLOTS = 8
 
-    def __init__(self, model, cfg, global_step=0, process_group=None, bucket_mb=25.0):
+    def __init__(self, model, cfg, global_step=0, process_group=None, bucket_mb=25.0, last_bucket_mb=8.0):
         self.model, self.cfg = model, cfg
         self.global_step = global_step
         self.adam_step = 0
@@ -191,7 +191,7 @@ class Trainer(object):
         if process_group is not None:
             from . import dist as _dist
             self.world = torch.distributed.get_world_size(process_group)
-            self.comm = _dist.BucketedAllReduce(self.arena, process_group, bucket_mb)
+            self.comm = _dist.BucketedAllReduce(self.arena, process_group, bucket_mb, last_bucket_mb)
 
     def close(self):
         """Detach the gradient-exchange hooks (call before building another Trainer on the same model)."""
@@ -297,6 +297,7 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
             self.comm.arm()
         ops.SideStream.stream = self.side_stream
         ops.SideStream.main = torch.cuda.current_stream() if self.side_stream is not None else None
+        ops.SideStream.capturing = self.side_stream is not None and torch.cuda.is_current_stream_capturing()
         # weight-norm backward of 8 layers per launch (ops.WnBwdBatch) unless gradient-ready hooks want every
         # parameter's gradient as early as possible (data parallel buckets)
         ops.WnBwdBatch.active = self.batch_wn_bwd and not ops.grad_ready_hooks
@@ -332,24 +333,37 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         self._set_hyper()
         self.arena.grad.zero_()
         scal = self.forward_backward(batch)
+        n = self.cfg.range_check_every
+        if n and (self.global_step + 1) % n == 0 and self.check_range():
+            # operands left the fp16 range in THIS step's forward (or since the last check): its gradients may hold
+            # Inf / NaN -- they must not reach clip / Adam.  check_range() has moved the run to bf16x3 (same decision
+            # on every rank); the step is redone there before anything is applied.
+            if self.comm is not None:
+                self.comm.finish()       # the buckets of the discarded backward are in flight: join them first
+            self.arena.grad.zero_()
+            scal = self.forward_backward(batch)
         self.optimizer_step()
         scal["grad_norm"] = self.norm_out[0] * (1.0 / self.world)
         scal["learning_rate"] = self.hyper[0].clone()
         if ops.gemm_precision() == "f16x3" and self.device.type == "cuda":
             scal["f16_range_events"] = ops.f16_range_events_tensor(self.device)
         self.global_step += 1
-        n = self.cfg.range_check_every
-        if n and self.global_step % n == 0:
-            self.check_range(scal)
         return scal
 
-    def check_range(self, scal=None):
-        """f16x3 range guard (ops.f16_range_events): when forward operands left the fp16 range since the last
-        check, warn and continue in the bf16x3 mode (full exponent range; the weight images are re-packed on the
-        next step).  One host synchronisation.  -> number of events"""
+    def check_range(self):
+        """f16x3 range guard (ops.f16_range_events): when forward operands left the fp16 range since the last check
+        ON ANY RANK (MAX all-reduce: every rank takes the same decision and stays in the same GEMM mode), warn and
+        continue in the bf16x3 mode (full exponent range; the weight images are re-packed on the next forward).  One
+        host synchronisation.  Called by step() BEFORE the update is applied (every `range_check_every` steps), so a
+        poisoned gradient is never stepped into the parameters.  A GraphedTrainer can not switch mode inside its
+        captured graph: see GraphedTrainer.check_range.  -> number of events (max over ranks)"""
         if ops.gemm_precision() != "f16x3" or self.device.type != "cuda":
             return 0
         n = ops.f16_range_events(reset=True, device=self.device)
+        if self.pg is not None and self.world > 1:
+            t = torch.tensor([n], dtype=torch.int64, device=self.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+            n = int(t.item())
         if n:
             import warnings
             warnings.warn("%d operand units left the fp16 range of the f16x3 GEMM mode (|activation| > 4094 or "
@@ -434,6 +448,15 @@ class GraphedTrainer(object):
         ops.bump_param_epoch()           # the replayed clip/Adam wrote the parameters
         self.t.global_step += 1
         return self.scal
+
+    def check_range(self):
+        """The f16x3 range guard for replayed steps.  A captured graph cannot change its GEMM mode and its clip / Adam
+        nodes have already run when the host looks, so the guard here is: call this every N replays (one host sync);
+        when operands left the fp16 range on any rank it switches the process to bf16x3 (Trainer.check_range) and
+        returns the event count -- the caller must then discard this object (`close()`), restore the parameters from
+        its last checkpoint if the step's `grad_norm` was not finite, and capture a new GraphedTrainer (the new
+        capture packs bf16x3 operands).  0 = in range, keep replaying."""
+        return self.t.check_range()
 
     def close(self):
         """Give the process-wide dropout state back: the device seed offset installed for the replays would

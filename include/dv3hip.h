@@ -559,6 +559,11 @@ int dv3_conv_step_f32(const dv3_conv_step_desc* d, void* stream);
 /* fwd_pack ([J*Cin][lda] fp32; gated: `a` rows at column 0, gate rows at column a_half) -> the step-tile image
  * dv3_conv_step_f32 reads.  Cg = gated ? rows per half : 0.  out holds dv3_conv_step_pack_floats(...) floats. */
 int dv3_conv_step_pack_floats(int32_t Ktot, int32_t M, int32_t Cg);
+/* LDS bytes one dv3_conv_step_f32 launch of a J-tap layer with Cin input channels needs (its k-tap window of the
+ * batch group + the two reduction stages); the launch is refused above DV3_CONV_STEP_LDS_MAX.  The Python decoders ask
+ * this before they choose the fused step program (deepvoice3.py / nyanko.py: _fast_decode_eligible). */
+#define DV3_CONV_STEP_LDS_MAX 65536
+int dv3_conv_step_lds_bytes(int32_t J, int32_t Cin);
 int dv3_conv_step_pack_f32(const float* fwd_pack, int32_t lda, int32_t a_half, int32_t Ktot, int32_t M, int32_t Cg,
                            float* out, void* stream);
 

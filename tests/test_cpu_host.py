@@ -529,18 +529,6 @@ def test_checkpoint_written_by_the_reference_loads():
     ref_opt.load_state_dict(back["optimizer"])        # torch accepts what we write
 
 
-def test_torch_library_shim_loads_and_registers_every_operator():
-    """TORCH_LIBRARY(dv3hip) (csrc/torch_ops.cpp): the shim loads next to libdv3hip.so, agrees on the ABI version
-    and registers the operators; on a CPU tensor they refuse (no fallback) instead of computing."""
-    from deepvoice3_pytorch_amd import torch_ops, _lib
-    ops = torch_ops.load()
-    assert ops.abi_version() == _lib.CONSTS["DV3_ABI_VERSION"]
-    for name in ("weight_norm_split_pack", "conv1d_glu", "conv1x1", "sincos_pos", "grad_sqnorm", "clip_adam_"):
-        assert hasattr(ops, name), name
-    with pytest.raises((RuntimeError, NotImplementedError)):
-        ops.grad_sqnorm(torch.zeros(8))
-
-
 def test_c8_storage_host_logic():
     """bf16 storage bookkeeping that needs no GPU: group counts, which layer forms take the c8 kernels, layout test"""
     import torch

@@ -287,3 +287,81 @@ def test_c8_gated_layers_pin_to_the_same_rounding_oracle(dev, modes, kind, C, k,
     assert frac < 2e-2, "too many stored values differ from round_bf16(oracle): %.4f" % frac
     ulp2 = torch.maximum(ulp, _bf16_ulp(got))        # a flip across a power of two moves by the larger binade's ulp
     assert float(((got - stored).abs() - ulp2 * 1.0001 - slack)[flips].max() if flips.any() else -1.0) <= 0.0   # by one ulp
+
+
+# the 256 x 256 k32 ping-pong c8 kernel (csrc/conv_c8pp.hip) against the 128-row planes kernel it replaces where its
+# grid fills the chip: same operand images, same accumulation order, same fused tails -> bit-identical outputs
+C8PP = [("glu", 64, 3, 2, False, 75, 3), ("glu", 256, 3, 27, False, 150, 2), ("glu", 128, 3, 1, True, 100, 2),
+        ("glu", 96, 3, 9, False, 61, 5), ("glu", 256, 3, 3, False, 800, 4), ("glu_nores", 64, 3, 3, False, 61, 2),
+        ("highway", 64, 3, 2, False, 75, 3), ("highway", 128, 1, 1, False, 50, 3), ("highway", 512, 3, 27, True, 150, 2),
+        ("glu", 32, 3, 1, False, 33, 7), ("glu", 128, 1, 1, False, 50, 3)]
+
+
+@pytest.mark.parametrize("kind,C,k,d,causal,T,B", C8PP)
+def test_c8pp_kernel_is_bit_identical_to_the_planes_kernel(dev, modes, kind, C, k, d, causal, T, B):
+    ops = modes
+    from deepvoice3_pytorch_amd import modules, _lib
+    L = _lib.lib()
+    torch.manual_seed(0)
+    if kind == "highway":
+        layer = modules.HighwayConv1d(C, C, k, dilation=d, causal=causal, dropout=0.1)
+    else:
+        layer = modules.Conv1dGLU(1, 16, C, C, k, dropout=0.2, dilation=d, causal=causal, residual=(kind == "glu"))
+    layer = layer.to(dev).train()
+    with torch.no_grad():
+        layer.conv.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(B, C, T, device=dev)
+    out = {}
+    try:
+        for tag, thr in (("planes", 0), ("c8pp", 1)):
+            L.dv3_debug_set(19, thr)
+            out[tag] = _run(layer, x, True, "bf16", ops)
+            # the last tap-GEMM of backward is the input gradient: served by the kernel under test
+            assert L.dv3_debug_get(10) // 1000 == (9 if thr else 8), (tag, L.dv3_debug_get(10))
+    finally:
+        L.dv3_debug_set(19, 128)
+    y0, dx0, dp0 = out["planes"]
+    y1, dx1, dp1 = out["c8pp"]
+    assert torch.equal(y0, y1), float((y0 - y1).abs().max())
+    assert torch.equal(dx0, dx1), float((dx0 - dx1).abs().max())
+    for n in dp0:
+        assert torch.equal(dp0[n], dp1[n]), n
+
+
+def test_c8pp_plain_and_fp32_output_forms(dev, modes):
+    """1 x 1 layers through the same kernel: c8 -> c8 with activation / residuals, c8 -> fp32 (513 rows: not a multiple
+    of anything), and their input gradients -- bit-identical to the planes kernel"""
+    ops = modes
+    from deepvoice3_pytorch_amd import modules, _lib
+    L = _lib.lib()
+    B, T = 3, 130
+    ops.set_gemm_precision("bf16")
+    ops.bf16_storage = True
+    res = {}
+    try:
+        for tag, thr in (("planes", 0), ("c8pp", 1)):
+            L.dv3_debug_set(19, thr)
+            outs = []
+            for (Ci, Co, mode, o8) in ((64, 128, ops.EPI_RELU, True), (128, 64, ops.EPI_LINEAR, True),
+                                       (64, 513, ops.EPI_SIGMOID, False), (513, 64, ops.EPI_LINEAR, True),
+                                       (256, 256, ops.EPI_SOFTSIGN, True)):
+                torch.manual_seed(1)
+                f = modules.Conv1d(Ci, Co, 1, dropout=0.1).to(dev).train()
+                xin = torch.randn(B, Ci, T, device=dev).requires_grad_(True)
+                ops.dropout_state.manual_seed(5)
+                y = f(ops.to_c8(xin), mode=mode, out_c8=o8)
+                y = ops.from_c8(y) if ops.is_c8(y) else y
+                (y * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+                outs += [y.detach(), xin.grad.detach()] + [p.grad.detach().clone() for p in f.parameters()]
+            torch.manual_seed(2)
+            lin = modules.Linear(64, 128).to(dev).train()
+            ins = [torch.randn(B, 64, T, device=dev).requires_grad_(True), torch.randn(B, 128, T, device=dev).requires_grad_(True),
+                   torch.randn(B, 128, T, device=dev).requires_grad_(True)]
+            y = ops.from_c8(lin.forward_bct(ops.to_c8(ins[0]), r=ops.to_c8(ins[1]), r2=ops.to_c8(ins[2]), out_c8=True))
+            (y * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+            outs += [y.detach()] + [t.grad.detach() for t in ins]
+            res[tag] = outs
+    finally:
+        L.dv3_debug_set(19, 128)
+    for i, (a, b) in enumerate(zip(res["planes"], res["c8pp"])):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))

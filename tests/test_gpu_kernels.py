@@ -507,48 +507,6 @@ def test_conv_gemm_full_size_properties(dev):
         assert abs(acc - float(a1[b, o, t])) < (1e-5 if pk.fwd_s is None else 5e-5) * max(1.0, abs(acc))
 
 
-def test_torch_ops_dv3hip(dev, gemm_mode):
-    """the operators as torch.ops.dv3hip.* (TORCH_LIBRARY shim over the C ABI): Conv1dGLU / HighwayConv1d forward,
-    a 1x1 conv + ReLU, the position encoding and the fused clip + Adam against the oracle"""
-    if gemm_mode == "f32":
-        pytest.skip("the operator form serves the split-operand kernels")
-    from deepvoice3_pytorch_amd import torch_ops
-    T_ = torch_ops.load()
-    f16 = gemm_mode == "f16x3"
-    rng = np.random.RandomState(5)
-    B, C, T, k = 3, 48, 70, 3
-    sd = _glu_sd(C, k, rng)
-    x = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
-    fs, bs, scale = T_.weight_norm_split_pack(sd["l.conv.weight_v"].to(dev), sd["l.conv.weight_g"].to(dev), C, f16)
-    for d, causal, residual in ((1, False, True), (3, True, False), (9, True, True)):
-        y = T_.conv1d_glu(x.to(dev), fs, f16, sd["l.conv.bias"].to(dev), k, d, causal, residual, False)
-        assert rel_err(y.cpu(), O.conv1d_glu(sd, "l", x, k, d, causal, residual)) < KTOL
-    y = T_.conv1d_glu(x.to(dev), fs, f16, sd["l.conv.bias"].to(dev), k, 3, False, False, True)
-    assert rel_err(y.cpu(), O.highway_conv1d(sd, "l", x, k, 3, False)) < KTOL
-    # 1x1 conv + ReLU
-    w = torch.from_numpy(rng.randn(40, C, 1).astype(np.float32) * 0.2)
-    b1 = torch.from_numpy(rng.randn(40).astype(np.float32) * 0.1)
-    f1, _, _ = T_.weight_norm_split_pack(w.to(dev), None, 0, f16)
-    y = T_.conv1x1(x.to(dev), f1, f16, b1.to(dev), 40, 1)
-    assert rel_err(y.cpu(), torch.relu(torch.nn.functional.conv1d(x, w, b1))) < KTOL
-    # position encoding
-    table = O.position_encoding_table(64, 24, 1.0, sinusoidal=False)
-    pos = torch.tensor([[1, 2, 3, 0], [5, 60, 7, 8]]).long()
-    got = T_.sincos_pos(pos.to(dev), table.to(dev), 1.385)
-    assert rel_err(got.cpu(), O.sinusoidal_encoding(table, pos, 1.385)) < 1e-5
-    # clip + Adam
-    n = 10007
-    p0 = torch.from_numpy(rng.randn(n).astype(np.float32))
-    g0 = torch.from_numpy(rng.randn(n).astype(np.float32) * 0.01)
-    pc, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
-    gn = O.clip_and_adam([pc], [g0], [m], [v], 1, 5e-4)
-    pg, mg, vg, gg = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev), g0.to(dev)
-    out2 = T_.grad_sqnorm(gg)
-    hyper = torch.tensor([5e-4, 1 - 0.5, math.sqrt(1 - 0.9)], device=dev)
-    T_.clip_adam_(pg, gg, mg, vg, out2, 0.1, hyper, 0.5, 0.9, 1e-6, 0.0, 1.0)
-    assert rel_err(out2[0].cpu(), gn) < 1e-5 and rel_err(pg.cpu(), pc) < 1e-6
-
-
 @pytest.mark.parametrize("B,E,Tq,Tk,p", [(3, 48, 50, 37, 0.0), (2, 256, 201, 150, 0.05), (4, 20, 33, 64, 0.1),
                                          (1, 8, 2, 5, 0.0), (2, 64, 70, 511, 0.0)])
 def test_fused_attention_forward_equals_unfused(dev, gemm_mode, B, E, Tq, Tk, p):

@@ -11,6 +11,7 @@
 """
 import json
 import math
+import os
 
 import numpy as np
 import pytest
@@ -232,10 +233,12 @@ def test_training_forward_backward_matches_oracle(dev, name):
     assert worst[1] < 5e-4, worst
 
 
-def test_train_step_matches_reference_golden(dev):
+def test_train_step_matches_reference_golden(dev, gemm_mode):
     """Two optimisation steps of the reference's own train.train() (tests/golden/trainstep.npz,
     dropout 0): HIP forward + fused losses + backward + fused clip/Adam on the flat arena."""
     from deepvoice3_pytorch_amd import builder, train_step
+    tight = gemm_mode in ("f16x3", "f32")
+    measured = {}
     fx = load_golden("trainstep")
     hpo = json.loads(str(fx["hp_over"]))
     hp = dict(n_vocab=149, embed_dim=hpo["text_embed_dim"], mel_dim=hpo["num_mels"],
@@ -267,14 +270,33 @@ def test_train_step_matches_reference_golden(dev):
         assert abs(scal["mel_l1_loss"] - fx["scalar/mel_l1_loss"][it]) < 2e-4 * fx["scalar/mel_l1_loss"][it]
         assert abs(scal["linear_binary_div_loss"] - fx["scalar/linear_binary_div_loss"][it]) < \
             2e-4 * fx["scalar/linear_binary_div_loss"][it]
-        assert abs(scal["grad_norm"] - fx["scalar/gradient_norm"][it]) < 2e-3 * fx["scalar/gradient_norm"][it]
+        # fp32-class modes: the reference's own pre-clip gradient norm to 2e-4 (round 3 allowed 2e-3 for every mode)
+        gn_err = abs(scal["grad_norm"] - fx["scalar/gradient_norm"][it]) / fx["scalar/gradient_norm"][it]
+        measured["grad_norm_rel_err_step%d" % it] = gn_err
+        assert gn_err < (2e-4 if tight else 2e-3), gn_err
     sdn = model.state_dict()
+    worst_rms, worst_max = 0.0, 0.0
     for k in sdn:
         if k.endswith("positions.weight"):
             continue
-        moved = float(np.abs(fx["sd2/" + k] - fx["sd0/" + k]).max())
-        diff = float(np.abs(sdn[k].cpu().numpy() - fx["sd2/" + k]).max())
+        d0 = fx["sd2/" + k].astype(np.float64) - fx["sd0/" + k]
+        dd = sdn[k].cpu().numpy().astype(np.float64) - fx["sd2/" + k]
+        moved = float(np.abs(d0).max())
+        diff = float(np.abs(dd).max())
+        # Adam's first updates are sign-like (m / sqrt(v) = g / |g| at step 1): ONE element whose tiny gradient changes
+        # sign moves by a whole step, so the maximum keeps the loose bound and the tensor as a whole (rms) carries the
+        # tight one: within 2 % of its movement in the fp32-class modes
+        rms_moved = float(np.sqrt((d0 ** 2).mean()))
+        rms_diff = float(np.sqrt((dd ** 2).mean()))
+        worst_rms = max(worst_rms, rms_diff / max(rms_moved, 1e-12))
+        worst_max = max(worst_max, diff / max(moved, 1e-12))
         assert diff < 0.1 * max(moved, 1e-6) + 1e-6, (k, diff, moved)
+        assert rms_diff < (0.02 if tight else 0.1) * max(rms_moved, 1e-7) + 1e-8, (k, rms_diff, rms_moved)
+    measured.update(worst_rms_diff_over_movement=worst_rms, worst_max_diff_over_movement=worst_max, mode=gemm_mode)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "trainstep_golden_%s.json" % gemm_mode), "w") as f:
+            json.dump(measured, f)
 
 
 def test_graphed_train_step_matches_reference_golden(dev):

@@ -6,6 +6,8 @@ The forward operands of the default mode are v * 2^4 (activations) / v * 2^8 (we
 that left the range, values stay usable to twice the range and turn non-finite beyond it, NaN / Inf inputs
 propagate as in the fp32 reference (deepvoice3_pytorch/modules.py:145-164 run on such inputs), and the host side
 can re-run a computation in the bf16x3 mode (fp32's exponent range) with parity kept."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -173,8 +175,12 @@ def test_trainer_reports_and_leaves_the_mode(dev):
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         scal = tr.step(batch)
-    assert int(scal["f16_range_events"]) > 0
+    # the guard acts BEFORE the update: the step was redone in bf16x3 and only that result was applied
     assert ops.gemm_precision() == "bf16x3" and any("fp16 range" in str(x.message) for x in w)
-    scal = tr.step(batch)       # continues (re-packed images) in the full-range mode
     assert "f16_range_events" not in scal
+    assert math.isfinite(float(scal["grad_norm"])) and math.isfinite(float(scal["loss"]))
+    assert bool(torch.isfinite(tr.arena.flat).all()) and bool(torch.isfinite(tr.arena.exp_avg_sq).all())
+    assert tr.adam_step == 2 and tr.global_step == 2       # one update per step() call, redo included
+    scal = tr.step(batch)       # continues (re-packed images) in the full-range mode
+    assert "f16_range_events" not in scal and math.isfinite(float(scal["loss"]))
     tr.close()
