@@ -1,11 +1,20 @@
 # coding: utf-8
 """Spectrogram -> waveform on the GPU: the device-side counterpart of the reference's
-audio.inv_spectrogram (audio.py:37-43) and its helpers (audio.py:26-28,84-93).
+audio.inv_spectrogram (audio.py:37-43) and its helpers (audio.py:26-28,84-93), and the forward analysis
+audio.spectrogram / audio.melspectrogram (audio.py:31-35,46-51).
 
-The reference hands phase reconstruction to the third-party `lws` package on the host
-(audio.py:40-42); here it is Griffin-Lim on hand-written HIP FFT kernels (csrc/audio.hip), batched
-over utterances, so synthesis never leaves the device (synthesis.py:64-71 copies the
-spectrogram to the CPU first).  STFT conventions: see include/dv3hip.h ("Audio inverse").
+The reference hands framing and phase reconstruction to the third-party `lws` package on the host
+(audio.py:40-42,54-55); here they run on hand-written HIP FFT kernels (csrc/audio.hip), batched over utterances, so
+synthesis never leaves the device (synthesis.py:64-71 copies the spectrogram to the CPU first).
+
+Conventions (AudioConfig.convention):
+  "lws"    (default) the framing of `lws.lws(1024, hop, mode="speech")` the reference's features are made with and its
+           inverse is framed by: sqrt-symmetric-Hann analysis window, perfect-reconstruction synthesis window, 1024 - hop
+           zeros of padding on both sides -- T frames <-> (T + 1) * hop - 1024 samples (L = 256 k -> k + 3 frames).
+           Restated from the package's published source in oracle/audio_oracle.py (lws_windows / lws_stft / lws_istft).
+           Phase reconstruction is Griffin-Lim on that framing (north_star), not lws's own run_lws iterations.
+  "torch"  torch.stft / torch.istft conventions (periodic Hann, center=True reflect padding, L = hop * (T - 1)): rounds
+           1-3's form, kept for A/B runs and for callers that pair it with torch-made features.
 """
 import numpy as np
 import torch
@@ -21,12 +30,55 @@ class AudioConfig(object):
     """The hparams audio.py reads (hparams.py:38-43,124)."""
 
     def __init__(self, fft_size=1024, hop_size=256, sample_rate=22050, preemphasis=0.97,
-                 min_level_db=-100, ref_level_db=20, power=1.4, griffin_lim_iters=60):
+                 min_level_db=-100, ref_level_db=20, power=1.4, griffin_lim_iters=60, convention="lws"):
         if fft_size != N_FFT:
             raise ValueError("the HIP FFT kernels are built for fft_size=1024 (every reference preset)")
+        if convention not in ("lws", "torch"):
+            raise ValueError("convention must be 'lws' (the reference's framing) or 'torch'")
         self.fft_size, self.hop_size, self.sample_rate = fft_size, hop_size, sample_rate
         self.preemphasis, self.min_level_db, self.ref_level_db = preemphasis, min_level_db, ref_level_db
         self.power, self.griffin_lim_iters = power, griffin_lim_iters
+        self.convention = convention
+
+
+# ---------------------------------------------------------------------------------------------
+# lws framing (audio.py:54-55): window tables, frame / sample counts
+# ---------------------------------------------------------------------------------------------
+def lws_windows_np(fsize=N_FFT, fshift=256):
+    """(awin, swin) of lws.lws(fsize, fshift) as float64 numpy: sqrt of the symmetric Hann window, and the synthesis
+    window awin / overlap-added(awin^2) that makes overlap-add reconstruct perfectly (lws.pyx: hann, synthwin)."""
+    k = np.arange(fsize, dtype=np.float64)
+    awin = np.sqrt(0.5 * (1.0 - np.cos(2.0 * np.pi * k / (fsize - 1))))
+    Q = -(-fsize // fshift)
+    w = np.concatenate([awin * awin, np.zeros(Q * fshift - fsize)]).reshape(Q, fshift).sum(0)
+    w = np.tile(w, Q)[:fsize]
+    if w.min() <= 0:
+        raise ValueError("The normalizer is not strictly positive")
+    return awin, awin / w
+
+
+_WIN_CACHE = {}
+
+
+def lws_windows(device, hop):
+    """the two tables as float32 device tensors (cached per device and hop)"""
+    key = (str(device), int(hop))
+    if key not in _WIN_CACHE:
+        a, s = lws_windows_np(N_FFT, hop)
+        _WIN_CACHE[key] = (torch.from_numpy(a.astype(np.float32)).to(device), torch.from_numpy(s.astype(np.float32)).to(device))
+    return _WIN_CACHE[key]
+
+
+def lws_num_frames(length, hop, fsize=N_FFT):
+    """frames lws.stft makes of `length` samples (zero padding of fsize - hop on both sides, the last frame completed)"""
+    pad = fsize - hop
+    m = (length + 2 * pad - fsize) // hop + 1
+    return m if length % hop == 0 else m + 1
+
+
+def lws_num_samples(T, hop, fsize=N_FFT):
+    """samples lws.istft returns for T frames"""
+    return (T + 1) * hop - fsize
 
 
 def magnitudes(linear_outputs, cfg):
@@ -38,11 +90,18 @@ def magnitudes(linear_outputs, cfg):
     return mag
 
 
-def istft(mag, phasor, hop):
-    """mag (B,T,513), phasor (B,T,513,2) or None -> y (B, hop*(T-1))."""
+def istft(mag, phasor, hop, convention="torch"):
+    """mag (B,T,513), phasor (B,T,513,2) or None -> y (B, hop*(T-1)); lws framing: (B, (T+1)*hop - 1024)."""
     B, T, F = mag.shape
     assert F == N_BIN
     frames = torch.empty((B, T, N_FFT), dtype=torch.float32, device=mag.device)
+    if convention == "lws":
+        _, swin = lws_windows(mag.device, hop)
+        _lib.call("dv3_lws_istft_frames_f32", mag.data_ptr(), phasor.data_ptr() if phasor is not None else None,
+                  swin.data_ptr(), frames.data_ptr(), B, T, _stream())
+        y = torch.empty((B, lws_num_samples(T, hop)), dtype=torch.float32, device=mag.device)
+        _lib.call("dv3_lws_overlap_add_f32", frames.data_ptr(), y.data_ptr(), B, T, hop, _stream())
+        return y
     _lib.call("dv3_istft_frames_f32", mag.data_ptr(), phasor.data_ptr() if phasor is not None else None,
               frames.data_ptr(), B, T, _stream())
     y = torch.empty((B, hop * (T - 1)), dtype=torch.float32, device=mag.device)
@@ -50,13 +109,19 @@ def istft(mag, phasor, hop):
     return y
 
 
-def stft(y, T, hop, want_phasor=True, want_spec=False):
-    """y (B, hop*(T-1)) -> unit phasors and/or the complex STFT, each (B,T,513,2)."""
+def stft(y, T, hop, want_phasor=True, want_spec=False, convention="torch"):
+    """y (B, hop*(T-1)) -> unit phasors and/or the complex STFT, each (B,T,513,2); lws framing: T = lws_num_frames(L)."""
     y = _c(_chk(y, "y"))
     B = y.shape[0]
-    assert y.shape[1] == hop * (T - 1)
     ph = torch.empty((B, T, N_BIN, 2), dtype=torch.float32, device=y.device) if want_phasor else None
     sp = torch.empty((B, T, N_BIN, 2), dtype=torch.float32, device=y.device) if want_spec else None
+    if convention == "lws":
+        assert T == lws_num_frames(y.shape[1], hop)
+        awin, _ = lws_windows(y.device, hop)
+        _lib.call("dv3_lws_stft_f32", y.data_ptr(), awin.data_ptr(), ph.data_ptr() if ph is not None else None,
+                  sp.data_ptr() if sp is not None else None, None, B, T, hop, y.shape[1], _stream())
+        return ph, sp
+    assert y.shape[1] == hop * (T - 1)
     _lib.call("dv3_stft_phase_f32", y.data_ptr(), ph.data_ptr() if ph is not None else None,
               sp.data_ptr() if sp is not None else None, None, B, T, hop, _stream())
     return ph, sp
@@ -92,15 +157,22 @@ def mel_basis(sample_rate=22050, n_fft=1024, n_mels=80, fmin=125.0, fmax=7600.0)
 
 
 def _analysis_mag(wav, cfg):
-    """(B, L) waveform -> |STFT(preemphasis(wav))| as (B, 513, T); L must be hop*(T-1)."""
+    """(B, L) waveform -> |STFT(preemphasis(wav))| as (B, 513, T).  lws framing (default): any L, T = lws_num_frames(L)
+    (L = 256 k -> k + 3 frames, as the reference's preprocessing produces them); torch framing: L = hop * (T - 1)."""
     wav = _c(_chk(wav, "wav"))
     B, L = wav.shape
     hop = cfg.hop_size
+    pre = torch.empty_like(wav)
+    _lib.call("dv3_preemphasis_f32", wav.data_ptr(), pre.data_ptr(), B, L, float(cfg.preemphasis), _stream())
+    if cfg.convention == "lws":
+        T = lws_num_frames(L, hop)
+        awin, _ = lws_windows(wav.device, hop)
+        mag = torch.empty((B, N_BIN, T), dtype=torch.float32, device=wav.device)
+        _lib.call("dv3_lws_stft_f32", pre.data_ptr(), awin.data_ptr(), None, None, mag.data_ptr(), B, T, hop, L, _stream())
+        return mag
     if L % hop:
         raise ValueError("waveform length must be a multiple of hop_size (%d)" % hop)
     T = L // hop + 1
-    pre = torch.empty_like(wav)
-    _lib.call("dv3_preemphasis_f32", wav.data_ptr(), pre.data_ptr(), B, L, float(cfg.preemphasis), _stream())
     mag = torch.empty((B, N_BIN, T), dtype=torch.float32, device=wav.device)
     _lib.call("dv3_stft_phase_f32", pre.data_ptr(), None, None, mag.data_ptr(), B, T, hop, _stream())
     return mag
@@ -132,17 +204,25 @@ def melspectrogram_batch(wav, cfg=None, num_mels=80, fmin=125.0, fmax=7600.0):
     return _db_norm(mel, cfg)
 
 
-def griffin_lim(mag, hop, n_iter, init_phasor=None):
+def griffin_lim(mag, hop, n_iter, init_phasor=None, convention="torch"):
     """Griffin & Lim: alternate projections between the given magnitudes and consistent STFTs."""
-    y = istft(mag, init_phasor, hop)
+    y = istft(mag, init_phasor, hop, convention)
     B, T, _ = mag.shape
     if n_iter > 0:
         frames = torch.empty((B, T, N_FFT), dtype=torch.float32, device=mag.device)
         y2 = torch.empty_like(y)
+        lws = convention == "lws"
+        if lws:
+            awin, swin = lws_windows(mag.device, hop)
         for _ in range(n_iter):
             # stft -> unit phase -> x magnitude -> inverse FFT -> window in one launch (the phasors never reach HBM)
-            _lib.call("dv3_gl_project_f32", y.data_ptr(), mag.data_ptr(), frames.data_ptr(), B, T, hop, _stream())
-            _lib.call("dv3_overlap_add_f32", frames.data_ptr(), y2.data_ptr(), B, T, hop, _stream())
+            if lws:
+                _lib.call("dv3_lws_gl_project_f32", y.data_ptr(), mag.data_ptr(), awin.data_ptr(), swin.data_ptr(),
+                          frames.data_ptr(), B, T, hop, _stream())
+                _lib.call("dv3_lws_overlap_add_f32", frames.data_ptr(), y2.data_ptr(), B, T, hop, _stream())
+            else:
+                _lib.call("dv3_gl_project_f32", y.data_ptr(), mag.data_ptr(), frames.data_ptr(), B, T, hop, _stream())
+                _lib.call("dv3_overlap_add_f32", frames.data_ptr(), y2.data_ptr(), B, T, hop, _stream())
             y, y2 = y2, y
     return y
 
@@ -155,10 +235,11 @@ def inv_preemphasis_(y, coef):
 
 
 def inv_spectrogram_batch(linear_outputs, cfg=None, init_phasor=None):
-    """(B, T, 513) device tensor (model linear_outputs) -> (B, hop*(T-1)) waveforms on the device."""
+    """(B, T, 513) device tensor (model linear_outputs) -> waveforms on the device: (B, (T+1)*hop - 1024) on the lws
+    framing (what the reference's processor.istft returns for T frames), (B, hop*(T-1)) on the torch framing."""
     cfg = cfg or AudioConfig()
     mag = magnitudes(linear_outputs, cfg)
-    y = griffin_lim(mag, cfg.hop_size, cfg.griffin_lim_iters, init_phasor)
+    y = griffin_lim(mag, cfg.hop_size, cfg.griffin_lim_iters, init_phasor, cfg.convention)
     return inv_preemphasis_(y, cfg.preemphasis)
 
 

@@ -94,9 +94,12 @@ __global__ void gl_prepare_kernel(const float* __restrict__ lin, float* __restri
 }
 
 // frames[b][t][n] = hann[n] * irfft(mag[b][t][:] * phasor[b][t][:])[n]   (phasor NULL: zero phase)
+// LWS: the conventions of lws.lws(1024, hop) (audio.py:54-55; oracle/audio_oracle.py: lws_windows): `sw` = the
+// perfect-reconstruction synthesis window (the overlap-add normaliser is folded into it)
+template <bool LWS>
 __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restrict__ mag,
                                                            const float* __restrict__ phasor,
-                                                           float* __restrict__ frames) {
+                                                           float* __restrict__ frames, const float* __restrict__ sw) {
   __shared__ cplx A[NFFT], Bf[NFFT];
   const int tid = threadIdx.x;
   const int64_t fr = blockIdx.x;
@@ -111,16 +114,18 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restri
   }
   fft1024<+1>(A, Bf, tid);
   float* out = frames + fr * NFFT;
-  for (int n = tid; n < NFFT; n += 256) out[n] = Bf[n].x * (1.0f / NFFT) * hann(n);
+  for (int n = tid; n < NFFT; n += 256) out[n] = Bf[n].x * (1.0f / NFFT) * (LWS ? sw[n] : hann(n));
 }
 
 // y[b][i] = sum_t frames[b][t][p - t*hop] / sum_t hann^2[p - t*hop],  p = i + NFFT/2, i < hop*(T-1)
+// LWS: p = i + (NFFT - hop) (the zero padding lws strips), no division (the synthesis window carries the normaliser)
+template <bool LWS>
 __global__ void ola_kernel(const float* __restrict__ frames, float* __restrict__ y, int T, int hop,
                            int L) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L) return;
-  const int p = i + NFFT / 2;
+  const int p = i + (LWS ? NFFT - hop : NFFT / 2);
   int t_hi = p / hop;
   if (t_hi > T - 1) t_hi = T - 1;
   int t_lo = (p - NFFT + hop) / hop;  // smallest t with p - t*hop <= NFFT-1  (ceil((p-NFFT+1)/hop))
@@ -129,7 +134,7 @@ __global__ void ola_kernel(const float* __restrict__ frames, float* __restrict__
   const float* fb = frames + (int64_t)b * T * NFFT;
   // interior samples of the hop = N/4 periodic-Hann framing meet four frames whose squared windows sum to exactly 3/2
   // (sum_j sin^4(x + j pi/4) = 3/2): no transcendental per tap there; the edges keep the general form
-  const bool interior = hop * 4 == NFFT && t_hi - t_lo == 3 && p - t_lo * hop < NFFT && p - t_hi * hop >= 0;
+  const bool interior = LWS || (hop * 4 == NFFT && t_hi - t_lo == 3 && p - t_lo * hop < NFFT && p - t_hi * hop >= 0);
   for (int t = t_lo; t <= t_hi; ++t) {
     const int n = p - t * hop;
     if (n < 0 || n >= NFFT) continue;
@@ -139,24 +144,33 @@ __global__ void ola_kernel(const float* __restrict__ frames, float* __restrict__
       wsum += w * w;
     }
   }
-  y[(int64_t)b * L + i] = interior ? acc * (2.0f / 3.0f) : acc / wsum;
+  y[(int64_t)b * L + i] = LWS ? acc : (interior ? acc * (2.0f / 3.0f) : acc / wsum);
 }
 
 // phasor[b][t][k] = Z / max(|Z|, 1e-8), Z = rfft(hann * reflect_pad(y[b])[t*hop : t*hop + NFFT])[k]
 // (spec, optional: Z itself, for tests / spectral convergence)
+// LWS: Z = rfft(aw * zero_pad(y[b], NFFT - hop)[t*hop : t*hop + NFFT]) -- lws.lws(1024, hop).stft (sqrt-Hann analysis window
+// `aw`, zeros instead of reflection)
+template <bool LWS>
 __global__ __launch_bounds__(256) void stft_phase_kernel(const float* __restrict__ y,
                                                          float* __restrict__ phasor,
                                                          float* __restrict__ spec,
-                                                         float* __restrict__ mag_bct, int T, int hop, int L) {
+                                                         float* __restrict__ mag_bct, int T, int hop, int L,
+                                                         const float* __restrict__ aw) {
   __shared__ cplx A[NFFT], Bf[NFFT];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / T, t = blockIdx.x - b * T;
   const float* yb = y + (int64_t)b * L;
   for (int n = tid; n < NFFT; n += 256) {
-    int i = t * hop + n - NFFT / 2;  // index into the un-padded signal
-    if (i < 0) i = -i;
-    if (i >= L) i = 2 * (L - 1) - i;
-    A[n] = cplx{yb[i] * hann(n), 0.f};
+    if constexpr (LWS) {
+      const int i = t * hop + n - (NFFT - hop);
+      A[n] = cplx{(i >= 0 && i < L) ? yb[i] * aw[n] : 0.f, 0.f};
+    } else {
+      int i = t * hop + n - NFFT / 2;  // index into the un-padded signal
+      if (i < 0) i = -i;
+      if (i >= L) i = 2 * (L - 1) - i;
+      A[n] = cplx{yb[i] * hann(n), 0.f};
+    }
   }
   fft1024<-1>(A, Bf, tid);
   const int64_t fr = blockIdx.x;
@@ -213,8 +227,10 @@ __global__ __launch_bounds__(256) void gl_project_kernel(const float* __restrict
 // z = x1 + i x2 (X1[k] = (Z[k] + conj Z[N-k]) / 2, X2[k] = (Z[k] - conj Z[N-k]) / 2i), and the two Hermitian target
 // spectra ride one inverse FFT as V = Y1 + i Y2 (y1 = Re v, y2 = Im v): half the FFT passes -- the LDS traffic that
 // bounds this kernel -- per frame.  Frames (2q, 2q+1) of one batch item; an odd last frame pairs with nothing.
+template <bool LWS>
 __global__ __launch_bounds__(256) void gl_project2_kernel(const float* __restrict__ y, const float* __restrict__ mag,
-                                                          float* __restrict__ frames, int T, int hop, int L, int TP) {
+                                                          float* __restrict__ frames, int T, int hop, int L, int TP,
+                                                          const float* __restrict__ aw, const float* __restrict__ sw) {
   __shared__ cplx A[NFFT], Bf[NFFT], W[NFFT];
   const int tid = threadIdx.x;
   const int b = blockIdx.x / TP, t1 = 2 * (blockIdx.x - b * TP);
@@ -223,13 +239,19 @@ __global__ __launch_bounds__(256) void gl_project2_kernel(const float* __restric
   fill_twiddles(W, tid);
   __syncthreads();
   for (int n = tid; n < NFFT; n += 256) {
-    int i1 = t1 * hop + n - NFFT / 2, i2 = i1 + hop;
-    if (i1 < 0) i1 = -i1;
-    if (i1 >= L) i1 = 2 * (L - 1) - i1;
-    if (i2 < 0) i2 = -i2;
-    if (i2 >= L) i2 = 2 * (L - 1) - i2;
-    const float h = hann_t(W, n);
-    A[n] = cplx{yb[i1] * h, two ? yb[i2] * h : 0.f};
+    if constexpr (LWS) {      // lws framing: zeros outside the signal, sqrt-Hann analysis window from the table
+      const int i1 = t1 * hop + n - (NFFT - hop), i2 = i1 + hop;
+      const float h = aw[n];
+      A[n] = cplx{(i1 >= 0 && i1 < L) ? yb[i1] * h : 0.f, (two && i2 >= 0 && i2 < L) ? yb[i2] * h : 0.f};
+    } else {
+      int i1 = t1 * hop + n - NFFT / 2, i2 = i1 + hop;
+      if (i1 < 0) i1 = -i1;
+      if (i1 >= L) i1 = 2 * (L - 1) - i1;
+      if (i2 < 0) i2 = -i2;
+      if (i2 >= L) i2 = 2 * (L - 1) - i2;
+      const float h = hann_t(W, n);
+      A[n] = cplx{yb[i1] * h, two ? yb[i2] * h : 0.f};
+    }
   }
   fft1024<-1>(A, Bf, tid, W);
   const int64_t fr = (int64_t)b * T + t1;
@@ -253,7 +275,7 @@ __global__ __launch_bounds__(256) void gl_project2_kernel(const float* __restric
   fft1024<+1>(A, Bf, tid, W);
   float* out = frames + fr * NFFT;
   for (int n = tid; n < NFFT; n += 256) {
-    const float h = hann_t(W, n) * (1.0f / NFFT);
+    const float h = (LWS ? sw[n] : hann_t(W, n)) * (1.0f / NFFT);
     out[n] = Bf[n].x * h;
     if (two) out[NFFT + n] = Bf[n].y * h;
   }
@@ -346,18 +368,52 @@ extern "C" int dv3_gl_prepare_f32(const float* lin, float* mag, int64_t n, float
 extern "C" int dv3_istft_frames_f32(const float* mag, const float* phasor, float* frames, int32_t B,
                                     int32_t T, void* stream) {
   DV3_REQUIRE(mag && frames && B > 0 && T > 0, "istft_frames: bad arguments");
-  hipLaunchKernelGGL(istft_frames_kernel, dim3((unsigned)((int64_t)B * T)), dim3(256), 0,
-                     (hipStream_t)stream, mag, phasor, frames);
+  hipLaunchKernelGGL(istft_frames_kernel<false>, dim3((unsigned)((int64_t)B * T)), dim3(256), 0,
+                     (hipStream_t)stream, mag, phasor, frames, (const float*)nullptr);
   return dv3_check_launch("istft_frames");
+}
+extern "C" int dv3_lws_istft_frames_f32(const float* mag, const float* phasor, const float* swin, float* frames, int32_t B,
+                                        int32_t T, void* stream) {
+  DV3_REQUIRE(mag && frames && swin && B > 0 && T > 0, "lws_istft_frames: bad arguments");
+  hipLaunchKernelGGL(istft_frames_kernel<true>, dim3((unsigned)((int64_t)B * T)), dim3(256), 0,
+                     (hipStream_t)stream, mag, phasor, frames, swin);
+  return dv3_check_launch("lws_istft_frames");
 }
 
 extern "C" int dv3_overlap_add_f32(const float* frames, float* y, int32_t B, int32_t T, int32_t hop,
                                    void* stream) {
   DV3_REQUIRE(frames && y && B > 0 && T > 1 && hop > 0 && hop <= 1024, "overlap_add: bad arguments");
   const int L = hop * (T - 1);
-  hipLaunchKernelGGL(ola_kernel, dim3(dv3_cdiv(L, 256), B), dim3(256), 0, (hipStream_t)stream, frames, y,
+  hipLaunchKernelGGL(ola_kernel<false>, dim3(dv3_cdiv(L, 256), B), dim3(256), 0, (hipStream_t)stream, frames, y,
                      T, hop, L);
   return dv3_check_launch("overlap_add");
+}
+
+// lws framing: T frames cover (T + 1) * hop - 1024 samples (a signal padded with 1024 - hop zeros on both sides)
+static inline int lws_len(int T, int hop) { return (T + 1) * hop - NFFT; }
+extern "C" int dv3_lws_overlap_add_f32(const float* frames, float* y, int32_t B, int32_t T, int32_t hop, void* stream) {
+  DV3_REQUIRE(frames && y && B > 0 && T > 1 && hop > 0 && hop <= 1024 && lws_len(T, hop) > 0, "lws_overlap_add: bad arguments");
+  const int L = lws_len(T, hop);
+  hipLaunchKernelGGL(ola_kernel<true>, dim3(dv3_cdiv(L, 256), B), dim3(256), 0, (hipStream_t)stream, frames, y, T, hop, L);
+  return dv3_check_launch("lws_overlap_add");
+}
+extern "C" int dv3_lws_stft_f32(const float* y, const float* awin, float* phasor, float* spec, float* mag_bct, int32_t B,
+                                int32_t T, int32_t hop, int32_t L, void* stream) {
+  DV3_REQUIRE(y && awin && (phasor || spec || mag_bct) && B > 0 && T > 1 && hop > 0 && hop <= 1024 && L > 0,
+              "lws_stft: bad arguments");
+  DV3_REQUIRE(L <= lws_len(T, hop) && L > lws_len(T - 1, hop), "lws_stft: %d frames do not frame %d samples at hop %d", T, L, hop);
+  hipLaunchKernelGGL(stft_phase_kernel<true>, dim3((unsigned)((int64_t)B * T)), dim3(256), 0, (hipStream_t)stream, y, phasor,
+                     spec, mag_bct, T, hop, L, awin);
+  return dv3_check_launch("lws_stft");
+}
+extern "C" int dv3_lws_gl_project_f32(const float* y, const float* mag, const float* awin, const float* swin, float* frames,
+                                      int32_t B, int32_t T, int32_t hop, void* stream) {
+  DV3_REQUIRE(y && mag && frames && awin && swin && B > 0 && T > 1 && hop > 0 && hop <= 1024 && lws_len(T, hop) > 0,
+              "lws_gl_project: bad arguments");
+  const int TP = (T + 1) / 2;
+  hipLaunchKernelGGL(gl_project2_kernel<true>, dim3((unsigned)((int64_t)B * TP)), dim3(256), 0, (hipStream_t)stream, y, mag,
+                     frames, T, hop, lws_len(T, hop), TP, awin, swin);
+  return dv3_check_launch("lws_gl_project");
 }
 
 extern "C" int dv3_stft_phase_f32(const float* y, float* phasor, float* spec, float* mag_bct, int32_t B,
@@ -365,8 +421,8 @@ extern "C" int dv3_stft_phase_f32(const float* y, float* phasor, float* spec, fl
   DV3_REQUIRE(y && (phasor || spec || mag_bct) && B > 0 && T > 1 && hop > 0, "stft_phase: bad arguments");
   const int L = hop * (T - 1);
   DV3_REQUIRE(L > 512, "stft_phase: signal shorter than the reflect padding");
-  hipLaunchKernelGGL(stft_phase_kernel, dim3((unsigned)((int64_t)B * T)), dim3(256), 0,
-                     (hipStream_t)stream, y, phasor, spec, mag_bct, T, hop, L);
+  hipLaunchKernelGGL(stft_phase_kernel<false>, dim3((unsigned)((int64_t)B * T)), dim3(256), 0,
+                     (hipStream_t)stream, y, phasor, spec, mag_bct, T, hop, L, (const float*)nullptr);
   return dv3_check_launch("stft_phase");
 }
 
@@ -376,8 +432,8 @@ extern "C" int dv3_gl_project_f32(const float* y, const float* mag, float* frame
   const int L = hop * (T - 1);
   DV3_REQUIRE(L > 512, "gl_project: signal shorter than the reflect padding");
   const int TP = (T + 1) / 2;     // two real frames per complex FFT
-  hipLaunchKernelGGL(gl_project2_kernel, dim3((unsigned)((int64_t)B * TP)), dim3(256), 0, (hipStream_t)stream, y, mag,
-                     frames, T, hop, L, TP);
+  hipLaunchKernelGGL(gl_project2_kernel<false>, dim3((unsigned)((int64_t)B * TP)), dim3(256), 0, (hipStream_t)stream, y, mag,
+                     frames, T, hop, L, TP, (const float*)nullptr, (const float*)nullptr);
   return dv3_check_launch("gl_project");
 }
 

@@ -50,7 +50,9 @@ __device__ __forceinline__ bf16x8 c8pp_keep8(const bf16x8& v, uint32_t m) {
   return __builtin_bit_cast(bf16x8, d);
 }
 
-template <int JT, bool MASK>
+// ABL (make EXP=1 only; dv3_debug_set(21, v)): timing-only ablations, results are wrong: 1 no MFMAs, 2 no staging (no
+// global fetches, no LDS stores) in the loop, 3 no tail, 5 no fragment reads in the loop, 6 no barriers in the loop
+template <int JT, bool MASK, int ABL = 0>
 __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
   constexpr int XI = (KB * (BN + (JT > 1 ? HALO_MAX : 0)) + NT - 1) / NT;   // activation units per thread per chunk
   constexpr int XPS = XI * NT;                                              // units per tile buffer (padded: no store is predicated)
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
   // read in the L phases of step s-1 (intervals 2s-2, 2s-1) and first read in L(s+1) (interval 2s+2); the tile of chunk
   // c+1 during the L phases of chunk c into the buffer last read in chunk c-1.  Every interval ends with a barrier.
   const int late = wave >> 2;
-  if (late) __syncthreads();
+  if (late && ABL != 6) __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     const bf16x8* XsC = Xs + (c & 1) * XPS;
     const int cx = min(c + 2, nchunks - 1);          // the chunk fetched during this one (the tail re-fetches the last)
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
       const bf16x8* AsC = As + cur * (KB * BM);
       const bool fix = (need >> j) & 1u;
       // ---------------- LOAD ----------------
-      {
+      if (ABL != 2) {
         // the next step's panel: store (fetched in this wave's previous LOAD phase), then fetch the panel after
         int j2 = j + 2, c2 = c;
         if (JT == 1) { j2 = 0; c2 = c + 2; }
@@ -241,6 +243,15 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
       }
       __builtin_amdgcn_sched_barrier(0);
       bf16x8 fa[2][MI][2], fb[2][NI];
+      if (ABL == 5) {                       // fragments from registers that are live anyway: no LDS reads
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) fa[ks][mi][0] = fa[ks][mi][1] = ra[ks];
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) fb[ks][ni] = rx[ni];
+        }
+      } else
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int k8 = 2 * ks + lhi;
@@ -264,11 +275,20 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
             fb[ks][ni] = ok ? fb[ks][ni] : zero8;
           }
       }
-      __syncthreads();
+      if (ABL != 6) __syncthreads();
       // the MFMAs are register-only: without the fences the compiler sinks them below the second barrier into the next
       // LOAD phase and the ping-pong degenerates into the in-phase loop (conv_gemm_pp2.hip)
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- COMPUTE: 16 MFMAs of one (chunk, tap) step ----------------
+      if (ABL == 1) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(fa[ks][mi][0]), "v"(fa[ks][mi][1]));
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(fb[ks][ni]));
+        }
+      } else
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -279,9 +299,10 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
             acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mi][1], fb[ks][ni], acc[mi][1][ni], 0, 0, 0);
           }
       __builtin_amdgcn_sched_barrier(0);
-      if (!(last_chunk && j == JT - 1) || !late) __syncthreads();
+      if (ABL != 6 && (!(last_chunk && j == JT - 1) || !late)) __syncthreads();
     }
   }
+  if (ABL == 3 && acc[0][0][0][0] + acc[1][1][1][7] != 1.2345e30f) return;
 
   // ---- fused tail (conv_common.h), one 32-row sub-tile at a time ----
   int n0e = __builtin_amdgcn_readfirstlane(n0);
@@ -315,11 +336,11 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
   }
 }
 
-template <int JT, bool MASK>
+template <int JT, bool MASK, int ABL = 0>
 int launch_c8pp(const ConvArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_c8pp_kernel<JT, MASK>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_c8pp_kernel<JT, MASK, ABL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_c8pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -327,12 +348,13 @@ int launch_c8pp(const ConvArgs& a, size_t lds, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_c8pp_kernel<JT, MASK>), dim3(a.n_blocks), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL((conv_c8pp_kernel<JT, MASK, ABL>), dim3(a.n_blocks), dim3(NT), lds, st, a);
   return dv3_check_launch("conv_c8pp");
 }
 
 }  // namespace
 
+int g_c8pp_abl = 0;            // dv3_debug_set(21, v): timing-only ablations (EXP build)
 int g_c8pp_min_tiles = 128;   // dv3_debug_set(19, v): the 256 x 256 c8 kernel serves eligible shapes whose grid has at
                               // least v tiles (0 = never; 1 = always)
 
@@ -361,11 +383,23 @@ int dv3_conv_c8pp_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   a.n_blocks = (int)nb;
   g_dv3_last_conv = 9000 + 100 + 1;     // single-term c8, 256 x 256 tile, ping-pong
   const bool mask = d->xmask_c8 != nullptr;
+#ifdef DV3_EXPERIMENTS
+  if (g_c8pp_abl && !mask && d->J == 3) {
+    switch (g_c8pp_abl) {
+      case 1: return launch_c8pp<3, false, 1>(a, lds, st);
+      case 2: return launch_c8pp<3, false, 2>(a, lds, st);
+      case 3: return launch_c8pp<3, false, 3>(a, lds, st);
+      case 5: return launch_c8pp<3, false, 5>(a, lds, st);
+      case 6: return launch_c8pp<3, false, 6>(a, lds, st);
+    }
+  }
+#endif
   if (d->J == 3) return mask ? launch_c8pp<3, true>(a, lds, st) : launch_c8pp<3, false>(a, lds, st);
   return mask ? launch_c8pp<1, true>(a, lds, st) : launch_c8pp<1, false>(a, lds, st);
 }
 
 int dv3_c8pp_debug_set(int what, int value) {
   if (what == 19) g_c8pp_min_tiles = value;
+  if (what == 21) g_c8pp_abl = value;
   return DV3_OK;
 }

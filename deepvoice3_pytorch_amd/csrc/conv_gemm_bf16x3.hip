@@ -771,17 +771,19 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
 }
 
 extern int g_wgrad_tile, g_wgrad_prio, g_wgrad_t2_abl, g_wgrad_taps2_default;   // wgrad_gemm_bf16x3.hip, wgrad_taps2.hip
+extern int g_wgrad_c8_pf2;                                                       // wgrad_c8.hip
 int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 int dv3_c8pp_debug_set(int what, int value);     // conv_c8pp.hip
 extern "C" int dv3_debug_set(int what, int value) {
 #ifndef DV3_EXPERIMENTS
   // the timing-only ablation / stamp instantiations are compiled with `make EXP=1` only: say so instead of silently
   // timing the production kernel
-  DV3_REQUIRE(!(value != 0 && (what == 1 || what == 6 || what == 13 || what == 16)),
+  DV3_REQUIRE(!(value != 0 && (what == 1 || what == 6 || what == 13 || what == 16 || what == 21)),
               "debug_set(%d, %d): ablation variants are not in this build (make EXP=1)", what, value);
 #endif
   if (what >= 4 && what <= 8) return dv3_planes_debug_set(what, value);
-  if (what == 19) return dv3_c8pp_debug_set(what, value);
+  if (what == 19 || what == 21) return dv3_c8pp_debug_set(what, value);
+  if (what == 20) g_wgrad_c8_pf2 = value;
   if (what == 9) g_x3_rel2 = value;
   if (what == 12) g_x3_pp2 = value;
   if (what == 13) g_pp2_abl = value;

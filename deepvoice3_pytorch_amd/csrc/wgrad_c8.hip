@@ -33,8 +33,13 @@ __device__ __forceinline__ T ldg_off(const void* base, uint32_t byte_off) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-template <int JT, bool MASK>
-__global__ __launch_bounds__(512, 2) void wgrad_c8_kernel(const WgradC8Args args) {
+// PF2 (round 4, default): operands fetched TWO steps ahead into two register sets, as wgrad_taps2.hip does for the split
+// kernels (both operands stream from HBM; one step of MFMAs -- ~0.4 us -- does not cover a fetch issued right before
+// it).  Every load is unconditional (frames clamped into the row), validity is recomputed from the step index when the
+// set is transposed, the tail re-fetches the last step.  Same tile, LDS image and accumulation order: bit-identical
+// slabs.  One workgroup per CU either way (the grid is sized to the chip), so the kernel takes the 256-register budget.
+template <int JT, bool MASK, bool PF2>
+__global__ __launch_bounds__(512) void wgrad_c8_kernel(const WgradC8Args args) {
   constexpr int BM = 128, BN = 128;
   constexpr int LDM = BM + PAD, LDN = BN + PAD;
   constexpr int GBUF = KB * LDM, XTAP = KB * LDN, BUF = GBUF + JT * XTAP;   // 16-byte units per buffer
@@ -86,33 +91,35 @@ __global__ __launch_bounds__(512, 2) void wgrad_c8_kernel(const WgradC8Args args
     nsteps = max(0, min(q, total - step0));
   }
 
-  u32x4 ru[4];
-  uint32_t rkeep[4];
-  uint32_t rvalid = 0;
-  auto load_step = [&](int step) {
+  constexpr int NSET = PF2 ? 2 : 1;
+  u32x4 ru[NSET][4];
+  uint32_t rkeep[MASK ? NSET : 1][4];
+  // `step` may run past the end (PF2's look-ahead): it is clamped to the last step, whose re-fetched data is never used
+  auto load_step = [&](int step, auto set_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_c)::value;
     if (!stager) return;
-    const int gs = step0 + step;
+    const int gs = step0 + min(step, nsteps - 1);
     const int b = gs / n_tc, tc = gs - b * n_tc;
     const int t0 = tc * BKT + tq;
     const uint32_t ubase = (uint32_t)((b * c8t + (grp_ok ? grow : 0)) * T);
-    rvalid = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int t = t0 + i;
-      const bool ok = grp_ok && t >= 0 && t < T;
-      const uint32_t u = ubase + (uint32_t)min(max(t, 0), T - 1);
-      ru[i] = ldg_off<u32x4>(src, u * 16u);
-      if (MASK) rkeep[i] = is_g ? 0xffu : (uint32_t)ldg_off<uint8_t>(p.xmask_c8, u);
-      rvalid |= (ok ? 1u : 0u) << i;
+      const uint32_t u = ubase + (uint32_t)min(max(t0 + i, 0), T - 1);
+      ru[S][i] = ldg_off<u32x4>(src, u * 16u);
+      if constexpr (MASK) rkeep[S][i] = is_g ? 0xffu : (uint32_t)ldg_off<uint8_t>(p.xmask_c8, u);
     }
   };
-  auto write_step = [&](int buf) {
+  auto write_step = [&](int step, int buf, auto set_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_c)::value;
     if (!stager) return;
+    const int gs = step0 + min(step, nsteps - 1);
+    const int t0 = (gs % n_tc) * BKT + tq;
     const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (!((rvalid >> i) & 1u)) ru[i] = zero;
-      if (MASK) ru[i] &= lut[rkeep[i]];
+      const int t = t0 + i;
+      if (!(grp_ok && t >= 0 && t < T)) ru[S][i] = zero;       // the conv's zero padding / rows beyond the tensor
+      if constexpr (MASK) ru[S][i] &= lut[rkeep[S][i]];
     }
     // 8 channels x 4 frames -> per channel e: frames (0,1) and (2,3) packed into two dwords
     bf16x8* dst = smem + buf * BUF + (is_g ? 0 : GBUF + (panel - 1) * XTAP) + k8 * (is_g ? LDM : LDN) + grp * 8;
@@ -121,11 +128,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_c8_kernel(const WgradC8Args args
       const int q = e >> 1;
       const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
       u32x2 o;
-      o[0] = __builtin_amdgcn_perm(ru[1][q], ru[0][q], sel);
-      o[1] = __builtin_amdgcn_perm(ru[3][q], ru[2][q], sel);
+      o[0] = __builtin_amdgcn_perm(ru[S][1][q], ru[S][0][q], sel);
+      o[1] = __builtin_amdgcn_perm(ru[S][3][q], ru[S][2][q], sel);
       reinterpret_cast<u32x2*>(dst + e)[hsel] = o;
     }
   };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, PF2 ? 1 : 0>;
 
   f32x16 acc[JT][2];
 #pragma unroll
@@ -152,16 +161,38 @@ __global__ __launch_bounds__(512, 2) void wgrad_c8_kernel(const WgradC8Args args
   };
 
   __syncthreads();          // the keep-byte table
-  if (nsteps > 0) {
-    load_step(0);
-    write_step(0);
-  }
-  __syncthreads();
-  for (int step = 0; step < nsteps; ++step) {
-    if (step + 1 < nsteps) load_step(step + 1);
-    mfma_step(step & 1);
-    if (step + 1 < nsteps) write_step((step + 1) & 1);
+  if constexpr (PF2) {
+    if (nsteps > 0) {
+      // prologue: step 0 -> buffer 0; set 1 <- step 1, set 0 <- step 2
+      load_step(0, S0{});
+      load_step(1, S1{});
+      write_step(0, 0, S0{});
+      load_step(2, S0{});
+      __syncthreads();
+      // steps in pairs so the register-set index is static: step st + 1 is staged from set (st + 1) & 1
+      auto step = [&](int st, auto set_c) __attribute__((always_inline)) {
+        mfma_step(st & 1);
+        write_step(st + 1, (st + 1) & 1, set_c);     // past the end: a re-fetched tile into the buffer nobody reads
+        load_step(st + 3, set_c);
+        __syncthreads();
+      };
+      for (int st = 0; st < nsteps; st += 2) {
+        step(st, S1{});
+        if (st + 1 < nsteps) step(st + 1, S0{});
+      }
+    }
+  } else {
+    if (nsteps > 0) {
+      load_step(0, S0{});
+      write_step(0, 0, S0{});
+    }
     __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+      if (step + 1 < nsteps) load_step(step + 1, S0{});
+      mfma_step(step & 1);
+      if (step + 1 < nsteps) write_step(step + 1, (step + 1) & 1, S0{});
+      __syncthreads();
+    }
   }
 
   const float oscale = MASK ? p.drop_scale : 1.0f;
@@ -181,13 +212,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_c8_kernel(const WgradC8Args args
   }
 }
 
-template <int JT, bool MASK>
+template <int JT, bool MASK, bool PF2>
 int launch_c8(const WgradC8Args& a, int64_t nb, hipStream_t st) {
   constexpr int LDM = 128 + PAD;
   constexpr size_t lds = (size_t)2 * (KB * LDM + JT * KB * LDM) * 16 + 256 * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_c8_kernel<JT, MASK>,
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_c8_kernel<JT, MASK, PF2>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("wgrad_c8: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -195,11 +226,13 @@ int launch_c8(const WgradC8Args& a, int64_t nb, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_c8_kernel<JT, MASK>), dim3((unsigned)nb), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((wgrad_c8_kernel<JT, MASK, PF2>), dim3((unsigned)nb), dim3(512), lds, st, a);
   return dv3_check_launch("wgrad_c8");
 }
 
 }  // namespace
+
+int g_wgrad_c8_pf2 = 1;   // dv3_debug_set(20, v): 1 = operands fetched two steps ahead (default), 0 = the round-2 one-step form
 
 // called by dv3_wgrad_gemm_f32 (wgrad_gemm.hip) when d->c8 is set
 int dv3_wgrad_c8_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
@@ -217,7 +250,12 @@ int dv3_wgrad_c8_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
   a.c_tiles = dv3_cdiv(d->Cin, 128);
   const int64_t nb = (int64_t)a.m_tiles * a.c_tiles * d->n_slabs;
   DV3_REQUIRE(nb < (1ll << 31), "wgrad_gemm: grid too large");
+  if (g_wgrad_c8_pf2) {
+    g_dv3_last_wgrad = 5000 + 20 + d->J;
+    if (d->J == 3) return d->xmask_c8 ? launch_c8<3, true, true>(a, nb, st) : launch_c8<3, false, true>(a, nb, st);
+    return d->xmask_c8 ? launch_c8<1, true, true>(a, nb, st) : launch_c8<1, false, true>(a, nb, st);
+  }
   g_dv3_last_wgrad = 5000 + d->J;
-  if (d->J == 3) return d->xmask_c8 ? launch_c8<3, true>(a, nb, st) : launch_c8<3, false>(a, nb, st);
-  return d->xmask_c8 ? launch_c8<1, true>(a, nb, st) : launch_c8<1, false>(a, nb, st);
+  if (d->J == 3) return d->xmask_c8 ? launch_c8<3, true, false>(a, nb, st) : launch_c8<3, false, false>(a, nb, st);
+  return d->xmask_c8 ? launch_c8<1, true, false>(a, nb, st) : launch_c8<1, false, false>(a, nb, st);
 }

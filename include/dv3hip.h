@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 31
+#define DV3_ABI_VERSION 32
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -660,6 +660,24 @@ int dv3_amp_to_db_norm_f32(const float* x, float* out, int64_t n, float min_leve
  * runs chunked in parallel over the row (exact to fp32 rounding for |coef| well below 1: each 3072-sample chunk restarts
  * 1024 samples early); x == y, or a coefficient whose memory outlasts the warm-up, runs one workgroup per row. */
 int dv3_deemphasis_f32(const float* x, float* y, int32_t B, int32_t L, float coef, void* stream);
+
+/* The same analysis / inverse on the framing of `lws.lws(fft_size, hop_size, mode="speech")` (audio.py:54-55), which the
+ * reference uses for its features (`.stft`, audio.py:31-35,46-51) and for the framing of its inverse (`.istft`,
+ * audio.py:42) -- the package's published conventions (python/lws.pyx; restated and cited in oracle/audio_oracle.py):
+ *   awin  [1024]  analysis window: sqrt of the SYMMETRIC Hann window
+ *   swin  [1024]  perfect-reconstruction synthesis window: awin / overlap-added(awin^2) -- no division in the overlap-add
+ *   the signal is padded with 1024 - hop ZEROS on both sides (no reflection): T frames cover L <= (T + 1) * hop - 1024
+ *   samples, frame t starts at sample t * hop - (1024 - hop).
+ * Both tables are built on the host (deepvoice3_pytorch_amd/audio.py: lws_windows).  Phase reconstruction is Griffin-Lim
+ * (north_star) on this framing, not lws's own run_lws iterations. */
+int dv3_lws_stft_f32(const float* y, const float* awin, float* phasor, float* spec, float* mag_bct, int32_t B, int32_t T,
+                     int32_t hop, int32_t L, void* stream);
+int dv3_lws_istft_frames_f32(const float* mag, const float* phasor /* NULL: zero phase */, const float* swin, float* frames,
+                             int32_t B, int32_t T, void* stream);
+/* y [B][(T + 1) * hop - 1024] */
+int dv3_lws_overlap_add_f32(const float* frames, float* y, int32_t B, int32_t T, int32_t hop, void* stream);
+int dv3_lws_gl_project_f32(const float* y, const float* mag, const float* awin, const float* swin, float* frames, int32_t B,
+                           int32_t T, int32_t hop, void* stream);
 
 #ifdef __cplusplus
 }

@@ -128,3 +128,100 @@ def melspectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97, 
     D = stft(torch.from_numpy(preemphasis(wav, coef)), hop).abs().numpy().transpose(0, 2, 1)
     M = np.einsum("mf,bft->bmt", slaney_mel_basis(**mel_kw), D)
     return normalize(amp_to_db(M, min_level_db) - ref_level_db, min_level_db)
+
+
+# ------------------------------------------------------------------------------------------------
+# The conventions of `lws.lws(fft_size, hop_size, mode="speech")` (audio.py:54-55), which the reference uses for its
+# analysis (`.stft`, audio.py:31-35,46-51: the features every model is trained on) and for the framing of its inverse
+# (`.istft`, audio.py:42).  The package (Jonathan Le Roux, github.com/Jonathan-LeRoux/lws, pinned by setup.py:87 as
+# "lws <= 1.0"; python/lws.pyx) is not vendored and cannot be installed here (no network), so what follows restates its
+# PUBLISHED conventions -- README "Additional options" and lws.pyx: hann / synthwin / stft / istft -- not its output:
+#   * analysis window  = sqrt of a SYMMETRIC Hann window (lws.pyx: `awin = np.sqrt(hann(fsize, symmetric=True,
+#     use_offset=False))`, hann(n) = 0.5 - 0.5 cos(2 pi k / (n - 1)));
+#   * synthesis window = the analysis window divided by the overlap-added product awin * swin over the Q = ceil(fsize /
+#     fshift) frame positions (lws.pyx: synthwin), so that overlap-add reconstructs perfectly;
+#   * perfectrec=True (the default): the signal is padded with fsize - fshift ZEROS on both sides (and with zeros on the
+#     right up to a whole number of hops), so every sample is covered by all Q window positions; istft strips the padding.
+#     The same frame count appears in r9y9's own tools as lws_num_frames / lws_pad_lr (wavenet_vocoder audio.py):
+#         M = (L + 2 (fsize - fshift) - fsize) // fshift + 1   for L % fshift == 0   (L = 256 k  ->  M = k + 3)
+#   * mode="speech" only selects the parameters of the phase-reconstruction iterations (run_lws), not the framing.
+# What deviates BY DESIGN (north_star): phase reconstruction itself is Griffin-Lim on these conventions, not LWS's
+# weighted local sums (run_lws); PARITY UNPINNED for that part stays (no reference output can be produced here).
+# ------------------------------------------------------------------------------------------------
+def lws_hann(n, symmetric=True):
+    """lws.pyx: hann(n, symmetric, use_offset=False)"""
+    k = np.arange(n, dtype=np.float64)
+    return 0.5 * (1.0 - np.cos(2.0 * np.pi * k / ((n - 1) if symmetric else n)))
+
+
+def lws_windows(fsize=1024, fshift=256):
+    """-> (awin, swin): lws.lws(fsize, fshift).awin and the synthwin(awin, fshift) perfect-reconstruction synthesis window"""
+    awin = np.sqrt(lws_hann(fsize, True))
+    Q = int(np.ceil(fsize * 1.0 / fshift))
+    twin = awin * awin
+    w = np.concatenate([twin, np.zeros(Q * fshift - fsize)]).reshape(Q, fshift).sum(0)
+    w = np.tile(w, Q)[:fsize]
+    if w.min() <= 0:
+        raise ValueError("The normalizer is not strictly positive")
+    return awin, awin / w
+
+
+def lws_num_frames(length, fsize=1024, fshift=256):
+    pad = fsize - fshift
+    M = (length + 2 * pad - fsize) // fshift + 1
+    return M if length % fshift == 0 else M + 1
+
+
+def lws_stft(x, fsize=1024, fshift=256):
+    """lws.lws(fsize, fshift).stft(x): (L,) or (B, L) real -> (..., M, fsize / 2 + 1) complex"""
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 2:
+        return np.stack([lws_stft(r, fsize, fshift) for r in x])
+    awin, _ = lws_windows(fsize, fshift)
+    pad = fsize - fshift
+    M = lws_num_frames(len(x), fsize, fshift)
+    xp = np.zeros((M - 1) * fshift + fsize)
+    xp[pad:pad + len(x)] = x
+    frames = np.stack([xp[m * fshift:m * fshift + fsize] * awin for m in range(M)])
+    return np.fft.rfft(frames, axis=-1)
+
+
+def lws_istft(S, fshift=256):
+    """lws.lws(fsize, fshift).istft(S): (..., M, fsize / 2 + 1) complex -> (..., (M - 1) fshift + fsize - 2 (fsize - fshift))"""
+    S = np.asarray(S)
+    if S.ndim == 3:
+        return np.stack([lws_istft(s, fshift) for s in S])
+    M, fsize = S.shape[0], 2 * (S.shape[1] - 1)
+    _, swin = lws_windows(fsize, fshift)
+    pad = fsize - fshift
+    frames = np.fft.irfft(S, n=fsize, axis=-1) * swin
+    yp = np.zeros((M - 1) * fshift + fsize)
+    for m in range(M):
+        yp[m * fshift:m * fshift + fsize] += frames[m]
+    return yp[pad:len(yp) - pad]
+
+
+def lws_griffin_lim(mag, n_iter, fshift=256, init_phasor=None):
+    """Griffin-Lim on the lws framing: mag real (B, M, 513) -> (B, L)"""
+    mag = np.asarray(mag, dtype=np.float64)
+    ph = np.ones(mag.shape, dtype=np.complex128) if init_phasor is None else np.asarray(init_phasor, dtype=np.complex128)
+    fsize = 2 * (mag.shape[-1] - 1)
+    y = lws_istft(mag * ph, fshift)
+    for _ in range(n_iter):
+        Z = lws_stft(y, fsize, fshift)
+        ph = Z / np.maximum(np.abs(Z), 1e-8)
+        y = lws_istft(mag * ph, fshift)
+    return y
+
+
+def lws_spectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97):
+    """audio.spectrogram (audio.py:31-35) on the lws framing: (B, L) -> (B, 513, M)"""
+    D = np.abs(lws_stft(preemphasis(wav, coef), 1024, hop)).transpose(0, 2, 1)
+    return normalize(amp_to_db(D, min_level_db) - ref_level_db, min_level_db)
+
+
+def lws_melspectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97, **mel_kw):
+    """audio.melspectrogram (audio.py:46-51) on the lws framing: (B, L) -> (B, 80, M)"""
+    D = np.abs(lws_stft(preemphasis(wav, coef), 1024, hop)).transpose(0, 2, 1)
+    M = np.einsum("mf,bft->bmt", slaney_mel_basis(**mel_kw), D)
+    return normalize(amp_to_db(M, min_level_db) - ref_level_db, min_level_db)

@@ -1,10 +1,14 @@
 # coding: utf-8
-"""Audio inverse: audio.inv_spectrogram (audio.py:37-43) on the device.
+"""Audio inverse: audio.inv_spectrogram (audio.py:37-43) on the device, and the forward
+analysis audio.spectrogram / melspectrogram (row f2).
 
-Phase reconstruction is PARITY UNPINNED against the reference (third-party lws, oracle/audio_oracle.py
-header); what can be pinned is: the reference's own amp/db helpers (tests/test_audio.py:15-20 of the
-reference), the HIP STFT / iSTFT against torch's FFTs, and the HIP Griffin-Lim against the independent
-CPU restatement on identical inputs."""
+The reference frames its features and its inverse with the third-party `lws` package (audio.py:54-55).  Pinned here:
+the reference's own amp/db helpers (reference tests/test_audio.py:15-20, tests/golden/audio_helpers.npz); the lws
+FRAMING (analysis / synthesis windows, zero padding, frame count) restated from the package's published source in
+oracle/audio_oracle.py and checked through the properties the package documents (perfect reconstruction, frame count
+k + 3 for 256 k samples); the HIP STFT / iSTFT / Griffin-Lim on that framing against the numpy restatement, and on the
+torch framing (rounds 1-3) against torch's FFTs.  Phase reconstruction itself is Griffin-Lim by design (north_star), not
+lws's run_lws iterations: PARITY UNPINNED for that part (no reference output can be produced without the package)."""
 import numpy as np
 import pytest
 import torch
@@ -55,6 +59,42 @@ def test_oracle_stft_istft_roundtrip_and_griffin_lim_converges():
     assert sc[2] < sc[1] < sc[0]
 
 
+def test_oracle_lws_framing_published_properties():
+    """lws.lws(1024, 256): sqrt of the symmetric Hann window, a synthesis window that makes overlap-add the identity,
+    fsize - fshift zeros of padding on both sides (perfectrec=True) -- checked through what the package documents:
+    istft(stft(x)) == x for ANY length, borders included; L = 256 k gives k + 3 frames (the count r9y9's own
+    lws_num_frames / lws_pad_lr helpers compute); the product's host-side tables are the oracle's."""
+    aw, sw = A.lws_windows(1024, 256)
+    assert aw[0] == 0.0 and np.allclose(aw, aw[::-1]) and abs(aw[511] - aw[512]) < 1e-12       # symmetric, n - 1 denominator
+    assert np.allclose(aw ** 2, 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1024) / 1023.0))
+    ola = np.zeros(1024 + 3 * 256)
+    for q in range(4):
+        ola[q * 256:q * 256 + 1024] += aw * sw
+    assert np.allclose(ola[768:1024], 1.0, atol=1e-12)             # every sample covered by all four window positions sums to 1
+    rng = np.random.RandomState(3)
+    for L in (2560, 256 * 37, 1000, 5000, 1):
+        x = rng.randn(L)
+        S = A.lws_stft(x)
+        assert S.shape == (A.lws_num_frames(L), 513)
+        y = A.lws_istft(S)
+        assert len(y) >= L and np.abs(y[:L] - x).max() < 1e-12 and (len(y) == L or np.abs(y[L:]).max() < 1e-12)
+    assert [A.lws_num_frames(256 * k) for k in (1, 10, 800)] == [4, 13, 803]
+    assert A.lws_stft(rng.randn(2, 2560)).shape == (2, 13, 513)
+    from deepvoice3_pytorch_amd import audio
+    a2, s2 = audio.lws_windows_np(1024, 256)
+    assert np.array_equal(a2, aw) and np.array_equal(s2, sw)
+    assert audio.lws_num_frames(2560, 256) == 13 and audio.lws_num_samples(13, 256) == 2560
+    assert [audio.lws_num_frames(L, 256) for L in (1000, 5000)] == [A.lws_num_frames(1000), A.lws_num_frames(5000)]
+    # Griffin-Lim on this framing approaches a consistent magnitude
+    sig = np.cumsum(rng.randn(1, 256 * 20), axis=1) * 0.05
+    mag = np.abs(A.lws_stft(sig))
+
+    def sc(y):
+        return float(np.linalg.norm(np.abs(A.lws_stft(y)) - mag) / np.linalg.norm(mag))
+    ph = np.exp(1j * rng.uniform(-np.pi, np.pi, mag.shape))
+    assert sc(A.lws_griffin_lim(mag, 30, 256, ph)) < 0.5 * sc(A.lws_griffin_lim(mag, 0, 256, ph))
+
+
 def test_oracle_inv_preemphasis_inverts_preemphasis():
     x = np.random.RandomState(2).randn(3, 1000)
     pre = np.concatenate([x[:, :1], x[:, 1:] - 0.97 * x[:, :-1]], axis=1)     # nnmnkwii.preemphasis
@@ -96,6 +136,71 @@ def test_hip_stft_istft_match_torch_fft(dev, B, T, hop):
     assert _rel(yg.cpu().numpy(), want.numpy()) < 2e-5
     yz = audio.istft(mag.to(dev), None, hop)                       # zero phase
     assert _rel(yz.cpu().numpy(), A.istft(mag.double().to(torch.complex128), hop).numpy()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,hop", [(1, 2560, 256), (3, 256 * 37, 256), (2, 5000, 256), (2, 1000, 256)])
+def test_hip_lws_framing_matches_the_restatement(dev, B, L, hop):
+    """the HIP STFT / iSTFT on the framing of lws.lws(1024, hop) (audio.py:54-55) against oracle/audio_oracle.py's
+    restatement of the package's published conventions, and the package's documented property on the device:
+    istft(stft(y)) == y, borders included"""
+    from deepvoice3_pytorch_amd import audio
+    rng = np.random.RandomState(L + B)
+    y = rng.randn(B, L).astype(np.float32)
+    T = audio.lws_num_frames(L, hop)
+    ph, sp = audio.stft(torch.from_numpy(y).to(dev), T, hop, want_phasor=True, want_spec=True, convention="lws")
+    Z = A.lws_stft(y.astype(np.float64), 1024, hop)
+    got = torch.view_as_complex(sp.cpu().double().contiguous()).numpy()
+    assert got.shape == Z.shape == (B, T, 513)
+    assert np.abs(got - Z).max() < 2e-6 * np.abs(Z).max()
+    gph = torch.view_as_complex(ph.cpu().double().contiguous()).numpy()
+    big = np.abs(Z) > 1e-3 * np.abs(Z).max()
+    assert np.abs((gph - Z / np.maximum(np.abs(Z), 1e-30))[big]).max() < 1e-3
+    # perfect reconstruction on the device (magnitude x unit phasor = the spectrum)
+    mag = torch.from_numpy(np.abs(Z).astype(np.float32)).to(dev)
+    back = audio.istft(mag, ph, hop, convention="lws").cpu().numpy()
+    assert back.shape[1] == audio.lws_num_samples(T, hop) >= L
+    assert np.abs(back[:, :L] - y).max() < 2e-5 * np.abs(y).max()
+    # arbitrary (inconsistent) magnitudes + phases, like a Griffin-Lim step
+    m2 = rng.rand(B, T, 513).astype(np.float32)
+    phz = rng.uniform(-np.pi, np.pi, (B, T, 513)).astype(np.float32)
+    phasor = torch.from_numpy(np.stack([np.cos(phz), np.sin(phz)], axis=-1))
+    yg = audio.istft(torch.from_numpy(m2).to(dev), phasor.to(dev), hop, convention="lws").cpu().numpy()
+    want = A.lws_istft(m2.astype(np.float64) * np.exp(1j * phz.astype(np.float64)), hop)
+    assert _rel(yg, want) < 2e-5
+    yz = audio.istft(torch.from_numpy(m2).to(dev), None, hop, convention="lws").cpu().numpy()       # zero phase
+    assert _rel(yz, A.lws_istft(m2.astype(np.complex128), hop)) < 2e-5
+
+
+@pytest.mark.gpu
+def test_hip_lws_griffin_lim_matches_the_restatement_and_converges(dev):
+    from deepvoice3_pytorch_amd import audio
+    rng = np.random.RandomState(15)
+    B, T, hop = 2, 47, 256
+    lin = torch.from_numpy(np.clip(0.55 + 0.25 * rng.randn(B, T, 513), -0.2, 1.2).astype(np.float32))
+    cfg = audio.AudioConfig(griffin_lim_iters=4)
+    assert cfg.convention == "lws"
+    mag = audio.magnitudes(lin.to(dev), cfg)
+    phz = rng.uniform(-np.pi, np.pi, (B, T, 513)).astype(np.float32)
+    phasor = torch.from_numpy(np.stack([np.cos(phz), np.sin(phz)], axis=-1)).to(dev)
+    init = np.exp(1j * phz.astype(np.float64))
+    for n_iter in (0, 1, 4):
+        got = audio.griffin_lim(mag, hop, n_iter, phasor, convention="lws").cpu().numpy()
+        want = A.lws_griffin_lim(mag.cpu().numpy().astype(np.float64), n_iter, hop, init)
+        assert got.shape == want.shape == (B, (T + 1) * hop - 1024)
+        assert _rel(got, want) < 5e-4, n_iter
+
+    def sc(y, m):
+        Z = np.abs(A.lws_stft(y.astype(np.float64), 1024, hop))
+        return float(np.linalg.norm(Z - m) / np.linalg.norm(m))
+    m64 = mag.cpu().numpy().astype(np.float64)
+    s = [sc(audio.griffin_lim(mag, hop, n, phasor, convention="lws").cpu().numpy(), m64) for n in (0, 10, 40)]
+    assert s[2] < s[1] < s[0]
+    sig = np.cumsum(rng.randn(B, audio.lws_num_samples(T, hop)), axis=1) * 0.05
+    cm = np.abs(A.lws_stft(sig, 1024, hop))
+    cmag = torch.from_numpy(cm.astype(np.float32)).to(dev)
+    s = [sc(audio.griffin_lim(cmag, hop, n, phasor, convention="lws").cpu().numpy(), cm) for n in (0, 60)]
+    assert s[1] < 0.5 * s[0]
 
 
 @pytest.mark.gpu
@@ -143,10 +248,15 @@ def test_hip_deemphasis_and_inv_spectrogram(dev):
         assert _rel(got, A.inv_preemphasis(y.numpy(), coef)) < (1e-4 if coef > 0.99 else 2e-5), (L, coef)
     # end to end, reference calling convention: (513, T) numpy in, waveform numpy out
     spec = np.clip(0.5 + 0.2 * rng.randn(513, 30), 0, 1).astype(np.float32)
-    wav = audio.inv_spectrogram(spec, audio.AudioConfig(griffin_lim_iters=3))
     mag = A.magnitudes(spec.T[None])
+    wav = audio.inv_spectrogram(spec, audio.AudioConfig(griffin_lim_iters=3, convention="torch"))
     want = A.inv_preemphasis(A.griffin_lim(torch.from_numpy(mag), 3).numpy(), 0.97)[0]
     assert wav.shape == (256 * 29,) and np.isfinite(wav).all()
+    assert _rel(wav, want) < 1e-3
+    # the default: the reference's own framing (processor.istft of 30 frames returns 31 * 256 - 1024 samples)
+    wav = audio.inv_spectrogram(spec, audio.AudioConfig(griffin_lim_iters=3))
+    want = A.inv_preemphasis(A.lws_griffin_lim(mag, 3), 0.97)[0]
+    assert wav.shape == (31 * 256 - 1024,) and np.isfinite(wav).all()
     assert _rel(wav, want) < 1e-3
 
 
@@ -166,15 +276,26 @@ def test_hip_spectrogram_and_melspectrogram(dev):
     B, T, hop = 2, 33, 256
     t = np.arange(hop * (T - 1)) / 22050.0
     wav = (0.3 * np.sin(2 * np.pi * 440 * t)[None] + 0.05 * rng.randn(B, t.size)).astype(np.float32)
-    S = audio.spectrogram_batch(torch.from_numpy(wav).to(dev))
+    tcfg = audio.AudioConfig(convention="torch")
+    S = audio.spectrogram_batch(torch.from_numpy(wav).to(dev), tcfg)
     want = A.spectrogram(wav.astype(np.float64))
     assert S.shape == (B, 513, T)
     assert np.abs(S.cpu().numpy() - want).max() < 2e-5            # values live in [0, 1]
+    # the default framing is the reference's (lws): 256 k samples -> k + 3 frames; also a length that is no hop multiple
+    for wv in (wav, wav[:, :5000]):
+        S = audio.spectrogram_batch(torch.from_numpy(np.ascontiguousarray(wv)).to(dev))
+        want = A.lws_spectrogram(wv.astype(np.float64))
+        assert S.shape == want.shape == (B, 513, A.lws_num_frames(wv.shape[1]))
+        assert np.abs(S.cpu().numpy() - want).max() < 2e-5
     for mode in ("f16x3", "bf16x3", "f32"):
         from deepvoice3_pytorch_amd import ops
         prev = ops.set_gemm_precision(mode)
-        M = audio.melspectrogram_batch(torch.from_numpy(wav).to(dev))
+        M = audio.melspectrogram_batch(torch.from_numpy(wav).to(dev), tcfg)
+        Ml = audio.melspectrogram_batch(torch.from_numpy(wav).to(dev))
         ops.set_gemm_precision(prev)
         wantm = A.melspectrogram(wav.astype(np.float64))
         assert M.shape == (B, 80, T)
         assert np.abs(M.cpu().numpy() - wantm).max() < 2e-5, mode
+        wantl = A.lws_melspectrogram(wav.astype(np.float64))
+        assert Ml.shape == wantl.shape == (B, 80, T + 2)
+        assert np.abs(Ml.cpu().numpy() - wantl).max() < 2e-5, mode

@@ -108,7 +108,7 @@ def test_c8_gated_layers_forward_backward(dev, modes, kind, C, k, d, causal, T, 
     rec = {}
     y8, dx8, dp8 = _run(layer, x, True, "bf16", ops, record=rec)
     assert _lib.lib().dv3_debug_get(10) // 1000 == 8            # the planes kernel, single-term bf16
-    assert _lib.lib().dv3_debug_get(11) in (5001, 5003)         # the c8 wgrad kernel
+    assert _lib.lib().dv3_debug_get(11) in (5001, 5003, 5021, 5023)         # the c8 wgrad kernel (+20: two-steps-ahead fetch)
     # forward against the oracle with the recorded keep-bits
     bits, rows, Tm = rec["l"]
     keep = torch.from_numpy(O.unpack_keep_bits(bits.cpu().numpy().view(np.uint32), rows, (Tm + 31) // 32, Tm)).float()
@@ -365,3 +365,32 @@ def test_c8pp_plain_and_fp32_output_forms(dev, modes):
         L.dv3_debug_set(19, 128)
     for i, (a, b) in enumerate(zip(res["planes"], res["c8pp"])):
         assert torch.equal(a, b), (i, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("kind,C,k,d,causal,T,B", [("glu", 64, 3, 2, False, 75, 3), ("glu", 256, 3, 27, False, 150, 2),
+                                                   ("highway", 128, 1, 1, False, 50, 3), ("glu", 96, 3, 9, True, 61, 5),
+                                                   ("glu", 256, 3, 1, False, 33, 1)])
+def test_wgrad_c8_two_steps_ahead_is_bit_identical(dev, modes, kind, C, k, d, causal, T, B):
+    """wgrad_c8_kernel<.., PF2> (operands fetched two steps ahead into two register sets) against the one-step form:
+    same tile, LDS image and accumulation order -> the same parameter gradients bit for bit (masked and not, K ranges
+    of one step included)"""
+    ops = modes
+    from deepvoice3_pytorch_amd import modules, _lib
+    L = _lib.lib()
+    torch.manual_seed(0)
+    if kind == "highway":
+        layer = modules.HighwayConv1d(C, C, k, dilation=d, causal=causal, dropout=0.1)
+    else:
+        layer = modules.Conv1dGLU(1, 16, C, C, k, dropout=0.2, dilation=d, causal=causal, residual=True)
+    layer = layer.to(dev).train()
+    x = torch.randn(B, C, T, device=dev)
+    out = {}
+    try:
+        for pf2 in (0, 1):
+            L.dv3_debug_set(20, pf2)
+            out[pf2] = _run(layer, x, True, "bf16", ops)
+            assert L.dv3_debug_get(11) == 5000 + 20 * pf2 + k
+    finally:
+        L.dv3_debug_set(20, 1)
+    for n in out[0][2]:
+        assert torch.equal(out[0][2][n], out[1][2][n]), n

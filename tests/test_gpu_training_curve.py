@@ -26,11 +26,15 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS, WINDOW = 240, 20
-# Two fp32 oracle runs that differ only in their dropout draws are themselves up to 4.9 % apart in single windows, 1.8 %
-# on average and 1.0 % at the end (recorded as `oracle_seed_noise` in the report): the bands sit at twice that noise.
-BAND = 0.10        # every window mean within 10 % of the oracle's window mean
-MEAN_DEV = 0.04    # window deviations averaged over the run within 4 %
-END_TOL = 0.05     # mean of the last two windows within 5 %
+# Two fp32 oracle runs that differ only in their dropout draws are themselves up to 6.6 % apart in single windows, 2.8 %
+# on average and 2.2 % at the end on the GPU box (4.9 / 1.8 / 1.0 % on the build container: the trajectories are chaotic
+# in the rounding of the host's thread count too; recorded as `oracle_seed_noise` in the report).  First measured HIP
+# deviations (profiles/r04a_training_curves_first_run.json): f16x3 7.0 / 3.4 / 4.4 %, bf16 7.4 / 3.7 / 1.8 % -- i.e. at
+# the noise.  The bands sit at about twice the noise: a mode that trains differently (a wrong gradient scale, a dead
+# layer, a loss that stalls) misses them by far more.
+BAND = 0.15        # every window mean within 15 % of the oracle's window mean
+MEAN_DEV = 0.07    # window deviations averaged over the run within 7 %
+END_TOL = 0.08     # mean of the last two windows within 8 %
 LR = 1e-3          # constant (the Noam warm-up would keep lr below 6e-5 for the whole run and nothing would move)
 
 HP = dict(n_vocab=40, embed_dim=64, mel_dim=32, linear_dim=65, r=1, downsample_step=4, n_speakers=1, padding_idx=0,
@@ -173,9 +177,10 @@ def test_loss_trajectories_of_bf16_f16x3_and_the_fp32_oracle_agree(dev):
         with open(os.path.join(out_dir, "training_curves.json"), "w") as f:
             json.dump(report, f)
     # the run must actually have trained: the loss falls by a clear factor
-    assert ref[0] / ref[-1] > 1.25, report["loss_drop"]
+    assert ref[0] / ref[-1] > 2.5, report["loss_drop"]
     for mode in ("f16x3", "bf16"):
         assert np.isfinite(curves[mode]).all()
+        assert win[mode][0] / win[mode][-1] > 2.5, (mode, report["loss_drop"])      # the HIP run trains too (3.7-4.0 x measured)
         assert worst[mode]["max_window_dev"] < BAND, (mode, worst)
         assert worst[mode]["mean_window_dev"] < MEAN_DEV, (mode, worst)
         assert worst[mode]["end_dev"] < END_TOL, (mode, worst)
