@@ -767,7 +767,7 @@ def ddp_world1_config(dev, preset, gemm, args, no_group_ms, steps=12, warmup=4):
             if mode == "hipgraph" and not run.use_graph:
                 out[mode] = dict(error=run.graph_error or "capture failed")
                 continue
-            m = run.measure(steps, warmup)
+            m = run.measure(steps, warmup, settle_s=args.settle)     # same clock-settle time as the headline's measurement
             comm = run.trainer.comm
             out.setdefault("gradient_buckets", len(comm.buckets))
             out.setdefault("bucket_mb", [round((hi - lo) * 4 / 2 ** 20, 2) for lo, hi, _ in comm.buckets])

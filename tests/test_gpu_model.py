@@ -270,10 +270,11 @@ def test_train_step_matches_reference_golden(dev, gemm_mode):
         assert abs(scal["mel_l1_loss"] - fx["scalar/mel_l1_loss"][it]) < 2e-4 * fx["scalar/mel_l1_loss"][it]
         assert abs(scal["linear_binary_div_loss"] - fx["scalar/linear_binary_div_loss"][it]) < \
             2e-4 * fx["scalar/linear_binary_div_loss"][it]
-        # fp32-class modes: the reference's own pre-clip gradient norm to 2e-4 (round 3 allowed 2e-3 for every mode)
+        # the reference's own pre-clip gradient norm: 2e-5 in the fp32-class modes, 2e-4 in bf16x3 (round 3 allowed 2e-3
+        # everywhere; measured in round 4: 1.8e-7 f32, 7.8e-7 f16x3, 3.1e-6 bf16x3)
         gn_err = abs(scal["grad_norm"] - fx["scalar/gradient_norm"][it]) / fx["scalar/gradient_norm"][it]
         measured["grad_norm_rel_err_step%d" % it] = gn_err
-        assert gn_err < (2e-4 if tight else 2e-3), gn_err
+        assert gn_err < (2e-5 if tight else 2e-4), gn_err
     sdn = model.state_dict()
     worst_rms, worst_max, worst_rms_name = 0.0, 0.0, None
     for k in sdn:
@@ -285,7 +286,8 @@ def test_train_step_matches_reference_golden(dev, gemm_mode):
         diff = float(np.abs(dd).max())
         # Adam's first updates are sign-like (m / sqrt(v) = g / |g| at step 1): ONE element whose tiny gradient changes
         # sign moves by a whole step, so the maximum keeps the loose bound and the tensor as a whole (rms) carries the
-        # tight one: within 2 % of its movement in the fp32-class modes
+        # tight one: within 0.1 % of its movement in the fp32-class modes, 1 % in bf16x3 (round 3: 10 % of the maximum;
+        # measured in round 4: 2.4e-5 f32, 1.4e-4 f16x3, 1.2e-4 bf16x3)
         rms_moved = float(np.sqrt((d0 ** 2).mean()))
         rms_diff = float(np.sqrt((dd ** 2).mean()))
         worst_max = max(worst_max, diff / max(moved, 1e-12))
@@ -299,7 +301,7 @@ def test_train_step_matches_reference_golden(dev, gemm_mode):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "trainstep_golden_%s.json" % gemm_mode), "w") as f:
             json.dump(measured, f)
-    assert worst_rms < (0.02 if tight else 0.1), measured
+    assert worst_rms < (1e-3 if tight else 1e-2), measured
 
 
 def test_graphed_train_step_matches_reference_golden(dev):

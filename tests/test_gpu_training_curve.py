@@ -117,6 +117,17 @@ def _run_hip(mode, sd0, batches, dev):
 
 
 def _run_oracle(sd0, batches, seed=17):
+    # a toy model on a many-core host: torch's default thread count (one per core: 256 on the GPU box) makes every small
+    # op a thread-pool round trip -- 8 threads run these 240 steps in ~15 s instead of minutes
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(min(8, prev_threads))
+    try:
+        return _run_oracle_steps(sd0, batches, seed)
+    finally:
+        torch.set_num_threads(prev_threads)
+
+
+def _run_oracle_steps(sd0, batches, seed):
     spec = O.build_spec("deepvoice3", **HP)
     sd = {k: v.clone() for k, v in sd0.items()}
     frozen = ("seq2seq.decoder.embed_query_positions.weight", "seq2seq.decoder.embed_keys_positions.weight")
