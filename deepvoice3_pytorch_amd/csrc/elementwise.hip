@@ -737,6 +737,29 @@ extern "C" int dv3_axpby_f32(const float* a, const float* b, float* out, int64_t
   return dv3_check_launch("axpby_f32");
 }
 
+__global__ void sum_scalars_kernel(const float* a, const float* b, const float* c, const float* d, float* out) {
+  float s = a[0] + b[0];
+  if (c) s += c[0];
+  if (d) s += d[0];
+  out[0] = s;
+}
+extern "C" int dv3_sum_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out,
+                                   void* stream) {
+  DV3_REQUIRE(a && b && out, "sum_scalars: bad args");
+  hipLaunchKernelGGL(sum_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, b, c, d, out);
+  return dv3_check_launch("sum_scalars_f32");
+}
+extern "C" int dv3_memset_b8(void* p, int32_t value, int64_t bytes, void* stream) {
+  DV3_REQUIRE(p && bytes >= 0, "memset: bad args");
+  if (bytes == 0) return DV3_OK;
+  hipError_t e = hipMemsetAsync(p, value, (size_t)bytes, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    dv3_set_error("memset: %s", hipGetErrorString(e));
+    return DV3_ELAUNCH;
+  }
+  return DV3_OK;
+}
+
 extern "C" int dv3_deinterleave2_f32(const float* dy, float* out, int32_t B, int32_t O, int32_t T,
                                      void* stream) {
   DV3_REQUIRE(dy && out && B > 0 && O > 0 && T > 0, "deinterleave2: bad args");

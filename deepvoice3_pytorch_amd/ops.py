@@ -403,6 +403,12 @@ def planes_eligible(J, dil, Tin, Tout):
 bf16_storage = _os.environ.get("DV3_BF16_STORAGE", "1") not in ("0", "")
 
 
+def zero_(t):
+    """t.zero_() through the library (hipMemsetAsync on the op stream) -- no torch fill kernel"""
+    _lib.call("dv3_memset_b8", t.data_ptr(), 0, t.numel() * t.element_size(), _stream())
+    return t
+
+
 def storage_c8():
     """True when the conv stacks should run on channel-blocked bf16 activations"""
     return bf16_storage and _gemm_mode == "bf16"
@@ -420,8 +426,9 @@ def _c8_empty(B, C, T, device):
     """uninitialised c8 tensor; zero-filled when C leaves padding channels / groups (the kernels write whole valid
     groups only; padding must read as zero)"""
     shape = (B, c8_groups(C), T, 8)
-    t = torch.zeros(shape, dtype=torch.bfloat16, device=device) if C % 32 else \
-        torch.empty(shape, dtype=torch.bfloat16, device=device)
+    t = torch.empty(shape, dtype=torch.bfloat16, device=device)
+    if C % 32:
+        zero_(t)
     t._dv3_C = C
     return t
 
@@ -1498,6 +1505,23 @@ def dropout(x, p, training, site=None):
     return DropoutFn.apply(x, p, site)
 
 
+_const_cache = {}
+
+
+def _const1(value, device):
+    """a cached one-element fp32 device tensor holding `value` (a position rate: torch.full would launch a fill kernel
+    per call; during a hipGraph capture nothing is cached -- a tensor made inside a capture lives in the graph's pool)"""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.full((1,), float(value), dtype=torch.float32, device=device)
+    key = (float(value), str(device))
+    t = _const_cache.get(key)
+    if t is None:
+        if len(_const_cache) > 64:
+            _const_cache.clear()
+        t = _const_cache[key] = torch.full((1,), float(value), dtype=torch.float32, device=device)
+    return t
+
+
 def sincos_pos_bct(pos, table, w=None, base=None, apply_sincos=True):
     """SinusoidalEncoding.forward (modules.py:45-64) -> BCT; w: None | float | tensor[B]; the
     (frozen) table gets no gradient; `base` is added (gradient passes straight through)."""
@@ -1510,7 +1534,7 @@ def sincos_pos_bct(pos, table, w=None, base=None, apply_sincos=True):
             wt = _c(w.detach().float().view(-1))
             per_batch = 1 if wt.numel() > 1 else 0
         else:
-            wt = torch.full((1,), float(w), dtype=torch.float32, device=table.device)
+            wt = _const1(w, table.device)
     out = torch.empty((B, C, T), dtype=torch.float32, device=table.device)
     _lib.call("dv3_sincos_pos_bct_f32", pos.data_ptr(), _c(table).data_ptr(), _ptr(wt), per_batch,
               _ptr(_c(base.detach()) if base is not None else None), out.data_ptr(), B, T, C, n_pos,
@@ -1535,7 +1559,7 @@ class _PosEncFn(torch.autograd.Function):
                     wt = _c(w.detach().float().view(-1))
                     per_batch = 1 if wt.numel() > 1 else 0
                 else:
-                    wt = torch.full((1,), float(w), dtype=torch.float32, device=table.device)
+                    wt = _const1(w, table.device)
             ctx.table_grad = (_c(pos.long()), table.detach(), wt, per_batch, int(apply_sincos))
         if torch.is_tensor(w) and w.requires_grad:
             if not apply_sincos:
@@ -1621,6 +1645,46 @@ class SpecLossFn(torch.autograd.Function):
 
 def spec_loss(y_hat, y, lengths, r=1, w_masked=0.5, w_bd=0.1):
     return SpecLossFn.apply(y_hat, y, lengths, r, w_masked, w_bd)
+
+
+class _NoCtx(object):
+    """stand-in for the autograd context when a loss Function's forward is called directly: the fused kernels write
+    value AND gradient in one pass, so the trainer takes the gradient tensor and feeds it to autograd.backward itself --
+    no select / mul / fill / add nodes between the loss terms and the model outputs (train_step.Trainer)"""
+    needs_input_grad = (True,)
+
+
+def spec_loss_with_grad(y_hat, y, lengths, r=1, w_masked=0.5, w_bd=0.1):
+    """-> (tensor[4] as spec_loss, d total / d y_hat laid out like y_hat); no autograd graph"""
+    c = _NoCtx()
+    out4 = SpecLossFn.forward(c, y_hat.detach(), y, lengths, r, w_masked, w_bd)
+    return out4, c.dyh
+
+
+def guided_attention_loss_with_grad(attn, in_len, out_len, g=0.2):
+    c = _NoCtx()
+    out1 = GuidedAttnLossFn.forward(c, attn.detach(), in_len, out_len, g)
+    return out1, c.dattn
+
+
+def bce_loss_with_grad(p, t):
+    c = _NoCtx()
+    out1 = BCELossFn.forward(c, p.detach(), t)
+    return out1, c.dp
+
+
+def sum_scalars(a, b, c=None, d=None):
+    """a[0] + b[0] (+ c[0]) (+ d[0]) -> tensor[1], one tiny launch"""
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    _lib.call("dv3_sum_scalars_f32", a.data_ptr(), b.data_ptr(), _ptr(c), _ptr(d), out.data_ptr(), _stream())
+    return out
+
+
+def scaled_copy(a, alpha=1.0):
+    """alpha * a as a new tensor (dv3_axpby_f32): device scalars handed to the caller without a torch kernel"""
+    out = torch.empty_like(a)
+    _lib.call("dv3_axpby_f32", a.data_ptr(), None, out.data_ptr(), a.numel(), float(alpha), _stream())
+    return out
 
 
 class GuidedAttnLossFn(torch.autograd.Function):

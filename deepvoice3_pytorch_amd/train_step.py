@@ -272,27 +272,48 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         finally:
             ops.prepacked = None
         wm, w = c.masked_loss_weight, c.binary_divergence_weight
-        m4 = ops.spec_loss(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w)
         lin_len = batch.linear_mask_lengths if wm > 0 else None
-        l4 = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, w)
-        lin_loss = l4[2]
-        if c.priority_freq_weight > 0:
-            # l1 := (1 - pw) * l1 + pw * l1(first n bins)   (train.py:562-569): two more passes of the fused loss
-            # kernel with the binary-divergence weight 0, whose third output IS the (masked) L1 and carries gradient
-            n_pri = int(c.priority_freq / (c.sample_rate * 0.5) * lin_out.size(-1))
-            l1_all = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, 0.0)[2]
-            l1_pri = ops.spec_loss(lin_out[:, :, :n_pri], batch.y[:, :, :n_pri], lin_len, r, wm, 0.0)[2]
-            lin_loss = lin_loss + (1.0 - w) * c.priority_freq_weight * (l1_pri - l1_all)
-        done_loss = ops.bce_loss(done_hat, batch.done)
-        loss = m4[2] + lin_loss + done_loss[0]
+        direct = c.priority_freq_weight <= 0 and self.device.type == "cuda"
+        if direct:
+            # The fused loss kernels write value AND gradient in one pass and every term enters the total with weight 1
+            # (train.py:728-740): the gradients go straight to autograd.backward below -- no select / mul / ones / add
+            # nodes between the loss terms and the model outputs (round 3: 16 torch launches per step, two of them
+            # 100 MB multiplications by 1.0).
+            m4, g_mel = ops.spec_loss_with_grad(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w)
+            l4, g_lin = ops.spec_loss_with_grad(lin_out, batch.y, lin_len, r, wm, w)
+            done_loss, g_done = ops.bce_loss_with_grad(done_hat, batch.done)
+            lin_loss = l4[2]
+            roots, grads = [mel_out, lin_out, done_hat], [g_mel, g_lin, g_done]
+            attn_loss = None
+            if c.use_guided_attention:
+                attn_loss, g_attn = ops.guided_attention_loss_with_grad(attn, batch.input_lengths, batch.decoder_lengths,
+                                                                         c.guided_attention_sigma)
+                roots.append(attn)
+                grads.append(g_attn)
+            loss = ops.sum_scalars(m4[2:3], l4[2:3], done_loss, attn_loss)
+        else:
+            m4 = ops.spec_loss(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w)
+            l4 = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, w)
+            lin_loss = l4[2]
+            if c.priority_freq_weight > 0:
+                # l1 := (1 - pw) * l1 + pw * l1(first n bins)   (train.py:562-569): two more passes of the fused loss
+                # kernel with the binary-divergence weight 0, whose third output IS the (masked) L1 and carries gradient
+                n_pri = int(c.priority_freq / (c.sample_rate * 0.5) * lin_out.size(-1))
+                l1_all = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, 0.0)[2]
+                l1_pri = ops.spec_loss(lin_out[:, :, :n_pri], batch.y[:, :, :n_pri], lin_len, r, wm, 0.0)[2]
+                lin_loss = lin_loss + (1.0 - w) * c.priority_freq_weight * (l1_pri - l1_all)
+            done_loss = ops.bce_loss(done_hat, batch.done)
+            loss = m4[2] + lin_loss + done_loss[0]
+            attn_loss = None
+            if c.use_guided_attention:
+                attn_loss = ops.guided_attention_loss(attn, batch.input_lengths, batch.decoder_lengths,
+                                                      c.guided_attention_sigma)
+                loss = loss + attn_loss[0]
         scal = dict(mel_l1_loss=m4[0], mel_binary_div_loss=m4[1], mel_loss=m4[2], linear_l1_loss=l4[0],
                     linear_binary_div_loss=l4[1], linear_loss=lin_loss, done_loss=done_loss[0])
-        if c.use_guided_attention:
-            attn_loss = ops.guided_attention_loss(attn, batch.input_lengths, batch.decoder_lengths,
-                                                  c.guided_attention_sigma)
-            loss = loss + attn_loss[0]
+        if attn_loss is not None:
             scal["attn_loss"] = attn_loss[0]
-        scal["loss"] = loss
+        scal["loss"] = loss[0] if direct else loss
         if self.comm is not None:
             self.comm.arm()
         ops.SideStream.stream = self.side_stream
@@ -302,7 +323,10 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         # parameter's gradient as early as possible (data parallel buckets)
         ops.WnBwdBatch.active = self.batch_wn_bwd and not ops.grad_ready_hooks
         try:
-            loss.backward()
+            if direct:
+                torch.autograd.backward(roots, grads)
+            else:
+                loss.backward()
             if ops.WnBwdBatch.active:       # the layers still queued, on the stream their weight gradients ran on
                 if self.side_stream is not None:
                     with ops.SideStream._section:
@@ -331,7 +355,7 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         """One full optimisation step; returns device scalars (loss terms, grad_norm, lr)."""
         self.check_lengths(batch)        # host-side numpy on the batch's length vectors: no device sync
         self._set_hyper()
-        self.arena.grad.zero_()
+        self._zero_grad()
         scal = self.forward_backward(batch)
         n = self.cfg.range_check_every
         if n and (self.global_step + 1) % n == 0 and self.check_range():
@@ -340,15 +364,28 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
             # on every rank); the step is redone there before anything is applied.
             if self.comm is not None:
                 self.comm.finish()       # the buckets of the discarded backward are in flight: join them first
-            self.arena.grad.zero_()
+            self._zero_grad()
             scal = self.forward_backward(batch)
         self.optimizer_step()
-        scal["grad_norm"] = self.norm_out[0] * (1.0 / self.world)
-        scal["learning_rate"] = self.hyper[0].clone()
+        scal["grad_norm"] = self._scalar(self.norm_out[0:1], 1.0 / self.world)
+        scal["learning_rate"] = self._scalar(self.hyper[0:1])
         if ops.gemm_precision() == "f16x3" and self.device.type == "cuda":
             scal["f16_range_events"] = ops.f16_range_events_tensor(self.device)
         self.global_step += 1
         return scal
+
+    def _zero_grad(self):
+        """optimizer.zero_grad() (train.py:683) on the flat gradient arena: one hipMemsetAsync through the library"""
+        if self.device.type == "cuda":
+            ops.zero_(self.arena.grad)
+        else:
+            self.arena.grad.zero_()
+
+    def _scalar(self, t1, alpha=1.0):
+        """alpha * t1 (a one-element device tensor) as its own tensor, without a torch kernel; -> 0-dim"""
+        if self.device.type == "cuda":
+            return ops.scaled_copy(t1, alpha)[0]
+        return (t1 * alpha)[0]
 
     def check_range(self):
         """f16x3 range guard (ops.f16_range_events): when forward operands left the fp16 range since the last check
@@ -410,10 +447,10 @@ class GraphedTrainer(object):
 
     def _body(self):
         t = self.t
-        t.arena.grad.zero_()
+        t._zero_grad()
         scal = t.forward_backward(self.batch)
         t.optimizer_step()
-        scal["grad_norm"] = t.norm_out[0] * (1.0 / t.world)
+        scal["grad_norm"] = t._scalar(t.norm_out[0:1], 1.0 / t.world)
         if ops.gemm_precision() == "f16x3":
             scal["f16_range_events"] = ops.f16_range_events_tensor(t.device)
         self.seed_offset.add_(1)

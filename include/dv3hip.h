@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 32
+#define DV3_ABI_VERSION 33
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -430,6 +430,11 @@ int dv3_transpose_f32(const float* x, float* y, const float* add, int32_t B, int
 /* out[i] = alpha * (a[i] + b[i]) ; b may be NULL                                       */
 int dv3_axpby_f32(const float* a, const float* b, float* out, int64_t n, float alpha,
                   void* stream);
+/* out[0] = a[0] + b[0] (+ c[0]) (+ d[0]): the total of the loss terms (train.py:728-740); c, d may be NULL  */
+int dv3_sum_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out, void* stream);
+/* bytes of device memory to `value` (hipMemsetAsync on the caller's stream): the gradient arena before backward
+ * (optimizer.zero_grad(), train.py:683), the padding channels of a c8 tensor                                   */
+int dv3_memset_b8(void* p, int32_t value, int64_t bytes, void* stream);
 /* Embedding gather into BCT with optional dropout: out[b][c][t] = W[idx[b][t]][c]
  * (deepvoice3.py:74-75, nyanko.py:63).  Backward: dense scatter-add into dW.           */
 int dv3_embedding_bct_f32(const int64_t* idx, const float* w, float* out,

@@ -584,10 +584,22 @@ def test_archived_bench_line_meets_the_contract():
     assert cb["kind"] in ("reference", "port")
     assert abs(d["value"] - d["config"]["global_batch"] * 800 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
     # round 3: the host's issue time and the launch-mode probe are reported for the headline and for every side config
-    for cfg in [d["config"]] + [c["config"] for k, c in d["configs"].items() if k != "synth_rtf"]:
+    for cfg in [d["config"]] + [c["config"] for k, c in d["configs"].items() if k not in ("synth_rtf", "ddp_world1")]:
         assert cfg["host_enqueue_ms_per_step"] > 0 and "hipgraph" in cfg and "launch_bound" in cfg
         assert cfg["launch_probe"] is None or {"eager_ms_per_step", "hipgraph_ms_per_step"} <= set(cfg["launch_probe"])
     assert "roofline_wgrad" in d and d["roofline_wgrad"]["alg_bytes"] > 2e8       # g + x + dW
+    # round 4: the reference's own operating points (preset batch 16, ragged LJSpeech-shaped lengths) and the
+    # data-parallel step armed on one GPU (world-size-1 RCCL group, both launch modes) are in the line
+    for k in ("dv3lj_b16", "dv3lj_b64_ragged", "dv3lj_b16_ragged"):
+        assert d["configs"][k]["config"]["per_gpu_batch"] in (16, 64) and d["configs"][k]["value"] > 0
+    assert d["configs"]["dv3lj_b64_ragged"]["config"]["lengths"].startswith("ragged")
+    w1 = d["configs"]["ddp_world1"]
+    assert w1["backend"] == "nccl" and w1["rccl_ranks"] == 1
+    for k, e in w1.items():
+        if isinstance(e, dict):
+            assert e["gradient_buckets"] >= 2 and e["autograd_hooks_after_first_step"] < 10
+            for mode in ("eager", "hipgraph"):
+                assert e[mode]["host_enqueue_ms_per_step"] > 0 and e[mode]["ms_per_step"] > 0
 
 
 def test_bench_self_launches_its_ranks_dry():
