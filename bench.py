@@ -560,13 +560,13 @@ class TrainRun(object):
                                                    bt["text_positions"], bt["frame_positions"], bt["done"],
                                                    bt["target_lengths"], self.spk, downsample_step=4, device=dev)
         self.trainer.check_lengths(self.batch)
-        # Launch mode.  The step is ~300-390 kernel launches.  A replayed whole-step hipGraph (forward, losses,
-        # backward, RCCL buckets, clip + Adam captured once) costs the host 1.5-3 ms per step against 7-10 ms of
-        # Python + ctypes for eager launches, but the graph executor overlaps the weight-gradient branch of backward
-        # (ops.SideStream) with the input-gradient chain less well than two real streams do.  Which one wins depends
-        # on the configuration (measured: eager 15.5 vs graph 16.3 ms at the north-star f16x3 step, graph 12.3 vs
-        # eager 13.1 ms for nyanko bf16; scripts/graph_host_cost.py), so the default PROBES both for a few steps and
-        # keeps the faster; --graph / --no-graph force one.  All ranks take the same decision (MAX over ranks).
+        # Launch mode.  The step is ~300-390 kernel launches: 5-16 ms of Python + ctypes per step for eager launches
+        # (box dependent) against 1.5-4 ms for a replay.  A single whole-step hipGraph serialises the two backward
+        # branches (round 3: 4-7 % slower than eager whenever the GPU is the bound), so since round 4 the replay is
+        # THREE graphs -- step stream | weight-gradient branch on the real second stream | optimiser
+        # (train_step.GraphedTrainer(split_streams), include/dv3hip.h: dv3_graph_fork) -- which runs at the eager
+        # step's GPU time (profiles/r04_three_graph_probe.txt).  The default still PROBES eager against the replay for
+        # a few steps and keeps the faster; --graph / --no-graph force one.  All ranks take the same decision (MAX).
         self.runner = None
         self.use_graph = False
         self.graph_error = None
@@ -603,6 +603,12 @@ class TrainRun(object):
                 self.runner, self.use_graph = None, False
                 torch.cuda.synchronize()
                 torch.cuda.empty_cache()
+
+    def graph_form(self):
+        if not self.use_graph or self.runner is None:
+            return None
+        return ("three hipGraphs: step stream | weight-gradient branch on the second stream | optimiser"
+                if getattr(self.runner, "split", False) else "one hipGraph")
 
     def _probe(self, n):
         """ms per step of the current launch mode over n steps (after 2 untimed ones), MAX over ranks"""
@@ -727,7 +733,7 @@ def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup, batch=N
                    graph=launch_mode(args, world), ragged=ragged)
     try:
         m = run.measure(steps, warmup)
-        used_graph, probe = bool(run.use_graph), run.launch_probe
+        used_graph, probe, gform = bool(run.use_graph), run.launch_probe, run.graph_form()
         shape = dict(text_len=int(run.bt["text"].shape[1]), padded_frames=int(run.bt["mel"].shape[1]),
                      frames_per_step=m["frames_per_step"])
     finally:
@@ -740,7 +746,7 @@ def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup, batch=N
                             lengths=("ragged LJSpeech-shaped (SURVEY 8d cfg2: frames ~ clip(N(566,180),120,870), text ~ "
                                      "clip(N(100,30),20,187)), padded to the batch maximum as train.collate_fn does"
                                      if ragged else "fixed"), shape=shape,
-                            hipgraph=used_graph, launch_probe=probe,
+                            hipgraph=used_graph, graph_form=gform, launch_probe=probe,
                             host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"],
                             host_loop_ms_per_step=m["host_loop_ms_per_step"],
                             launch_bound=bool(m["host_enqueue_ms_per_step"] > 0.97 * m["ms_per_step"]),
@@ -970,7 +976,7 @@ def main():
                                         "(fwd+losses+bwd+clip+Adam), synthetic LJSpeech-shaped batches" % (run.bname, args.preset),
                                per_gpu_batch=args.batch, global_batch=args.batch * world, text_len=args.text_len,
                                frames_per_item=args.frames, parallelism="dp%d" % world,
-                               hipgraph=bool(run.use_graph), launch_probe=run.launch_probe, gemm=gemm,
+                               hipgraph=bool(run.use_graph), graph_form=run.graph_form(), launch_probe=run.launch_probe, gemm=gemm,
                                final_loss=m["final_loss"],
                                host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"],
                                host_loop_ms_per_step=m["host_loop_ms_per_step"],

@@ -99,6 +99,12 @@ class BucketedAllReduce(object):
         b = self.bucket_of[i]
         self.pending[b] -= 1
         if self.pending[b] == 0:
+            from . import ops as _ops
+            if _ops.SideStream.split_capture:
+                # the weight-gradient branch is being captured into its own hipGraph (train_step.GraphedTrainer): a
+                # collective that waits on both captures would tie them together again, so the buckets of such a
+                # replayed step are launched by finish(), in the optimiser graph, after the join
+                return
             self._launch(b)
 
     def _on_inplace_grad(self, *params):

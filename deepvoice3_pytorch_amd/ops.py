@@ -896,6 +896,9 @@ class SideStream(object):
     main = None            # the step stream while `stream` is set
     keep = []              # [event | None, [tensors...]] per section, oldest first
     capturing = False      # set by the trainer: no event queries while a hipGraph is being captured
+    split_capture = False  # set by GraphedTrainer: the side stream is captured into ITS OWN hipGraph (dv3_graph_fork)
+    split_exec = None      # ... whose instantiated handle join() leaves here
+    split_nodes = 0
     release_every = 4      # sections between two release points (an event on the side stream + a poll of the oldest)
     _n = 0
     _events = []           # recycled torch.cuda.Event objects
@@ -917,7 +920,10 @@ class SideStream(object):
     @classmethod
     def fork(cls, *tensors):
         # the section's inputs are complete on the step stream: the side stream waits for exactly that point
-        _lib.call("dv3_stream_fork", cls.main.cuda_stream, cls.stream.cuda_stream)
+        if cls.split_capture:       # two captures: an event-record node here, an event-wait node there (include/dv3hip.h)
+            _lib.call("dv3_graph_fork", cls.main.cuda_stream, cls.stream.cuda_stream)
+        else:
+            _lib.call("dv3_stream_fork", cls.main.cuda_stream, cls.stream.cuda_stream)
         cls.keep.append([None, [tensors]])
         return cls._section
 
@@ -954,6 +960,16 @@ class SideStream(object):
 
     @classmethod
     def join(cls):
+        if cls.stream is not None and cls.split_capture:
+            # the side stream's own capture ends here; the replay joins the two streams with an ordinary event
+            # (train_step.GraphedTrainer.step).  The operands stay referenced until the step stream's capture is over.
+            ex, n = ctypes.c_void_p(), ctypes.c_int32()
+            _lib.call("dv3_graph_side_end", cls.stream.cuda_stream, ctypes.byref(ex), ctypes.byref(n))
+            cls.split_exec, cls.split_nodes = ex, int(n.value)
+            cls.split_keep = cls.keep
+            cls.keep = []
+            cls._n = 0
+            return
         if cls.stream is not None:
             _lib.call("dv3_stream_fork", cls.stream.cuda_stream, cls.main.cuda_stream)
         for ev, _ in cls.keep:

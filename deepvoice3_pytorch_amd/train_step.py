@@ -12,6 +12,7 @@ sequence masks, ~12 .item() syncs, per-tensor Adam -- is done here on the device
     global-norm clip + Adam over ONE flat parameter arena (csrc/optim.hip)
 Scalars stay on the device; nothing in step() synchronises with the host.
 """
+import ctypes
 import math
 import os
 
@@ -410,22 +411,38 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
 
 
 class GraphedTrainer(object):
-    """Whole-step hipGraph: forward + losses + backward + (bucketed all-reduce) + clip/Adam captured once per
-    batch shape and replayed -- removes the per-kernel host launch cost (~390 launches/step: 10-15 ms of host
-    time against a 17 ms step at the north-star batch).  Dropout masks still change every replay: the Philox
-    seed offset lives on the device.  `step(batch)` copies a fresh batch of the captured shape into the static
-    one first (device-to-device, on the step stream); batches of another shape raise -- bucket the input
-    pipeline by shape (data.LengthBucketedSampler pads to the batch maximum) or run those eagerly.
+    """Whole-step hipGraph replay: forward + losses + backward + (bucketed all-reduce) + clip/Adam captured once per
+    batch shape and replayed -- removes the per-kernel host launch cost (~330 launches/step: 5-16 ms of host time,
+    box dependent, against a 12-16 ms step at the north-star batch).  Dropout masks still change every replay: the
+    Philox seed offset lives on the device.  `step(batch)` copies a fresh batch of the captured shape into the static
+    one first (device-to-device, on the step stream); batches of another shape raise -- bucket the input pipeline by
+    shape (data.LengthBucketedSampler pads to the batch maximum) or run those eagerly.
 
-    Data parallel: the RCCL all-reduces issued on the collective stream are captured with the step (the side
-    stream forks from and joins the capturing stream through the events BucketedAllReduce records), so a replay
-    re-issues them in the same order on every rank."""
+    split_streams (default when the trainer has its second backward stream): THREE graphs instead of one.  A single
+    captured step replays with its two backward branches serialised (4-7 % slower than eager launches whenever the GPU
+    is the bound: profiles/r03_side_stream_ab.txt), so the weight-gradient branch (ops.SideStream) is captured into
+    its own hipGraph and replayed on the real second stream:
+        g1   step stream: zero_grad, forward, losses, the input-gradient chain; every fork point is an event-record node
+        side the weight-gradient GEMMs + weight-norm backward, each layer behind an event-wait node (include/dv3hip.h:
+             dv3_graph_fork); launched right after g1, so every wait sees the record of the same step
+        g2   step stream, behind an ordinary event on the side stream: (all-reduce buckets,) clip + Adam
+    Measured (profiles/r04_three_graph_probe.txt): the eager step's GPU time at the replay's host cost -- 15.64 vs 16.44
+    ms (one graph) vs 15.62 (eager) for deepvoice3_ljspeech f16x3 B=64, 12.46 vs 13.30 vs 16.17 (eager, host bound on that
+    box) for deepvoice3_vctk bf16.
 
-    def __init__(self, trainer, static_batch, warmup=3):
+    Data parallel: the RCCL all-reduces issued on the collective stream are captured with the step (the collective stream
+    forks from and joins the capturing stream through the events BucketedAllReduce records), so a replay re-issues them
+    in the same order on every rank.  With split_streams the buckets are launched in g2, after the join (a collective
+    that waited on both captures would tie them together again): no overlap with backward in that mode."""
+
+    def __init__(self, trainer, static_batch, warmup=3, split_streams=None):
         self.t = trainer
         self.batch = static_batch
         trainer.check_lengths(static_batch)
         dev = trainer.device
+        if split_streams is None:
+            split_streams = trainer.side_stream is not None and os.environ.get("DV3_SPLIT_GRAPH", "1") not in ("0", "")
+        self.split = bool(split_streams) and trainer.side_stream is not None
         self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
         self._prev_offset = ops.dropout_state.dev_offset        # restored by close()
         ops.dropout_state.dev_offset = self.seed_offset
@@ -437,24 +454,66 @@ class GraphedTrainer(object):
                 self._body()
                 trainer.global_step += 1
         torch.cuda.current_stream().wait_stream(s)
-        self.graph = torch.cuda.CUDAGraph()
         site0 = ops.dropout_state.site
         # a process group brings its watchdog thread: its event queries must not invalidate this thread's capture
         mode = dict(capture_error_mode="thread_local") if trainer.comm is not None else {}
-        with torch.cuda.graph(self.graph, **mode):
-            self.scal = self._body()
+        self.side_exec, self._side_keep, self._join_event = None, None, None
+        if not self.split:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, **mode):
+                self.scal = self._body()
+        else:
+            from . import _lib
+            n_forks = 4 + 2 * sum(1 for _ in trainer.arena.params)          # an upper bound on the fork points of a step
+            _lib.call("dv3_graph_prepare", n_forks)
+            self.graph, self.graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            SS = ops.SideStream
+            SS.split_capture, SS.split_exec, SS.split_nodes = True, None, 0
+            side_raw = trainer.side_stream.cuda_stream
+            side_open = False
+            try:
+                with torch.cuda.graph(self.graph, **mode):
+                    _lib.call("dv3_graph_side_begin", side_raw)
+                    side_open = True
+                    trainer._zero_grad()
+                    self.scal = trainer.forward_backward(self.batch)      # its join() ends the side capture
+                    side_open = SS.split_exec is None
+                self.side_exec, self._side_keep = SS.split_exec, getattr(SS, "split_keep", None)
+                with torch.cuda.graph(self.graph2, pool=self.graph.pool(), **mode):
+                    self._tail(self.scal)
+                # the branch's operands were referenced until here: nothing the step graph allocated later could take
+                # their memory while the branch still reads it; what frees now can only be reused by later captures
+                # into this pool, which replay after the join
+                self._side_keep = None
+            finally:
+                if side_open and SS.split_exec is None:      # a failed capture must not leave the side stream capturing
+                    try:
+                        ex, n = ctypes.c_void_p(), ctypes.c_int32()
+                        _lib.call("dv3_graph_side_end", side_raw, ctypes.byref(ex), ctypes.byref(n))
+                        _lib.call("dv3_graph_destroy", ex)
+                    except Exception:
+                        pass
+                SS.split_capture, SS.split_exec = False, None
+                SS.split_keep = None
+            if self.side_exec is None:
+                raise RuntimeError("GraphedTrainer(split_streams): the step has no weight-gradient branch to split off")
+            self._join_event = torch.cuda.Event()
         ops.dropout_state.site = site0
 
-    def _body(self):
+    def _tail(self, scal):
         t = self.t
-        t._zero_grad()
-        scal = t.forward_backward(self.batch)
         t.optimizer_step()
         scal["grad_norm"] = t._scalar(t.norm_out[0:1], 1.0 / t.world)
         if ops.gemm_precision() == "f16x3":
             scal["f16_range_events"] = ops.f16_range_events_tensor(t.device)
         self.seed_offset.add_(1)
         return scal
+
+    def _body(self):
+        t = self.t
+        t._zero_grad()
+        scal = t.forward_backward(self.batch)
+        return self._tail(scal)
 
     _TENSORS = ("text", "text_positions", "frame_positions", "mel", "y", "done", "speaker_ids", "input_lengths",
                 "target_lengths", "decoder_lengths")
@@ -482,6 +541,15 @@ class GraphedTrainer(object):
             self.load(batch)
         self.t._set_hyper()
         self.graph.replay()
+        if self.split:
+            # the weight-gradient branch on the real second stream (launched AFTER the step graph: its waits see this
+            # step's records), an ordinary event joins it, then (buckets,) clip + Adam
+            side = self.t.side_stream
+            from . import _lib
+            _lib.call("dv3_graph_launch", self.side_exec, side.cuda_stream)
+            self._join_event.record(side)
+            torch.cuda.current_stream().wait_event(self._join_event)
+            self.graph2.replay()
         ops.bump_param_epoch()           # the replayed clip/Adam wrote the parameters
         self.t.global_step += 1
         return self.scal
@@ -501,6 +569,11 @@ class GraphedTrainer(object):
         if ops.dropout_state.dev_offset is self.seed_offset:
             ops.dropout_state.dev_offset = self._prev_offset
         self._prev_offset = None
+        if self.side_exec is not None:
+            from . import _lib
+            torch.cuda.synchronize()
+            _lib.call("dv3_graph_destroy", self.side_exec)
+            self.side_exec, self._side_keep = None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -37,6 +37,29 @@ hip.hipGraphLaunch.argtypes = [vp, vp]
 hip.hipGetErrorString.restype = ctypes.c_char_p
 
 
+hip.hipStreamGetCaptureInfo_v2.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(vp),
+                                           ctypes.POINTER(ctypes.POINTER(vp)), ctypes.POINTER(ctypes.c_size_t)]
+hip.hipGraphAddEventRecordNode.argtypes = [ctypes.POINTER(vp), vp, ctypes.POINTER(vp), ctypes.c_size_t, vp]
+hip.hipGraphAddEventWaitNode.argtypes = [ctypes.POINTER(vp), vp, ctypes.POINTER(vp), ctypes.c_size_t, vp]
+hip.hipStreamUpdateCaptureDependencies.argtypes = [vp, ctypes.POINTER(vp), ctypes.c_size_t, ctypes.c_uint]
+
+
+def add_event_node(stream_raw, event, record):
+    """an event record / wait node at the current frontier of the capture on `stream_raw` (the runtime bundled with this
+    torch rejects hipEventRecordWithFlags(.., hipEventRecordExternal) during capture: hipErrorInvalidValue)"""
+    status, cid, graph = ctypes.c_int(), ctypes.c_ulonglong(), vp()
+    deps, nd = ctypes.POINTER(vp)(), ctypes.c_size_t()
+    ck(hip.hipStreamGetCaptureInfo_v2(stream_raw, ctypes.byref(status), ctypes.byref(cid), ctypes.byref(graph),
+                                      ctypes.byref(deps), ctypes.byref(nd)), "hipStreamGetCaptureInfo_v2")
+    if status.value != 1:
+        raise RuntimeError("stream is not capturing (status %d)" % status.value)
+    node = vp()
+    fn = hip.hipGraphAddEventRecordNode if record else hip.hipGraphAddEventWaitNode
+    ck(fn(ctypes.byref(node), graph, deps, nd.value, event), "hipGraphAddEvent%sNode" % ("Record" if record else "Wait"))
+    arr = (vp * 1)(node)
+    ck(hip.hipStreamUpdateCaptureDependencies(stream_raw, arr, 1, 1), "hipStreamUpdateCaptureDependencies")
+
+
 def ck(rc, what):
     if rc != 0:
         raise RuntimeError("%s: hip error %d (%s)" % (what, rc, hip.hipGetErrorString(rc).decode()))
@@ -80,8 +103,8 @@ def probe(preset, gemm, batch):
     def ext_fork(cls, *tensors):
         e = events[state["n"]]
         state["n"] += 1
-        ck(hip.hipEventRecordWithFlags(e, cls.main.cuda_stream, 1), "record external")
-        ck(hip.hipStreamWaitEvent(side_raw, e, 1), "wait external")
+        add_event_node(cls.main.cuda_stream, e, True)
+        add_event_node(side_raw, e, False)
         cls.keep.append([None, [tensors]])
         return cls._section
 
@@ -133,7 +156,10 @@ def probe(preset, gemm, batch):
     r.close()
 
 
-for (preset, gemm, batch) in (("deepvoice3_ljspeech", "f16x3", 64), ("deepvoice3_ljspeech", "f16x3", 16), ("deepvoice3_vctk", "bf16", 64)):
+cfgs = [("deepvoice3_ljspeech", "f16x3", 64), ("deepvoice3_ljspeech", "f16x3", 16), ("deepvoice3_vctk", "bf16", 64)]
+if len(sys.argv) > 1:
+    cfgs = [cfgs[int(a)] for a in sys.argv[1:]]
+for (preset, gemm, batch) in cfgs:
     try:
         probe(preset, gemm, batch)
     except Exception as e:

@@ -346,6 +346,62 @@ def test_graphed_train_step_matches_reference_golden(dev):
     assert ops.dropout_state.dev_offset is None      # the process-wide dropout state is handed back
 
 
+def test_split_stream_graph_replay_is_bit_identical(dev, gemm_mode):
+    """GraphedTrainer(split_streams=True): the weight-gradient branch of backward captured into its OWN hipGraph and
+    replayed on the real second stream (three graphs, event-record / event-wait nodes at the fork points) must give,
+    replay after replay, the bits of the single whole-step graph and of eager launches -- same kernels, same order per
+    stream; a wait that saw a stale record, or an operand whose memory was reused too early, would show here.  Preset
+    channel counts (multi-workgroup launches), dropout on (the device-side seed offset advances per replay)."""
+    if gemm_mode == "f32":
+        pytest.skip("one fp32-class mode is enough for the launch plumbing")
+    import bench
+    from deepvoice3_pytorch_amd import builder, ops, train_step
+    hp = dict(bench.DV3_LJ)
+    rng = np.random.RandomState(7)
+    bt = bench.synth_batch(rng, 4, 40, 120, hp)
+
+    def run(kind, steps=4):
+        torch.manual_seed(0)
+        model = builder.deepvoice3(**hp).to(dev)
+        tr = train_step.Trainer(model, train_step.TrainConfig(max_positions=hp["max_positions"]))
+        batch = train_step.Batch.from_collate(bt["text"], bt["input_lengths"], bt["mel"], bt["y"], bt["text_positions"],
+                                              bt["frame_positions"], bt["done"], bt["target_lengths"], None,
+                                              downsample_step=4, device=dev)
+        ops.dropout_state.manual_seed(11)
+        norms = []
+        if kind == "eager":
+            # a GraphedTrainer draws its masks from (seed, site, device offset): the warm-up step uses the first N sites
+            # at offset 0, the captured step the NEXT N sites, and replay k sees offset k -- the same triples here
+            off = torch.zeros(1, dtype=torch.int64, device=dev)
+            prev, ops.dropout_state.dev_offset = ops.dropout_state.dev_offset, off
+            try:
+                tr.step(batch)
+                site_n = ops.dropout_state.site
+                for _ in range(steps - 1):
+                    off.add_(1)
+                    ops.dropout_state.site = site_n
+                    norms.append(float(tr.step(batch)["grad_norm"]))
+            finally:
+                ops.dropout_state.dev_offset = prev
+        else:
+            g = train_step.GraphedTrainer(tr, batch, warmup=1, split_streams=(kind == "split"))
+            assert g.split == (kind == "split")
+            for _ in range(steps - 1):
+                norms.append(float(g.step()["grad_norm"]))
+            g.close()
+        torch.cuda.synchronize()
+        w = tr.arena.flat.detach().cpu().clone()
+        tr.close()
+        return w, norms
+    w1, n1 = run("single")
+    w3, n3 = run("split")
+    assert all(math.isfinite(x) for x in n1 + n3), (n1, n3)
+    assert n1 == n3, (n1, n3)
+    assert torch.equal(w1, w3), float((w1 - w3).abs().max())
+    we, ne = run("eager")
+    assert torch.equal(we, w3), (float((we - w3).abs().max()), ne, n3)
+
+
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
 def test_bf16_mode_forward_and_gradients(dev, name, gemm_mode):
     """GEMM mode "bf16" (operands rounded to bf16 at the matrix cores, one MFMA per product, fp32
