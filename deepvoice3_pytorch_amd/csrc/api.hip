@@ -71,48 +71,7 @@ extern "C" int dv3_stream_fork(void* from, void* to) {
   }
   return DV3_OK;
 }
-// ---- the weight-gradient branch of a captured step as its own hipGraph (include/dv3hip.h) ----
-namespace {
-std::mutex g_graph_mu;
-std::vector<hipEvent_t> g_graph_events;      // never destroyed: instantiated graphs keep referring to them
-size_t g_graph_next = 0;
-
-int graph_event_node(hipStream_t st, hipEvent_t ev, bool record) {
-  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
-  unsigned long long id = 0;
-  hipGraph_t graph = nullptr;
-  const hipGraphNode_t* deps = nullptr;
-  size_t nd = 0;
-  hipError_t e = hipStreamGetCaptureInfo_v2(st, &status, &id, &graph, &deps, &nd);
-  if (e != hipSuccess || status != hipStreamCaptureStatusActive || !graph) {
-    dv3_set_error("graph_fork: stream %p is not being captured (%s)", (void*)st, hipGetErrorString(e));
-    return DV3_EINVAL;
-  }
-  hipGraphNode_t node = nullptr;
-  e = record ? hipGraphAddEventRecordNode(&node, graph, deps, nd, ev) : hipGraphAddEventWaitNode(&node, graph, deps, nd, ev);
-  if (e == hipSuccess) e = hipStreamUpdateCaptureDependencies(st, &node, 1, hipStreamSetCaptureDependencies);
-  if (e != hipSuccess) {
-    dv3_set_error("graph_fork: %s node: %s", record ? "record" : "wait", hipGetErrorString(e));
-    return DV3_ELAUNCH;
-  }
-  return DV3_OK;
-}
-}  // namespace
-
-extern "C" int dv3_graph_prepare(int32_t n_events) {
-  DV3_REQUIRE(n_events > 0 && n_events <= 65536, "graph_prepare: bad event count");
-  std::lock_guard<std::mutex> lk(g_graph_mu);
-  while (g_graph_events.size() - g_graph_next < (size_t)n_events) {
-    hipEvent_t ev;
-    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e != hipSuccess) {
-      dv3_set_error("graph_prepare: hipEventCreate: %s", hipGetErrorString(e));
-      return DV3_ELAUNCH;
-    }
-    g_graph_events.push_back(ev);
-  }
-  return DV3_OK;
-}
+// ---- the weight-gradient branch of a captured step as its own hipGraphs (include/dv3hip.h) ----
 extern "C" int dv3_graph_side_begin(void* side_stream) {
   DV3_REQUIRE(side_stream, "graph_side_begin: the side stream must be a real (non-default) stream");
   hipError_t e = hipStreamBeginCapture((hipStream_t)side_stream, hipStreamCaptureModeRelaxed);
@@ -121,17 +80,6 @@ extern "C" int dv3_graph_side_begin(void* side_stream) {
     return DV3_ELAUNCH;
   }
   return DV3_OK;
-}
-extern "C" int dv3_graph_fork(void* from, void* to) {
-  hipEvent_t ev;
-  {
-    std::lock_guard<std::mutex> lk(g_graph_mu);
-    DV3_REQUIRE(g_graph_next < g_graph_events.size(), "graph_fork: event pool exhausted (dv3_graph_prepare before the capture)");
-    ev = g_graph_events[g_graph_next++];
-  }
-  const int rc = graph_event_node((hipStream_t)from, ev, true);
-  if (rc != DV3_OK) return rc;
-  return graph_event_node((hipStream_t)to, ev, false);
 }
 extern "C" int dv3_graph_side_end(void* side_stream, void** exec_out, int32_t* n_nodes_out) {
   DV3_REQUIRE(side_stream && exec_out, "graph_side_end: null argument");
@@ -144,6 +92,11 @@ extern "C" int dv3_graph_side_end(void* side_stream, void** exec_out, int32_t* n
   size_t n = 0;
   (void)hipGraphGetNodes(graph, nullptr, &n);
   if (n_nodes_out) *n_nodes_out = (int32_t)n;
+  *exec_out = nullptr;
+  if (n == 0) {
+    (void)hipGraphDestroy(graph);
+    return DV3_OK;
+  }
   hipGraphExec_t exec = nullptr;
   e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);

@@ -896,9 +896,8 @@ class SideStream(object):
     main = None            # the step stream while `stream` is set
     keep = []              # [event | None, [tensors...]] per section, oldest first
     capturing = False      # set by the trainer: no event queries while a hipGraph is being captured
-    split_capture = False  # set by GraphedTrainer: the side stream is captured into ITS OWN hipGraph (dv3_graph_fork)
-    split_exec = None      # ... whose instantiated handle join() leaves here
-    split_nodes = 0
+    split_capture = False  # set by GraphedTrainer: the side stream is captured into ITS OWN hipGraphs (include/dv3hip.h:
+    split_on_fork = None   # dv3_graph_side_begin / _end); called at every fork point: the segment boundaries
     release_every = 4      # sections between two release points (an event on the side stream + a poll of the oldest)
     _n = 0
     _events = []           # recycled torch.cuda.Event objects
@@ -920,8 +919,11 @@ class SideStream(object):
     @classmethod
     def fork(cls, *tensors):
         # the section's inputs are complete on the step stream: the side stream waits for exactly that point
-        if cls.split_capture:       # two captures: an event-record node here, an event-wait node there (include/dv3hip.h)
-            _lib.call("dv3_graph_fork", cls.main.cuda_stream, cls.stream.cuda_stream)
+        if cls.split_capture:
+            # two separate captures: nothing ties them here; GraphedTrainer closes both every few fork points and the
+            # replay orders step-stream segment j before side segment j with an ordinary event
+            if cls.split_on_fork is not None:
+                cls.split_on_fork()
         else:
             _lib.call("dv3_stream_fork", cls.main.cuda_stream, cls.stream.cuda_stream)
         cls.keep.append([None, [tensors]])
@@ -961,12 +963,11 @@ class SideStream(object):
     @classmethod
     def join(cls):
         if cls.stream is not None and cls.split_capture:
-            # the side stream's own capture ends here; the replay joins the two streams with an ordinary event
-            # (train_step.GraphedTrainer.step).  The operands stay referenced until the step stream's capture is over.
-            ex, n = ctypes.c_void_p(), ctypes.c_int32()
-            _lib.call("dv3_graph_side_end", cls.stream.cuda_stream, ctypes.byref(ex), ctypes.byref(n))
-            cls.split_exec, cls.split_nodes = ex, int(n.value)
-            cls.split_keep = cls.keep
+            # GraphedTrainer ends the last pair of captures itself; the replay joins the streams with an ordinary event.
+            # The operands were referenced until here: no later allocation of the step could take their memory.
+            for ev, _ in cls.keep:
+                if ev is not None:
+                    cls._events.append(ev)
             cls.keep = []
             cls._n = 0
             return

@@ -418,24 +418,29 @@ class GraphedTrainer(object):
     one first (device-to-device, on the step stream); batches of another shape raise -- bucket the input pipeline by
     shape (data.LengthBucketedSampler pads to the batch maximum) or run those eagerly.
 
-    split_streams (default when the trainer has its second backward stream): THREE graphs instead of one.  A single
-    captured step replays with its two backward branches serialised (4-7 % slower than eager launches whenever the GPU
-    is the bound: profiles/r03_side_stream_ab.txt), so the weight-gradient branch (ops.SideStream) is captured into
-    its own hipGraph and replayed on the real second stream:
-        g1   step stream: zero_grad, forward, losses, the input-gradient chain; every fork point is an event-record node
-        side the weight-gradient GEMMs + weight-norm backward, each layer behind an event-wait node (include/dv3hip.h:
-             dv3_graph_fork); launched right after g1, so every wait sees the record of the same step
-        g2   step stream, behind an ordinary event on the side stream: (all-reduce buckets,) clip + Adam
-    Measured (profiles/r04_three_graph_probe.txt): the eager step's GPU time at the replay's host cost -- 15.64 vs 16.44
-    ms (one graph) vs 15.62 (eager) for deepvoice3_ljspeech f16x3 B=64, 12.46 vs 13.30 vs 16.17 (eager, host bound on that
-    box) for deepvoice3_vctk bf16.
+    split_streams (default when the trainer has its second backward stream).  A single captured step replays with its
+    two backward branches serialised (4-7 % slower than eager launches whenever the GPU is the bound:
+    profiles/r03_side_stream_ab.txt), so the step is captured as SEGMENTS and the weight-gradient branch
+    (ops.SideStream) is replayed on the real second stream:
+        step-stream segment j   torch.cuda.CUDAGraph: (zero_grad, forward, losses for j = 0,) the input-gradient chain
+                                of `chunk` layers
+        side segment j          the side stream's own capture over the same stretch (include/dv3hip.h:
+                                dv3_graph_side_begin / _end): weight-gradient GEMMs + weight-norm backward of those layers
+        tail                    (all-reduce buckets,) clip + Adam
+    Replay: for j: launch step segment j; record an ordinary event; the side stream waits for it; launch side segment j.
+    Then the step stream waits for the side stream and the tail runs.  Every dependency is a host-issued
+    hipEventRecord / hipStreamWaitEvent (event NODES between two graphs were tried first and read stale at the
+    benchmark's sizes: DESIGN.md 3.7).  Measured with the first form, which has the same overlap
+    (profiles/r04_three_graph_probe.txt): the eager step's GPU time at the replay's host cost -- 15.64 vs 16.44 ms (one
+    graph) vs 15.62 (eager) for deepvoice3_ljspeech f16x3 B=64; 12.46 vs 13.30 vs 16.17 (eager, host bound on that box)
+    for deepvoice3_vctk bf16.
 
     Data parallel: the RCCL all-reduces issued on the collective stream are captured with the step (the collective stream
     forks from and joins the capturing stream through the events BucketedAllReduce records), so a replay re-issues them
-    in the same order on every rank.  With split_streams the buckets are launched in g2, after the join (a collective
-    that waited on both captures would tie them together again): no overlap with backward in that mode."""
+    in the same order on every rank.  With split_streams the buckets are launched in the tail, after the join (a
+    collective waiting on both captures would tie them together): no overlap with backward in that mode."""
 
-    def __init__(self, trainer, static_batch, warmup=3, split_streams=None):
+    def __init__(self, trainer, static_batch, warmup=3, split_streams=None, chunk=None):
         self.t = trainer
         self.batch = static_batch
         trainer.check_lengths(static_batch)
@@ -443,6 +448,7 @@ class GraphedTrainer(object):
         if split_streams is None:
             split_streams = trainer.side_stream is not None and os.environ.get("DV3_SPLIT_GRAPH", "1") not in ("0", "")
         self.split = bool(split_streams) and trainer.side_stream is not None
+        self.chunk = int(chunk or os.environ.get("DV3_SPLIT_CHUNK", "6"))
         self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
         self._prev_offset = ops.dropout_state.dev_offset        # restored by close()
         ops.dropout_state.dev_offset = self.seed_offset
@@ -455,50 +461,87 @@ class GraphedTrainer(object):
                 trainer.global_step += 1
         torch.cuda.current_stream().wait_stream(s)
         site0 = ops.dropout_state.site
-        # a process group brings its watchdog thread: its event queries must not invalidate this thread's capture
-        mode = dict(capture_error_mode="thread_local") if trainer.comm is not None else {}
-        self.side_exec, self._side_keep, self._join_event = None, None, None
+        self.segs, self._seg_events, self._join_event, self.graph2 = [], [], None, None
         if not self.split:
+            # a process group brings its watchdog thread: its event queries must not invalidate this thread's capture
+            mode = dict(capture_error_mode="thread_local") if trainer.comm is not None else {}
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, **mode):
                 self.scal = self._body()
         else:
-            from . import _lib
-            n_forks = 4 + 2 * sum(1 for _ in trainer.arena.params)          # an upper bound on the fork points of a step
-            _lib.call("dv3_graph_prepare", n_forks)
-            self.graph, self.graph2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            SS = ops.SideStream
-            SS.split_capture, SS.split_exec, SS.split_nodes = True, None, 0
-            side_raw = trainer.side_stream.cuda_stream
-            side_open = False
-            try:
-                with torch.cuda.graph(self.graph, **mode):
-                    _lib.call("dv3_graph_side_begin", side_raw)
-                    side_open = True
-                    trainer._zero_grad()
-                    self.scal = trainer.forward_backward(self.batch)      # its join() ends the side capture
-                    side_open = SS.split_exec is None
-                self.side_exec, self._side_keep = SS.split_exec, getattr(SS, "split_keep", None)
-                with torch.cuda.graph(self.graph2, pool=self.graph.pool(), **mode):
-                    self._tail(self.scal)
-                # the branch's operands were referenced until here: nothing the step graph allocated later could take
-                # their memory while the branch still reads it; what frees now can only be reused by later captures
-                # into this pool, which replay after the join
-                self._side_keep = None
-            finally:
-                if side_open and SS.split_exec is None:      # a failed capture must not leave the side stream capturing
-                    try:
-                        ex, n = ctypes.c_void_p(), ctypes.c_int32()
-                        _lib.call("dv3_graph_side_end", side_raw, ctypes.byref(ex), ctypes.byref(n))
-                        _lib.call("dv3_graph_destroy", ex)
-                    except Exception:
-                        pass
-                SS.split_capture, SS.split_exec = False, None
-                SS.split_keep = None
-            if self.side_exec is None:
-                raise RuntimeError("GraphedTrainer(split_streams): the step has no weight-gradient branch to split off")
-            self._join_event = torch.cuda.Event()
+            self.graph = None
+            self._capture_segments()
         ops.dropout_state.site = site0
+
+    def _capture_segments(self):
+        """capture the step as segments (class docstring).  Backward runs on autograd's worker thread and the segment
+        boundaries fall inside it, so every capture is begun in the RELAXED mode (a capture of another mode must be ended
+        by the thread that began it)."""
+        import gc
+        from . import _lib
+        t, SS = self.t, ops.SideStream
+        side_raw = t.side_stream.cuda_stream
+        pool = torch.cuda.graph_pool_handle()
+        st = dict(g=None, side_open=False, forks=0)
+
+        def begin_seg():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=pool, capture_error_mode="relaxed")
+            st["g"] = g
+            _lib.call("dv3_graph_side_begin", side_raw)
+            st["side_open"] = True
+
+        def end_seg():
+            ex, n = ctypes.c_void_p(), ctypes.c_int32()
+            _lib.call("dv3_graph_side_end", side_raw, ctypes.byref(ex), ctypes.byref(n))
+            st["side_open"] = False
+            g, st["g"] = st["g"], None
+            g.capture_end()
+            self.segs.append((g, ex if (ex.value and n.value > 0) else None))
+
+        def on_fork():
+            st["forks"] += 1
+            if st["forks"] % self.chunk == 0:
+                end_seg()
+                begin_seg()
+
+        torch.cuda.synchronize()
+        gc.collect()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        SS.split_capture, SS.split_on_fork = True, on_fork
+        try:
+            with torch.cuda.stream(cap):
+                begin_seg()
+                t._zero_grad()
+                self.scal = t.forward_backward(self.batch)
+                end_seg()
+                g2 = torch.cuda.CUDAGraph()
+                g2.capture_begin(pool=pool, capture_error_mode="relaxed")
+                try:
+                    self._tail(self.scal)
+                finally:
+                    g2.capture_end()
+                self.graph2 = g2
+        finally:
+            SS.split_capture, SS.split_on_fork = False, None
+            if st["side_open"]:          # a failed capture must not leave the side stream capturing
+                try:
+                    ex, n = ctypes.c_void_p(), ctypes.c_int32()
+                    _lib.call("dv3_graph_side_end", side_raw, ctypes.byref(ex), ctypes.byref(n))
+                    _lib.call("dv3_graph_destroy", ex)
+                except Exception:
+                    pass
+            if st["g"] is not None:
+                try:
+                    st["g"].capture_end()
+                except Exception:
+                    pass
+        torch.cuda.current_stream().wait_stream(cap)
+        if not any(ex is not None for _, ex in self.segs):
+            raise RuntimeError("GraphedTrainer(split_streams): the step has no weight-gradient branch to split off")
+        self._seg_events = [torch.cuda.Event() for _ in self.segs]
+        self._join_event = torch.cuda.Event()
 
     def _tail(self, scal):
         t = self.t
@@ -540,15 +583,20 @@ class GraphedTrainer(object):
         if batch is not None:
             self.load(batch)
         self.t._set_hyper()
-        self.graph.replay()
-        if self.split:
-            # the weight-gradient branch on the real second stream (launched AFTER the step graph: its waits see this
-            # step's records), an ordinary event joins it, then (buckets,) clip + Adam
-            side = self.t.side_stream
+        if not self.split:
+            self.graph.replay()
+        else:
             from . import _lib
-            _lib.call("dv3_graph_launch", self.side_exec, side.cuda_stream)
+            cur, side = torch.cuda.current_stream(), self.t.side_stream
+            side_raw = side.cuda_stream
+            for (g, ex), ev in zip(self.segs, self._seg_events):
+                g.replay()
+                if ex is not None:        # side segment j reads what step segment j wrote: an ordinary event orders them
+                    ev.record(cur)
+                    side.wait_event(ev)
+                    _lib.call("dv3_graph_launch", ex, side_raw)
             self._join_event.record(side)
-            torch.cuda.current_stream().wait_event(self._join_event)
+            cur.wait_event(self._join_event)
             self.graph2.replay()
         ops.bump_param_epoch()           # the replayed clip/Adam wrote the parameters
         self.t.global_step += 1
@@ -569,11 +617,13 @@ class GraphedTrainer(object):
         if ops.dropout_state.dev_offset is self.seed_offset:
             ops.dropout_state.dev_offset = self._prev_offset
         self._prev_offset = None
-        if self.side_exec is not None:
+        if self.segs:
             from . import _lib
             torch.cuda.synchronize()
-            _lib.call("dv3_graph_destroy", self.side_exec)
-            self.side_exec, self._side_keep = None, None
+            for _, ex in self.segs:
+                if ex is not None:
+                    _lib.call("dv3_graph_destroy", ex)
+            self.segs = []
 
 
 # ------------------------------------------------------------------------------------------------

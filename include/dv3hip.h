@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 34
+#define DV3_ABI_VERSION 35
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -212,23 +212,19 @@ int dv3_f16_range_events(int32_t* dst, int32_t reset, void* stream);
  * event calls per layer.  Replaces: nothing in the reference (single stream; train.py:755 loss.backward()). */
 int dv3_stream_fork(void* from, void* to);
 
-/* The weight-gradient branch of a CAPTURED step as its own hipGraph.  A whole-step hipGraph (forward + backward on two
+/* The weight-gradient branch of a CAPTURED step as its own hipGraphs.  A whole-step hipGraph (forward + backward on two
  * streams joined by dv3_stream_fork) replays with the two branches serialised: measured 4-7 % slower than eager launches
- * whenever the GPU is the bound (profiles/r03_side_stream_ab.txt, r04_three_graph_probe.txt).  These entry points cut
- * the branch out: while the step stream is being captured (by the caller: torch.cuda.graph), the side stream is
- * captured SEPARATELY (relaxed mode); a fork point becomes an event-RECORD node at the frontier of the step stream's
- * capture and an event-WAIT node at the frontier of the side stream's capture (hipGraphAddEventRecordNode /
- * hipGraphAddEventWaitNode + hipStreamUpdateCaptureDependencies; events from a pool the library owns).  Replay: launch
- * the step graph, then dv3_graph_launch(side graph) on a real second stream -- every wait then sees the record of the
- * same step -- then join with an ordinary event before the optimiser graph.  Replaces: nothing in the reference.
- *   dv3_graph_prepare     create `n_events` events BEFORE any capture starts (event creation is not capture-safe)
+ * whenever the GPU is the bound (profiles/r03_side_stream_ab.txt, r04_three_graph_probe.txt).  The caller
+ * (train_step.GraphedTrainer) therefore cuts the step into segments: while the step stream is being captured
+ * (torch.cuda.CUDAGraph), the side stream is captured SEPARATELY (relaxed mode) through these entry points, and both
+ * captures are closed every few layers.  Replay: step-stream segment j, an ordinary event, side segment j on the real
+ * second stream -- host-issued hipEventRecord / hipStreamWaitEvent only.  (Event-record / event-wait NODES between two
+ * graphs were tried first: bit-identical at small sizes, stale waits -- NaN -- at the benchmark's)
+ * Replaces: nothing in the reference.
  *   dv3_graph_side_begin  begin the side stream's own capture
- *   dv3_graph_fork        `from` and `to` are streams in two DIFFERENT active captures
- *   dv3_graph_side_end    end the side capture and instantiate it; *n_nodes_out = kernel / event nodes captured
+ *   dv3_graph_side_end    end it and instantiate; *n_nodes_out = nodes captured (0: *exec_out is NULL)
  */
-int dv3_graph_prepare(int32_t n_events);
 int dv3_graph_side_begin(void* side_stream);
-int dv3_graph_fork(void* from, void* to);
 int dv3_graph_side_end(void* side_stream, void** exec_out, int32_t* n_nodes_out);
 int dv3_graph_launch(void* exec, void* stream);
 int dv3_graph_destroy(void* exec);

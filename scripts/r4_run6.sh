@@ -3,7 +3,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 O=gpurun_out
-( timeout -s KILL 500 python -m pytest tests/test_gpu_model.py tests/test_gpu_ddp.py -q -m gpu -x -k "split_stream or graphed_train or world1 or ranks or train_step_matches" 2>&1 | tail -30 ) > $O/r4_6_tests.log
+( timeout -s KILL 500 python -m pytest tests/test_gpu_model.py tests/test_gpu_ddp.py -q -m gpu -x -k "split_stream or graphed_train or world1 or ranks or train_step_matches or graphed_decode or eval_after" 2>&1 | tail -30 ) > $O/r4_6_tests.log
 ( timeout -s KILL 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r4_6_bench.json ) 2> $O/r4_6_bench.err
 cat $O/r4_6_tests.log; tail -c 400 $O/r4_6_bench.err; python - <<'P'
 import json
