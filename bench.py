@@ -256,11 +256,12 @@ def wgrad_roofline(dev, iters=50, mode=None):
     tiles = ((2 * C + 127) // 128) * ((C + 127) // 128) * k
     # as ops.ConvLayerFn.backward sizes it: one 8-wave workgroup per (tile, slab) serves the three taps
     S = ops._ksplit_count(B * ((T + 31) // 32), tiles // k, slots=256) if x3 else ops._slab_count(B, tiles)
-    out_t = torch.empty((S, k, 2 * C, C), dtype=torch.float32, device=dev)
+    rows = bool(ops.slab_rows_default and S > 1)       # the K-split partial sums as the step lays them out (round 4)
+    out_t = torch.empty((k, 2 * C, S, C) if rows else (S, k, 2 * C, C), dtype=torch.float32, device=dev)
 
     def launch():
         ops.wgrad_gemm(gm, x, B=B, M=2 * C, Cin=C, T=T, Tin=T, J=k, dil=1, padL=1, n_slabs=S, xmask=bits,
-                       xmask_rs=rs, drop_scale=1.0 / 0.95, split_bf16=x3, k_split=x3, out=out_t)
+                       xmask_rs=rs, drop_scale=1.0 / 0.95, split_bf16=x3, k_split=x3, out=out_t, rows_of_slabs=rows)
     us = _time_launches(launch, iters, settle=50)
     variant = _lib.lib().dv3_debug_get(11)
     ops.set_gemm_precision(prev)
@@ -269,7 +270,8 @@ def wgrad_roofline(dev, iters=50, mode=None):
     tf = flops / (us * 1e-6) / 1e12
     fam = variant // 1000
     peak = {1: PEAK_F32_MFMA_TF, 4: PEAK_16BIT_MFMA_TF}.get(fam, PEAK_16BIT_MFMA_TF / 3.0)
-    out = dict(bound="mfma", kernel="wgrad variant %d (Conv1dGLU wgrad B=64 M=512 Cin=256 T=1024 k=3, %d K-slabs)" % (variant, S),
+    out = dict(bound="mfma", kernel="wgrad variant %d (Conv1dGLU wgrad B=64 M=512 Cin=256 T=1024 k=3, %d K-slabs%s)" % (
+                   variant, S, " as rows [J][M][S][C]" if rows else ""),
                achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
                traffic=None, us_per_launch=round(us, 2), alg_flops=flops, alg_bytes=byts,
                hbm_gbs=round(byts / (us * 1e-6) / 1e9, 1), variant=variant)
@@ -598,7 +600,9 @@ class TrainRun(object):
         if graph == "auto" and self.use_graph:
             t_graph = self._probe(4)
             self.launch_probe = dict(eager_ms_per_step=round(t_eager, 3), hipgraph_ms_per_step=round(t_graph, 3), steps=4)
-            if t_graph > 0.995 * t_eager:       # no gain: keep the two real streams
+            # the replay has the eager step's GPU time since round 4 (three-way segment graphs) and a tenth of its host
+            # cost, so a tie goes to the replay: it stays GPU-bound on a slow or busy host; eager only when clearly faster
+            if t_graph > 1.01 * t_eager:
                 self.runner.close()
                 self.runner, self.use_graph = None, False
                 torch.cuda.synchronize()
