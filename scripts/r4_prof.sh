@@ -9,7 +9,7 @@ f = glob.glob("gpurun_out/${TAG}_prof/*/*kernel_stats.csv")[0]
 shutil.copy(f, "gpurun_out/${TAG}_kernel_stats.csv")
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("total kernel time %.1f ms over 7 steps -> %.2f ms/step; %d launches/step" % (tot / 1e6, tot / 7e6, sum(int(r["Calls"]) for r in rows) / 7))
+print("total kernel time %.1f ms over 10 steps (2 warm-up + 5 timed + 3 issue-time probes) -> %.2f ms/step; %d launches/step" % (tot / 1e6, tot / 1e7, sum(int(r["Calls"]) for r in rows) / 10))
 for r in rows[:45]:
     print("%-110s %6d %9.2f ms %8.1f us %5.1f%%" % (r["Name"][:110], int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 PY
