@@ -26,8 +26,14 @@ accumulate; 1e-4 parity with the fp32 reference at the preset sizes), bf16x3, f3
   step_flop_frac      whole step: algorithmic FLOPs per mel-frame x frames / step time vs the
                       same MFMA roof
   value_exact_f32     the same step with every GEMM on the exact fp32 MFMA chain (5 steps)
-  configs             BASELINE.json configs[2..4] from the same process: nyanko_ljspeech bf16,
-                      deepvoice3_vctk bf16 (n_gpus = this run's), synthesis RTF (64 utterances)
+  launch_mode /       how the timed step was issued: "eager_two_streams", or "graph" with graph_form "segments" (a chain
+  graph_form          of segment hipGraphs, the weight-gradient branch replayed on a real second stream) or "single";
+                      probed per configuration (both timed, the faster kept; ties go to eager)
+  configs             BASELINE.json configs[2..4] from the same process: nyanko_ljspeech bf16, deepvoice3_vctk bf16
+                      (n_gpus = this run's), synthesis RTF (64 utterances); plus dv3lj_b16 (the preset's own batch),
+                      dv3lj_b64_ragged / dv3lj_b16_ragged (LJSpeech-like length spread instead of full-length rows)
+                      and ddp_world1 (the headline step with a one-rank RCCL group armed: what the bucketed
+                      all-reduce path costs on one GPU, eager and replayed)
   input_pipeline      the same step fed by data.Prefetcher (rank-sharded length-bucketed sampler, pinned
                       staging, H2D + device-side collate on a side stream) instead of a resident batch
   host_buffers        the step rate if the boundary is handed pinned host tensors synchronously (never `value`)

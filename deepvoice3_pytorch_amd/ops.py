@@ -916,9 +916,13 @@ class SideStream(object):
             SideStream._release_point()
             return False
 
+    forks_last = 0         # ... of the step before
+    forks = 0              # fork points since the last join (GraphedTrainer sizes its segments from a warm-up step's count)
+
     @classmethod
     def fork(cls, *tensors):
         # the section's inputs are complete on the step stream: the side stream waits for exactly that point
+        cls.forks += 1
         if cls.split_capture:
             # two separate captures: nothing ties them here; GraphedTrainer closes both every few fork points and the
             # replay orders step-stream segment j before side segment j with an ordinary event
@@ -962,6 +966,7 @@ class SideStream(object):
 
     @classmethod
     def join(cls):
+        cls.forks_last, cls.forks = cls.forks, 0
         if cls.stream is not None and cls.split_capture:
             # GraphedTrainer ends the last pair of captures itself; the replay joins the streams with an ordinary event.
             # The operands were referenced until here: no later allocation of the step could take their memory.

@@ -448,7 +448,7 @@ class GraphedTrainer(object):
         if split_streams is None:
             split_streams = trainer.side_stream is not None and os.environ.get("DV3_SPLIT_GRAPH", "1") not in ("0", "")
         self.split = bool(split_streams) and trainer.side_stream is not None
-        self.chunk = int(chunk or os.environ.get("DV3_SPLIT_CHUNK", "6"))
+        self.chunk = int(chunk or os.environ.get("DV3_SPLIT_CHUNK", "0"))      # 0: chosen after the warm-up steps
         self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
         self._prev_offset = ops.dropout_state.dev_offset        # restored by close()
         ops.dropout_state.dev_offset = self.seed_offset
@@ -462,6 +462,13 @@ class GraphedTrainer(object):
         torch.cuda.current_stream().wait_stream(s)
         site0 = ops.dropout_state.site
         self.segs, self._seg_events, self._join_event, self.graph2 = [], [], None, None
+        if self.chunk <= 0:
+            # fork points per segment.  Measured (profiles/r04_split_chunk_ab.txt): flat between 4 and 10 -- 2 costs graph
+            # launches, 20 and more lose the overlap (one segment = the single graph's time); the 46-fork
+            # deepvoice3_ljspeech step is 0.5 % faster at 4 (15.20 vs 15.28 ms), the 58-fork nyanko step 0.9 % faster at
+            # 10 (10.80 vs 10.90 ms), batch 16 the same at both
+            n = ops.SideStream.forks_last if warmup > 0 else 0
+            self.chunk = 4 if 0 < n < 52 else 10
         if not self.split:
             # a process group brings its watchdog thread: its event queries must not invalidate this thread's capture
             mode = dict(capture_error_mode="thread_local") if trainer.comm is not None else {}

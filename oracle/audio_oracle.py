@@ -1,16 +1,19 @@
 # coding: utf-8
-"""CPU restatement of the audio inverse -- TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py).
+"""CPU restatement of the audio analysis / inverse -- TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py).
 
-PARITY UNPINNED for the phase-reconstruction part: the reference (audio.py:37-43) calls
-`lws.lws(1024, 256, mode="speech").run_lws(...)` / `.istft`, a third-party package (unpinned version,
-setup.py:87) that is not vendored and not installed; the reference has no test or golden vector
-for it (tests/test_audio.py covers _amp_to_db/_db_to_amp only).  What IS restated exactly, and pinned bit
-for bit against the reference's own functions run unmodified (tests/golden/audio_helpers.npz,
-oracle/make_golden.py:gen_audio_helpers):
-_denormalize / _db_to_amp (audio.py:84-93), magnitude ** power (audio.py:41, hparams.py:124) and
-inv_preemphasis = lfilter([1], [1, -0.97]) (audio.py:26-28, nnmnkwii).  Phase reconstruction is
-Griffin-Lim on torch-CPU FFTs (torch.stft / torch.istft, periodic Hann 1024, hop 256, center=True
-reflect) -- an independent implementation of the algorithm the HIP kernels implement.
+The reference frames its features and its inverse with the third-party `lws` package (audio.py:31-55: `.stft`,
+`.run_lws`, `.istft` of `lws.lws(fft_size, hop_size, mode="speech")`; setup.py:87 "lws <= 1.0"; not vendored, not
+installable here, no test or golden vector in the reference).  Two parts, two statuses:
+  * FRAMING (windows, padding, frame count): restated below (`lws_*`) from the package's published source and README,
+    each convention cited, checked through the properties the package documents (perfect reconstruction for any length,
+    k + 3 frames for 256 k samples).  The HIP kernels are held to it.  Pinned to the dependency's published algorithm --
+    not to a run of the package.
+  * PHASE RECONSTRUCTION: Griffin-Lim by design (north_star), not `run_lws`'s weighted local sums: PARITY UNPINNED.
+Restated exactly, and pinned bit for bit against the reference's own functions run unmodified
+(tests/golden/audio_helpers.npz, oracle/make_golden.py:gen_audio_helpers): _denormalize / _db_to_amp (audio.py:84-93),
+magnitude ** power (audio.py:41, hparams.py:124) and inv_preemphasis = lfilter([1], [1, -0.97]) (audio.py:26-28,
+nnmnkwii).  The torch-framing functions (`stft` / `istft` / `griffin_lim`: torch.stft conventions) check the
+torch-framing HIP kernels of rounds 1-3, which are still shipped.
 """
 import numpy as np
 import torch
