@@ -661,7 +661,8 @@ class TrainRun(object):
         for _ in range(warmup):
             scal = self.step(nxt())
         if comm is not None:
-            comm.exposed_events = [] if not self.use_graph else None
+            # measurable whenever the collectives are issued from the host: eager, and the segmented replay
+            comm.exposed_events = [] if (not self.use_graph or getattr(self.runner, "split", False)) else None
         if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -723,16 +724,17 @@ class TrainRun(object):
 
 
 def launch_mode(args, world=1):
-    """--graph / --no-graph force the launch mode; the default PROBES both (TrainRun) and keeps the faster step --
-    also under a world-size-1 process group (--force-group: RCCL collectives captured into the whole-step hipGraph,
-    tests/test_gpu_ddp.py).  With more than one rank the default stays eager: a capture that contains RCCL collectives
-    has only ever run at world size 1 on this project's hardware (no multi-GPU node was available to any round), and a
-    capture that hangs would void the scaling run; DV3_BENCH_DDP_GRAPH=auto (or --graph) opts in."""
+    """--graph / --no-graph force the launch mode; the default PROBES both (TrainRun) and keeps the faster step, on every
+    world size: the segmented replay (train_step.GraphedTrainer) captures nothing of the process group -- its
+    all-reduces are ordinary c10d calls issued from the host between segment launches, in an order fixed by the model
+    -- so a multi-rank replay runs the same collective code path as the eager step.  All ranks take the same decision
+    (a MIN over "did my capture succeed", a MAX over the probe times).  DV3_BENCH_DDP_GRAPH=0 keeps more than one rank
+    eager without probing."""
     if args.no_graph:
         return False
     if args.graph:
         return True
-    if world > 1 and os.environ.get("DV3_BENCH_DDP_GRAPH", "") != "auto":
+    if world > 1 and os.environ.get("DV3_BENCH_DDP_GRAPH", "auto") in ("0", "eager"):
         return False
     return "auto"
 
@@ -768,7 +770,7 @@ def ddp_world1_config(dev, preset, gemm, args, no_group_ms, steps=12, warmup=4):
     """The data-parallel step with its gradient exchange ARMED, on the one GPU a bench box has: a world-size-1 "nccl"
     (RCCL) group, dist.BucketedAllReduce's notifications, bucketed all-reduces on the collective stream, clip with
     the 1/world prescale.  Measured in both launch modes: eager (two real backward streams + the collective stream)
-    and the replayed whole-step hipGraph with the RCCL collectives captured.  What it shows: the host cost of a step
+    and the segmented replay, whose all-reduces are issued from the host between segment launches.  What it shows: the host cost of a step
     with the group armed, and the step time against the same step without a group."""
     import torch.distributed as tdist
     pg = tdist.group.WORLD
@@ -1088,8 +1090,9 @@ def main():
                 import torch.distributed as tdist
                 d1 = dict(backend=tdist.get_backend(), rccl_ranks=tdist.get_world_size(),
                           note="world-size-1 nccl group in the bench process: gradient buckets armed, all-reduces on the "
-                               "collective stream; eager = per-kernel launches on three streams, hipgraph = the whole "
-                               "step incl. the RCCL collectives captured and replayed")
+                               "collective stream; eager = per-kernel launches on three streams, hipgraph = the "
+                               "segmented replay, the bucket all-reduces issued from the host between segment launches "
+                               "(nothing of the process group inside a capture)")
                 d1["dv3lj_" + gemm] = ddp_world1_config(dev, args.preset, gemm, args, m["ms_per_step"])
                 d1["nyanko_bf16"] = ddp_world1_config(dev, "nyanko_ljspeech", "bf16", args, cfgs["nyanko_bf16"]["ms_per_step"])
                 d1["vctk_bf16"] = ddp_world1_config(dev, "deepvoice3_vctk", "bf16", args, cfgs["vctk_bf16"]["ms_per_step"])

@@ -22,9 +22,12 @@ class BucketedAllReduce(object):
      -- sit in smaller buckets of `last_bucket_mb` over the first `last_span_mb` of the arena:
     clip + Adam need the whole reduced arena, so the all-reduce of the bucket that closes last is never hidden behind
     backward and its size is the exposed time (one encoder layer is 6.3 MB; an 8 MB ring all-reduce over xGMI is
-    still bandwidth- rather than latency-bound).  last_bucket_mb=None: one size everywhere."""
+    still bandwidth- rather than latency-bound).  last_bucket_mb=None: one size everywhere.
+    isolate: arena indices of parameters that get a bucket of their own -- tables every layer contributes to (the speaker
+    embedding: registered last, final only when the ENCODER's backward is done; in a shared bucket it held the 25 MB of
+    converter gradients back until the end of backward: scripts/r4_group_replay_check.py)."""
 
-    def __init__(self, arena, process_group=None, bucket_mb=25.0, last_bucket_mb=8.0, last_span_mb=40.0):
+    def __init__(self, arena, process_group=None, bucket_mb=25.0, last_bucket_mb=8.0, last_span_mb=40.0, isolate=()):
         self.arena = arena
         self.pg = process_group
         self.side = torch.cuda.Stream() if arena.grad.is_cuda else None
@@ -36,10 +39,11 @@ class BucketedAllReduce(object):
         hi = arena.total
         lo = hi
         cur = []
+        isolate = set(isolate)
         for i in range(len(arena.params) - 1, -1, -1):
             o = arena.offsets[i]
             c = cap_last if hi <= span_last else cap
-            if hi - o > c and cur:
+            if cur and (hi - o > c or i in isolate or cur[-1] in isolate):
                 self.buckets.append((lo, hi, cur))
                 hi, cur = lo, []
             lo = o
@@ -54,6 +58,7 @@ class BucketedAllReduce(object):
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self._armed = False
+        self._completed = []
         # measurement (bench.py): when a list, finish() appends an (event, event) pair bracketing the point where
         # the step stream joins the collective stream -- their distance is the all-reduce time NOT hidden behind
         # backward.  Timing events can not be recorded while a hipGraph is being captured.
@@ -101,9 +106,10 @@ class BucketedAllReduce(object):
         if self.pending[b] == 0:
             from . import ops as _ops
             if _ops.SideStream.split_capture:
-                # the weight-gradient branch is being captured into its own hipGraph (train_step.GraphedTrainer): a
-                # collective that waits on both captures would tie them together again, so the buckets of such a
-                # replayed step are launched by finish(), in the optimiser graph, after the join
+                # the step is being captured as segment graphs (train_step.GraphedTrainer): nothing of the process
+                # group goes into a capture -- the bucket is remembered with the segment that completes it and the
+                # replay issues its all-reduce from the host, between two segment launches
+                self._completed.append(b)
                 return
             self._launch(b)
 
@@ -135,7 +141,41 @@ class BucketedAllReduce(object):
             self.pending[b] = len(plist)
             self.launched[b] = False
         self.notified = [False] * len(self.arena.params)
+        self._completed = []
         self._armed = True
+
+    def take_completed(self):
+        """the buckets that became complete since the last call (segment capture only; see _report)"""
+        done, self._completed = self._completed, []
+        return done
+
+    def disarm(self):
+        self._armed = False
+
+    def launch_after(self, bucket_ids, streams):
+        """all-reduce `bucket_ids` on the collective stream once everything enqueued on `streams` so far has run
+        (the replay of a segmented step: called between two segment launches, never inside a capture)"""
+        for st in streams:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            for b in bucket_ids:
+                lo, hi, _ = self.buckets[b]
+                dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+
+    def join(self, cur=None):
+        """the step stream waits for the collective stream (timed when exposed_events is a list)"""
+        cur = cur or torch.cuda.current_stream()
+        timed = self.exposed_events is not None and not torch.cuda.is_current_stream_capturing()
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+        cur.wait_stream(self.side)
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(cur)
+            self.exposed_events.append((e0, e1))
 
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
@@ -167,16 +207,7 @@ class BucketedAllReduce(object):
             if not self.launched[b]:
                 self._launch(b)
         if self.side is not None:
-            cur = torch.cuda.current_stream()
-            timed = self.exposed_events is not None and not torch.cuda.is_current_stream_capturing()
-            if timed:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e0.record(cur)
-            cur.wait_stream(self.side)
-            if timed:
-                e1 = torch.cuda.Event(enable_timing=True)
-                e1.record(cur)
-                self.exposed_events.append((e0, e1))
+            self.join()
 
     def exposed_ms(self):
         """mean GPU time per step the step stream spent waiting for the collective stream (call after a

@@ -192,7 +192,10 @@ class Trainer(object):
         if process_group is not None:
             from . import dist as _dist
             self.world = torch.distributed.get_world_size(process_group)
-            self.comm = _dist.BucketedAllReduce(self.arena, process_group, bucket_mb, last_bucket_mb)
+            # the speaker table receives a gradient from every layer of every module: a bucket of its own
+            shared = set(id(p) for n, p in model.named_parameters() if n.split(".")[-2:-1] == ["embed_speakers"])
+            isolate = [i for i, p in enumerate(self.arena.params) if id(p) in shared]
+            self.comm = _dist.BucketedAllReduce(self.arena, process_group, bucket_mb, last_bucket_mb, isolate=isolate)
 
     def close(self):
         """Detach the gradient-exchange hooks (call before building another Trainer on the same model)."""
@@ -341,9 +344,11 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
             ops.SideStream.stream = ops.SideStream.main = None
         return {k: v.detach() for k, v in scal.items()}
 
-    def optimizer_step(self):
+    def optimizer_step(self, reduce=True):
+        """reduce=False: the caller has already issued and joined the gradient all-reduces (GraphedTrainer's segmented
+        replay issues them from the host between segment launches)"""
         c, a = self.cfg, self.arena
-        if self.comm is not None:
+        if self.comm is not None and reduce:
             self.comm.finish()           # all buckets reduced (sum); 1/world folded into grad_prescale
         prescale = 1.0 / self.world
         if c.clip_thresh > 0:
@@ -435,10 +440,16 @@ class GraphedTrainer(object):
     graph) vs 15.62 (eager) for deepvoice3_ljspeech f16x3 B=64; 12.46 vs 13.30 vs 16.17 (eager, host bound on that box)
     for deepvoice3_vctk bf16.
 
-    Data parallel: the RCCL all-reduces issued on the collective stream are captured with the step (the collective stream
-    forks from and joins the capturing stream through the events BucketedAllReduce records), so a replay re-issues them
-    in the same order on every rank.  With split_streams the buckets are launched in the tail, after the join (a
-    collective waiting on both captures would tie them together): no overlap with backward in that mode."""
+    Data parallel.  With split_streams NOTHING of the process group is captured: while the segments are captured,
+    dist.BucketedAllReduce notes which segment completes which bucket, and the replay issues those all-reduces from the
+    host on the collective stream right after launching that segment (it waits for both streams' events of the segment)
+    -- the same overlap with the rest of backward as the eager step, the same order on every rank (the capture is a
+    function of the model), and the ordinary c10d call path.  The buckets no segment completed (parameters without a
+    gradient) go before the tail, which the step stream enters after joining the side and the collective stream.
+    (Round 4's first form captured the collectives into the tail graph: c10d's watchdog thread then queried an event
+    last recorded in a capturing stream -- hipErrorCapturedEvent, process abort -- once in three runs at the
+    benchmark's sizes.)  Without split_streams (single graph) the collectives are still captured with the step, in
+    the thread-local capture mode."""
 
     def __init__(self, trainer, static_batch, warmup=3, split_streams=None, chunk=None):
         self.t = trainer
@@ -462,6 +473,7 @@ class GraphedTrainer(object):
         torch.cuda.current_stream().wait_stream(s)
         site0 = ops.dropout_state.site
         self.segs, self._seg_events, self._join_event, self.graph2 = [], [], None, None
+        self.seg_buckets, self.rest_buckets = [], []
         if self.chunk <= 0:
             # fork points per segment.  Measured (profiles/r04_split_chunk_ab.txt): flat between 4 and 10 -- 2 costs graph
             # launches, 20 and more lose the overlap (one segment = the single graph's time); the 46-fork
@@ -505,6 +517,7 @@ class GraphedTrainer(object):
             g, st["g"] = st["g"], None
             g.capture_end()
             self.segs.append((g, ex if (ex.value and n.value > 0) else None))
+            self.seg_buckets.append(t.comm.take_completed() if t.comm is not None else [])
 
         def on_fork():
             st["forks"] += 1
@@ -523,6 +536,10 @@ class GraphedTrainer(object):
                 t._zero_grad()
                 self.scal = t.forward_backward(self.batch)
                 end_seg()
+                if t.comm is not None:
+                    t.comm.disarm()
+                    seen = set(b for bs in self.seg_buckets for b in bs)
+                    self.rest_buckets = [b for b in range(len(t.comm.buckets)) if b not in seen]
                 g2 = torch.cuda.CUDAGraph()
                 g2.capture_begin(pool=pool, capture_error_mode="relaxed")
                 try:
@@ -552,7 +569,8 @@ class GraphedTrainer(object):
 
     def _tail(self, scal):
         t = self.t
-        t.optimizer_step()
+        # inside the segmented capture the all-reduces are not part of the tail graph (class docstring)
+        t.optimizer_step(reduce=not (self.split and torch.cuda.is_current_stream_capturing()))
         scal["grad_norm"] = t._scalar(t.norm_out[0:1], 1.0 / t.world)
         if ops.gemm_precision() == "f16x3":
             scal["f16_range_events"] = ops.f16_range_events_tensor(t.device)
@@ -596,14 +614,21 @@ class GraphedTrainer(object):
             from . import _lib
             cur, side = torch.cuda.current_stream(), self.t.side_stream
             side_raw = side.cuda_stream
-            for (g, ex), ev in zip(self.segs, self._seg_events):
+            comm = self.t.comm
+            for j, ((g, ex), ev) in enumerate(zip(self.segs, self._seg_events)):
                 g.replay()
                 if ex is not None:        # side segment j reads what step segment j wrote: an ordinary event orders them
                     ev.record(cur)
                     side.wait_event(ev)
                     _lib.call("dv3_graph_launch", ex, side_raw)
+                if comm is not None and self.seg_buckets[j]:
+                    comm.launch_after(self.seg_buckets[j], (cur, side))
             self._join_event.record(side)
             cur.wait_event(self._join_event)
+            if comm is not None:
+                if self.rest_buckets:
+                    comm.launch_after(self.rest_buckets, (cur,))
+                comm.join(cur)
             self.graph2.replay()
         ops.bump_param_epoch()           # the replayed clip/Adam wrote the parameters
         self.t.global_step += 1

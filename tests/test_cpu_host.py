@@ -262,6 +262,35 @@ def test_bucketed_allreduce_gloo_world2():
     assert res[0][1] == res[1][1]      # both ranks hold the same reduced gradient arena
 
 
+def test_bucket_cutting_isolates_the_shared_table_and_segment_notes():
+    """host logic of dist.BucketedAllReduce that needs no process group: an isolated parameter (the speaker table) is a
+    bucket of its own and every parameter is in exactly one contiguous bucket; while a step is captured as segment
+    graphs a completed bucket is NOTED, not launched (train_step.GraphedTrainer issues it from the host at replay)."""
+    from deepvoice3_pytorch_amd import dist as dv3dist, ops
+    from deepvoice3_pytorch_amd.train_step import FlatArena
+    params = [torch.nn.Parameter(torch.randn(n)) for n in (3000, 40, 5000, 7, 2500, 16)]
+    arena = FlatArena(params)
+    comm = dv3dist.BucketedAllReduce(arena, None, bucket_mb=0.02, last_bucket_mb=None, isolate=[5, 1])
+    try:
+        assert [pl for _, _, pl in comm.buckets if 5 in pl] == [[5]] and [pl for _, _, pl in comm.buckets if 1 in pl] == [[1]]
+        assert sorted(i for _, _, pl in comm.buckets for i in pl) == list(range(6))
+        spans = sorted((lo, hi) for lo, hi, _ in comm.buckets)
+        assert spans[0][0] == 0 and spans[-1][1] == arena.total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        launched = []
+        comm._launch = lambda b: launched.append(b)
+        comm.arm()
+        ops.SideStream.split_capture = True
+        try:
+            comm._on_inplace_grad(params[5])
+            assert comm.take_completed() == [comm.bucket_of[5]] and comm.take_completed() == [] and launched == []
+        finally:
+            ops.SideStream.split_capture = False
+        comm._on_inplace_grad(params[1], None)
+        assert launched == [comm.bucket_of[1]]
+    finally:
+        comm.close()
+
+
 def test_pack_batch_layout():
     """data.pack_batch: items back to back, no padding; padded_frames restates the frame arithmetic of
     train.collate_fn (train.py:307-316) that collate_fn itself is pinned on"""

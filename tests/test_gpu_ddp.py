@@ -104,8 +104,8 @@ def test_two_rank_step_equals_single_process_step():
 # ----------------------------------------------------------------------------------------------------------------
 # The RCCL path itself on the one GPU a test box has: a world-size-1 "nccl" group.  Proves that librccl loads next
 # to libdv3hip.so, that the side-stream hand-off in dist.BucketedAllReduce (event -> collective stream ->
-# wait_stream in finish()) and the bucket notification order are right under the real backend, and that the
-# collectives can be captured into the whole-step hipGraph.
+# wait_stream in finish()) and the bucket notification order are right under the real backend, and that the segmented
+# replay (train_step.GraphedTrainer) issues the same all-reduces from the host between its segment launches.
 # ----------------------------------------------------------------------------------------------------------------
 def _run_nccl(port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
@@ -128,9 +128,10 @@ def _run_nccl(port, q):
         tr = train_step.Trainer(model, train_step.TrainConfig(max_positions=128), process_group=pg, bucket_mb=0.05)
         info = {}
         if graphed:
-            g = train_step.GraphedTrainer(tr, batch(), warmup=1)
+            g = train_step.GraphedTrainer(tr, batch(), warmup=1, chunk=2)
             for _ in range(steps - 1):
                 scal = g.step()
+            info["split"], info["seg_buckets"], info["rest_buckets"] = g.split, g.seg_buckets, g.rest_buckets
             g.close()
         else:
             if tr.comm is not None:
@@ -189,4 +190,9 @@ def test_world1_nccl_group_step_is_the_plain_step_eager_and_captured():
     assert info1["buckets"] >= 2 and info1["exposed_ms"] is not None and info1["exposed_ms"] >= 0.0
     assert np.array_equal(w0, w1) and g0 == g1, "RCCL world-1 eager step differs from the no-group step"
     assert np.array_equal(w0, w3) and g0 == g3, "whole-step hipGraph differs from the eager step"
-    assert np.array_equal(w0, w2) and g0 == g2, "hipGraph with captured RCCL all-reduces differs from the eager step"
+    assert np.array_equal(w0, w2) and g0 == g2, "replayed step with the RCCL all-reduces armed differs from the eager step"
+    # the segmented replay issues every bucket exactly once, from the host, and not all of them at the end
+    assert info2["split"]
+    issued = [b for bs in info2["seg_buckets"] for b in bs] + list(info2["rest_buckets"])
+    assert sorted(issued) == list(range(info2["buckets"])), (info2["seg_buckets"], info2["rest_buckets"])
+    assert any(info2["seg_buckets"][:-1]), "no bucket became complete before the last segment: no overlap with backward"
