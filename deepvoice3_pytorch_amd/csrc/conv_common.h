@@ -15,6 +15,10 @@ struct ConvArgs {
   int wide = 1;                    // 16-byte input-gradient epilogue through LDS (0 = off)
   uint32_t* range_ctr = nullptr;   // f16x3: sticky fp16-range event counter (common.h), NULL = do not count
   int prio = 0;  // ping-pong tap-GEMM: wave priority scheme (dv3_debug_set(14, v); 0 = none)
+  // stream-K form of the 256 x 256 kernels: n_blocks = workgroups (one per CU), sk_units = tiles x chunks
+  int sk_units = 0, sk_base = 0, sk_rem = 0, sk_shift = 0, sk_mshift = 0, sk_abl = 0;   // units; units / n_blocks, the remainder; log2(chunks per tile)
+  float* sk_ws = nullptr;      // [n_blocks][128 accumulator registers][512 threads]
+  int* sk_flags = nullptr;     // [n_blocks], zero between launches
 };
 
 template <typename T>

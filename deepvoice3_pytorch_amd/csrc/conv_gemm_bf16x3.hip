@@ -712,7 +712,9 @@ int g_x3_pp2 = 128;  // dv3_debug_set(12, v): the 256 x 256 k16 ping-pong kernel
                      // whose grid has at least v tiles (0 = never).  Measured at B=64 over the presets' conv shapes
                      // (scripts/pp2_sweep.py, profiles/r03_pp2_sweep.txt): 0.73-0.88 of the 128 x 256 / 128 x 64 kernels'
                      // time from 152 tiles up, 1.3-1.9 x at 50-100 tiles (half the chip idle).
-extern int g_pp2_abl;
+extern int g_pp2_abl, g_pp2_sk, g_pp2_sk_overhead, g_pp2_sk_gain, g_pp2_sk_abl;
+int g_x3_pp2_sk_units = 8;   // measured (scripts/pp2_sk_check.py): at 9.5 units per CU (the encoder layers: 152 / 76 tiles) the
+                             // stream-K form beats the 128-wide kernels by 6-8 %, at 6.3 (101 tiles x 16) it loses to them
 int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st);   // conv_gemm_pp2.hip
 int g_x3_wide = 1;  // dv3_debug_set(18, v): 16-byte epilogue through LDS (conv_common.h): 0 off, 1 DGRAD, 
 int g_x3_prio = 0; // dv3_debug_set(14, v): wave priority scheme of the ping-pong main loop
@@ -730,7 +732,10 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   // 256 x 256 tile, k16 ping-pong (conv_gemm_pp2.hip): tile_hint 30 forces it, dv3_debug_set(12, 1) prefers it
   const bool gated0 = d->mode == DV3_EPI_GLU || d->mode == DV3_EPI_HIGHWAY;
   const int64_t pp2_tiles = (int64_t)(gated0 ? dv3_cdiv(d->Cg, 128) : dv3_cdiv(d->M, 256)) * dv3_cdiv64((int64_t)d->B * d->Tout, 256);
-  if (d->tile_hint == 30 || (g_x3_pp2 > 0 && d->tile_hint == 0 && pp2_tiles >= g_x3_pp2)) {
+  // with a stream-K workspace the 256 x 256 kernel no longer needs a grid that fills the chip: enough (tile, chunk)
+  // units for every CU instead (g_x3_pp2_sk_units per CU, dv3_debug_set(25, v))
+  const bool sk_fill = d->sk_ws && g_pp2_sk && (d->mode != DV3_EPI_DGRAD || g_pp2_sk >= 2) && g_x3_pp2 > 0 && pp2_tiles * (d->Cin / 32) >= (int64_t)g_x3_pp2_sk_units * 256;
+  if (d->tile_hint == 30 || (g_x3_pp2 > 0 && d->tile_hint == 0 && (pp2_tiles >= g_x3_pp2 || sk_fill))) {
     const int rc = dv3_conv_gemm_pp2_dispatch(d, st);
     if (rc != 1) return rc;
     if (d->tile_hint == 30) return 1;
@@ -787,6 +792,11 @@ extern "C" int dv3_debug_set(int what, int value) {
   if (what == 9) g_x3_rel2 = value;
   if (what == 12) g_x3_pp2 = value;
   if (what == 13) g_pp2_abl = value;
+  if (what == 22) g_pp2_sk = value;
+  if (what == 23) g_pp2_sk_overhead = value;
+  if (what == 24) g_pp2_sk_gain = value;
+  if (what == 25) g_x3_pp2_sk_units = value;
+  if (what == 26) g_pp2_sk_abl = value;
   if (what == 14) g_x3_prio = value;
   if (what == 18) g_x3_wide = value;
   if (what == 15) g_wgrad_prio = value;

@@ -55,6 +55,16 @@ __device__ __forceinline__ f32x16 pp2_mma(const bf16x8& a, const bf16x8& b, cons
   else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+template <bool OPAQUE>
+__device__ __forceinline__ const ConvArgs* dv3_opaque_args(const ConvArgs* a) {
+  if constexpr (OPAQUE) {
+    int off = 0;
+    asm volatile("" : "+s"(off));
+    return reinterpret_cast<const ConvArgs*>(reinterpret_cast<const char*>(a) + off);
+  } else {
+    return a;
+  }
+}
 template <typename T>
 __device__ __forceinline__ T pp2_ldg(const void* base, uint32_t byte_off) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -65,7 +75,11 @@ __device__ __forceinline__ T pp2_ldg(const void* base, uint32_t byte_off) {
 constexpr int PP2_STAMPS = 320;
 __device__ unsigned long long g_pp2_stamps[8 * PP2_STAMPS * 2];
 
-template <bool MASK, bool F16, int ABL = 0>
+// SK (stream-K form, see the note above dv3_conv_gemm_pp2_dispatch): the grid is one workgroup per CU and a workgroup
+// walks a contiguous range of (tile, 32-channel chunk) units -- at most one leading segment that ends a tile another
+// workgroup began (its accumulators go to the workspace) and then segments that begin a tile (the workgroup that
+// holds a tile's chunk 0 adds the other workgroups' parts and runs the fused tail).
+template <bool MASK, bool F16, int ABL = 0, bool SK = false>
 __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) {
   const dv3_conv_desc& p = args.d;
   int n_stamp = 0;
@@ -84,21 +98,60 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   stamp();                               // slot 0: kernel entry
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int J = JT;
-  const int dil = p.dil;
-  const int BNH = BN + (J - 1) * dil;
   bf16x8* const As = reinterpret_cast<bf16x8*>(smem_raw);   // [2 buffers][hi | lo][KB][BM]
   bf16x8* const Xs = As + 2 * 2 * KB * BM;                  // [2 buffers][hi | lo][KB][BNH]
-  const int xbuf = 2 * KB * BNH;
 
-  const int tid = threadIdx.x;
+  const int pid = dv3_xcd_remap(blockIdx.x, args.n_blocks);
+  const int nchunks = p.Cin / BKC;       // whole chunks only (dispatcher)
+  // stream-K: this workgroup's unit range [seg_u, seg_end); unit = tile * nchunks + chunk
+  int seg_u = 0, seg_end = 0, sk_base = 0, sk_rem = 0;
+  if constexpr (SK) {
+    sk_base = args.sk_base;                 // sk_units / n_blocks and the remainder, divided on the host: a uniform
+    sk_rem = args.sk_rem;                   // division here leaves its reciprocal (and a zero) in vector registers
+    seg_u = pid * sk_base + min(pid, sk_rem);
+    seg_end = seg_u + sk_base + (pid < sk_rem ? 1 : 0);
+  }
+  // weight panels by LDS-DMA (dma_A_unit): the experiment of round 3 (+2 % on the tile-per-workgroup kernel, retired
+  // there) -- and the form the stream-K variants use: it frees the eight staging registers of the panel unit, which is
+  // what keeps their main loop free of scratch reloads
+  constexpr bool DMA_A = ABL == 11;
+  int tid_ = threadIdx.x;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+  do {   // one pass per segment (a single pass without SK)
+  // The descriptor is read through a pointer made opaque once per segment (and once more before the tail): its ~60
+  // scalar fields are invariant, and hoisted out of the segment loop they would all be live -- spilled -- across the
+  // main loop (144 scalar spills and 20 vector reloads per chunk in the first build of this form).
+  const ConvArgs& A = *dv3_opaque_args<SK>(&args);
+  const dv3_conv_desc& p = A.d;
+  const int dil = p.dil;
+  const int BNH = BN + (J - 1) * dil;
+  const int xbuf = 2 * KB * BNH;
+  // ... and the thread index likewise: everything derived from it (staging offsets, validity bits: ~50 registers) is
+  // then recomputed per segment instead of being hoisted and held across the main loop
+  // (no vector register may carry it from one segment to the next: anything live through the tail -- the part with the
+  // highest register pressure -- is spilled there and then RELOADED AT EVERY USE in the main loop, each reload behind a
+  // vmcnt(0): the wave index is kept as a scalar, the lane index is produced by a volatile v_mbcnt pair)
+  if constexpr (SK) {
+    int lane_;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
+    tid_ = wave_s * 64 + lane_;
+  }
+  const int tid = tid_;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lhi = lane >> 5;
-
-  const int pid = dv3_xcd_remap(blockIdx.x, args.n_blocks);
-  const int mt = pid % args.m_tiles;
-  const int nt = pid / args.m_tiles;
+  int tile_ = pid, c0_ = 0, c1_ = nchunks;
+  if constexpr (SK) {
+    tile_ = seg_u >> A.sk_shift;            // chunks per tile is a power of two in this form (dispatcher)
+    c0_ = seg_u - tile_ * nchunks;
+    c1_ = min(nchunks, c0_ + (seg_end - seg_u));
+  }
+  const int tile = tile_, c0 = SK ? c0_ : 0, c1 = SK ? c1_ : nchunks;
+  // (stream-K form: row tiles per column tile is a power of two too -- every uniform division costs a reciprocal and a
+  // zero in vector registers that the allocator then carries, spilled, through the main loop)
+  const int mt = SK ? (tile & (A.m_tiles - 1)) : tile % A.m_tiles;
+  const int nt = SK ? (tile >> A.sk_mshift) : tile / A.m_tiles;
   const int n0 = nt * BN;
 
   const bool gated = (p.mode == DV3_EPI_GLU || p.mode == DV3_EPI_HIGHWAY);
@@ -111,7 +164,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
 
   const int Cin = p.Cin, T = p.Tout, lda = p.lda, B = p.B;
   const int Ntot = B * T;
-  const int k8_total = args.kp >> 3;
+  const int k8_total = A.kp >> 3;
   const bf16x8* __restrict__ Wh = reinterpret_cast<const bf16x8*>(p.a_split);
   const int64_t plane = (int64_t)J * k8_total * lda;   // 16-byte units per plane
   const float xscale = F16 ? (float)(1 << DV3_F16_ACT_SHIFT) : 1.0f;
@@ -137,6 +190,11 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
 
   // ---- this thread's activation staging items: flat column -> (batch, time), fixed over chunks ----
   uint32_t xoff[XI];                // byte offset of (b, k8*8, t) from p.x
+  // stream-K form: the three offsets live in LDS behind the operand images (a ds_read_b32 per half item) -- the
+  // segment loop costs the register allocator a handful of registers, and every vector spill in the main loop is a
+  // scratch reload behind a vmcnt(0), i.e. the whole fetch latency inside a LOAD phase
+  constexpr bool XOFF_LDS = false;
+  uint32_t* const xoff_l = reinterpret_cast<uint32_t*>(Xs + 2 * xbuf);
   const int n_items = KB * BNH;
   const uint32_t x_rsb = (uint32_t)p.x_rs * 4u;
   const uint32_t c8p = (uint32_t)((Cin + 31) / 32 * 4);
@@ -152,6 +210,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
     }
     const int xk8 = k8 < KB ? k8 * 8 : 0;
     xoff[i] = ((uint32_t)bf * (uint32_t)p.x_bs + (uint32_t)tf) * 4u + (uint32_t)xk8 * x_rsb;
+    if constexpr (SK && XOFF_LDS) xoff_l[i * NT + tid] = xoff[i];
   }
   // weight panel: per-unit column offset inside a (tap, k8) row of the split image; recomputed at each use from an
   // opaque copy of the thread index (a handful of VALU) instead of living in registers across the loop
@@ -169,8 +228,6 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   bf16x8 ra[2];            // ONE weight-panel unit (hi, lo) in flight: fetched in one LOAD phase, stored in the next
   float rx[XI][8];
   uint32_t rk[MASK ? XI : 1];
-
-  const int nchunks = Cin / BKC;       // whole chunks only (dispatcher)
 
   // Every load below is UNCONDITIONAL and every k16 phase of a chunk issues the same loads in the same order (the
   // tail re-fetches the last panel / chunk and stores into buffers nobody reads any more): the compiler then counts
@@ -219,7 +276,16 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
     asm volatile("" : "+s"(rs));      // opaque per call site: the 24 row offsets are recomputed (one SALU + one VALU per
                                       // load), not hoisted out of the loop into 24 live registers
 #pragma unroll
-    for (int e = 4 * h; e < 4 * h + 4; ++e) rx[i][e] = pp2_ldg<float>(xb, xoff[i] + (uint32_t)e * rs);
+    for (int e = 4 * h; e < 4 * h + 4; ++e) {
+      uint32_t er = (uint32_t)e * rs;
+      if constexpr (SK) {
+        // row 0 too as base + 32-bit register offset: as a folded `xoff + 0` the compiler addresses it with a 64-bit
+        // register pair that it keeps (in this form: spills, and reloads behind a vmcnt(0)) across the loop
+        if (e == 0) { er = 0; asm volatile("" : "+s"(er)); }
+      }
+      if constexpr (SK && XOFF_LDS) rx[i][e] = pp2_ldg<float>(xb, xoff_l[i * NT + tid] + er);
+      else rx[i][e] = pp2_ldg<float>(xb, xoff[i] + er);
+    }
     if constexpr (MASK && h == 1) {
       // keep-byte (b, chunk * 4 + k8, t) of this item: its offset is recomputed here (two integer divisions per item and
       // chunk) rather than held in a register across the loop
@@ -242,14 +308,19 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
     bf16x8* dst = Xs + buf * xbuf;
     const int idx = tid + i * NT;
     float v[8];
+    uint32_t keep = MASK ? rk[i] : 0u;
+    // stream-K form: hide that `keep` is a zero-extended byte -- the compiler tests bit 7 as a signed-byte compare against a
+    // ZERO REGISTER, takes the zero from a 64-bit pair that lives (spilled) across the segment loop, and reloads the pair
+    // here, in the main loop, behind a vmcnt(0)
+    if constexpr (MASK && SK) asm("" : "+v"(keep));
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       v[e] = rx[i][e];
-      if constexpr (MASK) v[e] *= ((rk[i] >> e) & 1u) ? dscale : 0.f;
+      if constexpr (MASK) v[e] *= ((keep >> e) & 1u) ? dscale : 0.f;
       else if (F16) v[e] *= xscale;
     }
     bf16x8 hi, lo;
-    if constexpr (F16) dv3_note_range(args.range_ctr, dv3_split8_f16(v, hi, lo)); else pp2_split8(v, hi, lo);
+    if constexpr (F16) dv3_note_range(A.range_ctr, dv3_split8_f16(v, hi, lo)); else pp2_split8(v, hi, lo);
     if (idx < n_items) {
       dst[idx] = hi;
       dst[KB * BNH + idx] = lo;
@@ -261,6 +332,9 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   static_assert(XI == 3 && JT == 3, "three activation items per thread, one per tap's pair of k16 phases");
 
   f32x16 acc[MI][2][NI];   // [row sub-tile][a rows | gate rows][column sub-tile]
+  float zero_ = 0.f;
+  if constexpr (SK) asm volatile("" : "+v"(zero_));   // per segment, opaque: a constant zero block would be hoisted out of
+                                                      // the segment loop and held (spilled) across the main loop
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -268,31 +342,31 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] = zero_;
 
   const int a_off = wm * (MI * 32) + l31;
   const int x_off = wn * (NI * 32) + l31;
 
   // ---- prologue: step 0's panel and chunk 0's tile into buffer 0; then the fetches that run a step / a chunk ahead,
   //      issued in the order the loop issues them ----
-  load_A_unit(0, 0, U0{});
+  load_A_unit(c0, 0, U0{});
   write_A_unit(0, U0{});
-  load_A_unit(0, 0, U1{});
-  load_X_half(0, U0{}, U0{}); load_X_half(0, U0{}, U1{});
-  load_X_half(0, U1{}, U0{}); load_X_half(0, U1{}, U1{});
-  load_X_half(0, U2{}, U0{}); load_X_half(0, U2{}, U1{});
+  load_A_unit(c0, 0, U1{});
+  load_X_half(c0, U0{}, U0{}); load_X_half(c0, U0{}, U1{});
+  load_X_half(c0, U1{}, U0{}); load_X_half(c0, U1{}, U1{});
+  load_X_half(c0, U2{}, U0{}); load_X_half(c0, U2{}, U1{});
   write_A_unit(0, U1{});
   write_X_item(0, U0{});
   write_X_item(0, U1{});
   write_X_item(0, U2{});
   __syncthreads();
   {
-    const int c1 = min(1, nchunks - 1);
-    if (ABL != 11) load_A_unit(0, 1, U0{});           // unit 0 of step 1's panel: stored by the first LOAD phase
-    load_X_half(c1, U0{}, U0{});
-    load_X_half(c1, U0{}, U1{});
-    load_X_half(c1, U1{}, U0{}); load_X_half(c1, U1{}, U1{});
-    load_X_half(c1, U2{}, U0{}); load_X_half(c1, U2{}, U1{});
+    const int cp = min(c0 + 1, c1 - 1);
+    if (!DMA_A) load_A_unit(c0, 1, U0{});          // unit 0 of step 1's panel: stored by the first LOAD phase
+    load_X_half(cp, U0{}, U0{});
+    load_X_half(cp, U0{}, U1{});
+    load_X_half(cp, U1{}, U0{}); load_X_half(cp, U1{}, U1{});
+    load_X_half(cp, U2{}, U0{}); load_X_half(cp, U2{}, U1{});
   }
 
   // ---- ping-pong main loop: waves w and w+4 share a SIMD and run the same phase sequence one phase apart ----
@@ -306,16 +380,17 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   const int late = wave >> 2;
   stamp();                               // slot 1: prologue done
   if (late) __syncthreads();
-  for (int c = 0; c < nchunks; ++c) {
-    const bf16x8* XsH = Xs + (c & 1) * xbuf;
+  for (int c = c0; c < c1; ++c) {
+    const int cr = c - c0;                           // buffer parities count from the segment's first chunk
+    const bf16x8* XsH = Xs + (cr & 1) * xbuf;
     const bf16x8* XsL = XsH + KB * BNH;
-    const int cx = min(c + 2, nchunks - 1);          // the chunk fetched during this one (the tail re-fetches the last)
-    const bool last_chunk = c + 1 == nchunks;
+    const int cx = min(c + 2, c1 - 1);               // the chunk fetched during this one (the tail re-fetches the last)
+    const bool last_chunk = c + 1 == c1;
 #pragma unroll
     for (int q = 0; q < 2 * JT; ++q) {
       constexpr int dummy = 0; (void)dummy;
       const int j = q >> 1, s = q & 1;
-      const int cur = (c * JT + j) & 1;
+      const int cur = (cr * JT + j) & 1;
       const bf16x8* AsH = As + cur * (2 * KB * BM);
       const bf16x8* AsL = AsH + KB * BM;
       const bool fix = (need >> j) & 1u;
@@ -331,9 +406,9 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
         if (jn >= JT) { jn = 0; cn = c + 1; }
         int j2 = jn + 1, c2 = cn;
         if (j2 >= JT) { j2 = 0; c2 = cn + 1; }
-        if (cn >= nchunks) { cn = c; jn = j; }          // past the end: re-fetch the current panel
-        if (c2 >= nchunks) { c2 = c; j2 = j; }
-        if constexpr (ABL == 11) {
+        if (cn >= c1) { cn = c; jn = j; }               // past the end: re-fetch the current panel
+        if (c2 >= c1) { c2 = c; j2 = j; }
+        if constexpr (DMA_A) {
           // both units of the NEXT step's panel by LDS-DMA in the step's first phase: their buffer (cur ^ 1) was last
           // read in the previous step and is first read two LOAD phases from now (the buffer of the step after is
           // still being read during this one, so nothing can be sent there yet)
@@ -352,11 +427,11 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
         // activation item j of the next chunk: convert + store in the tap's first phase, fetch its halves for the
         // chunk after in the tap's two phases
         constexpr bool WX = ABL != 8, LX = ABL != 6;      // timing-only ablations: no conversion + store / no fetch
-        if (q == 0) { if (WX) write_X_item((c + 1) & 1, U0{}); if (LX) load_X_half(cx, U0{}, U0{}); }
+        if (q == 0) { if (WX) write_X_item((cr + 1) & 1, U0{}); if (LX) load_X_half(cx, U0{}, U0{}); }
         if (q == 1) { if (LX) load_X_half(cx, U0{}, U1{}); }
-        if (q == 2) { if (WX) write_X_item((c + 1) & 1, U1{}); if (LX) load_X_half(cx, U1{}, U0{}); }
+        if (q == 2) { if (WX) write_X_item((cr + 1) & 1, U1{}); if (LX) load_X_half(cx, U1{}, U0{}); }
         if (q == 3) { if (LX) load_X_half(cx, U1{}, U1{}); }
-        if (q == 4) { if (WX) write_X_item((c + 1) & 1, U2{}); if (LX) load_X_half(cx, U2{}, U0{}); }
+        if (q == 4) { if (WX) write_X_item((cr + 1) & 1, U2{}); if (LX) load_X_half(cx, U2{}, U0{}); }
         if (q == 5) { if (LX) load_X_half(cx, U2{}, U1{}); }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -434,8 +509,88 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   }
   stamp();                               // main loop left
 
+  bool run_tail = true;
+  if constexpr (SK) {
+    constexpr int ACC = MI * 2 * NI * 16;            // accumulator registers per thread (128)
+    float* const ws = A.sk_ws;
+    int* const flags = A.sk_flags;
+    if (c0 != 0) {
+      // a tile another workgroup began: hand the accumulators over.  Image [32 groups of 4 registers][512 threads][4]:
+      // one 16-byte store / load per thread and group, consecutive threads consecutive (layout-agnostic)
+      char* dst = reinterpret_cast<char*>(ws) + ((size_t)pid * (ACC * NT) + (size_t)tid * 4) * 4;
+      if (!(A.sk_abl & 1))
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              typedef float f32x4_ __attribute__((ext_vector_type(4)));
+              const f32x4_ v4 = {acc[mi][h][ni][r4 * 4], acc[mi][h][ni][r4 * 4 + 1], acc[mi][h][ni][r4 * 4 + 2], acc[mi][h][ni][r4 * 4 + 3]};
+              const char* d4 = dst + (size_t)((((mi * 2 + h) * NI + ni) * 4 + r4) * NT) * 16;
+              asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(d4), "v"(v4) : "memory");
+            }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // The consumer may sit on another XCD (its own L2).  The image goes out as system-scope stores (sc0 sc1: written
+      // through to the memory side) and only their completion is awaited before the flag -- an agent-scope RELEASE fence instead
+      // would write back the whole L2 of this XCD (buffer_wbl2), once per wave, and the matching ACQUIRE would invalidate
+      // the consumer's: the first build of this form lost 30-70 us per launch to exactly that.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flags + pid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      run_tail = false;
+    } else if (c1 < nchunks) {
+      // this workgroup began the tile: add the parts of the workgroups that follow it (their FIRST segments, finished
+      // long before this one -- the last of this workgroup's range), in workgroup order (deterministic sum)
+      for (int w2 = pid + 1; w2 < A.n_blocks; ++w2) {
+        const int s2 = w2 * sk_base + min(w2, sk_rem);
+        if (s2 >= (tile + 1) * nchunks) break;
+        if (tid == 0 && !(A.sk_abl & 4))
+          while (__hip_atomic_load(flags + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // the image comes in by LDS-DMA (global_load_lds_dwordx4, sc0 sc1: read at the memory side), 16 loads per thread in
+        // flight and no staging registers, in two halves of 128 KB (every LDS read of the main loop is behind the barrier
+        // above); each lane reads back the 16 bytes the DMA put at its own slot
+        const char* src = reinterpret_cast<const char*>(ws) + ((size_t)w2 * (ACC * NT) + (size_t)tid * 4) * 4;
+        typedef const __attribute__((address_space(1))) void* gptr_;
+        typedef __attribute__((address_space(3))) void* lptr_;
+        if (!(A.sk_abl & 2))
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int jq = 0; jq < 16; ++jq) {
+            const int qg = half * 16 + jq;
+            __builtin_amdgcn_global_load_lds((gptr_)(src + (size_t)(qg * NT) * 16), (lptr_)(smem_raw + (jq * NT + wave * 64) * 16), 16, 0, 17);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int jq = 0; jq < 16; ++jq) {
+            const int qg = half * 16 + jq;
+            typedef float f32x4_ __attribute__((ext_vector_type(4)));
+            const f32x4_ t4 = *reinterpret_cast<const f32x4_*>(smem_raw + (jq * NT + tid) * 16);
+            const int blk = qg >> 2, r4 = qg & 3;
+            const int mi = blk / (2 * NI), h = (blk / NI) & 1, ni = blk % NI;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mi][h][ni][r4 * 4 + e] += t4[e];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the second half lands in the same slots
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + w2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+    }
+  }
+
   // ---- fused tail (conv_common.h), one 32-row sub-tile at a time ----
-  if (ABL != 3 || acc[0][0][0][0] + acc[1][1][1][7] == 1.2345e30f) {
+  // Inside the segment loop of the stream-K form the tail reads the descriptor through an opaque pointer: its ~40
+  // scalar fields are loop invariant, and hoisted out of the segment loop they would be live (and spilled) across the
+  // main loop.
+  const ConvArgs& AT = *dv3_opaque_args<SK>(&args);
+  const dv3_conv_desc& pt = AT.d;
+  if (run_tail && (ABL != 3 || acc[0][0][0][0] + acc[1][1][1][7] == 1.2345e30f)) {
     if constexpr (F16) {   // the accumulators carry 2^(weight shift + activation shift) x the result
       constexpr float kInv = 1.0f / (float)(1 << (DV3_F16_WEIGHT_SHIFT + DV3_F16_ACT_SHIFT));
 #pragma unroll
@@ -458,7 +613,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
       bcol[ni] = n / T;
       tcol[ni] = n - bcol[ni] * T;
     }
-    if (ABL != 10 && dv3_wide_epilogue_ok(p, args.wide)) {
+    if (ABL != 10 && dv3_wide_epilogue_ok(pt, AT.wide)) {
       // 16-byte epilogue through LDS (conv_common.h): every LDS read of the main loop is behind the last barrier this
       // wave passed, so the whole allocation is free; each wave transposes in its own 8.5 KB
       float* wl = reinterpret_cast<float*>(smem_raw) + wave * (DV3_WIDE_LDS / 4);
@@ -466,22 +621,27 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int row0 = wm * (MI * 32) + mi * 32;
-        conv_epilogue_wide_block<BM, BMH>(p, acc[mi][0], mt, row0, 0, lane, nw0, Ntot, wl);
-        conv_epilogue_wide_block<BM, BMH>(p, acc[mi][1], mt, row0, 1, lane, nw0, Ntot, wl);
+        conv_epilogue_wide_block<BM, BMH>(pt, acc[mi][0], mt, row0, 0, lane, nw0, Ntot, wl);
+        conv_epilogue_wide_block<BM, BMH>(pt, acc[mi][1], mt, row0, 1, lane, nw0, Ntot, wl);
       }
     } else {
-      conv_epilogue<BM, BMH, NI, 0, false>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
-      conv_epilogue<BM, BMH, NI, 0, false>(p, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+      conv_epilogue<BM, BMH, NI, 0, false>(pt, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+      conv_epilogue<BM, BMH, NI, 0, false>(pt, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
     }
   }
   stamp();                               // tail stores issued
+  if constexpr (SK) {
+    seg_u += c1 - c0;
+    __syncthreads();                     // the next segment's prologue overwrites the LDS the wide tail used
+  }
+  } while (SK && seg_u < seg_end);
 }
 
-template <bool MASK, bool F16, int ABL = 0>
+template <bool MASK, bool F16, int ABL = 0, bool SK = false>
 int launch_pp2(const ConvArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_pp2_kernel<MASK, F16, ABL>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_pp2_kernel<MASK, F16, ABL, SK>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_gemm_pp2: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -489,7 +649,7 @@ int launch_pp2(const ConvArgs& a, size_t lds, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_gemm_pp2_kernel<MASK, F16, ABL>), dim3(a.n_blocks), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_pp2_kernel<MASK, F16, ABL, SK>), dim3(a.n_blocks), dim3(NT), lds, st, a);
   return dv3_check_launch("conv_gemm_pp2");
 }
 
@@ -501,6 +661,31 @@ int dv3_pp2_read_stamps(void* dst, int64_t bytes) {
 }
 extern int g_x3_wide;
 int g_pp2_abl = 0;   // dv3_debug_set(13, v): timing-only ablations of the unmasked kernel (1 no MFMAs, 2 no staging, 3 no tail)
+
+// Stream-K (round 4).  A 256 x 256 tile grid rarely divides the 256 CUs: the encoder layers of the benchmark step are 152
+// tiles (41 % of the chip idle for the whole launch), the 512-channel converter layers 808 (3.16 rounds: the last one a
+// sixth full), the decoder's 102.  With a caller-provided workspace (dv3_conv_desc.sk_ws) the launch is instead ONE
+// workgroup per CU, each walking an equal share of the (tile, 32-channel chunk) units; a tile cut between workgroups
+// is summed by the one that holds its first chunk.  Taken when the share (+ g_pp2_sk_overhead chunks for the extra
+// prologue, the hand-over and the wait) is below g_pp2_sk_gain % of the tile-per-workgroup schedule's chunks per CU.
+// Results differ from the tile-per-workgroup launch by the fp32 summation order of the cut tiles only (deterministic:
+// the cut is a function of the shape).
+int g_pp2_sk = 1;            // dv3_debug_set(22, v): 0 never, 1 by the rule above (forward launches), 2 whenever a workspace is given,
+                             // 3 by the rule in both directions
+int g_pp2_sk_overhead = 2;   // dv3_debug_set(23, v)
+int g_pp2_sk_gain = 80;      // dv3_debug_set(24, v)
+int g_pp2_sk_abl = 0;        // dv3_debug_set(26, v): timing-only ablations (1 no hand-over stores, 2 no hand-over loads, 4 no wait)
+static int pp2_cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+int64_t dv3_pp2_sk_ws_bytes() { return (int64_t)pp2_cu_count() * (128 * NT * 4 + 64); }
+extern "C" int dv3_conv_streamk_ws_bytes(void) { return (int)dv3_pp2_sk_ws_bytes(); }
 
 // Shapes this kernel takes (called by dv3_conv_gemm_bf16x3_dispatch): three-term split operands, fp32 (B, C, T)
 // activations, dropout as keep-bytes.  Returns 1 when not eligible.
@@ -527,6 +712,33 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   a.n_blocks = (int)nb;
   g_dv3_last_conv = (f16 ? 5000 : 3000) + 100 + 1;     // tile id 10, ping-pong
   const bool mask = d->xmask_c8 != nullptr;
+  {
+    const int P = pp2_cu_count(), S = d->Cin / BKC;
+    const int64_t units = nb * S;
+    const int64_t dp = dv3_cdiv64(nb, P) * S, sk = dv3_cdiv64(units, P) + g_pp2_sk_overhead;
+    const bool ws_ok = d->sk_ws && d->sk_ws_bytes >= dv3_pp2_sk_ws_bytes() && units < (1ll << 30);
+    // Forward launches only by default (g_pp2_sk 1): the input-gradient launches of a training step run beside the
+    // weight-gradient stream, whose workgroups take the CUs a short grid leaves idle -- there the one-workgroup-per-CU
+    // form gains nothing for the step (measured: forward alone -1.7 %, whole step +-0.1 % with both directions in this
+    // form, scripts/r4_sk_step_ab.py).  3 = both directions.
+    const bool dir_ok = d->mode != DV3_EPI_DGRAD || g_pp2_sk >= 2;
+    if (ws_ok && dir_ok && g_pp2_sk && (S & (S - 1)) == 0 && (a.m_tiles & (a.m_tiles - 1)) == 0 && units >= 2 * P && (g_pp2_sk == 2 || sk * 100 < dp * g_pp2_sk_gain)) {
+      if (lds + XI * NT * 4 > 160 * 1024) return 1;      // (the offsets table of the stream-K form; never with dil <= 27)
+      a.sk_abl = g_pp2_sk_abl;
+      a.sk_units = (int)units;
+      a.sk_base = (int)(units / P);
+      a.sk_rem = (int)(units % P);
+      a.sk_shift = __builtin_ctz((unsigned)S);
+      a.sk_mshift = __builtin_ctz((unsigned)a.m_tiles);
+      a.n_blocks = P;
+      a.sk_flags = reinterpret_cast<int*>(d->sk_ws);
+      a.sk_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(d->sk_ws) + (size_t)P * 64);
+      g_dv3_last_conv += 1;                            // ...102: stream-K form
+      const size_t lds_sk = lds + XI * NT * 4;
+      if (f16) return mask ? launch_pp2<true, true, 0, true>(a, lds_sk, st) : launch_pp2<false, true, 0, true>(a, lds_sk, st);
+      return mask ? launch_pp2<true, false, 0, true>(a, lds_sk, st) : launch_pp2<false, false, 0, true>(a, lds_sk, st);
+    }
+  }
 #ifdef DV3_EXPERIMENTS
   if (g_pp2_abl && !mask && f16) {
     switch (g_pp2_abl) {

@@ -601,8 +601,32 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
         # the image carries its operand type (split_pack / pack_weights tag it): scaled fp16 hi/lo or bf16
         d.split_terms = CONSTS["DV3_SPLIT_F16X3"] if getattr(a_split, "_dv3_f16", False) else \
             (1 if _gemm_mode == "bf16" else 0)
+    if a_split is not None and J == 3 and d.split_terms != 1 and (tile_hint == 0 or streamk == "force"):
+        ws = _streamk_ws(y.device)
+        if ws is not None:
+            d.sk_ws, d.sk_ws_bytes = ws
     _lib.call("dv3_conv_gemm_f32", ctypes.byref(d), _stream())
     return y
+
+
+# stream-K workspaces of the 256 x 256 tap-GEMM kernels (include/dv3hip.h: dv3_conv_desc.sk_ws), one per (device, stream):
+# launches that share one must be ordered, which launches on one stream are.  Allocated and zeroed on first use by the
+# stream that will use it (inside a graph capture: from the capture's pool, with the zeroing as a node).  DV3_STREAMK=0
+# turns the form off.
+streamk = _os.environ.get("DV3_STREAMK", "1") not in ("0", "")     # "force": also with a forced tile (scripts)
+_sk_ws = {}
+
+
+def _streamk_ws(device):
+    if not streamk or _stream_override.handle is not None:
+        return None
+    key = (device.index, _stream())
+    e = _sk_ws.get(key)
+    if e is None:
+        n = int(_lib.lib().dv3_conv_streamk_ws_bytes())
+        t = torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
+        e = _sk_ws[key] = (t.data_ptr(), n, t)
+    return e[0], e[1]
 
 
 def _conv_gemm_c8(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J, dil, padL, mode, Cg, bias, spk, spk_strides, r, r2,

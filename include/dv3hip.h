@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 35
+#define DV3_ABI_VERSION 36
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -139,6 +139,15 @@ typedef struct dv3_conv_desc {
                                                 (dv3_mask_bits_to_c8); applied while staging, 1/(1-p) = drop_scale in
                                                 the epilogue.  NULL = no dropout.                                     */
   const uint8_t* ymask_c8;                   /* DGRAD with DV3_IO_OUT_C8: keep-bytes over the output rows            */
+  void* sk_ws;                               /* optional stream-K workspace (dv3_conv_streamk_ws_bytes() bytes, its first
+                                                4 KiB zero before the first launch that uses it; the launches leave them
+                                                zero).  With it the 256 x 256 tap-GEMM kernels may run as ONE workgroup
+                                                per CU over equal shares of (tile, 32-channel chunk) units instead of one
+                                                tile per workgroup -- for grids that do not divide the CUs (152 tiles, 808
+                                                tiles ...).  Launches that share a workspace must be ordered (same
+                                                stream).  NULL = one tile per workgroup.  Results differ between the
+                                                two forms by fp32 summation order only.                              */
+  int64_t sk_ws_bytes;
 } dv3_conv_desc;
 #define DV3_IO_IN_BF16 1
 #define DV3_IO_OUT_BF16 2
@@ -157,6 +166,9 @@ typedef struct dv3_conv_desc {
  */
 #define DV3_IO_OUT_C8 16
 int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream);
+/* size in bytes of the stream-K workspace (dv3_conv_desc.sk_ws) on the current device: one accumulator image per CU
+ * (128 registers x 512 threads x 4 bytes) behind a 64-byte flag slot per CU                                         */
+int dv3_conv_streamk_ws_bytes(void);
 
 /* fp32 (B,C,T) <-> c8 converters (stack entry / exit and their gradients); x strides in elements.            */
 int dv3_to_c8_f32(const float* x, int64_t x_bs, int64_t x_rs, uint16_t* out, int32_t B, int32_t C, int32_t T, void* stream);

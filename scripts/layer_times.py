@@ -5,7 +5,8 @@ import sys, os, collections
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from deepvoice3_pytorch_amd import builder, train_step, ops
+from deepvoice3_pytorch_amd import builder, train_step, ops, _lib
+_L = _lib.lib()
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda:0")
@@ -30,6 +31,7 @@ def timed(fn, key, flops, *a, **k):
     out = fn(*a, **k)
     e1.record()
     torch.cuda.synchronize()
+    key = key + ("v%d" % _L.dv3_debug_get(10),)
     r = rec[key]
     r[0] += 1; r[1] += e0.elapsed_time(e1) * 1e3; r[2] += flops
     return out
@@ -53,6 +55,6 @@ trainer.step(batch)
 torch.cuda.synchronize()
 tot = sum(r[1] for r in rec.values())
 print("GEMM launches %d, total %.2f ms" % (sum(r[0] for r in rec.values()), tot / 1e3))
-print("%-62s %5s %9s %8s %7s" % ("kind dir B Cin M T J dil arith flags", "n", "total us", "avg us", "TF/s"))
+print("%-70s %5s %9s %8s %7s" % ("kind dir B Cin M T J dil arith flags", "n", "total us", "avg us", "TF/s"))
 for key, r in sorted(rec.items(), key=lambda kv: -kv[1][1]):
-    print("%-62s %5d %9.0f %8.1f %7.1f" % (" ".join(str(v) for v in key), r[0], r[1], r[1] / r[0], r[2] / r[1] / 1e6))
+    print("%-70s %5d %9.0f %8.1f %7.1f" % (" ".join(str(v) for v in key), r[0], r[1], r[1] / r[0], r[2] / r[1] / 1e6))

@@ -628,3 +628,56 @@ def test_256x256_k16_pingpong_tap_gemm_equals_the_128_wide_kernels(dev, gemm_mod
         ops.conv_gemm(gm, None, pk.ldb, 0, y=dx, tile_hint=hint, **dkw)
         dxs.append(dx)
     assert torch.equal(dxs[0], dxs[1])
+
+
+@pytest.mark.parametrize("B,C,T,d,masked", [(64, 512, 150, 1, True), (64, 512, 150, 27, False), (48, 256, 201, 3, True),
+                                            (24, 256, 410, 1, False)])
+def test_stream_k_form_of_the_256x256_tap_gemm(dev, gemm_mode, B, C, T, d, masked):
+    """csrc/conv_gemm_pp2.hip, stream-K form (one workgroup per CU over equal shares of (tile, 32-channel chunk) units, a cut
+    tile summed by the workgroup that holds its first chunk): same operands, same products, fp32 partial sums added in
+    another order -- within 2e-6 of the tile-per-workgroup form relative to the output's range, run-to-run bit identical
+    (the cut is a function of the shape), flags left zero for the next launch (three launches on one workspace), forward
+    (Conv1dGLU with the pre-gate save, dropout as keep-bytes; modules.py:145-164) and input-gradient form.  The first
+    shape is the encoder layer of the benchmark step (152 tiles on 256 CUs), the last a grid smaller than the chip."""
+    if gemm_mode == "f32":
+        pytest.skip("split-operand kernel test")
+    from deepvoice3_pytorch_amd import ops, _lib
+    L = _lib.lib()
+    k = 3
+    torch.manual_seed(0)
+    x = torch.randn(B, C, T, device=dev)
+    v = torch.randn(2 * C, C, k, device=dev) * math.sqrt(4.0 * 0.95 / (k * C))
+    g = v.reshape(2 * C, -1).norm(dim=1).view(-1, 1, 1).clone()
+    bias = torch.randn(2 * C, device=dev) * 0.1
+    pk = ops.pack_weights(v, g, glu_cg=C, need_bwd=True)
+    bits = rs = kb = None
+    if masked:
+        ops.dropout_state.manual_seed(3)
+        bits, rs, kb = ops.dropout_bits_keep(B, C, T, 0.05, dev)
+    kw = dict(B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d, padL=d, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x, residual=1,
+              a_split=pk.fwd_s, xmask=bits, xmask_rs=rs or 0, xmask_c8=kb, drop_scale=1 / 0.95 if masked else 1.0, tile_hint=30)
+    gm = torch.randn(B, 2 * C, T, device=dev)
+    dkw = dict(B=B, Cin=2 * C, Tin=T, M=C, Tout=T, J=k, dil=d, padL=(k - 1) * d - d, mode=ops.EPI_DGRAD, r=x, r_scale=0.7071,
+               ymask=bits, ymask_rs=rs or 0, drop_scale=1 / 0.95 if masked else 1.0, a_split=pk.bwd_s, tile_hint=30)
+    prev = ops.streamk
+    ops.streamk = "force"
+    try:
+        res = {}
+        for sk in (0, 2, 2, 2):
+            L.dv3_debug_set(22, sk)
+            y, ab, dx = torch.empty(B, C, T, device=dev), torch.empty(B, 2 * C, T, device=dev), torch.empty(B, C, T, device=dev)
+            ops.conv_gemm(x, None, pk.lda, pk.a_half, y=y, ab=ab, **kw)
+            vf = L.dv3_debug_get(10)
+            ops.conv_gemm(gm, None, pk.ldb, 0, y=dx, **dkw)
+            vd = L.dv3_debug_get(10)
+            res.setdefault(sk, []).append((y, ab, dx, vf % 1000, vd % 1000))
+    finally:
+        L.dv3_debug_set(22, 1)
+        ops.streamk = prev
+    torch.cuda.synchronize()
+    (y0, ab0, dx0, vf0, vd0), sks = res[0][0], res[2]
+    assert vf0 == 101 and vd0 == 101 and sks[0][3] == 102 and sks[0][4] == 102
+    for (y1, ab1, dx1, _, _) in sks[1:]:
+        assert torch.equal(y1, sks[0][0]) and torch.equal(ab1, sks[0][1]) and torch.equal(dx1, sks[0][2])
+    for a, b in ((y0, sks[0][0]), (ab0, sks[0][1]), (dx0, sks[0][2])):
+        assert float((a - b).abs().max()) < 2e-6 * float(a.abs().max())
