@@ -672,6 +672,7 @@ int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
   return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3>(a, lds, st);
 }
 
+int g_x3_j1_flat = 1;   // dv3_debug_set(27, v)
 int g_x3_rel2 = 112;   // dv3_debug_set(9, v): relative cost (percent) of the 128x64 tile in the picker below
 // bf16x3 tile choice: padded work over the FLAT column axis, weight-panel traffic penalised
 // (a block re-reads its A panel every K step, so narrow column tiles starve the matrix pipe).
@@ -696,7 +697,12 @@ const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
     // 8-wave 256-wide tiles (one workgroup per CU): less weight-panel traffic per MFMA; the
     // 128-row-per-wave tile (7, one wave per SIMD) measured slower everywhere: opt-in only (hint 27)
     static const double kRel[10] = {0, 1.0, 1.12, 2.0, 2.2, 1.8, 2.0, 9.9, 0.93, 0.87};
-    const double rel = c.id == 2 ? g_x3_rel2 * 0.01 : kRel[c.id];
+    double rel = c.id == 2 ? g_x3_rel2 * 0.01 : kRel[c.id];
+    // 1 x 1 convolutions / Linear layers with K <= 512 (8-16 k32 steps per tile): prologue and tail dominate and the wide
+    // tiles' staging advantage is gone -- measured per unit of modeled work the 128 x 64, 128 x 128, 256 x 128 and
+    // 128 x 256 tiles cost the same (scripts/small_gemm_tiles.py: with the J = 3 weights the picker took the 128 x 256
+    // tile for 64 x 804 columns x 512 rows at 135 us where the 128 x 64 tile runs 107), so only the rounds decide
+    if (g_x3_j1_flat && d->J == 1 && d->Cin <= 512 && (c.id == 1 || c.id == 2 || c.id == 8 || c.id == 9)) rel = 1.0;
     const double cost = rounds * BM * BN * rel;
     if (!best || cost < best_cost) {
       best = &c;
@@ -797,6 +803,7 @@ extern "C" int dv3_debug_set(int what, int value) {
   if (what == 24) g_pp2_sk_gain = value;
   if (what == 25) g_x3_pp2_sk_units = value;
   if (what == 26) g_pp2_sk_abl = value;
+  if (what == 27) g_x3_j1_flat = value;
   if (what == 14) g_x3_prio = value;
   if (what == 18) g_x3_wide = value;
   if (what == 15) g_wgrad_prio = value;
