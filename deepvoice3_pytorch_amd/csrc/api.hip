@@ -163,6 +163,8 @@ extern "C" int dv3_sizeof(const char* name) {
   DV3_SZ(dv3_decode_entry);
   DV3_SZ(dv3_decode_program);
   DV3_SZ(dv3_attn_fwd_desc);
+  DV3_SZ(dv3_spk_layer);
+  DV3_SZ(dv3_spk_desc);
 #undef DV3_SZ
   return -1;
 }

@@ -782,7 +782,7 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
 }
 
 extern int g_wgrad_tile, g_wgrad_prio, g_wgrad_t2_abl, g_wgrad_taps2_default;   // wgrad_gemm_bf16x3.hip, wgrad_taps2.hip
-extern int g_wgrad_c8_pf2;                                                       // wgrad_c8.hip
+extern int g_wgrad_c8_pf2, g_spk_abl;                                                       // wgrad_c8.hip
 int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 int dv3_c8pp_debug_set(int what, int value);     // conv_c8pp.hip
 extern "C" int dv3_debug_set(int what, int value) {
@@ -804,6 +804,7 @@ extern "C" int dv3_debug_set(int what, int value) {
   if (what == 25) g_x3_pp2_sk_units = value;
   if (what == 26) g_pp2_sk_abl = value;
   if (what == 27) g_x3_j1_flat = value;
+  if (what == 28) g_spk_abl = value;
   if (what == 14) g_x3_prio = value;
   if (what == 18) g_x3_wide = value;
   if (what == 15) g_wgrad_prio = value;

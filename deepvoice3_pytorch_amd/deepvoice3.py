@@ -43,6 +43,25 @@ def _drop_speaker_embed(speaker_embed, T, p, training, site):
     return bct.transpose(1, 2)
 
 
+def _fuse_speaker_biases(speaker_embed_btc, modules):
+    """Training with dropout on the expanded speaker embedding (deepvoice3.py:78-81, 292-294): the per-frame biases
+    softsign(speaker_proj(e)) (modules.py:158-162) of every Conv1dGLU in `modules` -- the layers that share this dropped
+    embedding -- in ONE launch (ops.speaker_bias_block); Conv1dGLU.speaker_bias picks them up from the tensor."""
+    if speaker_embed_btc is None or not ops.fused_speaker_bias or not speaker_embed_btc.is_cuda:
+        return
+    if speaker_embed_btc.stride(1) == 0 or speaker_embed_btc.size(2) > 16:     # constant over time: a (B, C) bias
+        return
+    glus = [m for m in modules if isinstance(m, Conv1dGLU) and m.speaker_proj is not None]
+    if len(glus) < 2:
+        return
+    layers = []
+    for m in glus:
+        v, g = m.speaker_proj.wn_params()
+        layers.append((v, g, m.speaker_proj.bias))
+    outs = ops.speaker_bias_block(speaker_embed_btc.transpose(1, 2), layers)
+    speaker_embed_btc._dv3_block_bias = {id(m): o for m, o in zip(glus, outs)}
+
+
 def _c8_enter(x):
     """bf16 storage (ops.storage_c8: the bf16 GEMM mode): fp32 (B, C, T) -> channel-blocked bf16 at a stack entry"""
     if ops.storage_c8() and not ops.is_c8(x):
@@ -145,6 +164,7 @@ class Encoder(nn.Module):
         if speaker_embed_btc is not None:
             x = x + self._speaker_term(self.speaker_fc1, speaker_embed_btc)
         input_embedding = x
+        _fuse_speaker_biases(speaker_embed_btc, self.convolutions)
         x = _run_stack(self.convolutions, x, speaker_embed_btc)
         keys = x
         if speaker_embed_btc is not None:
@@ -338,6 +358,7 @@ class Decoder(nn.Module):
         x = inputs.transpose(1, 2).contiguous()
         x = ops.dropout(x, self.dropout, self.training, site + ".inputs")
 
+        _fuse_speaker_biases(speaker_embed_btc, list(self.preattention) + list(self.convolutions))
         x = _run_stack(self.preattention, x, speaker_embed_btc, keep_c8=True)
         if ops.is_c8(x) and frame_pos_embed is not None:
             frame_pos_embed = ops.to_c8(frame_pos_embed)
@@ -699,6 +720,14 @@ class Converter(nn.Module):
                                                 "%s.speaker_embed.t%d" % (site, x.size(2)))
         mods = self.convolutions
         n = len(mods)
+        # the Conv1dGLU layers by time resolution (each ConvTranspose1d doubles it; the embedding is dropped anew there)
+        by_t, cur_t = {}, x.size(2)
+        for f in mods:
+            if isinstance(f, _conv.ConvTranspose1d):
+                cur_t *= 2
+            elif isinstance(f, Conv1dGLU):
+                by_t.setdefault(cur_t, []).append(f)
+        _fuse_speaker_biases(speaker_embed_btc, by_t.get(x.size(2), ()))
         i = 0
         x = _c8_enter(x)            # bf16 storage: channel-blocked bf16 between the layers (see _run_stack)
         while i < n:
@@ -706,6 +735,7 @@ class Converter(nn.Module):
             if speaker_embed_btc is not None and speaker_embed_btc.size(1) != x.size(2):
                 speaker_embed_btc = _drop_speaker_embed(speaker_embed, x.size(2), self.dropout, self.training,
                                                         "%s.speaker_embed.t%d" % (site, x.size(2)))
+                _fuse_speaker_biases(speaker_embed_btc, by_t.get(x.size(2), ()))
             last = (i == n - 1)
             if isinstance(f, Conv1dGLU):
                 x = f(x, speaker_embed_btc)

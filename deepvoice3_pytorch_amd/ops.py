@@ -1200,6 +1200,101 @@ class ConvLayerFn(torch.autograd.Function):
         return dx, dv, dg, dbias, dspk, dr, dr2, None, None
 
 
+# ----------------------------------------------------------------------------------------------
+# per-frame speaker biases of a block of Conv1dGLU layers (include/dv3hip.h: dv3_speaker_bias_fwd_f32 / _bwd_f32)
+# ----------------------------------------------------------------------------------------------
+fused_speaker_bias = _os.environ.get("DV3_FUSED_SPK", "1") not in ("0", "")
+_spk_layer_t, _spk_desc_t = STRUCTS["dv3_spk_layer"], STRUCTS["dv3_spk_desc"]
+SPK_MAX_LAYERS = CONSTS["DV3_SPK_MAX_LAYERS"]
+
+
+class SpeakerBiasBlockFn(torch.autograd.Function):
+    """softsign(speaker_proj_l(e)) for the L <= 16 Conv1dGLU layers of a block that share the dropped per-frame speaker
+    embedding e (B, E, T) (modules.py:158-162 with deepvoice3.py:78-81): one launch forward, three backward, instead of
+    six launch-bound launches per layer.  params = (v_1, g_1, bias_1, ..., v_L, g_L, bias_L); -> L tensors (B, C_l, T).
+    Parameter gradients go straight into p.grad when the trainer marked the parameters (`_dv3_grad_inplace`), like
+    ConvLayerFn's."""
+
+    @staticmethod
+    def forward(ctx, e, *params):
+        L = len(params) // 3
+        B, E, T = e.shape
+        if e.stride(2) != 1:
+            e = e.contiguous()
+        layers = (_spk_layer_t * L)()
+        outs = []
+        for l in range(L):
+            v, g, b = params[3 * l:3 * l + 3]
+            C = v.shape[0]
+            if not v.is_contiguous() or v.numel() != C * E:
+                raise RuntimeError("speaker_bias_block: (C, E) contiguous weights expected")
+            o = torch.empty((B, C, T), dtype=torch.float32, device=e.device)
+            y = layers[l]
+            y.v, y.g, y.bias, y.out, y.C = v.data_ptr(), _ptr(g), _ptr(b), o.data_ptr(), C
+            outs.append(o)
+        d = _spk_desc_t()
+        d.e, d.e_bs, d.e_rs, d.B, d.E, d.T, d.n_layers = e.data_ptr(), e.stride(0), e.stride(1), B, E, T, L
+        _lib.call("dv3_speaker_bias_fwd_f32", ctypes.byref(d), layers, _stream())
+        ctx.L = L
+        ctx.save_for_backward(e, *params, *outs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        e, params, outs = saved[0], saved[1:1 + 3 * L], saved[1 + 3 * L:]
+        B, E, T = e.shape
+        leaves = [p for p in params if p is not None]
+        inplace = all(getattr(p, "_dv3_grad_inplace", False) and p.grad is not None and p.requires_grad for p in leaves)
+        layers = (_spk_layer_t * L)()
+        keep, grads = [], []
+        for l in range(L):
+            v, g, b = params[3 * l:3 * l + 3]
+            C = v.shape[0]
+            do = douts[l]
+            if do is None:
+                do = torch.zeros((B, C, T), dtype=torch.float32, device=e.device)
+            elif do.stride(2) != 1 or do.dtype != torch.float32:
+                do = do.float().contiguous()
+            keep.append(do)
+            y = layers[l]
+            y.v, y.g, y.bias, y.out, y.C = v.data_ptr(), _ptr(g), _ptr(b), outs[l].data_ptr(), C
+            y.dout, y.dout_bs, y.dout_rs = do.data_ptr(), do.stride(0), do.stride(1)
+            if inplace:
+                gv, gg, gb = v.grad, (g.grad if g is not None else None), (b.grad if b is not None else None)
+            else:
+                gv = torch.zeros_like(v)
+                gg = torch.zeros_like(g) if g is not None else None
+                gb = torch.zeros_like(b) if b is not None else None
+            y.dv, y.dg, y.dbias = gv.data_ptr(), _ptr(gg), _ptr(gb)
+            grads += [gv, gg, gb]
+        d = _spk_desc_t()
+        d.e, d.e_bs, d.e_rs, d.B, d.E, d.T, d.n_layers = e.data_ptr(), e.stride(0), e.stride(1), B, E, T, L
+        n = _lib.lib().dv3_speaker_bias_bwd_scratch_floats(ctypes.byref(d), layers)
+        if n <= 0:
+            raise RuntimeError("speaker_bias_block: workspace size")
+        scratch = torch.empty(n, dtype=torch.float32, device=e.device)
+        de = torch.empty((B, E, T), dtype=torch.float32, device=e.device)
+        d.de, d.scratch, d.scratch_floats = de.data_ptr(), scratch.data_ptr(), n
+        _lib.call("dv3_speaker_bias_bwd_f32", ctypes.byref(d), layers, _stream())
+        if inplace:
+            for l in range(L):
+                for hook in grad_ready_hooks:
+                    hook(*params[3 * l:3 * l + 3])
+            return (de if ctx.needs_input_grad[0] else None,) + (None,) * (3 * L)
+        return (de if ctx.needs_input_grad[0] else None,) + tuple(grads)
+
+
+def speaker_bias_block(e, layers):
+    """layers: [(v (C, E), g (C, 1) | None, bias (C) | None)] -> [softsign(speaker_proj_l(e))] (B, C_l, T) fp32"""
+    outs = []
+    for i in range(0, len(layers), SPK_MAX_LAYERS):
+        chunk = layers[i:i + SPK_MAX_LAYERS]
+        outs += list(SpeakerBiasBlockFn.apply(e, *[t for lay in chunk for t in lay]))
+    return outs
+
+
 class ConvLayerC8Fn(torch.autograd.Function):
     """ConvLayerFn on bf16 channel-blocked activations (bf16 GEMM mode, BASELINE configs 3/4).  x is a c8 tensor
     or an fp32 (B, C, T) one; the output is c8 when cfg.out_c8 (default: when x is), else fp32 (B, C, T).  With a

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 36
+#define DV3_ABI_VERSION 37
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -338,6 +338,37 @@ typedef struct dv3_wn_multi_entry {
 int dv3_weight_norm_split_pack_multi(const dv3_wn_multi_entry* table_dev, const int32_t* first_row_dev,
                                      const int32_t* first_block_dev, int32_t n_layers, int32_t total_rows,
                                      int32_t total_blocks, int32_t max_taps, void* stream);
+
+/*
+ * Per-frame speaker biases of a BLOCK of Conv1dGLU layers in one launch (forward) / three (backward).
+ * Replaces, for every Conv1dGLU of a multi-speaker model in training, modules.py:158-162
+ *     softsign = F.softsign(self.speaker_proj(speaker_embed)); a = a + softsign
+ * (speaker_proj = weight-normed Linear(speaker_embed_dim -> C), modules.py:135) and its autograd, where speaker_embed
+ * is the block's expanded and PER-FRAME dropped embedding (deepvoice3.py:78-81, 292-294): one tensor e (B, E, T) for all
+ * layers of the block.  forward: layer[l].out (B, C_l, T) = softsign(bias_l + W_l e), W_l = g_l v_l / ||v_l|| by rows --
+ * the tensor a layer's tap-GEMM then reads through dv3_conv_desc.spk.  backward: from layer[l].dout (the gradient of
+ * that tensor, element strides dout_bs / dout_rs) and the saved out: dv_l, dg_l, dbias_l += (weight-norm backward
+ * included) and de (B, E, T) = the gradient of e, overwritten.  Sums in a fixed order (bit-identical run to run).
+ * `layers` is HOST memory (n_layers <= DV3_SPK_MAX_LAYERS entries, copied into the kernel arguments), E <= 16.
+ * Workspace of the backward: dv3_speaker_bias_bwd_scratch_floats() floats.
+ */
+#define DV3_SPK_MAX_LAYERS 16
+typedef struct dv3_spk_layer {
+  const float* v; const float* g; const float* bias;   /* (C, E) direction, (C) magnitude or NULL, (C) bias or NULL */
+  float* out;                                           /* (B, C, T) fp32, contiguous: written by fwd, read by bwd    */
+  const float* dout; int64_t dout_bs; int64_t dout_rs;  /* bwd */
+  float* dv; float* dg; float* dbias;                   /* bwd, += */
+  int32_t C;
+} dv3_spk_layer;
+typedef struct dv3_spk_desc {
+  const float* e; int64_t e_bs; int64_t e_rs;           /* (B, E, T) fp32, element strides (frames contiguous)       */
+  float* de;                                            /* bwd: (B, E, T) fp32 contiguous                             */
+  float* scratch; int64_t scratch_floats;               /* bwd                                                        */
+  int32_t B, E, T, n_layers;
+} dv3_spk_desc;
+int dv3_speaker_bias_fwd_f32(const dv3_spk_desc* d, const dv3_spk_layer* layers, void* stream);
+int dv3_speaker_bias_bwd_scratch_floats(const dv3_spk_desc* d, const dv3_spk_layer* layers);
+int dv3_speaker_bias_bwd_f32(const dv3_spk_desc* d, const dv3_spk_layer* layers, void* stream);
 
 /*
  * Backward of weight norm from wgrad slabs: dW = sum_s slab[s]; dg, dv.

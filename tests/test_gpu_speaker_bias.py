@@ -1,0 +1,110 @@
+# coding: utf-8
+"""Per-frame speaker biases of a block of Conv1dGLU layers in one launch (csrc/speaker_bias.hip, include/dv3hip.h:
+dv3_speaker_bias_fwd_f32 / _bwd_f32) -- replaces, per layer, modules.py:158-162 of the reference
+    softsign = F.softsign(self.speaker_proj(speaker_embed)); a = a + softsign
+with speaker_embed the block's expanded, per-frame dropped embedding (deepvoice3.py:78-81, 292-294).
+(1) the kernels against the same expression in fp64 torch (weight norm included), forward and every gradient;
+(2) a multi-speaker model trained three steps with the fused block path against the per-layer path it replaces."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests.util import load_golden, split_model_fixture, rel_err  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("B,E,T,Cs", [(3, 16, 70, (32, 48)), (2, 16, 300, (256, 64, 20)), (4, 12, 257, (40,)),
+                                      (64, 16, 150, (512,) * 7), (2, 16, 33, tuple(range(8, 8 + 17)))])
+def test_block_kernels_match_fp64_torch(dev, B, E, T, Cs):
+    from deepvoice3_pytorch_amd import ops
+    torch.manual_seed(0)
+    e = (torch.randn(B, T, E, device=dev) * (torch.rand(B, T, E, device=dev) > 0.05)).transpose(1, 2)   # (B, E, T), strided
+    e.requires_grad_(True)
+    layers = []
+    for C in Cs:
+        v = torch.randn(C, E, device=dev, requires_grad=True)
+        g = (torch.rand(C, 1, device=dev) + 0.5).requires_grad_(True)
+        b = (torch.randn(C, device=dev) * 0.1).requires_grad_(True)
+        layers.append((v, g, b))
+    outs = ops.speaker_bias_block(e, layers)
+    douts = [torch.randn(B, 2 * C, T, device=dev)[:, :C, :] for C in Cs]        # strided, as a layer's d(pre-gate) slice
+    torch.autograd.backward(outs, douts)
+    # fp64 reference
+    e64 = e.detach().double().requires_grad_(True)
+    ref_outs, ref_par = [], []
+    for (v, g, b) in layers:
+        v64, g64, b64 = (t.detach().double().requires_grad_(True) for t in (v, g, b))
+        w = g64 * v64 / v64.norm(dim=1, keepdim=True)
+        z = torch.einsum("ce,bet->bct", w, e64) + b64.view(1, -1, 1)
+        ref_outs.append(torch.nn.functional.softsign(z))
+        ref_par.append((v64, g64, b64))
+    torch.autograd.backward(ref_outs, [d.double() for d in douts])
+    for o, r in zip(outs, ref_outs):
+        assert o.shape == r.shape and rel_err(o.detach().cpu(), r.detach().float().cpu()) < 2e-6
+    assert rel_err(e.grad.cpu(), e64.grad.float().cpu()) < 5e-6
+    for (v, g, b), (v64, g64, b64) in zip(layers, ref_par):
+        for t, r in ((v, v64), (g, g64), (b, b64)):
+            assert rel_err(t.grad.cpu(), r.grad.float().cpu()) < 2e-5, (t.shape,)
+    # deterministic sums: a second backward gives the same bits
+    e2 = e.detach().clone().requires_grad_(True)
+    for (v, g, b) in layers:
+        v.grad = g.grad = b.grad = None
+    keep = [t.clone() for t in (e.grad,)]
+    outs2 = ops.speaker_bias_block(e2, layers)
+    torch.autograd.backward(outs2, douts)
+    assert torch.equal(e2.grad, keep[0])
+
+
+def test_multispeaker_training_fused_block_equals_per_layer_path(dev):
+    """three optimisation steps of the multi-speaker fixture model with dropout (the speaker embedding dropped per frame),
+    fused block path against one weight-normed Linear launch chain per layer: same masks, parameters within the distance
+    two roundings of a K = 16 product chain can make (the per-layer path computes it with split-fp16 MFMAs)."""
+    from deepvoice3_pytorch_amd import builder, ops, train_step
+    prev_mode = ops.set_gemm_precision("f16x3")
+    try:
+        fx = load_golden("model_dv3_multispeaker")
+        b, hp, sd, x = split_model_fixture(fx)
+        xg = {k: v.to(dev) for k, v in x.items()}
+        B, Td = x["mel"].shape[0], x["mel"].shape[1]
+        rng = np.random.RandomState(1)
+        y = torch.from_numpy(rng.rand(B, Td * 4, hp["linear_dim"]).astype(np.float32)).to(dev)
+        batch = train_step.Batch(xg["text"], xg["text_positions"], xg["frame_positions"], xg["mel"], y,
+                                 torch.zeros(B, Td, 1, device=dev), x["input_lengths"].numpy(), np.full(B, Td * 4 - 4),
+                                 xg.get("speaker_ids"), 1, 4, dev)
+        cfg = train_step.TrainConfig(max_positions=hp.get("max_positions", 512), initial_learning_rate=2e-3)
+        res = {}
+        for fused in (False, True):
+            ops.fused_speaker_bias = fused
+            m = getattr(builder, b)(**hp)
+            m.load_state_dict(sd)
+            tr = train_step.Trainer(m.to(dev), cfg)
+            losses = []
+            for _ in range(3):
+                ops.dropout_state.manual_seed(7000 + tr.global_step)
+                losses.append(float(tr.step(batch)["loss"]))
+            res[fused] = ({k: v.clone() for k, v in tr.model.state_dict().items()}, losses)
+            tr.close()
+    finally:
+        ops.fused_speaker_bias = True
+        ops.set_gemm_precision(prev_mode)
+    for a, c in zip(res[False][1], res[True][1]):
+        assert abs(a - c) < 2e-5 * abs(a), (res[False][1], res[True][1])
+    worst = 0.0
+    for k in res[False][0]:
+        a, c = res[False][0][k].float(), res[True][0][k].float()
+        moved = float((a - sd[k].to(dev).float()).abs().max())
+        worst = max(worst, float((a - c).abs().max()) / max(moved, 1e-6))
+    assert worst < 2e-2, worst          # parameters agree to 2 % of the distance they moved in three Adam steps
