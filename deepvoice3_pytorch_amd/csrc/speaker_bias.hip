@@ -80,14 +80,14 @@ __global__ __launch_bounds__(NT) void spk_fwd_kernel(const SpkArgs a) {
 //                                                                                            the four partial tiles summed through LDS
 //   d emb [16][256 frames] += W^T [16 x 32 rows] . gp [32 x 256]     wave w: its own 64 frames, accumulators live across the tiles
 // (The first form did both with vector FMAs fed from LDS: 1 MB of LDS reads per tile and workgroup, 11 us per tile.)
-// LDS: gp rows 264 floats apart, the embedding as [frame][20] (conflict-free for the access patterns below).
-constexpr int GPL = NT + 8, EVL = EM + 4;
+// LDS: gp rows 264 floats apart, the embedding as [frame][17] (conflict-free for the access patterns below); the four
+// partial dW tiles go through the gp tile's own storage once it has been consumed: 53 KB, three workgroups per CU.
+constexpr int GPL = NT + 8, EVL = EM + 1;
 template <int ABL>
 __global__ __launch_bounds__(NT) void spk_bwd_kernel(const SpkArgs a, float* __restrict__ part, float* __restrict__ de_l) {
   __shared__ __attribute__((aligned(16))) float Ws[CB * EM];
   __shared__ __attribute__((aligned(16))) float gp[CB * GPL];
   __shared__ __attribute__((aligned(16))) float evs[NT * EVL];
-  __shared__ float red[4 * 16 * 64];
   const dv3_spk_desc& d = a.d;
   const int l = blockIdx.z;
   const dv3_spk_layer& L = a.layer[l];
@@ -171,6 +171,8 @@ __global__ __launch_bounds__(NT) void spk_bwd_kernel(const SpkArgs a, float* __r
         const float bv = l31 <= EM ? evs[f * EVL + l31] : 0.f;
         wacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, wacc, 0, 0, 0);
       }
+      __syncthreads();                       // every wave has read the gp tile for both products
+      float* red = gp;                       // [wave][16 registers][64 lanes] = 16 KB of the tile's 33 KB
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = wacc[r];
       __syncthreads();
