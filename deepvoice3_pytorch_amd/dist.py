@@ -155,6 +155,11 @@ class BucketedAllReduce(object):
     def launch_after(self, bucket_ids, streams):
         """all-reduce `bucket_ids` on the collective stream once everything enqueued on `streams` so far has run
         (the replay of a segmented step: called between two segment launches, never inside a capture)"""
+        if self.side is None:   # CPU / gloo (tests): synchronous
+            for b in bucket_ids:
+                lo, hi, _ = self.buckets[b]
+                dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+            return
         for st in streams:
             ev = torch.cuda.Event()
             ev.record(st)
@@ -166,6 +171,8 @@ class BucketedAllReduce(object):
 
     def join(self, cur=None):
         """the step stream waits for the collective stream (timed when exposed_events is a list)"""
+        if self.side is None:
+            return
         cur = cur or torch.cuda.current_stream()
         timed = self.exposed_events is not None and not torch.cuda.is_current_stream_capturing()
         if timed:

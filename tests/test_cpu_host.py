@@ -243,6 +243,37 @@ def _ddp_worker(rank, world, port, q):
     for i, p in enumerate(params):
         want = 0.0 if i == 3 else (2.0 if i == 1 else float(i + 1)) * tot
         assert torch.allclose(p.grad, torch.full_like(p.grad, want)), (rank, i)
+    # the segmented replay's schedule (train_step.GraphedTrainer): while the step is captured the completed buckets are
+    # only NOTED, segment by segment; the replay then issues exactly those all-reduces from the host after each segment
+    # and the never-completed rest before the optimiser -- every bucket once, same sums as the eager step
+    arena.grad.zero_()
+    comm.arm()
+    ops.SideStream.split_capture = True
+    try:
+        seg_buckets = []
+        for seg in ((4,), (2, 0), (1,)):          # parameter 3 never reports
+            for i in seg:
+                comm._on_inplace_grad(params[i])
+            seg_buckets.append(comm.take_completed())
+    finally:
+        ops.SideStream.split_capture = False
+    comm.disarm()
+    seen = [b for bs in seg_buckets for b in bs]
+    rest = [b for b in range(len(comm.buckets)) if b not in seen]
+    assert len(set(seen)) == len(seen) and rest and not any(comm.launched)
+    for step in range(2):                         # two "replays"
+        arena.grad.zero_()
+        for i, p in enumerate(params):
+            if i != 3:
+                p.grad.add_(float((i + 1) * (rank + 1 + step)))
+        for bs in seg_buckets:
+            if bs:
+                comm.launch_after(bs, ())
+        comm.launch_after(rest, ())
+        comm.join()
+        for i, p in enumerate(params):
+            want = 0.0 if i == 3 else (i + 1) * sum(rr + 1 + step for rr in range(world))
+            assert torch.allclose(p.grad, torch.full_like(p.grad, want)), (rank, i, step)
     q.put((rank, float(arena.grad.sum())))
     dist.destroy_process_group()
 
