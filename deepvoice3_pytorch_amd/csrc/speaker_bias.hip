@@ -108,6 +108,7 @@ __global__ __launch_bounds__(NT) void spk_bwd_kernel(const SpkArgs a, float* __r
     __syncthreads();                         // the previous tile's readers (gp, Ws, red) are done
     stage_w(L, d.E, c0, n, Ws, tid);
     for (int i = n * EM + tid; i < CB * EM; i += NT) Ws[i] = 0.f;       // rows past the layer's last: no contribution
+    const bool c8 = L.dout_c8p != 0;
     // gp tile: wave w loads rows w, w + 4, ...: a lane takes four consecutive frames of a row as ONE 16-byte load per
     // tensor (rows are only 4-byte aligned: T is arbitrary), so the sixteen loads of a thread are all in flight at once
     // -- as 64 four-byte loads the compiler issued them in small batches, one memory round trip each
@@ -123,14 +124,27 @@ __global__ __launch_bounds__(NT) void spk_bwd_kernel(const SpkArgs a, float* __r
         const float* pd = L.dout + (int64_t)b * L.dout_bs + (int64_t)c * L.dout_rs + t0 + f0;
         if (i < n && ABL != 3 && t0 + f0 + 3 < T) {
           yv[r] = *reinterpret_cast<const f32x4u*>(po);
-          dv_[r] = *reinterpret_cast<const f32x4u*>(pd);
+          if (!c8) dv_[r] = *reinterpret_cast<const f32x4u*>(pd);
         } else {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const bool ok = i < n && ABL != 3 && t0 + f0 + k < T;
             yv[r][k] = ok ? po[k] : 1.0f;
-            dv_[r][k] = ok ? pd[k] : 0.f;
+            if (!c8) dv_[r][k] = ok ? pd[k] : 0.f;
           }
+        }
+        if (c8) dv_[r] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};      // the tile first holds (1 - |out|)^2 alone
+      }
+      // c8 gradient (a bf16 tensor [B][c8p][T][8]): this thread's frame of the tile's four channel groups, 16 bytes each
+      typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+      u16x8 raw[CB / 8];
+      if (c8) {
+        const unsigned short* base = reinterpret_cast<const unsigned short*>(L.dout);
+#pragma unroll
+        for (int g = 0; g < CB / 8; ++g) {
+          const bool ok = c0 + 8 * g < C && t < T && ABL != 3;
+          raw[g] = ok ? *reinterpret_cast<const u16x8*>(base + (((int64_t)b * L.dout_c8p + (c0 >> 3) + g) * T + t) * 8)
+                      : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
       }
 #pragma unroll
@@ -140,9 +154,20 @@ __global__ __launch_bounds__(NT) void spk_bwd_kernel(const SpkArgs a, float* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float sg = 1.0f - fabsf(yv[r][k]);
-          g4[k] = dv_[r][k] * sg * sg;
+          g4[k] = dv_[r][k] * (sg * sg);        // same association as the c8 path below (factor first)
         }
         *reinterpret_cast<f32x4*>(gp + i * GPL + f0) = g4;
+      }
+      if (c8) {
+        __syncthreads();                     // the factor tile is complete
+#pragma unroll
+        for (int g = 0; g < CB / 8; ++g)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int i = 8 * g + j;
+            const float dv1 = __builtin_bit_cast(float, (unsigned)raw[g][j] << 16);
+            gp[i * GPL + tid] = i < n ? gp[i * GPL + tid] * dv1 : 0.f;     // only this thread touches (row, its frame)
+          }
       }
     }
     __syncthreads();
@@ -261,6 +286,7 @@ int fill_args(SpkArgs& a, const dv3_spk_desc* d, const dv3_spk_layer* layers, bo
     const dv3_spk_layer& L = layers[l];
     DV3_REQUIRE(L.C >= 1 && L.C <= 2048 && L.v && L.out, "speaker_bias: layer %d: bad arguments", l);
     if (bwd) DV3_REQUIRE(L.dout && L.dv && (L.dg || !L.g), "speaker_bias: layer %d: backward needs dout, dv (, dg)", l);
+    if (bwd && L.dout_c8p) DV3_REQUIRE(L.dout_c8p * 8 >= L.C, "speaker_bias: layer %d: c8 gradient with fewer channels than C", l);
     a.layer[l] = L;
     a.row0[l + 1] = a.row0[l] + L.C;
   }

@@ -1216,8 +1216,9 @@ class SpeakerBiasBlockFn(torch.autograd.Function):
     ConvLayerFn's."""
 
     @staticmethod
-    def forward(ctx, e, *params):
+    def forward(ctx, e, holder, *params):
         L = len(params) // 3
+        ctx.holder = holder
         B, E, T = e.shape
         if e.stride(2) != 1:
             e = e.contiguous()
@@ -1252,15 +1253,20 @@ class SpeakerBiasBlockFn(torch.autograd.Function):
         for l in range(L):
             v, g, b = params[3 * l:3 * l + 3]
             C = v.shape[0]
-            do = douts[l]
-            if do is None:
-                do = torch.zeros((B, C, T), dtype=torch.float32, device=e.device)
-            elif do.stride(2) != 1 or do.dtype != torch.float32:
-                do = do.float().contiguous()
-            keep.append(do)
             y = layers[l]
             y.v, y.g, y.bias, y.out, y.C = v.data_ptr(), _ptr(g), _ptr(b), outs[l].data_ptr(), C
-            y.dout, y.dout_bs, y.dout_rs = do.data_ptr(), do.stride(0), do.stride(1)
+            c8g = ctx.holder.pop(l, None)      # a c8 layer left its pre-gate gradient here (ConvLayerC8Fn.backward)
+            if c8g is not None:
+                keep.append(c8g)
+                y.dout, y.dout_c8p = c8g.data_ptr(), c8g.shape[1]
+            else:
+                do = douts[l]
+                if do is None:
+                    do = torch.zeros((B, C, T), dtype=torch.float32, device=e.device)
+                elif do.stride(2) != 1 or do.dtype != torch.float32:
+                    do = do.float().contiguous()
+                keep.append(do)
+                y.dout, y.dout_bs, y.dout_rs = do.data_ptr(), do.stride(0), do.stride(1)
             if inplace:
                 gv, gg, gb = v.grad, (g.grad if g is not None else None), (b.grad if b is not None else None)
             else:
@@ -1282,8 +1288,8 @@ class SpeakerBiasBlockFn(torch.autograd.Function):
             for l in range(L):
                 for hook in grad_ready_hooks:
                     hook(*params[3 * l:3 * l + 3])
-            return (de if ctx.needs_input_grad[0] else None,) + (None,) * (3 * L)
-        return (de if ctx.needs_input_grad[0] else None,) + tuple(grads)
+            return (de if ctx.needs_input_grad[0] else None, None) + (None,) * (3 * L)
+        return (de if ctx.needs_input_grad[0] else None, None) + tuple(grads)
 
 
 def speaker_bias_block(e, layers):
@@ -1291,8 +1297,26 @@ def speaker_bias_block(e, layers):
     outs = []
     for i in range(0, len(layers), SPK_MAX_LAYERS):
         chunk = layers[i:i + SPK_MAX_LAYERS]
-        outs += list(SpeakerBiasBlockFn.apply(e, *[t for lay in chunk for t in lay]))
+        holder = {}
+        got = SpeakerBiasBlockFn.apply(e, holder, *[t for lay in chunk for t in lay])
+        for l, o in enumerate(got):
+            # a bf16-storage layer that consumes this bias hands its pre-gate gradient (a c8 tensor) over through
+            # `holder` instead of converting its first C channels to an fp32 (B, C, T) tensor for autograd
+            o._dv3_spk_slot = (holder, l)
+        outs += list(got)
     return outs
+
+
+_spk_dummy = {}
+
+
+def _spk_dummy_grad(shape, device):
+    """a zero-stride fp32 stand-in of the given shape (autograd wants a gradient of the bias's shape; the real one travels
+    through SpeakerBiasBlockFn's holder)"""
+    z = _spk_dummy.get(device)
+    if z is None:
+        z = _spk_dummy[device] = torch.zeros(1, dtype=torch.float32, device=device)
+    return z.expand(*shape)
 
 
 class ConvLayerC8Fn(torch.autograd.Function):
@@ -1362,6 +1386,7 @@ class ConvLayerC8Fn(torch.autograd.Function):
             ctx.bits, ctx.bits_rs, ctx.dscale, ctx.keep8 = bits, bits_rs, dscale, keep8
             ctx.x8, ctx.out8 = x8, out8
             ctx.spk_dim = spk.dim() if spk is not None else 0
+            ctx.spk_slot = getattr(spk, "_dv3_spk_slot", None) if spk is not None else None
             ctx.has_r, ctx.has_r2, ctx.has_bias = (r is not None), (r2 is not None), bias is not None
             ctx.save_for_backward(x, v, g, ab if gated else y)
         return y
@@ -1385,6 +1410,10 @@ class ConvLayerC8Fn(torch.autograd.Function):
                 dres, r_scale = dy, rs2
             if ctx.spk_dim == 2:
                 dspk = part[:, :Cg].contiguous()
+            elif ctx.spk_dim == 3 and ctx.spk_slot is not None and fused_speaker_bias:
+                holder, slot = ctx.spk_slot          # the block's backward reads the c8 tensor itself
+                holder[slot] = gmat
+                dspk = _spk_dummy_grad((B, Cg, T), gmat.device)
             elif ctx.spk_dim == 3:      # per-frame speaker bias: the gradient of the `a` half, fp32 (B, Cg, T)
                 dspk = torch.empty((B, Cg, T), dtype=torch.float32, device=gmat.device)
                 _lib.call("dv3_from_c8_head_f32", gmat.data_ptr(), gmat.shape[1], dspk.data_ptr(), Cg * T, T, B, Cg, T,

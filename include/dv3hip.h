@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 37
+#define DV3_ABI_VERSION 38
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -359,6 +359,9 @@ typedef struct dv3_spk_layer {
   const float* dout; int64_t dout_bs; int64_t dout_rs;  /* bwd */
   float* dv; float* dg; float* dbias;                   /* bwd, += */
   int32_t C;
+  int32_t dout_c8p;                                     /* bwd: != 0: `dout` is a c8 bf16 tensor [B][dout_c8p][T][8] (the
+                                                           pre-gate gradient a c8 layer produced: its first C channels
+                                                           are the gradient of this bias); dout_bs / dout_rs unused   */
 } dv3_spk_layer;
 typedef struct dv3_spk_desc {
   const float* e; int64_t e_bs; int64_t e_rs;           /* (B, E, T) fp32, element strides (frames contiguous)       */

@@ -14,7 +14,7 @@ import bench  # noqa: E402
 from deepvoice3_pytorch_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-for gemm in ("bf16", "f16x3"):
+for gemm in (sys.argv[1:] or ["bf16", "f16x3"]):
     r = bench.TrainRun(dev, None, 0, 1, "deepvoice3_vctk", gemm, 64, 150, 800, graph=False)
     acc = {False: [], True: []}
     for f in (True, False):

@@ -108,3 +108,71 @@ def test_multispeaker_training_fused_block_equals_per_layer_path(dev):
         moved = float((a - sd[k].to(dev).float()).abs().max())
         worst = max(worst, float((a - c).abs().max()) / max(moved, 1e-6))
     assert worst < 2e-2, worst          # parameters agree to 2 % of the distance they moved in three Adam steps
+
+
+@pytest.mark.parametrize("B,T,Cs", [(3, 70, (48, 40)), (2, 300, (256, 44)), (64, 201, (256,) * 3)])
+def test_block_backward_reads_a_c8_gradient_in_place_of_an_fp32_one(dev, B, T, Cs):
+    """bf16 storage: a c8 Conv1dGLU hands its pre-gate gradient (a c8 tensor of 2 C channels; the first C are the
+    gradient of the bias) to the block's backward through the holder instead of converting it (dv3_spk_layer.dout_c8p):
+    bit-identical to the fp32 path fed the same bf16-rounded values -- also when C is not a multiple of 8."""
+    from deepvoice3_pytorch_amd import ops
+    E = 16
+    torch.manual_seed(1)
+    e0 = torch.randn(B, E, T, device=dev)
+    base = [(torch.randn(C, E, device=dev), torch.rand(C, 1, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1) for C in Cs]
+    g8s = [ops.to_c8(torch.randn(B, 2 * C, T, device=dev)) for C in Cs]
+    res = []
+    for use_c8 in (False, True):
+        e = e0.clone().requires_grad_(True)
+        layers = [tuple(t.clone().requires_grad_(True) for t in lay) for lay in base]
+        outs = ops.speaker_bias_block(e, layers)
+        if use_c8:
+            douts = []
+            for o, g8 in zip(outs, g8s):
+                holder, slot = o._dv3_spk_slot
+                holder[slot] = g8
+                douts.append(ops._spk_dummy_grad(o.shape, dev))
+        else:
+            douts = [ops.from_c8(g8, 2 * C)[:, :C, :] for g8, C in zip(g8s, Cs)]
+        torch.autograd.backward(outs, douts)
+        res.append([e.grad] + [t.grad for lay in layers for t in lay])
+    for a, c in zip(*res):
+        assert torch.equal(a, c)
+
+
+def test_multispeaker_bf16_storage_training_with_the_block_path(dev):
+    """the bf16 (c8 storage) mode of the multi-speaker fixture model, three steps with dropout: block path (exact fp32
+    speaker biases, c8 gradients read in place) against the per-layer path (bf16 MFMA Linear per layer): the two differ
+    by the rounding of a K = 16 product chain only -- losses within 1 %."""
+    from deepvoice3_pytorch_amd import builder, ops, train_step
+    prev_mode = ops.set_gemm_precision("bf16")
+    try:
+        fx = load_golden("model_dv3_multispeaker")
+        b, hp, sd, x = split_model_fixture(fx)
+        xg = {k: v.to(dev) for k, v in x.items()}
+        B, Td = x["mel"].shape[0], x["mel"].shape[1]
+        rng = np.random.RandomState(1)
+        y = torch.from_numpy(rng.rand(B, Td * 4, hp["linear_dim"]).astype(np.float32)).to(dev)
+        batch = train_step.Batch(xg["text"], xg["text_positions"], xg["frame_positions"], xg["mel"], y,
+                                 torch.zeros(B, Td, 1, device=dev), x["input_lengths"].numpy(), np.full(B, Td * 4 - 4),
+                                 xg.get("speaker_ids"), 1, 4, dev)
+        cfg = train_step.TrainConfig(max_positions=hp.get("max_positions", 512), initial_learning_rate=2e-3)
+        losses = {}
+        for fused in (False, True):
+            ops.fused_speaker_bias = fused
+            m = getattr(builder, b)(**hp)
+            m.load_state_dict(sd)
+            tr = train_step.Trainer(m.to(dev), cfg)
+            out = []
+            for _ in range(3):
+                ops.dropout_state.manual_seed(7000 + tr.global_step)
+                s = tr.step(batch)
+                out.append((float(s["loss"]), float(s["grad_norm"])))
+            losses[fused] = out
+            tr.close()
+    finally:
+        ops.fused_speaker_bias = True
+        ops.set_gemm_precision(prev_mode)
+    for (la, ga), (lc, gc) in zip(losses[False], losses[True]):
+        assert np.isfinite(lc) and np.isfinite(gc)
+        assert abs(la - lc) < 1e-2 * abs(la) and abs(ga - gc) < 5e-2 * abs(ga), (losses[False], losses[True])
