@@ -571,7 +571,7 @@ class TrainRun(object):
         # Launch mode.  The step is ~300-390 kernel launches: 5-16 ms of Python + ctypes per step for eager launches
         # (box dependent) against 1.5-4 ms for a replay.  A single whole-step hipGraph serialises the two backward
         # branches (round 3: 4-7 % slower than eager whenever the GPU is the bound), so since round 4 the replay is
-        # THREE graphs -- step stream | weight-gradient branch on the real second stream | optimiser
+        # a chain of SEGMENT graphs -- step stream | weight-gradient branch on the real second stream | optimiser
         # (train_step.GraphedTrainer(split_streams), include/dv3hip.h: dv3_graph_fork) -- which runs at the eager
         # step's GPU time (profiles/r04_three_graph_probe.txt).  The default still PROBES eager against the replay for
         # a few steps and keeps the faster; --graph / --no-graph force one.  All ranks take the same decision (MAX).
@@ -606,7 +606,7 @@ class TrainRun(object):
         if graph == "auto" and self.use_graph:
             t_graph = self._probe(4)
             self.launch_probe = dict(eager_ms_per_step=round(t_eager, 3), hipgraph_ms_per_step=round(t_graph, 3), steps=4)
-            # the replay has the eager step's GPU time since round 4 (three-way segment graphs) and a tenth of its host
+            # the replay has the eager step's GPU time since round 4 (segment graphs) and a tenth of its host
             # cost, so a tie goes to the replay: it stays GPU-bound on a slow or busy host; eager only when clearly faster
             if t_graph > 1.01 * t_eager:
                 self.runner.close()
@@ -617,8 +617,11 @@ class TrainRun(object):
     def graph_form(self):
         if not self.use_graph or self.runner is None:
             return None
-        return ("three hipGraphs: step stream | weight-gradient branch on the second stream | optimiser"
-                if getattr(self.runner, "split", False) else "one hipGraph")
+        if getattr(self.runner, "split", False):
+            return ("%d segment hipGraphs on the step stream, each followed by its weight-gradient segment on the second "
+                    "stream (and, under a process group, by the host-issued all-reduces of the buckets it completes) | "
+                    "optimiser graph" % len(self.runner.segs))
+        return "one hipGraph"
 
     def _probe(self, n):
         """ms per step of the current launch mode over n steps (after 2 untimed ones), MAX over ranks"""
