@@ -585,6 +585,12 @@ class TrainRun(object):
         self.use_graph = bool(graph)
         if self.use_graph:
             ok = 1
+            if t_eager is not None and os.environ.get("DV3_BENCH_EMPTY_CACHE", "1") != "0":
+                # the eager probe leaves its blocks cached in the default pool; the capture allocates from a private one:
+                # hand the memory back first (measured: the deepvoice3_vctk replay captured after an eager probe ran 6 %
+                # slower than the same replay captured in a fresh process state)
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
             try:
                 self.runner = train_step.GraphedTrainer(self.trainer, self.batch, warmup=2)
             except Exception as e:      # capture not possible: say so, go eager

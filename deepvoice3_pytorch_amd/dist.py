@@ -27,10 +27,16 @@ class BucketedAllReduce(object):
     embedding: registered last, final only when the ENCODER's backward is done; in a shared bucket it held the 25 MB of
     converter gradients back until the end of backward: scripts/r4_group_replay_check.py)."""
 
-    def __init__(self, arena, process_group=None, bucket_mb=25.0, last_bucket_mb=8.0, last_span_mb=40.0, isolate=()):
+    def __init__(self, arena, process_group=None, bucket_mb=25.0, last_bucket_mb=8.0, last_span_mb=40.0, isolate=(),
+                 beside=()):
         self.arena = arena
         self.pg = process_group
-        self.side = torch.cuda.Stream() if arena.grad.is_cuda else None
+        # the collective stream: one whose work really overlaps with the streams backward runs on (`beside`; see
+        # ops.concurrent_stream -- HIP streams share a few hardware queues)
+        self.side = None
+        if arena.grad.is_cuda:
+            from . import ops as _ops
+            self.side = _ops.concurrent_stream(list(beside)) if beside else torch.cuda.Stream()
         cap = max(1, int(bucket_mb * (1 << 20) / 4))
         cap_last = cap if last_bucket_mb is None else max(1, min(cap, int(last_bucket_mb * (1 << 20) / 4)))
         span_last = 0 if last_bucket_mb is None else int(last_span_mb * (1 << 20) / 4)

@@ -100,6 +100,49 @@ def _stream():
     return _raw_stream(_cur_device())
 
 
+def concurrent_stream(avoid, tries=12):
+    """A torch stream whose work REALLY runs beside the work of every stream in `avoid`.  HIP multiplexes its streams onto a
+    few hardware queues (GPU_MAX_HW_QUEUES, default 4): two streams that land on the same queue execute in issue order,
+    whatever the events between them say -- the step's second backward stream then adds nothing (measured: the same
+    replayed deepvoice3_vctk step at 11.76 or 12.75 ms, by which pool stream a Trainer instance happened to get,
+    scripts/r4_probe_order.py).  Probed with a pair of one-thread spin kernels (torch.cuda._sleep): a candidate is
+    taken when the pair takes about as long as one of them.  Falls back to the first candidate."""
+    first = None
+    if not avoid:
+        return torch.cuda.Stream()
+    dev = avoid[0].device
+    with torch.cuda.device(dev):
+        cycles = 200000
+
+        def spin_pair(a, s):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(a)
+            with torch.cuda.stream(a):
+                torch.cuda._sleep(cycles)
+            if s is not None:
+                with torch.cuda.stream(s):
+                    torch.cuda._sleep(cycles)
+                a.wait_stream(s)
+            e1.record(a)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+
+        try:
+            spin_pair(avoid[0], None)
+            one = min(spin_pair(avoid[0], None) for _ in range(2))
+        except Exception:      # no spin kernel in this build: take any stream
+            return torch.cuda.Stream()
+        want_shared = _os.environ.get("DV3_SIDE_STREAM_SAME_QUEUE", "") == "1"      # experiment: the opposite choice
+        for _ in range(tries):
+            s = torch.cuda.Stream()
+            first = first or s
+            beside = all(min(spin_pair(a, s), spin_pair(a, s)) < 1.5 * one for a in avoid)
+            if beside != want_shared:
+                return s
+    return first
+
+
 # ----------------------------------------------------------------------------------------------
 # range guard of the f16x3 mode (include/dv3hip.h, dv3_f16_range_events): the forward operands are
 # v * 2^4 (activations) / v * 2^8 (weights) in fp16, so |x| > 4094 or |w| > 255.9 leaves the range.

@@ -184,8 +184,11 @@ class Trainer(object):
         # already overlap with the input-gradient chain on the side stream, a fat launch every 8 layers competes with it
         self.batch_wn_bwd = os.environ.get("DV3_WN_BWD_BATCH", "0") == "1"
         # second stream for the weight-gradient branch of backward (ops.SideStream); DV3_WGRAD_STREAM=0 keeps one stream
-        self.side_stream = torch.cuda.Stream() if (dev.type == "cuda" and os.environ.get("DV3_WGRAD_STREAM", "1")
-                                                   not in ("0", "")) else None
+        # (a stream that shares no hardware queue with the step stream: ops.concurrent_stream)
+        self.side_stream = None
+        if dev.type == "cuda" and os.environ.get("DV3_WGRAD_STREAM", "1") not in ("0", ""):
+            with torch.cuda.device(dev):
+                self.side_stream = ops.concurrent_stream([torch.cuda.current_stream()])
         self.pg = process_group
         self.world = 1
         self.comm = None
@@ -195,7 +198,9 @@ class Trainer(object):
             # the speaker table receives a gradient from every layer of every module: a bucket of its own
             shared = set(id(p) for n, p in model.named_parameters() if n.split(".")[-2:-1] == ["embed_speakers"])
             isolate = [i for i, p in enumerate(self.arena.params) if id(p) in shared]
-            self.comm = _dist.BucketedAllReduce(self.arena, process_group, bucket_mb, last_bucket_mb, isolate=isolate)
+            self.comm = _dist.BucketedAllReduce(self.arena, process_group, bucket_mb, last_bucket_mb, isolate=isolate,
+                                                beside=[st for st in (torch.cuda.current_stream() if dev.type == "cuda" else None,
+                                                                      self.side_stream) if st is not None])
 
     def close(self):
         """Detach the gradient-exchange hooks (call before building another Trainer on the same model)."""
