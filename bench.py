@@ -1036,7 +1036,8 @@ def main():
                                      repeat=world)
             sampler = dv3data.LengthBucketedSampler(ds.frame_lengths, args.batch, rank=rank, world=world, seed=0)
             feed = dv3data.Prefetcher(ds, sampler, dev, outputs_per_step=1, downsample_step=4, depth=2, workers=4,
-                                      loop=True)
+                                      loop=True, beside=[st for st in (torch.cuda.current_stream(), run.trainer.side_stream)
+                                                         if st is not None])
             try:
                 mf = run.measure(max(10, args.steps // 2), 5, feed=iter(feed))
             finally:

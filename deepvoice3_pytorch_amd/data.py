@@ -301,7 +301,7 @@ class Prefetcher(object):
     flight.  next() makes the consumer's stream wait on the batch's event -- no host synchronisation."""
 
     def __init__(self, dataset, batch_sampler, device, outputs_per_step=1, downsample_step=4, depth=2, workers=2,
-                 loop=False):
+                 loop=False, beside=None):
         import queue
         import threading
         from concurrent.futures import ThreadPoolExecutor
@@ -310,7 +310,13 @@ class Prefetcher(object):
         self.r, self.ds = int(outputs_per_step), int(downsample_step)
         self.loop = loop
         self.cuda = self.device.type == "cuda"
-        self.side = torch.cuda.Stream(self.device) if self.cuda else None
+        # the copy / collate stream: one that shares no hardware queue with the consumer's streams (`beside`: default the
+        # current stream; pass the trainer's side stream too) -- see ops.concurrent_stream
+        self.side = None
+        if self.cuda:
+            from . import ops as _ops
+            with torch.cuda.device(self.device):
+                self.side = _ops.concurrent_stream(list(beside) if beside else [torch.cuda.current_stream()])
         self.q = queue.Queue(maxsize=max(1, depth))
         self.slots = [_Staging(self.cuda) for _ in range(max(1, depth) + 2)]
         self.pool = ThreadPoolExecutor(max(1, workers)) if workers > 0 else None
