@@ -190,11 +190,6 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
 
   // ---- this thread's activation staging items: flat column -> (batch, time), fixed over chunks ----
   uint32_t xoff[XI];                // byte offset of (b, k8*8, t) from p.x
-  // stream-K form: the three offsets live in LDS behind the operand images (a ds_read_b32 per half item) -- the
-  // segment loop costs the register allocator a handful of registers, and every vector spill in the main loop is a
-  // scratch reload behind a vmcnt(0), i.e. the whole fetch latency inside a LOAD phase
-  constexpr bool XOFF_LDS = false;
-  uint32_t* const xoff_l = reinterpret_cast<uint32_t*>(Xs + 2 * xbuf);
   const int n_items = KB * BNH;
   const uint32_t x_rsb = (uint32_t)p.x_rs * 4u;
   const uint32_t c8p = (uint32_t)((Cin + 31) / 32 * 4);
@@ -210,7 +205,6 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
     }
     const int xk8 = k8 < KB ? k8 * 8 : 0;
     xoff[i] = ((uint32_t)bf * (uint32_t)p.x_bs + (uint32_t)tf) * 4u + (uint32_t)xk8 * x_rsb;
-    if constexpr (SK && XOFF_LDS) xoff_l[i * NT + tid] = xoff[i];
   }
   // weight panel: per-unit column offset inside a (tap, k8) row of the split image; recomputed at each use from an
   // opaque copy of the thread index (a handful of VALU) instead of living in registers across the loop
@@ -283,8 +277,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
         // register pair that it keeps (in this form: spills, and reloads behind a vmcnt(0)) across the loop
         if (e == 0) { er = 0; asm volatile("" : "+s"(er)); }
       }
-      if constexpr (SK && XOFF_LDS) rx[i][e] = pp2_ldg<float>(xb, xoff_l[i * NT + tid] + er);
-      else rx[i][e] = pp2_ldg<float>(xb, xoff[i] + er);
+      rx[i][e] = pp2_ldg<float>(xb, xoff[i] + er);
     }
     if constexpr (MASK && h == 1) {
       // keep-byte (b, chunk * 4 + k8, t) of this item: its offset is recomputed here (two integer divisions per item and
@@ -512,13 +505,18 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   bool run_tail = true;
   if constexpr (SK) {
     constexpr int ACC = MI * 2 * NI * 16;            // accumulator registers per thread (128)
+#ifdef DV3_EXPERIMENTS
+    const int sk_abl = A.sk_abl;                     // timing-only ablations (dv3_debug_set(26, bits)): experiment build only
+#else
+    constexpr int sk_abl = 0;
+#endif
     float* const ws = A.sk_ws;
     int* const flags = A.sk_flags;
     if (c0 != 0) {
       // a tile another workgroup began: hand the accumulators over.  Image [32 groups of 4 registers][512 threads][4]:
       // one 16-byte store / load per thread and group, consecutive threads consecutive (layout-agnostic)
       char* dst = reinterpret_cast<char*>(ws) + ((size_t)pid * (ACC * NT) + (size_t)tid * 4) * 4;
-      if (!(A.sk_abl & 1))
+      if (!(sk_abl & 1))
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -547,7 +545,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
       for (int w2 = pid + 1; w2 < A.n_blocks; ++w2) {
         const int s2 = w2 * sk_base + min(w2, sk_rem);
         if (s2 >= (tile + 1) * nchunks) break;
-        if (tid == 0 && !(A.sk_abl & 4))
+        if (tid == 0 && !(sk_abl & 4))
           while (__hip_atomic_load(flags + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -557,7 +555,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
         const char* src = reinterpret_cast<const char*>(ws) + ((size_t)w2 * (ACC * NT) + (size_t)tid * 4) * 4;
         typedef const __attribute__((address_space(1))) void* gptr_;
         typedef __attribute__((address_space(3))) void* lptr_;
-        if (!(A.sk_abl & 2))
+        if (!(sk_abl & 2))
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -723,7 +721,6 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
     // form, scripts/r4_sk_step_ab.py).  3 = both directions.
     const bool dir_ok = d->mode != DV3_EPI_DGRAD || g_pp2_sk >= 2;
     if (ws_ok && dir_ok && g_pp2_sk && (S & (S - 1)) == 0 && (a.m_tiles & (a.m_tiles - 1)) == 0 && units >= 2 * P && (g_pp2_sk == 2 || sk * 100 < dp * g_pp2_sk_gain)) {
-      if (lds + XI * NT * 4 > 160 * 1024) return 1;      // (the offsets table of the stream-K form; never with dil <= 27)
       a.sk_abl = g_pp2_sk_abl;
       a.sk_units = (int)units;
       a.sk_base = (int)(units / P);
@@ -734,7 +731,7 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
       a.sk_flags = reinterpret_cast<int*>(d->sk_ws);
       a.sk_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(d->sk_ws) + (size_t)P * 64);
       g_dv3_last_conv += 1;                            // ...102: stream-K form
-      const size_t lds_sk = lds + XI * NT * 4;
+      const size_t lds_sk = lds;
       if (f16) return mask ? launch_pp2<true, true, 0, true>(a, lds_sk, st) : launch_pp2<false, true, 0, true>(a, lds_sk, st);
       return mask ? launch_pp2<true, false, 0, true>(a, lds_sk, st) : launch_pp2<false, false, 0, true>(a, lds_sk, st);
     }

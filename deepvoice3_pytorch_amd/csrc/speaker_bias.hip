@@ -295,7 +295,7 @@ int fill_args(SpkArgs& a, const dv3_spk_desc* d, const dv3_spk_layer* layers, bo
 
 }  // namespace
 
-int g_spk_abl = 0;   // dv3_debug_set(28, v): timing-only ablations of the backward (1 no dW, 2 no d emb, 3 no loads)
+int g_spk_abl = 0;   // dv3_debug_set(28, v): timing-only ablations of the backward (1 no dW, 2 no d emb, 3 no loads); make EXP=1
 
 extern "C" int dv3_speaker_bias_fwd_f32(const dv3_spk_desc* d, const dv3_spk_layer* layers, void* stream) {
   SpkArgs a;
@@ -336,12 +336,16 @@ extern "C" int dv3_speaker_bias_bwd_f32(const dv3_spk_desc* d, const dv3_spk_lay
   float* part = d->scratch;
   float* de_l = d->scratch + rows * d->B * nT * (EM + 1);
   hipStream_t st = (hipStream_t)stream;
+#ifdef DV3_EXPERIMENTS
   switch (g_spk_abl) {
     case 1: hipLaunchKernelGGL(spk_bwd_kernel<1>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l); break;
     case 2: hipLaunchKernelGGL(spk_bwd_kernel<2>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l); break;
     case 3: hipLaunchKernelGGL(spk_bwd_kernel<3>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l); break;
     default: hipLaunchKernelGGL(spk_bwd_kernel<0>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l);
   }
+#else
+  hipLaunchKernelGGL(spk_bwd_kernel<0>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l);
+#endif
   int rc2 = dv3_check_launch("speaker_bias_bwd");
   if (rc2 != DV3_OK) return rc2;
   hipLaunchKernelGGL(spk_finish_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, (const float*)part, d->B * nT);
