@@ -436,7 +436,7 @@ class GraphedTrainer(object):
                                 of `chunk` layers
         side segment j          the side stream's own capture over the same stretch (include/dv3hip.h:
                                 dv3_graph_side_begin / _end): weight-gradient GEMMs + weight-norm backward of those layers
-        tail                    (all-reduce buckets,) clip + Adam
+        tail                    clip + Adam (under a process group: after the host-issued all-reduces, see below)
     Replay: for j: launch step segment j; record an ordinary event; the side stream waits for it; launch side segment j.
     Then the step stream waits for the side stream and the tail runs.  Every dependency is a host-issued
     hipEventRecord / hipStreamWaitEvent (event NODES between two graphs were tried first and read stale at the
