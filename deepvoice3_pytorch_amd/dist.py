@@ -25,10 +25,12 @@ class BucketedAllReduce(object):
     still bandwidth- rather than latency-bound).  last_bucket_mb=None: one size everywhere.
     isolate: arena indices of parameters that get a bucket of their own -- tables every layer contributes to (the speaker
     embedding: registered last, final only when the ENCODER's backward is done; in a shared bucket it held the 25 MB of
-    converter gradients back until the end of backward: scripts/r4_group_replay_check.py)."""
+    converter gradients back until the end of backward: scripts/r4_group_replay_check.py).
+    boundaries: arena indices at which a bucket must START (a group of parameters that become final together and late --
+    the speaker projections of the fused block path -- is kept out of its neighbours' buckets)."""
 
     def __init__(self, arena, process_group=None, bucket_mb=25.0, last_bucket_mb=8.0, last_span_mb=40.0, isolate=(),
-                 beside=()):
+                 beside=(), boundaries=()):
         self.arena = arena
         self.pg = process_group
         # the collective stream: one whose work really overlaps with the streams backward runs on (`beside`; see
@@ -45,11 +47,11 @@ class BucketedAllReduce(object):
         hi = arena.total
         lo = hi
         cur = []
-        isolate = set(isolate)
+        isolate, boundaries = set(isolate), set(boundaries)
         for i in range(len(arena.params) - 1, -1, -1):
             o = arena.offsets[i]
             c = cap_last if hi <= span_last else cap
-            if cur and (hi - o > c or i in isolate or cur[-1] in isolate):
+            if cur and (hi - o > c or i in isolate or cur[-1] in isolate or (i + 1) in boundaries):
                 self.buckets.append((lo, hi, cur))
                 hi, cur = lo, []
             lo = o

@@ -155,6 +155,17 @@ class Trainer(object):
         self.global_step = global_step
         self.adam_step = 0
         params = list(model.get_trainable_parameters())
+        # The optimizer-facing order (checkpoint interop: torch.optim.Adam numbers its state by this order) ...
+        self.optimizer_order = list(params)
+        # ... and the arena's.  Data parallel, multi-speaker: the speaker projections of the Conv1dGLU layers get their
+        # gradients from ONE backward node per block (ops.SpeakerBiasBlockFn) that runs when the whole block's backward is
+        # done -- left between their layers' weights they would hold every bucket of the block back until then.  They
+        # go to the arena's tail as a group (one small bucket of their own, final when the encoder's backward is).
+        self.late_group = []
+        if process_group is not None and ops.fused_speaker_bias:
+            late = set(id(p) for n, p in model.named_parameters() if ".speaker_proj." in "." + n)
+            self.late_group = [p for p in params if id(p) in late]
+            params = [p for p in params if id(p) not in late] + self.late_group
         self.arena = FlatArena(params)
         # parameters the optimizer does not own (the frozen position tables, the text embedding under
         # freeze_embedding; reference __init__.py:48-63) take no gradient at all: a .grad outside the arena
@@ -198,7 +209,8 @@ class Trainer(object):
             # the speaker table receives a gradient from every layer of every module: a bucket of its own
             shared = set(id(p) for n, p in model.named_parameters() if n.split(".")[-2:-1] == ["embed_speakers"])
             isolate = [i for i, p in enumerate(self.arena.params) if id(p) in shared]
-            self.comm = _dist.BucketedAllReduce(self.arena, process_group, bucket_mb, last_bucket_mb, isolate=isolate,
+            group_start = len(self.arena.params) - len(self.late_group) if self.late_group else None
+            self.comm = _dist.BucketedAllReduce(self.arena, process_group, bucket_mb, last_bucket_mb, isolate=isolate, boundaries=() if group_start is None else (group_start,),
                                                 beside=[st for st in (torch.cuda.current_stream() if dev.type == "cuda" else None,
                                                                       self.side_stream) if st is not None])
 
@@ -674,8 +686,10 @@ def checkpoint_dict(trainer, global_epoch=0, save_optimizer_state=True):
     opt = None
     if save_optimizer_state:
         state = {}
+        slot = {id(p): (o, n) for o, n, p in zip(a.offsets, a.sizes, a.params)}
         if trainer.adam_step > 0:
-            for i, (o, n, p) in enumerate(zip(a.offsets, a.sizes, a.params)):
+            for i, p in enumerate(trainer.optimizer_order):      # torch.optim.Adam's numbering, whatever the arena's order
+                o, n = slot[id(p)]
                 state[i] = dict(step=torch.tensor(float(trainer.adam_step)),
                                 exp_avg=a.exp_avg[o:o + n].view(p.shape).clone(),
                                 exp_avg_sq=a.exp_avg_sq[o:o + n].view(p.shape).clone())
@@ -736,7 +750,9 @@ def load_checkpoint(path_or_dict, trainer, reset_optimizer=False, unsafe=False):
         if len(opt["param_groups"]) != 1 or len(opt["param_groups"][0]["params"]) != len(a.params):
             raise RuntimeError("optimizer state does not match get_trainable_parameters()")
         steps = set()
-        for i, (o, n) in enumerate(zip(a.offsets, a.sizes)):
+        slot = {id(p): (o, n) for o, n, p in zip(a.offsets, a.sizes, a.params)}
+        for i, p in enumerate(trainer.optimizer_order):
+            o, n = slot[id(p)]
             st = opt["state"].get(i)
             if st is None:
                 continue

@@ -322,6 +322,67 @@ def test_bucket_cutting_isolates_the_shared_table_and_segment_notes():
         comm.close()
 
 
+def _late_group_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import torch.distributed as dist
+    from deepvoice3_pytorch_amd import builder, train_step
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    hp = dict(n_vocab=20, embed_dim=16, mel_dim=8, linear_dim=17, r=1, downsample_step=4, n_speakers=3, speaker_embed_dim=16,
+              padding_idx=0, dropout=0.05, kernel_size=3, encoder_channels=16, decoder_channels=16, converter_channels=16,
+              max_positions=64)
+    torch.manual_seed(0)
+    m1, m2 = builder.deepvoice3_multispeaker(**hp), builder.deepvoice3_multispeaker(**hp)
+    m2.load_state_dict(m1.state_dict())
+    cfg = train_step.TrainConfig(max_positions=64)
+    t1 = train_step.Trainer(m1, cfg, process_group=dist.group.WORLD, bucket_mb=0.01, last_bucket_mb=None)
+    t2 = train_step.Trainer(m2, cfg)
+    names1 = {id(p): n for n, p in m1.named_parameters()}
+    late = [names1[id(p)] for p in t1.late_group]
+    n_late = len(late)
+    ok = n_late > 0 and all(".speaker_proj." in n for n in late)
+    ok = ok and [id(p) for p in t1.arena.params[-n_late:]] == [id(p) for p in t1.late_group]     # a group at the arena's tail
+    ok = ok and not any(".speaker_proj." in names1[id(p)] for p in t1.arena.params[:-n_late])
+    ok = ok and not t2.late_group and [id(p) for p in t2.arena.params] == [id(p) for p in t2.optimizer_order]
+    # ... in buckets of its own: no bucket mixes the group with other parameters
+    first = len(t1.arena.params) - n_late
+    for lo, hi, plist in t1.comm.buckets:
+        ok = ok and (all(i >= first for i in plist) or all(i < first for i in plist))
+    # checkpoint interop: the optimizer state is numbered in get_trainable_parameters() order whatever the arena's order
+    t1.adam_step = 3
+    for k, p in enumerate(t1.optimizer_order):
+        o, n = next((o, n) for o, n, q_ in zip(t1.arena.offsets, t1.arena.sizes, t1.arena.params) if q_ is p)
+        t1.arena.exp_avg[o:o + n] = float(k + 1)
+        t1.arena.exp_avg_sq[o:o + n] = float(2 * k + 1)
+    ck = train_step.checkpoint_dict(t1)
+    ref = torch.optim.Adam(list(m2.get_trainable_parameters()))
+    ok = ok and len(ck["optimizer"]["state"]) == len(ref.param_groups[0]["params"])
+    for k, p in enumerate(m1.get_trainable_parameters()):
+        st = ck["optimizer"]["state"][k]
+        ok = ok and st["exp_avg"].shape == p.shape and float(st["exp_avg"].flatten()[0]) == k + 1
+    train_step.load_checkpoint(ck, t2)
+    for k, p in enumerate(t2.optimizer_order):
+        o, n = next((o, n) for o, n, q_ in zip(t2.arena.offsets, t2.arena.sizes, t2.arena.params) if q_ is p)
+        ok = ok and float(t2.arena.exp_avg[o]) == k + 1 and float(t2.arena.exp_avg_sq[o + n - 1]) == 2 * k + 1
+    ok = ok and t2.adam_step == 3
+    q.put(bool(ok))
+    t1.close()
+    dist.destroy_process_group()
+
+
+def test_speaker_projections_form_a_late_group_under_data_parallel():
+    """Data parallel + multi-speaker: the Conv1dGLU speaker projections (final only when their block's fused backward
+    node has run) sit at the arena's tail in buckets of their own, and the checkpoint keeps torch.optim.Adam's numbering
+    (train.py:800-807 interop) although the arena's order differs from get_trainable_parameters()."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_late_group_worker, args=(29700 + os.getpid() % 2000, q))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_pack_batch_layout():
     """data.pack_batch: items back to back, no padding; padded_frames restates the frame arithmetic of
     train.collate_fn (train.py:307-316) that collate_fn itself is pinned on"""
