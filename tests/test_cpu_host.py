@@ -723,6 +723,21 @@ def test_archived_bench_line_meets_the_contract():
                 assert e[mode]["host_enqueue_ms_per_step"] > 0 and e[mode]["ms_per_step"] > 0
 
 
+def test_bench_probes_the_launch_mode_on_every_world_size(monkeypatch):
+    """bench.launch_mode: --graph / --no-graph force a mode; otherwise eager and the segmented replay are probed against
+    each other, with more than one rank too (the replay captures nothing of the process group); DV3_BENCH_DDP_GRAPH=0
+    keeps more than one rank eager."""
+    import argparse
+    import bench
+    a = argparse.Namespace(no_graph=False, graph=False)
+    monkeypatch.delenv("DV3_BENCH_DDP_GRAPH", raising=False)
+    assert bench.launch_mode(a, 1) == "auto" and bench.launch_mode(a, 8) == "auto"
+    monkeypatch.setenv("DV3_BENCH_DDP_GRAPH", "0")
+    assert bench.launch_mode(a, 1) == "auto" and bench.launch_mode(a, 8) is False
+    assert bench.launch_mode(argparse.Namespace(no_graph=True, graph=False), 8) is False
+    assert bench.launch_mode(argparse.Namespace(no_graph=False, graph=True), 8) is True
+
+
 def test_bench_self_launches_its_ranks_dry():
     """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (the driver's command
     line); --dry-launch keeps it to the rendezvous + bucketed all-reduce so it runs on a CPU-only box (gloo)."""
