@@ -413,9 +413,13 @@ def cpu_baseline_port(B, Tt, n_frames, max_seconds=25.0):
                       % (n, B, Tt, n_frames, dt),
                host_cpus=ncpu, thread_sweep_frames_per_s_at_batch8=sweep)
     try:      # port / reference time ratio recorded once in the build container (scripts/cpu_baseline_calibration.py)
-        cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_port_vs_reference.json")))
+        # round 5: re-measured at the headline batch (B = 64 and 16, all cores and one thread, the share of the reference's
+        # pure-Python guided_attention timed separately): the port takes 0.80 of the reference's step time at B = 64 on
+        # 8 cores (round 2's 0.185 was a B = 8 measurement, where guided_attention and Python overhead dominate)
+        cal = json.load(open(os.path.join(ROOT, "profiles", "r05_cpu_port_vs_reference.json")))
         out["port_over_reference_time"] = cal["port_over_reference_time"]
-        out["calibration"] = "profiles/r02_cpu_port_vs_reference.json"
+        out["reference_guided_attention_share"] = [r for r in cal["runs"] if r["batch"] == 64][0]["guided_attention_share_of_reference_step"]
+        out["calibration"] = "profiles/r05_cpu_port_vs_reference.json (%s, %d cores)" % (cal.get("cpu_model", "?"), cal.get("host_cpus", 0))
     except (IOError, OSError, KeyError, ValueError):
         pass
     return out
@@ -784,7 +788,9 @@ def ddp_world1_config(dev, preset, gemm, args, no_group_ms, steps=12, warmup=4):
     import torch.distributed as tdist
     pg = tdist.group.WORLD
     out = dict(no_group_ms_per_step=no_group_ms)
+    from deepvoice3_pytorch_amd import ops as _ops
     for mode in ("eager", "hipgraph"):
+        n_log = len(_ops.stream_probe_log)
         try:
             run = TrainRun(dev, pg, 0, 1, preset, gemm, args.batch, args.text_len, args.frames, graph=(mode == "hipgraph"))
         except Exception as e:
@@ -803,7 +809,15 @@ def ddp_world1_config(dev, preset, gemm, args, no_group_ms, steps=12, warmup=4):
             out[mode] = dict(ms_per_step=m["ms_per_step"], value=m["value"],
                              host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"],
                              allreduce_exposed_ms=m["allreduce_exposed_ms"],
-                             vs_no_group=round(m["ms_per_step"] / no_group_ms, 4) if no_group_ms else None)
+                             vs_no_group=round(m["ms_per_step"] / no_group_ms, 4) if no_group_ms else None,
+                             # which streams the step ran on and what the hardware-queue probe of each found: the ratio of
+                             # a pair of spin kernels (candidate beside each avoided stream) to one -- 1.0 runs beside, 2.0
+                             # shares a queue; the last candidate listed is the one taken
+                             stream_queues=dict(
+                                 collectives_issued_from="weight-gradient stream (async)" if comm.async_issue else "own collective stream",
+                                 probes=[dict(role=r["role"], found=r["found"], probed=r["probed"], ratios=r["candidates"][-3:])
+                                         for r in _ops.stream_probe_log[n_log:]],
+                                 GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")))
         except Exception as e:
             out[mode] = dict(error="%s: %s" % (type(e).__name__, e))
         finally:

@@ -30,11 +30,24 @@ class AudioConfig(object):
     """The hparams audio.py reads (hparams.py:38-43,124)."""
 
     def __init__(self, fft_size=1024, hop_size=256, sample_rate=22050, preemphasis=0.97,
-                 min_level_db=-100, ref_level_db=20, power=1.4, griffin_lim_iters=60, convention="lws"):
+                 min_level_db=-100, ref_level_db=20, power=1.4, griffin_lim_iters=60, convention="lws",
+                 window_scale=1.0):
+        """window_scale (lws framing only): amplitude factor of the analysis window.  UNCONFIRMED CONSTANT of the third-party
+        package (audio): this repository restates `awin = sqrt(hann(fsize))` (window_scale 1.0); if
+        the package's integer-argument constructor instead builds `sqrt(hann(fsize) * 2 * fshift / fsize)` (sum of squares
+        normalised for the hop), the right value is "hop_normalized" = sqrt(2 * hop / 1024) (0.7071 at hop 256): every
+        magnitude is then 3.01 dB lower, i.e. every normalised [0, 1] feature 0.0301 lower -- the observable
+        tests/test_audio.py::test_window_scale_is_the_unconfirmed_constant pins.  Perfect reconstruction, the frame count
+        and Griffin-Lim's fixed points do not depend on it (the synthesis window carries the inverse factor)."""
         if fft_size != N_FFT:
             raise ValueError("the HIP FFT kernels are built for fft_size=1024 (every reference preset)")
         if convention not in ("lws", "torch"):
             raise ValueError("convention must be 'lws' (the reference's framing) or 'torch'")
+        if window_scale == "hop_normalized":
+            window_scale = float(np.sqrt(2.0 * hop_size / fft_size))
+        if not (isinstance(window_scale, (int, float)) and window_scale > 0):
+            raise ValueError("window_scale must be a positive number or 'hop_normalized'")
+        self.window_scale = float(window_scale)
         self.fft_size, self.hop_size, self.sample_rate = fft_size, hop_size, sample_rate
         self.preemphasis, self.min_level_db, self.ref_level_db = preemphasis, min_level_db, ref_level_db
         self.power, self.griffin_lim_iters = power, griffin_lim_iters
@@ -44,11 +57,11 @@ class AudioConfig(object):
 # ---------------------------------------------------------------------------------------------
 # lws framing (audio.py:54-55): window tables, frame / sample counts
 # ---------------------------------------------------------------------------------------------
-def lws_windows_np(fsize=N_FFT, fshift=256):
-    """(awin, swin) of lws.lws(fsize, fshift) as float64 numpy: sqrt of the symmetric Hann window, and the synthesis
-    window awin / overlap-added(awin^2) that makes overlap-add reconstruct perfectly (lws.pyx: hann, synthwin)."""
+def lws_windows_np(fsize=N_FFT, fshift=256, scale=1.0):
+    """(awin, swin) of lws.lws(fsize, fshift) as float64 numpy: `scale` x sqrt of the symmetric Hann window, and the
+    synthesis window awin / overlap-added(awin^2) that makes overlap-add reconstruct perfectly (lws.pyx: hann, synthwin)."""
     k = np.arange(fsize, dtype=np.float64)
-    awin = np.sqrt(0.5 * (1.0 - np.cos(2.0 * np.pi * k / (fsize - 1))))
+    awin = float(scale) * np.sqrt(0.5 * (1.0 - np.cos(2.0 * np.pi * k / (fsize - 1))))
     Q = -(-fsize // fshift)
     w = np.concatenate([awin * awin, np.zeros(Q * fshift - fsize)]).reshape(Q, fshift).sum(0)
     w = np.tile(w, Q)[:fsize]
@@ -60,11 +73,11 @@ def lws_windows_np(fsize=N_FFT, fshift=256):
 _WIN_CACHE = {}
 
 
-def lws_windows(device, hop):
-    """the two tables as float32 device tensors (cached per device and hop)"""
-    key = (str(device), int(hop))
+def lws_windows(device, hop, scale=1.0):
+    """the two tables as float32 device tensors (cached per device, hop and window scale)"""
+    key = (str(device), int(hop), float(scale))
     if key not in _WIN_CACHE:
-        a, s = lws_windows_np(N_FFT, hop)
+        a, s = lws_windows_np(N_FFT, hop, scale)
         _WIN_CACHE[key] = (torch.from_numpy(a.astype(np.float32)).to(device), torch.from_numpy(s.astype(np.float32)).to(device))
     return _WIN_CACHE[key]
 
@@ -72,8 +85,7 @@ def lws_windows(device, hop):
 def lws_num_frames(length, hop, fsize=N_FFT):
     """frames lws.stft makes of `length` samples (zero padding of fsize - hop on both sides, the last frame completed)"""
     pad = fsize - hop
-    m = (length + 2 * pad - fsize) // hop + 1
-    return m if length % hop == 0 else m + 1
+    return -(-(length + 2 * pad - fsize) // hop) + 1      # ceil: also right for hops that do not divide fsize
 
 
 def lws_num_samples(T, hop, fsize=N_FFT):
@@ -90,13 +102,13 @@ def magnitudes(linear_outputs, cfg):
     return mag
 
 
-def istft(mag, phasor, hop, convention="torch"):
+def istft(mag, phasor, hop, convention="torch", window_scale=1.0):
     """mag (B,T,513), phasor (B,T,513,2) or None -> y (B, hop*(T-1)); lws framing: (B, (T+1)*hop - 1024)."""
     B, T, F = mag.shape
     assert F == N_BIN
     frames = torch.empty((B, T, N_FFT), dtype=torch.float32, device=mag.device)
     if convention == "lws":
-        _, swin = lws_windows(mag.device, hop)
+        _, swin = lws_windows(mag.device, hop, window_scale)
         _lib.call("dv3_lws_istft_frames_f32", mag.data_ptr(), phasor.data_ptr() if phasor is not None else None,
                   swin.data_ptr(), frames.data_ptr(), B, T, _stream())
         y = torch.empty((B, lws_num_samples(T, hop)), dtype=torch.float32, device=mag.device)
@@ -109,7 +121,7 @@ def istft(mag, phasor, hop, convention="torch"):
     return y
 
 
-def stft(y, T, hop, want_phasor=True, want_spec=False, convention="torch"):
+def stft(y, T, hop, want_phasor=True, want_spec=False, convention="torch", window_scale=1.0):
     """y (B, hop*(T-1)) -> unit phasors and/or the complex STFT, each (B,T,513,2); lws framing: T = lws_num_frames(L)."""
     y = _c(_chk(y, "y"))
     B = y.shape[0]
@@ -117,7 +129,7 @@ def stft(y, T, hop, want_phasor=True, want_spec=False, convention="torch"):
     sp = torch.empty((B, T, N_BIN, 2), dtype=torch.float32, device=y.device) if want_spec else None
     if convention == "lws":
         assert T == lws_num_frames(y.shape[1], hop)
-        awin, _ = lws_windows(y.device, hop)
+        awin, _ = lws_windows(y.device, hop, window_scale)
         _lib.call("dv3_lws_stft_f32", y.data_ptr(), awin.data_ptr(), ph.data_ptr() if ph is not None else None,
                   sp.data_ptr() if sp is not None else None, None, B, T, hop, y.shape[1], _stream())
         return ph, sp
@@ -166,7 +178,7 @@ def _analysis_mag(wav, cfg):
     _lib.call("dv3_preemphasis_f32", wav.data_ptr(), pre.data_ptr(), B, L, float(cfg.preemphasis), _stream())
     if cfg.convention == "lws":
         T = lws_num_frames(L, hop)
-        awin, _ = lws_windows(wav.device, hop)
+        awin, _ = lws_windows(wav.device, hop, cfg.window_scale)
         mag = torch.empty((B, N_BIN, T), dtype=torch.float32, device=wav.device)
         _lib.call("dv3_lws_stft_f32", pre.data_ptr(), awin.data_ptr(), None, None, mag.data_ptr(), B, T, hop, L, _stream())
         return mag
@@ -204,16 +216,16 @@ def melspectrogram_batch(wav, cfg=None, num_mels=80, fmin=125.0, fmax=7600.0):
     return _db_norm(mel, cfg)
 
 
-def griffin_lim(mag, hop, n_iter, init_phasor=None, convention="torch"):
+def griffin_lim(mag, hop, n_iter, init_phasor=None, convention="torch", window_scale=1.0):
     """Griffin & Lim: alternate projections between the given magnitudes and consistent STFTs."""
-    y = istft(mag, init_phasor, hop, convention)
+    y = istft(mag, init_phasor, hop, convention, window_scale)
     B, T, _ = mag.shape
     if n_iter > 0:
         frames = torch.empty((B, T, N_FFT), dtype=torch.float32, device=mag.device)
         y2 = torch.empty_like(y)
         lws = convention == "lws"
         if lws:
-            awin, swin = lws_windows(mag.device, hop)
+            awin, swin = lws_windows(mag.device, hop, window_scale)
         for _ in range(n_iter):
             # stft -> unit phase -> x magnitude -> inverse FFT -> window in one launch (the phasors never reach HBM)
             if lws:
@@ -239,7 +251,7 @@ def inv_spectrogram_batch(linear_outputs, cfg=None, init_phasor=None):
     framing (what the reference's processor.istft returns for T frames), (B, hop*(T-1)) on the torch framing."""
     cfg = cfg or AudioConfig()
     mag = magnitudes(linear_outputs, cfg)
-    y = griffin_lim(mag, cfg.hop_size, cfg.griffin_lim_iters, init_phasor, cfg.convention)
+    y = griffin_lim(mag, cfg.hop_size, cfg.griffin_lim_iters, init_phasor, cfg.convention, cfg.window_scale)
     return inv_preemphasis_(y, cfg.preemphasis)
 
 

@@ -52,7 +52,10 @@ __device__ __forceinline__ bf16x8 c8pp_keep8(const bf16x8& v, uint32_t m) {
 
 // ABL (make EXP=1 only; dv3_debug_set(21, v)): timing-only ablations, results are wrong: 1 no MFMAs, 2 no staging (no
 // global fetches, no LDS stores) in the loop, 3 no tail, 5 no fragment reads in the loop, 6 no barriers in the loop
-template <int JT, bool MASK, int ABL = 0>
+// RF (round 5): the twelve fragment reads of a LOAD phase are issued FIRST and the staging (panel / tile stores, the
+// refetches) runs while they land -- the phase is then max(reads, staging) long instead of their sum (the reads of four
+// waves take 200-350 cycles of the 512 a partner's 16 MFMAs last).  Same instructions, same results.
+template <int JT, bool MASK, int ABL = 0, bool RF = false>
 __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
   constexpr int XI = (KB * (BN + (JT > 1 ? HALO_MAX : 0)) + NT - 1) / NT;   // activation units per thread per chunk
   constexpr int XPS = XI * NT;                                              // units per tile buffer (padded: no store is predicated)
@@ -223,26 +226,8 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
       const bf16x8* AsC = As + cur * (KB * BM);
       const bool fix = (need >> j) & 1u;
       // ---------------- LOAD ----------------
-      if (ABL != 2) {
-        // the next step's panel: store (fetched in this wave's previous LOAD phase), then fetch the panel after
-        int j2 = j + 2, c2 = c;
-        if (JT == 1) { j2 = 0; c2 = c + 2; }
-        else if (j2 >= JT) { j2 -= JT; c2 = c + 1; }
-        if (c2 >= nchunks) { c2 = c; j2 = j; }            // past the end: re-fetch the current panel
-        write_A(cur ^ 1);
-        load_A(c2, j2);
-        // the next chunk's tile: one item per tap phase (three-tap layers) or all of it (1 x 1 layers)
-        if constexpr (JT == 1) {
-          write_X_all((c + 1) & 1);
-          load_X_all(cx);
-        } else {
-          if (j == 0) { write_X_item((c + 1) & 1, U0{}); load_X_item(cx, U0{}); }
-          if (j == 1) { write_X_item((c + 1) & 1, U1{}); load_X_item(cx, U1{}); }
-          if (j == 2) { write_X_item((c + 1) & 1, U2{}); load_X_item(cx, U2{}); }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
       bf16x8 fa[2][MI][2], fb[2][NI];
+      auto read_frags = [&]() {
       if (ABL == 5) {                       // fragments from registers that are live anyway: no LDS reads
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -264,6 +249,37 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
         const int xi = k8 * BNH + x_off + j * dil;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) fb[ks][ni] = XsC[xi + ni * 32];
+      }
+      };
+      auto stage = [&]() {
+      if (ABL != 2) {
+        // the next step's panel: store (fetched in this wave's previous LOAD phase), then fetch the panel after
+        int j2 = j + 2, c2 = c;
+        if (JT == 1) { j2 = 0; c2 = c + 2; }
+        else if (j2 >= JT) { j2 -= JT; c2 = c + 1; }
+        if (c2 >= nchunks) { c2 = c; j2 = j; }            // past the end: re-fetch the current panel
+        write_A(cur ^ 1);
+        load_A(c2, j2);
+        // the next chunk's tile: one item per tap phase (three-tap layers) or all of it (1 x 1 layers)
+        if constexpr (JT == 1) {
+          write_X_all((c + 1) & 1);
+          load_X_all(cx);
+        } else {
+          if (j == 0) { write_X_item((c + 1) & 1, U0{}); load_X_item(cx, U0{}); }
+          if (j == 1) { write_X_item((c + 1) & 1, U1{}); load_X_item(cx, U1{}); }
+          if (j == 2) { write_X_item((c + 1) & 1, U2{}); load_X_item(cx, U2{}); }
+        }
+      }
+      };
+      if constexpr (RF) {
+        read_frags();
+        __builtin_amdgcn_sched_barrier(0);
+        stage();
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        stage();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags();
       }
       if (fix) {
         const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -336,11 +352,11 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
   }
 }
 
-template <int JT, bool MASK, int ABL = 0>
+template <int JT, bool MASK, int ABL = 0, bool RF = false>
 int launch_c8pp(const ConvArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_c8pp_kernel<JT, MASK, ABL>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_c8pp_kernel<JT, MASK, ABL, RF>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_c8pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -348,12 +364,17 @@ int launch_c8pp(const ConvArgs& a, size_t lds, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_c8pp_kernel<JT, MASK, ABL>), dim3(a.n_blocks), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL((conv_c8pp_kernel<JT, MASK, ABL, RF>), dim3(a.n_blocks), dim3(NT), lds, st, a);
   return dv3_check_launch("conv_c8pp");
 }
 
 }  // namespace
 
+// dv3_debug_set(30, v): fragment reads first in a LOAD phase (RF instantiations; 0 = the round-4 order).  Default since
+// round 5: bit-identical, 0.87-0.93 of the staging-first time over the presets' shapes in one process
+// (scripts/r5_ship_check.py, profiles/r05_c8pp_reads_first.txt: north star eval 63.9 -> 59.3 us, masked training forward
+// 77.4 -> 72.0 us, input gradient 58.5 -> 54.3 us; C = 512, T = 800: 201.5 -> 183.0 / 241.0 -> 209.0 / 186.0 -> 164.2 us)
+int g_c8pp_rf = 1;
 int g_c8pp_abl = 0;            // dv3_debug_set(21, v): timing-only ablations (EXP build)
 int g_c8pp_min_tiles = 128;   // dv3_debug_set(19, v): the 256 x 256 c8 kernel serves eligible shapes whose grid has at
                               // least v tiles (0 = never; 1 = always)
@@ -394,6 +415,10 @@ int dv3_conv_c8pp_dispatch(const dv3_conv_desc* d, hipStream_t st) {
     }
   }
 #endif
+  if (g_c8pp_rf) {
+    if (d->J == 3) return mask ? launch_c8pp<3, true, 0, true>(a, lds, st) : launch_c8pp<3, false, 0, true>(a, lds, st);
+    return mask ? launch_c8pp<1, true, 0, true>(a, lds, st) : launch_c8pp<1, false, 0, true>(a, lds, st);
+  }
   if (d->J == 3) return mask ? launch_c8pp<3, true>(a, lds, st) : launch_c8pp<3, false>(a, lds, st);
   return mask ? launch_c8pp<1, true>(a, lds, st) : launch_c8pp<1, false>(a, lds, st);
 }
@@ -401,5 +426,6 @@ int dv3_conv_c8pp_dispatch(const dv3_conv_desc* d, hipStream_t st) {
 int dv3_c8pp_debug_set(int what, int value) {
   if (what == 19) g_c8pp_min_tiles = value;
   if (what == 21) g_c8pp_abl = value;
+  if (what == 30) g_c8pp_rf = value;
   return DV3_OK;
 }

@@ -286,6 +286,126 @@ __device__ __forceinline__ void conv_epilogue_wide_block(const dv3_conv_desc& p,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Wide form of the fp32 (B, C, T) Conv1dGLU / HighwayConv1d tail WITHOUT an LDS round trip (round 5).  The accumulator
+// gives a lane one frame and 16 rows; a 4 x 4 transpose inside each QUAD of lanes (two butterfly steps of DPP quad
+// permutes: lane j <-> j ^ 1 on register pairs (0,1) (2,3), then j <-> j ^ 2 on (0,2) (1,3); 8-16 vector ALU per block,
+// no memory) leaves lane j of quad q with ONE row (8k + 4 lhi + j of its group k) and FOUR CONSECUTIVE FRAMES 4q .. 4q+3,
+// so the residual load, the pre-gate save and the output store are 16-byte accesses (a wave instruction covers 8 rows
+// x 128 contiguous bytes).  The pre-activations a = acc + bias and g = acc + bias are transposed, everything after
+// them (save, sigmoid, fused multiply-add with the residual, scale) runs on the transposed values with the same
+// operations per element as conv_epilogue(): bit-identical results.  Needs Tout % 4 == 0 (a quad's four frames stay
+// inside one batch item of the flattened (b, t) axis), 16-byte aligned tensors, no speaker-bias tensor.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dv3_quad_swap1(float v) {   // value of lane j ^ 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dv3_quad_swap2(float v) {   // value of lane j ^ 2
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+}
+// in place: v[i] of lane j  <-  v[j] of lane i   (i, j = 0..3 inside the quad)
+__device__ __forceinline__ void dv3_quad_transpose4(float (&v)[4], bool odd1, bool odd2) {
+  // step 1: 2 x 2 blocks between lanes j, j ^ 1 on (v0, v1) and (v2, v3)
+  {
+    const float s0 = dv3_quad_swap1(odd1 ? v[0] : v[1]);
+    const float s1 = dv3_quad_swap1(odd1 ? v[2] : v[3]);
+    if (odd1) { v[0] = s0; v[2] = s1; } else { v[1] = s0; v[3] = s1; }
+  }
+  // step 2: between lanes j, j ^ 2 on (v0, v2) and (v1, v3)
+  {
+    const float s0 = dv3_quad_swap2(odd2 ? v[0] : v[2]);
+    const float s1 = dv3_quad_swap2(odd2 ? v[1] : v[3]);
+    if (odd2) { v[0] = s0; v[1] = s1; } else { v[2] = s0; v[3] = s1; }
+  }
+}
+
+__device__ __forceinline__ bool dv3_wide_glu_ok(const dv3_conv_desc& p) {
+  if (p.mode != DV3_EPI_GLU && p.mode != DV3_EPI_HIGHWAY) return false;
+  if (p.store_mode != DV3_STORE_BCT || (p.Tout & 3) || p.io_bf16 != 0 || p.spk) return false;
+  auto al = [](const void* q, int64_t rs, int64_t bs) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && (rs & 3) == 0 && (bs & 3) == 0); };
+  if (!al(p.y, p.y_rs, p.y_bs) || !al(p.r, p.r_rs, p.r_bs)) return false;
+  if (p.ab && ((((uintptr_t)p.ab) & 15) != 0)) return false;
+  return true;
+}
+
+// One 32-row sub-tile of a wave: acc[0][ni] = `a` rows, acc[1][ni] = gate rows (as conv_epilogue); n0w = flat index of
+// the wave's first column (the lane's quad q = (lane & 31) >> 2 owns frames n0w + ni * 32 + 4 q .. + 3).
+// ABL (experiment build): 12 = no residual load, 13 = no stores
+template <int BMH, int NI, int ABL = 0>
+__device__ __forceinline__ void conv_epilogue_glu_wide(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], int mt, int row0,
+                                                       int lane, int n0w, int Ntot) {
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int j = l31 & 3, q = l31 >> 2;
+  const bool odd1 = j & 1, odd2 = j & 2;
+  const uint32_t T = (uint32_t)p.Tout, M = (uint32_t)p.M, Cg = (uint32_t)p.Cg;
+  const bool glu = p.mode == DV3_EPI_GLU;
+  const bool has_r = !glu || p.residual;
+  const float oscale = (glu && p.residual) ? 0.70710678118654752440f : 1.0f;
+  // wide-side coordinates: row 8 k + 4 lhi + j of the sub-tile (k = 0..3), frames n4 .. n4 + 3 of column sub-tile ni
+  uint32_t yo[NI], ro[NI], ao[NI];
+  bool okw[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n4 = n0w + ni * 32 + q * 4;
+    okw[ni] = n4 < Ntot;
+    const uint32_t b4 = okw[ni] ? (uint32_t)n4 / T : 0u, t4 = okw[ni] ? (uint32_t)n4 - b4 * T : 0u;
+    yo[ni] = (b4 * (uint32_t)p.y_bs + t4) * 4u;
+    ro[ni] = (b4 * (uint32_t)p.r_bs + t4) * 4u;
+    ao[ni] = (b4 * M * T + t4) * 4u;
+  }
+  const uint32_t y_rs = (uint32_t)p.y_rs * 4u, r_rs = (uint32_t)p.r_rs * 4u;
+  uint32_t chw[4];
+  f32x4 xr[4][NI];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {        // residual rows in the wide layout, all requested before anything waits
+    chw[k] = (uint32_t)(mt * BMH + row0 + 8 * k + 4 * lhi + j);
+    const uint32_t chc = chw[k] < Cg ? chw[k] : Cg - 1;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      xr[k][ni] = (has_r && ABL != 12) ? dv3_ld<f32x4>(p.r, ro[ni] + chc * r_rs) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // bias of the rows this lane holds BEFORE the transpose (accumulator order: row 8 k + 4 lhi + i in register 4 k + i)
+    float ba[4], bg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t chr = (uint32_t)(mt * BMH + row0 + 8 * k + 4 * lhi + i);
+      const uint32_t chc = chr < Cg ? chr : Cg - 1;
+      ba[i] = p.bias ? p.bias[chc] : 0.f;
+      bg[i] = p.bias ? p.bias[Cg + chc] : 0.f;
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float a[4], g[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = acc[0][ni][4 * k + i] + ba[i];
+        g[i] = acc[1][ni][4 * k + i] + bg[i];
+      }
+      dv3_quad_transpose4(a, odd1, odd2);
+      dv3_quad_transpose4(g, odd1, odd2);
+      const uint32_t ch = chw[k];
+      if (ch >= Cg || !okw[ni]) continue;
+      if (p.ab) {
+        const uint32_t o = ao[ni] + ch * T * 4u;
+        if (ABL != 13) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.ab) + o) = f32x4{a[0], a[1], a[2], a[3]};
+          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.ab) + o + Cg * T * 4u) = f32x4{g[0], g[1], g[2], g[3]};
+        }
+      }
+      f32x4 y4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-g[e]));
+        const float x = xr[k][ni][e];
+        y4[e] = glu ? (a[e] * s + x) * oscale : s * a[e] + (1.0f - s) * x;
+      }
+      if (ABL != 13 || y4[0] == 1.2345e30f) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.y) + yo[ni] + ch * y_rs) = y4;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Epilogue of the bf16-storage path: y (and the saved pre-gate pair, the residual inputs, the DGRAD addend and its
 // keep-mask) live in the channel-blocked "c8" layout  bf16 [B][C8][T][8],  C8 = round_up(C,32)/8  (include/dv3hip.h).
 // The 32x32 accumulator tile gives every lane four CONSECUTIVE channels (r&3) of four 8-channel groups (r>>2) at

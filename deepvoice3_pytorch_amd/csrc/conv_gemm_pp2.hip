@@ -79,7 +79,17 @@ __device__ unsigned long long g_pp2_stamps[8 * PP2_STAMPS * 2];
 // walks a contiguous range of (tile, 32-channel chunk) units -- at most one leading segment that ends a tile another
 // workgroup began (its accumulators go to the workspace) and then segments that begin a tile (the workgroup that
 // holds a tile's chunk 0 adds the other workgroups' parts and runs the fused tail).
-template <bool MASK, bool F16, int ABL = 0, bool SK = false>
+// ORD (bit flags; round 5: what a LOAD phase spends its time on, profiles/r05_pp2_load_phase.txt):
+//   1  the twelve fragment reads are issued FIRST in a LOAD phase and the staging (panel unit store / fetch, activation
+//      item conversion + store, activation fetches) runs while they land; only the edge fix and the barrier wait for them
+//   2  lean staging: the two weight-panel unit offsets live in registers (two VGPRs instead of ~15 VALU per phase) and the
+//      fp16 pair of an in-range item is built without the clamps (the range test the kernel already makes picks the path)
+//  32  the Conv1dGLU / highway tail moves 16 bytes per access: a 4 x 4 transpose inside each quad of lanes (DPP) turns the
+//      accumulator's one-frame-per-lane layout into four consecutive frames of one row per lane (conv_common.h)
+//  64  the activation items are converted and stored in COMPUTE phases, between the MFMAs, instead of in LOAD phases
+//   4  the tile's residual rows are touched (one 4-byte load per 128-byte line) during the last chunk of the main loop, so
+//      that the tail reads them from L2 while the chip-wide tail burst only writes
+template <bool MASK, bool F16, int ABL = 0, bool SK = false, int ORD = 0>
 __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) {
   const dv3_conv_desc& p = args.d;
   int n_stamp = 0;
@@ -115,6 +125,7 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   // there) -- and the form the stream-K variants use: it frees the eight staging registers of the panel unit, which is
   // what keeps their main loop free of scratch reloads
   constexpr bool DMA_A = ABL == 11;
+  constexpr bool WIDE_GLU = (ORD & 32) != 0;   // 16-byte gated tail (quad transpose in registers)
   int tid_ = threadIdx.x;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   do {   // one pass per segment (a single pass without SK)
@@ -208,7 +219,10 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   }
   // weight panel: per-unit column offset inside a (tap, k8) row of the split image; recomputed at each use from an
   // opaque copy of the thread index (a handful of VALU) instead of living in registers across the loop
+  constexpr bool LEAN = (ORD & 2) != 0 && !SK;
+  uint32_t aoff_r[2] = {0u, 0u};
   auto aoff_of = [&](int u) -> uint32_t {
+    if constexpr (LEAN) return aoff_r[u];
     int t_ = tid;
     asm volatile("" : "+v"(t_));
     const int idx = t_ + u * NT;  // k8 * BM + col
@@ -217,6 +231,17 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
     const int gcol = (hi_half ? h1b : h0b) + (col - (hi_half ? BMH : 0));
     return (uint32_t)(k8 * lda + (gcol < lda ? gcol : 0)) * 16u;
   };
+
+  if constexpr (LEAN) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + u * NT;
+      const int col = idx % BM, k8 = idx / BM;
+      const bool hi_half = col >= BMH;
+      const int gcol = (hi_half ? h1b : h0b) + (col - (hi_half ? BMH : 0));
+      aoff_r[u] = (uint32_t)(k8 * lda + (gcol < lda ? gcol : 0)) * 16u;
+    }
+  }
 
   // ---- register staging ----
   bf16x8 ra[2];            // ONE weight-panel unit (hi, lo) in flight: fetched in one LOAD phase, stored in the next
@@ -313,15 +338,84 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
       else if (F16) v[e] *= xscale;
     }
     bf16x8 hi, lo;
-    if constexpr (F16) dv3_note_range(A.range_ctr, dv3_split8_f16(v, hi, lo)); else pp2_split8(v, hi, lo);
+    if constexpr (F16 && LEAN) {
+      // the range test first (it is made anyway); a wave whose eight values all sit inside the fp16 range -- every wave of
+      // a healthy run -- builds the pair without the clamps (identity there) and takes the residual as one fused
+      // multiply-add per element: a - hi is exact in fp32 either way, so the pair is bit-identical to dv3_split8_f16's
+      const float m0 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2]));
+      const float m1 = fmaxf(fmaxf(fabsf(v[3]), fabsf(v[4])), fabsf(v[5]));
+      const float m = fmaxf(fmaxf(m0, m1), fmaxf(fabsf(v[6]), fabsf(v[7])));
+      const bool bad = !(m <= 65504.f);
+      if (__builtin_expect(__any(bad), 0)) {
+        dv3_note_range(A.range_ctr, dv3_split8_f16(v, hi, lo));
+      } else {
+        f16x8 h8, l8;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 f = {v[e], v[e + 1]};
+          typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+          const f16x2_ h = __builtin_convertvector(f, f16x2_);
+          h8[e] = h[0]; h8[e + 1] = h[1];
+          if constexpr ((ORD & 8) != 0) {
+            // lo = fp16_rn(a - hi) as ONE mixed-precision fma per element (hi read as the fp16 half it is, a as fp32; the
+            // fp32 result a - hi is exact, so the single rounding is the one the convert / subtract / convert chain makes)
+            uint32_t l2 = 0u;
+            const uint32_t h2 = __builtin_bit_cast(uint32_t, h);
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(l2) : "v"(h2), "v"(v[e]));
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l2) : "v"(h2), "v"(v[e + 1]));
+            const f16x2_ l = __builtin_bit_cast(f16x2_, l2);
+            l8[e] = l[0]; l8[e + 1] = l[1];
+          } else {
+            l8[e] = (_Float16)(v[e] - (float)h[0]);
+            l8[e + 1] = (_Float16)(v[e + 1] - (float)h[1]);
+          }
+        }
+        hi = __builtin_bit_cast(bf16x8, h8);
+        lo = __builtin_bit_cast(bf16x8, l8);
+      }
+    } else if constexpr (F16) dv3_note_range(A.range_ctr, dv3_split8_f16(v, hi, lo)); else pp2_split8(v, hi, lo);
     if (idx < n_items) {
       dst[idx] = hi;
       dst[KB * BNH + idx] = lo;
     }
   };
+  // ORD & 64: the same conversion + store as straight-line code (it runs between the MFMAs of a COMPUTE phase: a branch
+  // would cut the scheduling region).  The range events of the wave are counted in a scalar (popcount of the ballot) and
+  // added to the sticky counter once, after the main loop; lanes without an item store to two spare units behind the
+  // activation buffers instead of being masked off.
+  uint32_t sbad = 0;
+  auto write_X_item_nb = [&](int buf, auto ic) {
+    constexpr int i = decltype(ic)::value;
+    bf16x8* dst = Xs + buf * xbuf;
+    const int idx = tid + i * NT;
+    float v[8];
+    const uint32_t keep = MASK ? rk[i] : 0u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = rx[i][e];
+      if constexpr (MASK) {
+        v[e] *= ((keep >> e) & 1u) ? dscale : 0.f;
+        // the product is ROUNDED before the pair is taken (write_X_item's arithmetic): without this the compiler contracts
+        // x * scale - hi into one fma here, i.e. takes the residual of the unrounded product (1 / (1 - p) is no power of two)
+        asm("" : "+v"(v[e]));
+      } else if (F16) v[e] *= xscale;
+    }
+    bf16x8 hi, lo;
+    if constexpr (F16) {
+      const bool bad = dv3_split8_f16(v, hi, lo);
+      sbad += (uint32_t)__builtin_popcountll(__ballot(bad));
+    } else {
+      pp2_split8(v, hi, lo);
+    }
+    const int spare = 2 * xbuf - buf * xbuf;          // unit index (from dst) of the two spare units
+    const bool live = i < 2 || idx < n_items;          // items 0 and 1 always exist (KB * BNH >= 2 * NT)
+    dst[live ? idx : spare] = hi;
+    dst[live ? KB * BNH + idx : spare + 1] = lo;
+  };
   using U0 = std::integral_constant<int, 0>;
   using U1 = std::integral_constant<int, 1>;
   using U2 = std::integral_constant<int, 2>;
+  constexpr bool CVC = (ORD & 64) != 0 && !SK;          // activation items converted in COMPUTE phases
   static_assert(XI == 3 && JT == 3, "three activation items per thread, one per tap's pair of k16 phases");
 
   f32x16 acc[MI][2][NI];   // [row sub-tile][a rows | gate rows][column sub-tile]
@@ -359,7 +453,8 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
     load_X_half(cp, U0{}, U0{});
     load_X_half(cp, U0{}, U1{});
     load_X_half(cp, U1{}, U0{}); load_X_half(cp, U1{}, U1{});
-    load_X_half(cp, U2{}, U0{}); load_X_half(cp, U2{}, U1{});
+    load_X_half(cp, U2{}, U0{});
+    if constexpr (!CVC) load_X_half(cp, U2{}, U1{});   // (CVC: fetched by the first LOAD phase of the loop)
   }
 
   // ---- ping-pong main loop: waves w and w+4 share a SIMD and run the same phase sequence one phase apart ----
@@ -370,6 +465,10 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   // stored during the four L phases of step t (two per half) into the buffer last read in the L phases of step t-1 and
   // first read in L of step t+1; the tile of chunk c+1 during the L phases of chunk c into the buffer last read in
   // chunk c-1.  Every interval ends with a workgroup barrier.
+  // ORD & 4: touch the residual rows of this tile during the last chunk (one 4-byte LDS-DMA load per 128-byte line and
+  // lane into a 2 KB scratch strip behind the operand buffers -- nothing returns to a register, nothing reads the strip):
+  // thread -> (row = tid / 4 of the 128 `a` rows, column segment tid % 4 of 64 columns); two loads per thread
+  const bool pf_on = (ORD & 4) != 0 && !SK && gated && p.r != nullptr;
   const int late = wave >> 2;
   stamp();                               // slot 1: prologue done
   if (late) __syncthreads();
@@ -392,6 +491,46 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
       // Order inside the phase: staging first, fragment reads last (pinned with sched_barrier) -- the twelve fragments
       // (48 registers) are dead until then, which keeps the conversion temporaries of the staging inside the
       // 256-register budget next to the 128 accumulator registers.
+      bf16x8 ah[MI][2], al[MI][2], bh[NI], bl[NI];
+      auto read_frags = [&](bool do_a, bool do_b) {
+        const int k8 = 2 * s + lhi;
+        if (do_a) {
+          const int ai = k8 * BM + a_off;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            ah[mi][0] = AsH[ai + mi * 32];
+            ah[mi][1] = AsH[ai + mi * 32 + BMH];
+            al[mi][0] = AsL[ai + mi * 32];
+            al[mi][1] = AsL[ai + mi * 32 + BMH];
+          }
+        }
+        if (do_b) {
+          const int xi = k8 * BNH + x_off + j * dil;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            bh[ni] = XsH[xi + ni * 32];
+            bl[ni] = XsL[xi + ni * 32];
+          }
+        }
+      };
+      auto fix_frags = [&]() {
+        const int k8 = 2 * s + lhi; (void)k8;
+        if (fix) {
+          const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            const bool ok = (vbits >> (j * NI + ni)) & 1u;
+            bh[ni] = ok ? bh[ni] : zero8;
+            bl[ni] = ok ? bl[ni] : zero8;
+          }
+        }
+      };
+      // ORD & 16 (with 1): only the eight weight fragments go first, the four activation fragments follow the staging (16
+      // registers less are live beside the conversion: what the masked instantiation needs to stay free of scratch reloads)
+      if constexpr ((ORD & 1) != 0) {
+        read_frags(true, (ORD & 16) == 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (ABL != 2) {
         // panel unit s of the next step: store (it was fetched in this wave's previous LOAD phase), then fetch the
         // unit the NEXT LOAD phase stores: one unit (8 registers) in flight, two barrier intervals to land (an L2 hit)
@@ -420,42 +559,47 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
         // activation item j of the next chunk: convert + store in the tap's first phase, fetch its halves for the
         // chunk after in the tap's two phases
         constexpr bool WX = ABL != 8, LX = ABL != 6;      // timing-only ablations: no conversion + store / no fetch
+        if constexpr (CVC) {
+          // conversion + store of item i in the COMPUTE phase 2 i (below); its halves for the chunk after come in the two
+          // LOAD phases that follow it (the second half of item 2 in the next chunk's first phase: cx1 = that chunk's successor)
+          const int cx1 = min(c + 1, c1 - 1);
+          if (q == 0) load_X_half(cx1, U2{}, U1{});
+          if (q == 1) load_X_half(cx, U0{}, U0{});
+          if (q == 2) load_X_half(cx, U0{}, U1{});
+          if (q == 3) load_X_half(cx, U1{}, U0{});
+          if (q == 4) load_X_half(cx, U1{}, U1{});
+          if (q == 5) load_X_half(cx, U2{}, U0{});
+        } else {
         if (q == 0) { if (WX) write_X_item((cr + 1) & 1, U0{}); if (LX) load_X_half(cx, U0{}, U0{}); }
         if (q == 1) { if (LX) load_X_half(cx, U0{}, U1{}); }
         if (q == 2) { if (WX) write_X_item((cr + 1) & 1, U1{}); if (LX) load_X_half(cx, U1{}, U0{}); }
         if (q == 3) { if (LX) load_X_half(cx, U1{}, U1{}); }
         if (q == 4) { if (WX) write_X_item((cr + 1) & 1, U2{}); if (LX) load_X_half(cx, U2{}, U0{}); }
         if (q == 5) { if (LX) load_X_half(cx, U2{}, U1{}); }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      stamp();                           // +1: staging issued
-      bf16x8 ah[MI][2], al[MI][2], bh[NI], bl[NI];
-      {
-        const int k8 = 2 * s + lhi;
-        const int ai = k8 * BM + a_off;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          ah[mi][0] = AsH[ai + mi * 32];
-          ah[mi][1] = AsH[ai + mi * 32 + BMH];
-          al[mi][0] = AsL[ai + mi * 32];
-          al[mi][1] = AsL[ai + mi * 32 + BMH];
         }
-        const int xi = k8 * BNH + x_off + j * dil;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          bh[ni] = XsH[xi + ni * 32];
-          bl[ni] = XsL[xi + ni * 32];
-        }
-        if (fix) {
-          const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            const bool ok = (vbits >> (j * NI + ni)) & 1u;
-            bh[ni] = ok ? bh[ni] : zero8;
-            bl[ni] = ok ? bl[ni] : zero8;
+        if constexpr ((ORD & 4) != 0 && !SK) {
+          if ((q == 1 || q == 3) && last_chunk && pf_on) {
+            typedef const __attribute__((address_space(1))) void* gptr;
+            typedef __attribute__((address_space(3))) void* lptr;
+            unsigned char* strip = smem_raw + (size_t)(2 * 2 * KB * BM + 2 * xbuf) * 16 + wave * 256;
+            // (the offset is computed here, twice per tile, from an opaque copy of the thread index: nothing lives in a
+            // register across the loop for it)
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int row = t_ >> 2, col = (t_ & 3) * 64 + (q >> 1) * 32;
+            const int ch = min(mt * BMH + row, p.Cg - 1);
+            const int n = min(n0 + col, Ntot - 1);
+            const int bb = n / T, tt = n - bb * T;
+            const uint32_t po = ((uint32_t)bb * (uint32_t)p.r_bs + (uint32_t)ch * (uint32_t)p.r_rs + (uint32_t)tt) * 4u;
+            __builtin_amdgcn_global_load_lds((gptr)(reinterpret_cast<const char*>(p.r) + po), (lptr)strip, 4, 0, 0);
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      stamp();                           // +1: staging issued
+      if constexpr ((ORD & 1) == 0) read_frags(true, true);
+      else if constexpr ((ORD & 16) != 0) read_frags(false, true);
+      fix_frags();
       if constexpr (ABL == 4) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp();                         // +2: fragments landed
@@ -495,12 +639,34 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(bh[ni]), "v"(bl[ni]));
       }
+      if constexpr (CVC) {
+        // the conversion + store of activation item q / 2 for the next chunk's tile, spread between the MFMAs: two vector
+        // ALU instructions behind each of the first 22, the two stores behind the last two (the matrix pipe takes one
+        // instruction per 32 cycles from this wave: the conversion rides in the issue slots it leaves)
+        if (q == 0) write_X_item_nb((cr + 1) & 1, U0{});
+        if (q == 2) write_X_item_nb((cr + 1) & 1, U1{});
+        if (q == 4) write_X_item_nb((cr + 1) & 1, U2{});
+        if ((q & 1) == 0) {
+#pragma unroll
+          for (int m = 0; m < 22; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // three VALU
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
       stamp();                           // +4: MFMAs issued
       if (ABL != 5) __builtin_amdgcn_sched_barrier(0);
       if (!(last_chunk && q == 2 * JT - 1) || !late) __syncthreads();
     }
   }
   stamp();                               // main loop left
+  if constexpr (CVC && F16) {
+    if (sbad != 0 && lane == 0 && A.range_ctr) atomicAdd(A.range_ctr, sbad);
+  }
 
   bool run_tail = true;
   if constexpr (SK) {
@@ -622,9 +788,16 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
         conv_epilogue_wide_block<BM, BMH>(pt, acc[mi][0], mt, row0, 0, lane, nw0, Ntot, wl);
         conv_epilogue_wide_block<BM, BMH>(pt, acc[mi][1], mt, row0, 1, lane, nw0, Ntot, wl);
       }
+    } else if (WIDE_GLU && dv3_wide_glu_ok(pt)) {
+      // 16-byte Conv1dGLU / highway tail through a quad transpose in registers (conv_common.h)
+      constexpr int TA = ABL == 12 ? 12 : ABL == 13 ? 13 : 0;
+      const int nw0 = n0e + wn * (NI * 32);
+      conv_epilogue_glu_wide<BMH, NI, TA>(pt, acc[0], mt, wm * (MI * 32), lane, nw0, Ntot);
+      conv_epilogue_glu_wide<BMH, NI, TA>(pt, acc[1], mt, wm * (MI * 32) + 32, lane, nw0, Ntot);
     } else {
-      conv_epilogue<BM, BMH, NI, 0, false>(pt, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
-      conv_epilogue<BM, BMH, NI, 0, false>(pt, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+      constexpr int TA = ABL == 12 ? 7 : ABL == 13 ? 8 : 0;     // experiment build: 12 = no residual load, 13 = no stores
+      conv_epilogue<BM, BMH, NI, TA, false>(pt, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+      conv_epilogue<BM, BMH, NI, TA, false>(pt, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
     }
   }
   stamp();                               // tail stores issued
@@ -635,11 +808,13 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   } while (SK && seg_u < seg_end);
 }
 
-template <bool MASK, bool F16, int ABL = 0, bool SK = false>
+#ifndef DV3_PP2_ISA_ONLY   // (developer: compile one instantiation for ISA inspection, scripts/pp2_isa.sh)
+template <bool MASK, bool F16, int ABL = 0, bool SK = false, int ORD = 0>
 int launch_pp2(const ConvArgs& a, size_t lds, hipStream_t st) {
+  if ((ORD & 4) != 0 && lds + 8 * 256 > 160 * 1024) return launch_pp2<MASK, F16, ABL, SK, (ORD & ~4)>(a, lds, st);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_pp2_kernel<MASK, F16, ABL, SK>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_pp2_kernel<MASK, F16, ABL, SK, ORD>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_gemm_pp2: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -647,17 +822,28 @@ int launch_pp2(const ConvArgs& a, size_t lds, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_gemm_pp2_kernel<MASK, F16, ABL, SK>), dim3(a.n_blocks), dim3(NT), lds, st, a);
+  if ((ORD & 4) != 0) lds += 8 * 256;   // the prefetch strip
+  else if ((ORD & 64) != 0) lds += 32;   // two spare units behind the activation buffers
+  hipLaunchKernelGGL((conv_gemm_pp2_kernel<MASK, F16, ABL, SK, ORD>), dim3(a.n_blocks), dim3(NT), lds, st, a);
   return dv3_check_launch("conv_gemm_pp2");
 }
 
+#endif  // DV3_PP2_ISA_ONLY
 }  // namespace
 
+#ifndef DV3_PP2_ISA_ONLY
 int dv3_pp2_read_stamps(void* dst, int64_t bytes) {
   if (bytes <= 0 || bytes > (int64_t)sizeof(unsigned long long) * 8 * PP2_STAMPS * 2) return DV3_EINVAL;
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pp2_stamps), (size_t)bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? DV3_OK : DV3_ELAUNCH;
 }
 extern int g_x3_wide;
+int g_pp2_ord = 0;   // experiment build: dv3_debug_set(29, v) with v outside {0, 17, 81}: further ORD variants of the fp16-pair kernel
+// dv3_debug_set(29 / 31, v): ORD of the unmasked / masked instantiations (0, 17, 81).  Round 5 default 81 (weight
+// fragments first, activation items converted between the MFMAs): bit-identical to ORD 0, measured in one process at the
+// north-star shape (scripts/r5_ship_check.py, profiles/r05_pp2_load_phase.txt): fp16-pair forward 152.3 -> 148.8 us, masked
+// training forward 169.8 -> 166.9 us, bf16-pair input gradient 134.3 -> 132.3 us.  The masked bf16-pair instantiation
+// (legacy bf16x3 mode) keeps ORD 0: there the compiler contracts the mask multiply differently in the two forms.
+int g_pp2_ord_u = 81, g_pp2_ord_m = 81;
 int g_pp2_abl = 0;   // dv3_debug_set(13, v): timing-only ablations of the unmasked kernel (1 no MFMAs, 2 no staging, 3 no tail)
 
 // Stream-K (round 4).  A 256 x 256 tile grid rarely divides the 256 CUs: the encoder layers of the benchmark step are 152
@@ -736,7 +922,30 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
       return mask ? launch_pp2<true, false, 0, true>(a, lds_sk, st) : launch_pp2<false, false, 0, true>(a, lds_sk, st);
     }
   }
+  {
+    // LOAD-phase structure (ORD, see the kernel): measured variants, selectable at run time (dv3_debug_set(29, v) for the
+    // unmasked instantiations, (31, v) for the masked ones); anything else needs the experiment build
+    const int o = mask ? (f16 ? g_pp2_ord_m : 0) : g_pp2_ord_u;
+#define DV3_PP2_ORD_SHIP(oo) \
+    if (o == oo) { \
+      if (f16) return mask ? launch_pp2<true, true, 0, false, oo>(a, lds, st) : launch_pp2<false, true, 0, false, oo>(a, lds, st); \
+      return mask ? launch_pp2<true, false, 0, false, oo>(a, lds, st) : launch_pp2<false, false, 0, false, oo>(a, lds, st); \
+    }
+    DV3_PP2_ORD_SHIP(17) DV3_PP2_ORD_SHIP(81)
+#undef DV3_PP2_ORD_SHIP
+  }
 #ifdef DV3_EXPERIMENTS
+  if (g_pp2_ord && f16) {
+    switch (g_pp2_ord) {
+#define DV3_PP2_ORD_CASE(o) case o: return mask ? launch_pp2<true, true, 0, false, o>(a, lds, st) : launch_pp2<false, true, 0, false, o>(a, lds, st);
+#define DV3_PP2_ORD_CASE_U(o) case o: if (!mask) return launch_pp2<false, true, 0, false, o>(a, lds, st); break;
+      DV3_PP2_ORD_CASE_U(1) DV3_PP2_ORD_CASE_U(2) DV3_PP2_ORD_CASE_U(3) DV3_PP2_ORD_CASE_U(4) DV3_PP2_ORD_CASE_U(5) DV3_PP2_ORD_CASE_U(7)
+      DV3_PP2_ORD_CASE_U(10) DV3_PP2_ORD_CASE_U(11) DV3_PP2_ORD_CASE_U(15)
+      DV3_PP2_ORD_CASE(19) DV3_PP2_ORD_CASE(27) DV3_PP2_ORD_CASE(31) DV3_PP2_ORD_CASE(32) DV3_PP2_ORD_CASE(49) DV3_PP2_ORD_CASE(64) DV3_PP2_ORD_CASE(65)
+#undef DV3_PP2_ORD_CASE_U
+#undef DV3_PP2_ORD_CASE
+    }
+  }
   if (g_pp2_abl && !mask && f16) {
     switch (g_pp2_abl) {
       case 1: return launch_pp2<false, true, 1>(a, lds, st);
@@ -750,9 +959,18 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
       case 9: return launch_pp2<false, true, 9>(a, lds, st);
       case 10: return launch_pp2<false, true, 10>(a, lds, st);
       case 11: return launch_pp2<false, true, 11>(a, lds, st);   // EXPERIMENT: weight panels by LDS-DMA (see dma_A_unit)
+      case 12: return launch_pp2<false, true, 12>(a, lds, st);   // tail without the residual load
+      case 13: return launch_pp2<false, true, 13>(a, lds, st);   // tail without the stores
+      case 14: return launch_pp2<false, true, 12, false, 32>(a, lds, st);   // ... the same two of the 16-byte tail
+      case 15: return launch_pp2<false, true, 13, false, 32>(a, lds, st);
     }
   }
 #endif
   if (f16) return mask ? launch_pp2<true, true>(a, lds, st) : launch_pp2<false, true>(a, lds, st);
   return mask ? launch_pp2<true, false>(a, lds, st) : launch_pp2<false, false>(a, lds, st);
 }
+#else
+namespace {
+template __global__ void conv_gemm_pp2_kernel<DV3_PP2_ISA_MASK, true, 0, false, DV3_PP2_ISA_ORD>(const ConvArgs);
+}
+#endif  // DV3_PP2_ISA_ONLY

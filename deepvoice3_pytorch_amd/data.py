@@ -316,7 +316,7 @@ class Prefetcher(object):
         if self.cuda:
             from . import ops as _ops
             with torch.cuda.device(self.device):
-                self.side = _ops.concurrent_stream(list(beside) if beside else [torch.cuda.current_stream()])
+                self.side = _ops.concurrent_stream(list(beside) if beside else [torch.cuda.current_stream()], role="prefetch")
         self.q = queue.Queue(maxsize=max(1, depth))
         self.slots = [_Staging(self.cuda) for _ in range(max(1, depth) + 2)]
         self.pool = ThreadPoolExecutor(max(1, workers)) if workers > 0 else None

@@ -30,15 +30,29 @@ class BucketedAllReduce(object):
     the speaker projections of the fused block path -- is kept out of its neighbours' buckets)."""
 
     def __init__(self, arena, process_group=None, bucket_mb=25.0, last_bucket_mb=8.0, last_span_mb=40.0, isolate=(),
-                 beside=(), boundaries=()):
+                 beside=(), boundaries=(), issue_stream=None):
+        """issue_stream (round 5): the stream the all-reduces are ISSUED from -- the step's second backward stream
+        (ops.SideStream), on which the weight-norm backward has just written the bucket's gradients.  The calls are
+        asynchronous (c10d runs the collective on its own communicator stream, which waits for the issuing stream's
+        position and nothing else) and the step stream picks their completion up in join(): no collective stream of our
+        own, so the step runs on three streams (step, weight-gradient, c10d's) instead of four -- HIP maps streams onto
+        GPU_MAX_HW_QUEUES = 4 hardware queues, and with step + weight-gradient + collective + prefetch + c10d's there
+        were more streams than queues: whichever two shared one serialised, cross-stream waits and all (BENCH_r04:
+        deepvoice3_vctk replay +16 % under a world-1 group on the driver's box, +1.4 % on another).  None: a collective
+        stream of this object's own, picked to run beside `beside` (rounds 2-4)."""
         self.arena = arena
         self.pg = process_group
         # the collective stream: one whose work really overlaps with the streams backward runs on (`beside`; see
         # ops.concurrent_stream -- HIP streams share a few hardware queues)
         self.side = None
+        self.async_issue = False
+        self._works = []
         if arena.grad.is_cuda:
             from . import ops as _ops
-            self.side = _ops.concurrent_stream(list(beside)) if beside else torch.cuda.Stream()
+            if issue_stream is not None:
+                self.side, self.async_issue = issue_stream, True
+            else:
+                self.side = _ops.concurrent_stream(list(beside), role="collective") if beside else torch.cuda.Stream()
         cap = max(1, int(bucket_mb * (1 << 20) / 4))
         cap_last = cap if last_bucket_mb is None else max(1, min(cap, int(last_bucket_mb * (1 << 20) / 4)))
         span_last = 0 if last_bucket_mb is None else int(last_span_mb * (1 << 20) / 4)
@@ -168,17 +182,32 @@ class BucketedAllReduce(object):
                 lo, hi, _ = self.buckets[b]
                 dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
             return
-        for st in streams:
-            ev = torch.cuda.Event()
-            ev.record(st)
-            self.side.wait_event(ev)
+        self._wait_for(streams)
         with torch.cuda.stream(self.side):
             for b in bucket_ids:
                 lo, hi, _ = self.buckets[b]
-                dist.all_reduce(self.arena.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+                self._all_reduce(self.arena.grad[lo:hi])
+
+    def _wait_for(self, streams):
+        """the issuing stream waits for everything enqueued so far on `streams` (itself excepted)"""
+        for st in streams:
+            if st is None or st == self.side:
+                continue
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self.side.wait_event(ev)
+
+    def _all_reduce(self, view):
+        """current stream = the issuing stream.  async_issue: the call returns a handle and the issuing stream is NOT made
+        to wait for the collective (its next kernels -- the following layers' weight gradients -- run beside it); join()
+        makes the step stream wait.  Inside a capture (single-graph replay) the call stays synchronous."""
+        if self.async_issue and not torch.cuda.is_current_stream_capturing():
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
 
     def join(self, cur=None):
-        """the step stream waits for the collective stream (timed when exposed_events is a list)"""
+        """the step stream waits for the collectives (timed when exposed_events is a list)"""
         if self.side is None:
             return
         cur = cur or torch.cuda.current_stream()
@@ -186,7 +215,13 @@ class BucketedAllReduce(object):
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record(cur)
-        cur.wait_stream(self.side)
+        works, self._works = self._works, []
+        if works:
+            with torch.cuda.stream(cur):
+                for w in works:
+                    w.wait()                 # the CURRENT stream waits for the communicator stream's end-of-collective event
+        if not self.async_issue:
+            cur.wait_stream(self.side)
         if timed:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(cur)
@@ -206,12 +241,9 @@ class BucketedAllReduce(object):
         for st in (_ops.SideStream.stream, _ops.SideStream.main):
             if st is not None:
                 streams.add(st)
-        for st in streams:
-            ev = torch.cuda.Event()
-            ev.record(st)
-            self.side.wait_event(ev)
+        self._wait_for(streams)
         with torch.cuda.stream(self.side):
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
+            self._all_reduce(view)
 
     def finish(self):
         """Launch whatever is left (parameters that received no gradient) and join the side stream."""

@@ -100,18 +100,32 @@ def _stream():
     return _raw_stream(_cur_device())
 
 
-def concurrent_stream(avoid, tries=12):
+stream_probe_log = []      # one record per concurrent_stream() call: bench.py prints them as `stream_queues`
+
+
+def concurrent_stream(avoid, tries=12, role="side", strict=None):
     """A torch stream whose work REALLY runs beside the work of every stream in `avoid`.  HIP multiplexes its streams onto a
     few hardware queues (GPU_MAX_HW_QUEUES, default 4): two streams that land on the same queue execute in issue order,
     whatever the events between them say -- the step's second backward stream then adds nothing (measured: the same
     replayed deepvoice3_vctk step at 11.76 or 12.75 ms, by which pool stream a Trainer instance happened to get,
-    scripts/r4_probe_order.py).  Probed with a pair of one-thread spin kernels (torch.cuda._sleep): a candidate is
-    taken when the pair takes about as long as one of them.  Falls back to the first candidate."""
-    first = None
+    scripts/r4_probe_order.py).  Probed with pairs of one-thread spin kernels (torch.cuda._sleep): a candidate is taken
+    when, against EVERY stream in `avoid`, the best of three pairs takes about as long as one kernel (ratio < 1.5; a
+    shared queue gives 2.0).  Every call leaves a record in `stream_probe_log` (role, the ratio of each candidate against
+    each avoided stream, whether a concurrent stream was found).  When none of `tries` candidates runs beside all of
+    them: a loud warning and the candidate with the smallest worst ratio -- or RuntimeError under strict
+    (DV3_STRICT_STREAMS=1).  While a capture is active (no synchronize allowed) or with DV3_STREAM_PROBE=0: a plain
+    stream, recorded as unprobed."""
+    import warnings
+    rec = dict(role=role, avoid=len(avoid), probed=False, found=None, candidates=[])
+    stream_probe_log.append(rec)
     if not avoid:
         return torch.cuda.Stream()
+    if strict is None:
+        strict = _os.environ.get("DV3_STRICT_STREAMS", "") == "1"
     dev = avoid[0].device
     with torch.cuda.device(dev):
+        if _os.environ.get("DV3_STREAM_PROBE", "1") in ("0", "") or torch.cuda.is_current_stream_capturing():
+            return torch.cuda.Stream()
         cycles = 200000
 
         def spin_pair(a, s):
@@ -130,17 +144,31 @@ def concurrent_stream(avoid, tries=12):
 
         try:
             spin_pair(avoid[0], None)
-            one = min(spin_pair(avoid[0], None) for _ in range(2))
+            one = min(spin_pair(avoid[0], None) for _ in range(3))
         except Exception:      # no spin kernel in this build: take any stream
             return torch.cuda.Stream()
+        rec["probed"] = True
         want_shared = _os.environ.get("DV3_SIDE_STREAM_SAME_QUEUE", "") == "1"      # experiment: the opposite choice
+        best, best_worst = None, None
         for _ in range(tries):
             s = torch.cuda.Stream()
-            first = first or s
-            beside = all(min(spin_pair(a, s), spin_pair(a, s)) < 1.5 * one for a in avoid)
+            ratios = [round(min(spin_pair(a, s) for _ in range(3)) / one, 2) for a in avoid]
+            rec["candidates"].append(ratios)
+            worst = max(ratios)
+            if best is None or worst < best_worst:
+                best, best_worst = s, worst
+            beside = worst < 1.5
             if beside != want_shared:
+                rec["found"] = not want_shared
                 return s
-    return first
+        rec["found"] = False
+        msg = ("no HIP stream runs beside all %d streams of the step (%s stream; ratios %s): hardware queues are shared, the "
+               "overlap this stream is for is lost (GPU_MAX_HW_QUEUES=%s)" % (len(avoid), role, rec["candidates"],
+                                                                           _os.environ.get("GPU_MAX_HW_QUEUES", "default 4")))
+        if strict:
+            raise RuntimeError(msg)
+        warnings.warn(msg)
+    return best
 
 
 # ----------------------------------------------------------------------------------------------

@@ -150,13 +150,26 @@ class FlatArena(object):
 class Trainer(object):
     HYPER_SLOTS = 8
 
-    def __init__(self, model, cfg, global_step=0, process_group=None, bucket_mb=25.0, last_bucket_mb=8.0):
+    def __init__(self, model, cfg, global_step=0, process_group=None, bucket_mb=25.0, last_bucket_mb=8.0,
+                 train_seq2seq=True, train_postnet=True):
+        """train_seq2seq / train_postnet: the reference's `--train-seq2seq-only` / `--train-postnet-only` runs
+        (train.py:608-616, 684-731): only model.seq2seq (mel + done + attention losses) or only model.postnet on the mel
+        TARGETS (linear loss) is run and updated.  The reference keeps ONE optimizer over every trainable parameter and
+        lets Adam skip those without a gradient; here the arena holds the trained sub-module's parameters only (the others
+        take no gradient, no moment decay and no update -- what skipping means), numbered as the reference's optimizer
+        numbers them (`optimizer_order`), so checkpoints interoperate in both modes."""
+        assert train_seq2seq or train_postnet
+        self.train_seq2seq, self.train_postnet = bool(train_seq2seq), bool(train_postnet)
         self.model, self.cfg = model, cfg
         self.global_step = global_step
         self.adam_step = 0
         params = list(model.get_trainable_parameters())
         # The optimizer-facing order (checkpoint interop: torch.optim.Adam numbers its state by this order) ...
         self.optimizer_order = list(params)
+        if not (self.train_seq2seq and self.train_postnet):
+            sub = model.seq2seq if self.train_seq2seq else model.postnet
+            inside = set(id(p) for p in sub.parameters())
+            params = [p for p in params if id(p) in inside]
         # ... and the arena's.  Data parallel, multi-speaker: the speaker projections of the Conv1dGLU layers get their
         # gradients from ONE backward node per block (ops.SpeakerBiasBlockFn) that runs when the whole block's backward is
         # done -- left between their layers' weights they would hold every bucket of the block back until then.  They
@@ -199,7 +212,7 @@ class Trainer(object):
         self.side_stream = None
         if dev.type == "cuda" and os.environ.get("DV3_WGRAD_STREAM", "1") not in ("0", ""):
             with torch.cuda.device(dev):
-                self.side_stream = ops.concurrent_stream([torch.cuda.current_stream()])
+                self.side_stream = ops.concurrent_stream([torch.cuda.current_stream()], role="weight-gradient")
         self.pg = process_group
         self.world = 1
         self.comm = None
@@ -210,9 +223,25 @@ class Trainer(object):
             shared = set(id(p) for n, p in model.named_parameters() if n.split(".")[-2:-1] == ["embed_speakers"])
             isolate = [i for i, p in enumerate(self.arena.params) if id(p) in shared]
             group_start = len(self.arena.params) - len(self.late_group) if self.late_group else None
+            # the all-reduces are issued (asynchronously) from the weight-gradient stream itself: no collective stream of
+            # the trainer's own to share a hardware queue with (dist.BucketedAllReduce); DV3_COLLECTIVE_STREAM=own: the
+            # round-4 form (a probed fourth stream), kept for A/B runs
+            own = os.environ.get("DV3_COLLECTIVE_STREAM", "") == "own" or self.side_stream is None
             self.comm = _dist.BucketedAllReduce(self.arena, process_group, bucket_mb, last_bucket_mb, isolate=isolate, boundaries=() if group_start is None else (group_start,),
                                                 beside=[st for st in (torch.cuda.current_stream() if dev.type == "cuda" else None,
-                                                                      self.side_stream) if st is not None])
+                                                                      self.side_stream) if st is not None],
+                                                issue_stream=None if own else self.side_stream)
+
+    def checkpoint_module(self):
+        """what train.save_checkpoint stores (train.py:788-797): the model, or the trained sub-module in a split mode"""
+        if self.train_seq2seq and self.train_postnet:
+            return self.model
+        return self.model.seq2seq if self.train_seq2seq else self.model.postnet
+
+    def checkpoint_suffix(self):
+        if self.train_seq2seq and self.train_postnet:
+            return ""
+        return "_seq2seq" if self.train_seq2seq else "_postnet"
 
     def close(self):
         """Detach the gradient-exchange hooks (call before building another Trainer on the same model)."""
@@ -286,12 +315,27 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
             p._dv3_pending = 0
         self.model.train()
         ops.prepacked = self._prepack_all()
+        s2s, pn = self.train_seq2seq, self.train_postnet
         try:
-            mel_out, lin_out, attn, done_hat = self.model(
-                batch.text, batch.mel, speaker_ids=batch.speaker_ids, text_positions=batch.text_positions,
-                frame_positions=batch.frame_positions, input_lengths=batch.input_lengths)
+            if s2s and pn:
+                mel_out, lin_out, attn, done_hat = self.model(
+                    batch.text, batch.mel, speaker_ids=batch.speaker_ids, text_positions=batch.text_positions,
+                    frame_positions=batch.frame_positions, input_lengths=batch.input_lengths)
+            elif s2s:                                    # train.py:689-697
+                assert batch.speaker_ids is None
+                mel_out, attn, done_hat, _ = self.model.seq2seq(
+                    batch.text, batch.mel, text_positions=batch.text_positions,
+                    frame_positions=batch.frame_positions, input_lengths=batch.input_lengths)
+                mel_out = mel_out.reshape(batch.mel.size(0), -1, batch.mel.size(-1))
+                lin_out = None
+            else:                                        # train.py:698-701: the post-net on the mel TARGETS
+                assert batch.speaker_ids is None
+                lin_out = self.model.postnet(batch.mel)
+                mel_out = attn = done_hat = None
         finally:
             ops.prepacked = None
+        if not (s2s and pn):
+            return self._split_losses_backward(batch, mel_out, lin_out, attn, done_hat)
         wm, w = c.masked_loss_weight, c.binary_divergence_weight
         lin_len = batch.linear_mask_lengths if wm > 0 else None
         direct = c.priority_freq_weight <= 0 and self.device.type == "cuda"
@@ -358,6 +402,49 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
             ops.WnBwdBatch.active = False
             ops.WnBwdBatch.discard()
             ops.SideStream.join()          # the step stream waits for the weight-gradient branch; its operands may go
+            ops.SideStream.stream = ops.SideStream.main = None
+        return {k: v.detach() for k, v in scal.items()}
+
+    def _split_losses_backward(self, batch, mel_out, lin_out, attn, done_hat):
+        """losses + backward of the seq2seq-only / postnet-only steps (train.py:704-740): the joint step's terms, those
+        of the part that ran"""
+        c = self.cfg
+        r, wm, w = c.outputs_per_step, c.masked_loss_weight, c.binary_divergence_weight
+        scal, terms = {}, []
+        if self.train_seq2seq:
+            m4 = ops.spec_loss(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w)
+            done_loss = ops.bce_loss(done_hat, batch.done)
+            scal.update(mel_l1_loss=m4[0], mel_binary_div_loss=m4[1], mel_loss=m4[2], done_loss=done_loss[0])
+            terms += [m4[2], done_loss[0]]
+            if c.use_guided_attention:
+                attn_loss = ops.guided_attention_loss(attn, batch.input_lengths, batch.decoder_lengths,
+                                                      c.guided_attention_sigma)
+                scal["attn_loss"] = attn_loss[0]
+                terms.append(attn_loss[0])
+        else:
+            lin_len = batch.linear_mask_lengths if wm > 0 else None
+            l4 = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, w)
+            lin_loss = l4[2]
+            if c.priority_freq_weight > 0:
+                n_pri = int(c.priority_freq / (c.sample_rate * 0.5) * lin_out.size(-1))
+                l1_all = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, 0.0)[2]
+                l1_pri = ops.spec_loss(lin_out[:, :, :n_pri], batch.y[:, :, :n_pri], lin_len, r, wm, 0.0)[2]
+                lin_loss = lin_loss + (1.0 - w) * c.priority_freq_weight * (l1_pri - l1_all)
+            scal.update(linear_l1_loss=l4[0], linear_binary_div_loss=l4[1], linear_loss=lin_loss)
+            terms.append(lin_loss)
+        loss = terms[0]
+        for t in terms[1:]:
+            loss = loss + t
+        scal["loss"] = loss
+        if self.comm is not None:
+            self.comm.arm()
+        ops.SideStream.stream = self.side_stream
+        ops.SideStream.main = torch.cuda.current_stream() if self.side_stream is not None else None
+        ops.SideStream.capturing = self.side_stream is not None and torch.cuda.is_current_stream_capturing()
+        try:
+            loss.backward()
+        finally:
+            ops.SideStream.join()
             ops.SideStream.stream = ops.SideStream.main = None
         return {k: v.detach() for k, v in scal.items()}
 
@@ -689,22 +776,24 @@ def checkpoint_dict(trainer, global_epoch=0, save_optimizer_state=True):
         slot = {id(p): (o, n) for o, n, p in zip(a.offsets, a.sizes, a.params)}
         if trainer.adam_step > 0:
             for i, p in enumerate(trainer.optimizer_order):      # torch.optim.Adam's numbering, whatever the arena's order
+                if id(p) not in slot:                            # split modes: Adam holds no state for what it never stepped
+                    continue
                 o, n = slot[id(p)]
                 state[i] = dict(step=torch.tensor(float(trainer.adam_step)),
                                 exp_avg=a.exp_avg[o:o + n].view(p.shape).clone(),
                                 exp_avg_sq=a.exp_avg_sq[o:o + n].view(p.shape).clone())
         group = dict(lr=float(trainer.current_lr()), betas=(c.adam_beta1, c.adam_beta2), eps=c.adam_eps,
                      weight_decay=c.weight_decay, amsgrad=False, maximize=False, foreach=None, capturable=False,
-                     differentiable=False, fused=None, params=list(range(len(a.params))))
+                     differentiable=False, fused=None, params=list(range(len(trainer.optimizer_order))))
         opt = dict(state=state, param_groups=[group])
-    return {"state_dict": {k: v.detach().clone() for k, v in trainer.model.state_dict().items()},
+    return {"state_dict": {k: v.detach().clone() for k, v in trainer.checkpoint_module().state_dict().items()},
             "optimizer": opt, "global_step": trainer.global_step, "global_epoch": global_epoch}
 
 
 def save_checkpoint(trainer, checkpoint_dir, global_epoch=0, save_optimizer_state=True):
     """train.save_checkpoint (train.py:788-809): checkpoint_step{:09d}.pth in `checkpoint_dir`."""
     import os
-    path = os.path.join(checkpoint_dir, "checkpoint_step{:09d}.pth".format(trainer.global_step))
+    path = os.path.join(checkpoint_dir, "checkpoint_step{:09d}{}.pth".format(trainer.global_step, trainer.checkpoint_suffix()))
     torch.save(checkpoint_dict(trainer, global_epoch, save_optimizer_state), path)
     return path
 
@@ -738,7 +827,7 @@ def load_checkpoint(path_or_dict, trainer, reset_optimizer=False, unsafe=False):
     ck = path_or_dict if isinstance(path_or_dict, dict) else _load_file(path_or_dict, unsafe)
     a = trainer.arena
     with torch.no_grad():     # copy INTO the arena views (load_state_dict would keep them too; be explicit)
-        own = trainer.model.state_dict()
+        own = trainer.checkpoint_module().state_dict()
         missing = [k for k in own if k not in ck["state_dict"]]
         unexpected = [k for k in ck["state_dict"] if k not in own]
         if missing or unexpected:
@@ -747,15 +836,15 @@ def load_checkpoint(path_or_dict, trainer, reset_optimizer=False, unsafe=False):
             own[k].copy_(v)
     opt = ck.get("optimizer")
     if opt is not None and not reset_optimizer:
-        if len(opt["param_groups"]) != 1 or len(opt["param_groups"][0]["params"]) != len(a.params):
+        if len(opt["param_groups"]) != 1 or len(opt["param_groups"][0]["params"]) != len(trainer.optimizer_order):
             raise RuntimeError("optimizer state does not match get_trainable_parameters()")
         steps = set()
         slot = {id(p): (o, n) for o, n, p in zip(a.offsets, a.sizes, a.params)}
         for i, p in enumerate(trainer.optimizer_order):
-            o, n = slot[id(p)]
             st = opt["state"].get(i)
-            if st is None:
+            if st is None or id(p) not in slot:      # (a split-mode trainer keeps the moments of its own part only)
                 continue
+            o, n = slot[id(p)]
             a.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
             a.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
             steps.add(int(float(st["step"])))

@@ -157,9 +157,11 @@ def lws_hann(n, symmetric=True):
     return 0.5 * (1.0 - np.cos(2.0 * np.pi * k / ((n - 1) if symmetric else n)))
 
 
-def lws_windows(fsize=1024, fshift=256):
-    """-> (awin, swin): lws.lws(fsize, fshift).awin and the synthwin(awin, fshift) perfect-reconstruction synthesis window"""
-    awin = np.sqrt(lws_hann(fsize, True))
+def lws_windows(fsize=1024, fshift=256, scale=1.0):
+    """-> (awin, swin): lws.lws(fsize, fshift).awin and the synthwin(awin, fshift) perfect-reconstruction synthesis window.
+    `scale`: amplitude factor of the analysis window -- the constant this restatement can NOT confirm offline (1.0 = plain
+    sqrt(hann); sqrt(2 fshift / fsize) if the package normalises the window's sum of squares for the hop)"""
+    awin = float(scale) * np.sqrt(lws_hann(fsize, True))
     Q = int(np.ceil(fsize * 1.0 / fshift))
     twin = awin * awin
     w = np.concatenate([twin, np.zeros(Q * fshift - fsize)]).reshape(Q, fshift).sum(0)
@@ -171,16 +173,15 @@ def lws_windows(fsize=1024, fshift=256):
 
 def lws_num_frames(length, fsize=1024, fshift=256):
     pad = fsize - fshift
-    M = (length + 2 * pad - fsize) // fshift + 1
-    return M if length % fshift == 0 else M + 1
+    return -(-(length + 2 * pad - fsize) // fshift) + 1
 
 
-def lws_stft(x, fsize=1024, fshift=256):
+def lws_stft(x, fsize=1024, fshift=256, scale=1.0):
     """lws.lws(fsize, fshift).stft(x): (L,) or (B, L) real -> (..., M, fsize / 2 + 1) complex"""
     x = np.asarray(x, dtype=np.float64)
     if x.ndim == 2:
-        return np.stack([lws_stft(r, fsize, fshift) for r in x])
-    awin, _ = lws_windows(fsize, fshift)
+        return np.stack([lws_stft(r, fsize, fshift, scale) for r in x])
+    awin, _ = lws_windows(fsize, fshift, scale)
     pad = fsize - fshift
     M = lws_num_frames(len(x), fsize, fshift)
     xp = np.zeros((M - 1) * fshift + fsize)
@@ -189,13 +190,13 @@ def lws_stft(x, fsize=1024, fshift=256):
     return np.fft.rfft(frames, axis=-1)
 
 
-def lws_istft(S, fshift=256):
+def lws_istft(S, fshift=256, scale=1.0):
     """lws.lws(fsize, fshift).istft(S): (..., M, fsize / 2 + 1) complex -> (..., (M - 1) fshift + fsize - 2 (fsize - fshift))"""
     S = np.asarray(S)
     if S.ndim == 3:
-        return np.stack([lws_istft(s, fshift) for s in S])
+        return np.stack([lws_istft(s, fshift, scale) for s in S])
     M, fsize = S.shape[0], 2 * (S.shape[1] - 1)
-    _, swin = lws_windows(fsize, fshift)
+    _, swin = lws_windows(fsize, fshift, scale)
     pad = fsize - fshift
     frames = np.fft.irfft(S, n=fsize, axis=-1) * swin
     yp = np.zeros((M - 1) * fshift + fsize)
@@ -217,9 +218,9 @@ def lws_griffin_lim(mag, n_iter, fshift=256, init_phasor=None):
     return y
 
 
-def lws_spectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97):
+def lws_spectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97, scale=1.0):
     """audio.spectrogram (audio.py:31-35) on the lws framing: (B, L) -> (B, 513, M)"""
-    D = np.abs(lws_stft(preemphasis(wav, coef), 1024, hop)).transpose(0, 2, 1)
+    D = np.abs(lws_stft(preemphasis(wav, coef), 1024, hop, scale)).transpose(0, 2, 1)
     return normalize(amp_to_db(D, min_level_db) - ref_level_db, min_level_db)
 
 

@@ -254,6 +254,67 @@ def gen_trainstep():
     print("wrote trainstep.npz; scalars:", {k: [round(s[1], 6) for s in v] for k, v in writer.scalars.items()})
 
 
+def gen_trainstep_split():
+    """Two steps each of the reference's own train.train(train_seq2seq=True, train_postnet=False) and of the converse
+    (train.py:608-616, 684-731, 788-797) on the trainstep fixture's model and batch (dropout 0), plus the checkpoint
+    files train.save_checkpoint writes for the two modes ("_seq2seq" / "_postnet": the sub-module's state_dict and the
+    full optimizer's state, which holds moments only for the parameters that received gradients)."""
+    train, hparams, Writer = refimport.load_train_module()
+    import deepvoice3_pytorch.frontend as fe
+    hparams.parse_json(open(os.path.join(refimport.REF_ROOT, "presets", "deepvoice3_ljspeech.json")).read())
+    hp_over = dict(dropout=0.0, text_embed_dim=24, encoder_channels=48, decoder_channels=32,
+                   converter_channels=32, num_mels=20, fft_size=64, batch_size=3, max_positions=128)
+    for k, v in hp_over.items():
+        setattr(hparams, k, v)
+    # use_decoder_state_for_postnet_input is True in the preset: the post-net then has decoder_channels // r inputs and
+    # can not be trained on mel targets alone (model.postnet(mel), train.py:701) -- the split modes need the mel-input form
+    hparams.use_decoder_state_for_postnet_input = False
+    train._frontend = fe.en
+    rng = np.random.RandomState(11)
+    items = []
+    for n_frames, n_text in [(37, 9), (52, 13), (44, 11)]:
+        text = np.concatenate([rng.randint(2, 149, size=n_text - 1), [1]]).astype(np.int32)
+        items.append((text, rng.rand(n_frames, 20).astype(np.float32), rng.rand(n_frames, 33).astype(np.float32)))
+    batch = train.collate_fn(items)
+    out = {"hp_over": json.dumps(dict(hp_over, use_decoder_state_for_postnet_input=False)), "global_step0": np.int64(3999)}
+    x, in_len, mel, y, (tp, fp), done, tgt_len, _ = batch
+    out.update({"in/text": _np(x), "in/input_lengths": _np(in_len), "in/mel": _np(mel), "in/y": _np(y),
+                "in/text_positions": _np(tp), "in/frame_positions": _np(fp), "in/done": _np(done),
+                "in/target_lengths": _np(tgt_len)})
+    import tempfile
+    for mode, (ts, tpn) in (("seq2seq", (True, False)), ("postnet", (False, True))):
+        torch.manual_seed(4321)
+        model = train.build_model()
+        if mode == "seq2seq":
+            for k, v in model.state_dict().items():
+                out["sd0/" + k] = _np(v).copy()
+        optimizer = torch.optim.Adam(model.get_trainable_parameters(), lr=hparams.initial_learning_rate,
+                                     betas=(hparams.adam_beta1, hparams.adam_beta2), eps=hparams.adam_eps,
+                                     weight_decay=hparams.weight_decay, amsgrad=hparams.amsgrad)
+        writer = Writer()
+        train.global_step, train.global_epoch = 3999, 0
+        train.train(torch.device("cpu"), model, [batch, batch], optimizer, writer,
+                    init_lr=hparams.initial_learning_rate, checkpoint_dir="/tmp", checkpoint_interval=10 ** 9, nepochs=1,
+                    clip_thresh=hparams.clip_thresh, train_seq2seq=ts, train_postnet=tpn)
+        for k, v in model.state_dict().items():
+            out["%s/sd2/%s" % (mode, k)] = _np(v)
+        for k, v in writer.scalars.items():
+            out["%s/scalar/%s" % (mode, k.replace(" ", "_"))] = np.array([s[1] for s in v], dtype=np.float64)
+        # the checkpoint the reference writes in this mode: names of its state_dict, which optimizer slots carry state
+        d = tempfile.mkdtemp()
+        hparams.save_optimizer_state = True
+        train.save_checkpoint(model, optimizer, train.global_step, d, train.global_epoch, ts, tpn)
+        fn = os.listdir(d)[0]
+        ck = torch.load(os.path.join(d, fn), map_location="cpu", weights_only=False)
+        out["%s/ckpt_name" % mode] = fn
+        out["%s/ckpt_keys" % mode] = json.dumps(sorted(ck["state_dict"].keys()))
+        out["%s/ckpt_opt_slots" % mode] = np.array(sorted(ck["optimizer"]["state"].keys()), dtype=np.int64)
+        out["%s/ckpt_opt_nparams" % mode] = np.int64(len(ck["optimizer"]["param_groups"][0]["params"]))
+        print(mode, fn, "scalars:", {k: [round(s[1], 6) for s in v] for k, v in writer.scalars.items()})
+    np.savez_compressed(os.path.join(OUT, "trainstep_split.npz"), **out)
+    print("wrote trainstep_split.npz")
+
+
 def gen_misc():
     pkg = refimport.load_model_package()
     from deepvoice3_pytorch.modules import position_encoding_init, SinusoidalEncoding
@@ -425,11 +486,15 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":
         gen_checkpoint()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "trainstep_split":
+        gen_trainstep_split()
+        return
     for name, b, hp in MODELS:
         gen_model(name, b, hp)
     gen_losses()
     gen_misc()
     gen_trainstep()
+    gen_trainstep_split()
     gen_collate()
     gen_audio_helpers()
     gen_presets()

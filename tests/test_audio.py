@@ -95,6 +95,41 @@ def test_oracle_lws_framing_published_properties():
     assert sc(A.lws_griffin_lim(mag, 30, 256, ph)) < 0.5 * sc(A.lws_griffin_lim(mag, 0, 256, ph))
 
 
+def test_window_scale_is_the_unconfirmed_constant():
+    """The one number of the lws framing this repository cannot confirm offline (audio): the amplitude of the
+    analysis window.  sqrt(hann) (window_scale 1.0, the default) against sqrt(hann * 2 * fshift / fsize)
+    ("hop_normalized" = 0.7071 at hop 256) differ in exactly one observable: every STFT magnitude by the factor itself,
+    i.e. the normalised [0, 1] spectrogram of audio.spectrogram (audio.py:31-35) by 20 log10(0.7071) / 100 = -0.0301
+    wherever it is not clipped -- here the peak of a -40 dBFS sine.  Everything the other tests check (perfect
+    reconstruction, frame counts, Griffin-Lim's convergence) holds for both, which is why they cannot tell them apart;
+    one reference-preprocessed .npy next to its wav would.  Also: frame counts for hops that do not divide the fft size."""
+    from deepvoice3_pytorch_amd import audio
+    hop = 256
+    s2 = float(np.sqrt(2.0 * hop / 1024))
+    cfg2 = audio.AudioConfig(window_scale="hop_normalized")
+    assert abs(cfg2.window_scale - s2) < 1e-15 and audio.AudioConfig().window_scale == 1.0
+    with pytest.raises(ValueError):
+        audio.AudioConfig(window_scale=0.0)
+    n = np.arange(256 * 40)
+    wav = 0.01 * np.sin(2 * np.pi * (64.0 / 1024.0) * n)[None]     # -40 dBFS (a full-scale sine clips at 1.0), centre of bin 64
+    S1 = A.lws_spectrogram(wav, hop, coef=0.0, scale=1.0)
+    S2 = A.lws_spectrogram(wav, hop, coef=0.0, scale=s2)
+    p1, p2 = float(S1[0, 64, 10:30].mean()), float(S2[0, 64, 10:30].mean())
+    assert 0.5 < p2 < p1 < 1.0
+    assert abs((p1 - p2) - 0.030103) < 1e-6, (p1, p2)              # 3.01 dB of a 100 dB range
+    # both reconstruct perfectly (the synthesis window carries the inverse factor) ...
+    x = np.random.RandomState(0).randn(3000)
+    for sc in (1.0, s2):
+        y = A.lws_istft(A.lws_stft(x, 1024, hop, sc), hop, sc)
+        assert np.abs(y[:3000] - x).max() < 1e-12
+    a1, w1 = audio.lws_windows_np(1024, hop, 1.0)
+    a2, w2 = audio.lws_windows_np(1024, hop, s2)
+    assert np.allclose(a2, s2 * a1) and np.allclose(w2, w1 / s2)
+    # ... and the frame count is the documented ceil for any hop (ADVICE r4: hop 300, 1200 samples -> 7 frames)
+    assert audio.lws_num_frames(1200, 300) == 7 == A.lws_num_frames(1200, 1024, 300)
+    assert [audio.lws_num_frames(L, 256) for L in (256, 2560, 1000, 1)] == [4, 13, 7, 4]
+
+
 def test_oracle_inv_preemphasis_inverts_preemphasis():
     x = np.random.RandomState(2).randn(3, 1000)
     pre = np.concatenate([x[:, :1], x[:, 1:] - 0.97 * x[:, :-1]], axis=1)     # nnmnkwii.preemphasis

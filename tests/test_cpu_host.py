@@ -293,6 +293,23 @@ def test_bucketed_allreduce_gloo_world2():
     assert res[0][1] == res[1][1]      # both ranks hold the same reduced gradient arena
 
 
+def test_bucketed_allreduce_and_segment_schedule_gloo_world8():
+    """the same worker on EIGHT ranks (the node BASELINE.json's metric is defined on): bucketed all-reduce, in-place
+    notifications, and the segmented replay's note-then-issue schedule give every rank the 8-rank sums"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(8))
+    assert [r for r, _ in res] == list(range(8)) and len(set(v for _, v in res)) == 1
+
+
 def test_bucket_cutting_isolates_the_shared_table_and_segment_notes():
     """host logic of dist.BucketedAllReduce that needs no process group: an isolated parameter (the speaker table) is a
     bucket of its own and every parameter is in exactly one contiguous bucket; while a step is captured as segment
@@ -738,21 +755,23 @@ def test_bench_probes_the_launch_mode_on_every_world_size(monkeypatch):
     assert bench.launch_mode(argparse.Namespace(no_graph=False, graph=True), 8) is True
 
 
-def test_bench_self_launches_its_ranks_dry():
-    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (the driver's command
-    line); --dry-launch keeps it to the rendezvous + bucketed all-reduce so it runs on a CPU-only box (gloo)."""
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_self_launches_its_ranks_dry(n):
+    """`python bench.py --gpus N` with no launcher around it must start N ranks itself (the driver's command
+    line; N = 8 is the node BASELINE.json's metric is defined on); --dry-launch keeps it to the rendezvous + bucketed
+    all-reduce so it runs on a CPU-only box (gloo)."""
     import json
     import subprocess
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, universal_newlines=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-launch"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, universal_newlines=True)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout            # rank 0 alone prints, one line
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["n_gpus"] == n and out["rccl_ranks"] == n and out["config"]["parallelism"] == "dp%d" % n
     assert out["dry_launch"] is True and out["buckets"] >= 2
     if not torch.cuda.is_available():
         assert out["backend"] == "gloo"

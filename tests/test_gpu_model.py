@@ -304,6 +304,89 @@ def test_train_step_matches_reference_golden(dev, gemm_mode):
     assert worst_rms < (1e-3 if tight else 1e-2), measured
 
 
+@pytest.mark.parametrize("mode", ["seq2seq", "postnet"])
+def test_split_mode_train_steps_match_reference_golden(dev, gemm_mode, mode, tmp_path):
+    """train.train(train_seq2seq=True, train_postnet=False) and the converse (train.py:608-616, 684-731): two steps of
+    the reference's own loop (tests/golden/trainstep_split.npz, generated by oracle/make_golden.py from the unmodified
+    reference, dropout 0) against Trainer(train_seq2seq=..., train_postnet=...): the loss terms of the part that ran,
+    its pre-clip gradient norm, its weights after two updates; the other part's weights untouched; and the checkpoint
+    the mode writes ("_seq2seq" / "_postnet": the sub-module's names, optimizer state for its parameters only,
+    train.py:788-809) loads back into a fresh trainer."""
+    from deepvoice3_pytorch_amd import builder, train_step
+    tight = gemm_mode in ("f16x3", "f32")
+    fx = load_golden("trainstep_split")
+    hpo = json.loads(str(fx["hp_over"]))
+    hp = dict(n_vocab=149, embed_dim=hpo["text_embed_dim"], mel_dim=hpo["num_mels"],
+              linear_dim=hpo["fft_size"] // 2 + 1, r=1, downsample_step=4, padding_idx=0, dropout=0.0,
+              kernel_size=3, encoder_channels=hpo["encoder_channels"],
+              decoder_channels=hpo["decoder_channels"], converter_channels=hpo["converter_channels"],
+              use_memory_mask=True, force_monotonic_attention=True,
+              use_decoder_state_for_postnet_input=False, max_positions=hpo["max_positions"],
+              key_projection=True, value_projection=True)
+    cfg = train_step.TrainConfig(
+        outputs_per_step=1, downsample_step=4, masked_loss_weight=0.5, binary_divergence_weight=0.1,
+        use_guided_attention=True, guided_attention_sigma=0.2, clip_thresh=0.1, adam_beta1=0.5,
+        adam_beta2=0.9, adam_eps=1e-6, initial_learning_rate=5e-4, lr_schedule="noam_learning_rate_decay")
+    sd0 = {k[4:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith("sd0/")}
+    model = builder.deepvoice3(**hp)
+    model.load_state_dict(sd0)
+    model.to(dev)
+    x = {k[3:]: torch.from_numpy(val) for k, val in fx.items() if k.startswith("in/")}
+    s2s = mode == "seq2seq"
+    trainer = train_step.Trainer(model, cfg, global_step=int(fx["global_step0"]), train_seq2seq=s2s, train_postnet=not s2s)
+    batch = train_step.Batch.from_collate(x["text"], x["input_lengths"], x["mel"], x["y"],
+                                          x["text_positions"], x["frame_positions"], x["done"],
+                                          x["target_lengths"], None, downsample_step=4, device=dev)
+    names = (["loss", "done_loss", "mel_l1_loss", "mel_binary_div_loss", "attn_loss"] if s2s else
+             ["loss", "linear_loss", "linear_l1_loss", "linear_binary_div_loss"])
+    for it in range(2):
+        scal = {k: float(v) for k, v in trainer.step(batch).items()}
+        tol = 2e-5 if it == 0 else 2e-4
+        for k in names:
+            ref = float(fx["%s/scalar/%s" % (mode, k)][it])
+            assert abs(scal[k] - ref) < (tol if k == "loss" else 2e-4) * abs(ref), (k, it, scal[k], ref)
+        assert ("linear_loss" in scal) == (not s2s) and ("mel_loss" in scal) == s2s
+        gn = float(fx["%s/scalar/gradient_norm" % mode][it])
+        assert abs(scal["grad_norm"] - gn) / gn < (2e-5 if tight else 2e-4), (scal["grad_norm"], gn)
+    sdn = model.state_dict()
+    own = "seq2seq." if s2s else "postnet."
+    worst = 0.0
+    for k in sdn:
+        if k.endswith("positions.weight"):
+            continue
+        ref2 = fx["%s/sd2/%s" % (mode, k)].astype(np.float64)
+        now = sdn[k].cpu().numpy().astype(np.float64)
+        if not k.startswith(own):
+            # the part that did not run: the reference's Adam skips parameters without a gradient -- bit-unchanged
+            assert np.array_equal(ref2, sd0[k].numpy().astype(np.float64)), k
+            assert np.array_equal(now, ref2), k
+            continue
+        d0 = ref2 - sd0[k].numpy().astype(np.float64)
+        dd = now - ref2
+        assert float(np.abs(dd).max()) < 0.1 * max(float(np.abs(d0).max()), 1e-6) + 1e-6, k
+        rm = float(np.sqrt((d0 ** 2).mean()))
+        if rm > 1e-6:
+            worst = max(worst, float(np.sqrt((dd ** 2).mean())) / rm)
+    assert worst < (1e-3 if tight else 1e-2), worst
+    # the checkpoint of the mode
+    path = train_step.save_checkpoint(trainer, str(tmp_path))
+    assert os.path.basename(path) == str(fx["%s/ckpt_name" % mode])
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert sorted(ck["state_dict"].keys()) == json.loads(str(fx["%s/ckpt_keys" % mode]))
+    assert sorted(ck["optimizer"]["state"].keys()) == [int(i) for i in fx["%s/ckpt_opt_slots" % mode]]
+    assert len(ck["optimizer"]["param_groups"][0]["params"]) == int(fx["%s/ckpt_opt_nparams" % mode])
+    trainer.close()
+    model2 = builder.deepvoice3(**hp)
+    model2.load_state_dict(sd0)
+    model2.to(dev)
+    t2 = train_step.Trainer(model2, cfg, train_seq2seq=s2s, train_postnet=not s2s)
+    train_step.load_checkpoint(path, t2)
+    assert t2.global_step == trainer.global_step and t2.adam_step == trainer.adam_step
+    a1, a2 = trainer.arena, t2.arena
+    assert torch.equal(a1.flat, a2.flat) and torch.equal(a1.exp_avg, a2.exp_avg) and torch.equal(a1.exp_avg_sq, a2.exp_avg_sq)
+    t2.close()
+
+
 def test_graphed_train_step_matches_reference_golden(dev):
     """the whole-step hipGraph (what bench.py times): one warm-up step + one captured replay must
     land on the reference's step-2 scalars, i.e. capture changes nothing numerically"""
