@@ -152,18 +152,49 @@ def synth_batch(rng, B, Tt, n_frames, hp, fixed=True):
 # -------------------------------------------------------------------------------------------------
 # kernel rooflines (HIP events on the launch stream)
 # -------------------------------------------------------------------------------------------------
-def _time_launches(launch, iters, settle=100):
+def _time_launches(launch, iters, settle=100, per_graph=25):
+    """us per launch, HIP events on the stream the launches run on.  Round 5: the launches are captured into one hipGraph
+    (`per_graph` of them) and the REPLAYS are timed -- eager launches through ctypes cost the host 30-120 us each
+    (box dependent), so any kernel shorter than that measured as the host's issue rate (the 60 us bf16 tap-GEMM read
+    63.8 us eager against 59.3 us replayed on one box, profiles/r05_ship_check.txt; a 30 us launch reads 123 us on a
+    slow host).  Falls back to eager launches if the capture fails."""
     for _ in range(settle):      # the clock governor needs ~20 ms of this load to settle (first launches run ~20 % slower)
         launch()
     torch.cuda.synchronize()
     s = torch.cuda.current_stream()      # the stream ops.* enqueue on
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    try:
+        cap = torch.cuda.Stream()
+        cap.wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            for _ in range(per_graph):
+                launch()
+        torch.cuda.synchronize()
+        replays = max(2, -(-iters // per_graph))
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        e0.record(s)
+        for _ in range(replays):
+            g.replay()
+        e1.record(s)
+        torch.cuda.synchronize()
+        _time_launches.last_mode = "hipGraph of %d launches, %d replays" % (per_graph, replays)
+        return e0.elapsed_time(e1) * 1e3 / (replays * per_graph)
+    except Exception as e:      # noqa: a capture that fails must not void the line
+        sys.stderr.write("roofline timing: graph capture failed (%s: %s); eager launches\n" % (type(e).__name__, e))
+        torch.cuda.synchronize()
     e0.record(s)
     for _ in range(iters):
         launch()
     e1.record(s)
     torch.cuda.synchronize()
+    _time_launches.last_mode = "eager launches"
     return e0.elapsed_time(e1) * 1e3 / iters
+
+
+_time_launches.last_mode = None
 
 
 def _traffic(kernel_key):
@@ -229,7 +260,8 @@ def conv_roofline(dev, iters=100, tile_hint=0, dil=1, mode=None, c8=False):
                achieved=round(tf, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(tf / peak, 4),
                traffic=None, us_per_launch=round(us, 2), alg_flops=flops, alg_bytes=byts,
                hbm_gbs=round(byts / (us * 1e-6) / 1e9, 1),
-               hbm_frac=round(byts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4), variant=variant)
+               hbm_frac=round(byts / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4), variant=variant,
+               timing=_time_launches.last_mode)
     if dil == 1 and tile_hint == 0:
         out["traffic"], src = _traffic(key)
         if src:

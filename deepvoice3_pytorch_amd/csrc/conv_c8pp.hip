@@ -55,7 +55,12 @@ __device__ __forceinline__ bf16x8 c8pp_keep8(const bf16x8& v, uint32_t m) {
 // RF (round 5): the twelve fragment reads of a LOAD phase are issued FIRST and the staging (panel / tile stores, the
 // refetches) runs while they land -- the phase is then max(reads, staging) long instead of their sum (the reads of four
 // waves take 200-350 cycles of the 512 a partner's 16 MFMAs last).  Same instructions, same results.
-template <int JT, bool MASK, int ABL = 0, bool RF = false>
+// RL (round 5): the residual of a Conv1dGLU / HighwayConv1d layer IS its input (modules.py:139,163,224-226: y = f(conv(x))
+// + x): the 128 `a` channels of this tile are four of the 32-channel chunks the main loop stages anyway.  Their units
+// (raw, before the keep-bytes) are stored a second time into a 64 KB strip [16 channel groups][256 columns] behind the
+// tile buffers, and the tail reads the residual from there instead of fetching 33.5 MB (north star) from memory inside
+// the chip-wide tail burst.  Taken when the descriptor's residual tensor is the input tensor itself.
+template <int JT, bool MASK, int ABL = 0, bool RF = false, bool RL = false>
 __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
   constexpr int XI = (KB * (BN + (JT > 1 ? HALO_MAX : 0)) + NT - 1) / NT;   // activation units per thread per chunk
   constexpr int XPS = XI * NT;                                              // units per tile buffer (padded: no store is predicated)
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
   const int BNH = BN + (JT - 1) * dil;
   bf16x8* const As = reinterpret_cast<bf16x8*>(smem_raw);   // [2 buffers][KB][BM]
   bf16x8* const Xs = As + 2 * KB * BM;                      // [2 buffers][XPS]  ([KB][BNH] + padding)
+  bf16x8* const Rs = Xs + 2 * XPS;                          // RL: [BMH / 8 channel groups][BN] residual units
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -160,9 +166,20 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
     rx[i] = c8pp_ldg<bf16x8>(src, xoff[i]);
     if constexpr (MASK) rk[i] = (uint32_t)c8pp_ldg<uint8_t>(xkeep + (int64_t)chunk * KB * T, xoff[i] >> 4);
   };
-  auto write_X_item = [&](int buf, auto ic) {
+  // `chunk`: the 32-channel chunk the item belongs to (RL: chunks [mt * 4, mt * 4 + 4) hold this tile's `a` channels)
+  auto write_X_item = [&](int buf, auto ic, int chunk) {
     constexpr int i = decltype(ic)::value;
     bf16x8 v = rx[i];
+    if constexpr (RL) {
+      const int cr = chunk - mt * (BMH / 32);                        // uniform
+      if (cr >= 0 && cr < BMH / 32) {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));                                  // (recomputed here, four times per tile: no register held for it)
+        const int idx = t_ + i * NT;
+        const int k8 = idx / BNH, col = idx - k8 * BNH - p.padL;      // unit (k8, q) of the haloed tile; output column q - padL
+        if (idx < n_items && col >= 0 && col < BN) Rs[(cr * KB + k8) * BN + col] = v;
+      }
+    }
     if constexpr (MASK) v = c8pp_keep8(v, rk[i]);
     Xs[buf * XPS + tid + i * NT] = v;
   };
@@ -174,10 +191,10 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
     load_X_item(chunk, U1{});
     if constexpr (XI == 3) load_X_item(chunk, U2{});
   };
-  auto write_X_all = [&](int buf) {
-    write_X_item(buf, U0{});
-    write_X_item(buf, U1{});
-    if constexpr (XI == 3) write_X_item(buf, U2{});
+  auto write_X_all = [&](int buf, int chunk) {
+    write_X_item(buf, U0{}, chunk);
+    write_X_item(buf, U1{}, chunk);
+    if constexpr (XI == 3) write_X_item(buf, U2{}, chunk);
   };
 
   f32x16 acc[MI][2][NI];   // [row sub-tile][a rows | gate rows][column sub-tile]
@@ -197,7 +214,7 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
   load_A(0, 0);
   load_X_all(0);
   write_A(0);
-  write_X_all(0);
+  write_X_all(0, 0);
   __syncthreads();
   {
     // step 1 = (chunk 0, tap 1) for three-tap layers, (chunk 1, tap 0) for 1 x 1 layers; past the end: re-fetch step 0
@@ -262,12 +279,12 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
         load_A(c2, j2);
         // the next chunk's tile: one item per tap phase (three-tap layers) or all of it (1 x 1 layers)
         if constexpr (JT == 1) {
-          write_X_all((c + 1) & 1);
+          write_X_all((c + 1) & 1, c + 1);
           load_X_all(cx);
         } else {
-          if (j == 0) { write_X_item((c + 1) & 1, U0{}); load_X_item(cx, U0{}); }
-          if (j == 1) { write_X_item((c + 1) & 1, U1{}); load_X_item(cx, U1{}); }
-          if (j == 2) { write_X_item((c + 1) & 1, U2{}); load_X_item(cx, U2{}); }
+          if (j == 0) { write_X_item((c + 1) & 1, U0{}, c + 1); load_X_item(cx, U0{}); }
+          if (j == 1) { write_X_item((c + 1) & 1, U1{}, c + 1); load_X_item(cx, U1{}); }
+          if (j == 2) { write_X_item((c + 1) & 1, U2{}, c + 1); load_X_item(cx, U2{}); }
         }
       }
       };
@@ -344,19 +361,22 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
           for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] *= ds;
   }
   if (p.io_bf16 & DV3_IO_OUT_C8) {
-    conv_epilogue_c8<BM, BMH, NI>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
-    conv_epilogue_c8<BM, BMH, NI>(p, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+    // RL: the residual units of this lane's columns sit in the strip (every store to it is behind a barrier this wave passed)
+    const unsigned char* rl = RL ? reinterpret_cast<const unsigned char*>(Rs) + (size_t)(wn * (NI * 32) + l31) * 16 : nullptr;
+    conv_epilogue_c8<BM, BMH, NI>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc, rl, BN);
+    conv_epilogue_c8<BM, BMH, NI>(p, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc, rl, BN);
   } else {
     conv_epilogue<BM, BMH, NI, 0, true>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
     conv_epilogue<BM, BMH, NI, 0, true>(p, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
   }
 }
 
-template <int JT, bool MASK, int ABL = 0, bool RF = false>
+template <int JT, bool MASK, int ABL = 0, bool RF = false, bool RL = false>
 int launch_c8pp(const ConvArgs& a, size_t lds, hipStream_t st) {
+  if (RL) lds += (size_t)(BMH / 8) * BN * 16;      // the residual strip
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_c8pp_kernel<JT, MASK, ABL, RF>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_c8pp_kernel<JT, MASK, ABL, RF, RL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_c8pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -364,7 +384,7 @@ int launch_c8pp(const ConvArgs& a, size_t lds, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_c8pp_kernel<JT, MASK, ABL, RF>), dim3(a.n_blocks), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL((conv_c8pp_kernel<JT, MASK, ABL, RF, RL>), dim3(a.n_blocks), dim3(NT), lds, st, a);
   return dv3_check_launch("conv_c8pp");
 }
 
@@ -375,6 +395,7 @@ int launch_c8pp(const ConvArgs& a, size_t lds, hipStream_t st) {
 // (scripts/r5_ship_check.py, profiles/r05_c8pp_reads_first.txt: north star eval 63.9 -> 59.3 us, masked training forward
 // 77.4 -> 72.0 us, input gradient 58.5 -> 54.3 us; C = 512, T = 800: 201.5 -> 183.0 / 241.0 -> 209.0 / 186.0 -> 164.2 us)
 int g_c8pp_rf = 1;
+int g_c8pp_rl = 0;             // dv3_debug_set(32, v), experiment build: the residual of a gated layer read from LDS (RL instantiations)
 int g_c8pp_abl = 0;            // dv3_debug_set(21, v): timing-only ablations (EXP build)
 int g_c8pp_min_tiles = 128;   // dv3_debug_set(19, v): the 256 x 256 c8 kernel serves eligible shapes whose grid has at
                               // least v tiles (0 = never; 1 = always)
@@ -415,6 +436,18 @@ int dv3_conv_c8pp_dispatch(const dv3_conv_desc* d, hipStream_t st) {
     }
   }
 #endif
+#ifdef DV3_EXPERIMENTS
+  // residual from LDS (RL): MEASURED AND RETIRED (round 5, profiles/r05_c8pp_residual_from_lds.txt): bit-identical, but 4-10 %
+  // SLOWER over the presets' shapes (north star eval 61.2 -> 65.6 us) -- the tail is not waiting for the residual fetch,
+  // and the second store of the staged units plus the strip reads cost more than the 33 MB they keep out of the burst.
+  const bool has_res = gated && d->r && (d->mode == DV3_EPI_HIGHWAY || d->residual);
+  const bool rl = g_c8pp_rl && g_c8pp_rf && has_res && (const void*)d->r == (const void*)d->x_planes && d->Cg == d->Cin && (d->io_bf16 & DV3_IO_OUT_C8) &&
+                  lds + (size_t)(BMH / 8) * BN * 16 <= 160 * 1024;
+  if (rl) {
+    if (d->J == 3) return mask ? launch_c8pp<3, true, 0, true, true>(a, lds, st) : launch_c8pp<3, false, 0, true, true>(a, lds, st);
+    return mask ? launch_c8pp<1, true, 0, true, true>(a, lds, st) : launch_c8pp<1, false, 0, true, true>(a, lds, st);
+  }
+#endif
   if (g_c8pp_rf) {
     if (d->J == 3) return mask ? launch_c8pp<3, true, 0, true>(a, lds, st) : launch_c8pp<3, false, 0, true>(a, lds, st);
     return mask ? launch_c8pp<1, true, 0, true>(a, lds, st) : launch_c8pp<1, false, 0, true>(a, lds, st);
@@ -427,5 +460,6 @@ int dv3_c8pp_debug_set(int what, int value) {
   if (what == 19) g_c8pp_min_tiles = value;
   if (what == 21) g_c8pp_abl = value;
   if (what == 30) g_c8pp_rf = value;
+  if (what == 32) g_c8pp_rl = value;
   return DV3_OK;
 }

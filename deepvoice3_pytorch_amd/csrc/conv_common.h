@@ -16,7 +16,8 @@ struct ConvArgs {
   uint32_t* range_ctr = nullptr;   // f16x3: sticky fp16-range event counter (common.h), NULL = do not count
   int prio = 0;  // ping-pong tap-GEMM: wave priority scheme (dv3_debug_set(14, v); 0 = none)
   // stream-K form of the 256 x 256 kernels: n_blocks = workgroups (one per CU), sk_units = tiles x chunks
-  int sk_units = 0, sk_base = 0, sk_rem = 0, sk_shift = 0, sk_mshift = 0, sk_abl = 0;   // units; units / n_blocks, the remainder; log2(chunks per tile)
+  int sk_units = 0, sk_base = 0, sk_rem = 0, sk_shift = 0, sk_mshift = 0, sk_abl = 0;   // units; per-workgroup share and remainder (groups with the extra tile); log2(chunks per tile)
+  int sk_base2 = 0, sk_rem2 = 0, sk_tg = 0, sk_tr = 0, sk_qshift = 0;                   // ... of the groups without it; tiles per XCD group, groups with one more; log2(workgroups per group)
   float* sk_ws = nullptr;      // [n_blocks][128 accumulator registers][512 threads]
   int* sk_flags = nullptr;     // [n_blocks], zero between launches
 };
@@ -432,10 +433,13 @@ __device__ __forceinline__ void dv3_st8(void* base, uint32_t byte_off, const uin
   *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// rl (gated forms, optional): the residual's c8 units of this lane's first column in LDS, [channel group of the tile's
+// `a` rows][rl_cols columns] (conv_c8pp.hip, RL); column sub-tile ni is 32 units further.
 template <int BM, int BMH, int NI>
 __device__ __forceinline__ void conv_epilogue_c8(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], bool gated,
                                                  int mt, int row0, int lhi, const int (&bcol)[NI],
-                                                 const int (&tcol)[NI], const bool (&okc)[NI]) {
+                                                 const int (&tcol)[NI], const bool (&okc)[NI],
+                                                 const unsigned char* rl = nullptr, int rl_cols = 0) {
   const uint32_t T = (uint32_t)p.Tout, M = (uint32_t)p.M, Cg = (uint32_t)p.Cg;
   const uint32_t Cout = gated ? Cg : M;
   const uint32_t c8y = (Cout + 31u) / 32u * 4u;        // 8-channel groups per batch item of y / r / r2
@@ -467,8 +471,10 @@ __device__ __forceinline__ void conv_epilogue_c8(const dv3_conv_desc& p, f32x16 
       g8v[k] = (uint32_t)(mt * BMH + row0) / 8u + (uint32_t)k;
       const uint32_t g8c = g8v[k] * 8u < Cg ? g8v[k] : 0u;
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        xr[k][ni] = has_r ? dv3_ld<uint2>(p.r, ubc[ni] + g8c * gsz) : uint2{0u, 0u};
+      for (int ni = 0; ni < NI; ++ni) {
+        if (rl) xr[k][ni] = *reinterpret_cast<const uint2*>(rl + ((size_t)((row0 >> 3) + k) * rl_cols + ni * 32) * 16 + half);
+        else xr[k][ni] = has_r ? dv3_ld<uint2>(p.r, ubc[ni] + g8c * gsz) : uint2{0u, 0u};
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -789,11 +789,11 @@ extern "C" int dv3_debug_set(int what, int value) {
 #ifndef DV3_EXPERIMENTS
   // the timing-only ablation / stamp instantiations are compiled with `make EXP=1` only: say so instead of silently
   // timing the production kernel
-  DV3_REQUIRE(!(value != 0 && (what == 1 || what == 6 || what == 13 || what == 16 || what == 21 || what == 26 || what == 28)),
+  DV3_REQUIRE(!(value != 0 && (what == 1 || what == 6 || what == 13 || what == 16 || what == 21 || what == 26 || what == 28 || what == 32)),
               "debug_set(%d, %d): ablation variants are not in this build (make EXP=1)", what, value);
 #endif
   if (what >= 4 && what <= 8) return dv3_planes_debug_set(what, value);
-  if (what == 19 || what == 21 || what == 30) return dv3_c8pp_debug_set(what, value);
+  if (what == 19 || what == 21 || what == 30 || what == 32) return dv3_c8pp_debug_set(what, value);
   if (what == 20) g_wgrad_c8_pf2 = value;
   if (what == 9) g_x3_rel2 = value;
   if (what == 12) g_x3_pp2 = value;

@@ -111,15 +111,33 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
   bf16x8* const As = reinterpret_cast<bf16x8*>(smem_raw);   // [2 buffers][hi | lo][KB][BM]
   bf16x8* const Xs = As + 2 * 2 * KB * BM;                  // [2 buffers][hi | lo][KB][BNH]
 
-  const int pid = dv3_xcd_remap(blockIdx.x, args.n_blocks);
-  const int nchunks = p.Cin / BKC;       // whole chunks only (dispatcher)
-  // stream-K: this workgroup's unit range [seg_u, seg_end); unit = tile * nchunks + chunk
-  int seg_u = 0, seg_end = 0, sk_base = 0, sk_rem = 0;
+  int pid_ = dv3_xcd_remap(blockIdx.x, args.n_blocks);
   if constexpr (SK) {
-    sk_base = args.sk_base;                 // sk_units / n_blocks and the remainder, divided on the host: a uniform
-    sk_rem = args.sk_rem;                   // division here leaves its reciprocal (and a zero) in vector registers
-    seg_u = pid * sk_base + min(pid, sk_rem);
-    seg_end = seg_u + sk_base + (pid < sk_rem ? 1 : 0);
+    // Round 5: the hand-over below makes the workgroup that BEGINS a cut tile wait for the workgroups that
+    // hold the rest of it -- the ones with the next HIGHER index, whose piece of that tile is their FIRST segment.  With
+    // indices in dispatch order that is a wait for workgroups dispatched LATER: fine while the whole grid is resident, a
+    // hang when it is not (a CU mask, CU-holding kernels of another stream).  The index used from here on therefore runs
+    // AGAINST the dispatch order inside an XCD's group of workgroups (dv3_xcd_remap gives XCD x the contiguous range
+    // [x q, (x + 1) q), slot s = blockIdx / 8): slot s takes index q - 1 - s.  "The next higher index" is then the
+    // workgroup dispatched 8 blocks EARLIER, and what is waited for is the first thing it does, which depends on
+    // nothing.  (The groups own whole numbers of tiles -- see the dispatcher -- so a wait never leaves the group.)
+    const int q = 1 << args.sk_qshift;
+    pid_ = (pid_ & ~(q - 1)) + (q - 1 - (pid_ & (q - 1)));
+  }
+  const int pid = pid_;
+  const int nchunks = p.Cin / BKC;       // whole chunks only (dispatcher)
+  // stream-K: this workgroup's unit range [seg_u, seg_end); unit = tile * nchunks + chunk.  A group (pid >> sk_qshift)
+  // owns a whole number of tiles and deals its units out evenly (divisions on the host: a uniform division here leaves
+  // its reciprocal -- and a zero -- in vector registers).
+  int seg_u = 0, seg_end = 0, sk_base = 0, sk_rem = 0, sk_g0 = 0;
+  if constexpr (SK) {
+    const int grp = pid >> args.sk_qshift, slot = pid & ((1 << args.sk_qshift) - 1);
+    const bool big = grp < args.sk_tr;      // the first sk_tr groups hold one tile more
+    sk_base = big ? args.sk_base : args.sk_base2;
+    sk_rem = big ? args.sk_rem : args.sk_rem2;
+    sk_g0 = (grp * args.sk_tg + min(grp, args.sk_tr)) << args.sk_shift;      // the group's first unit
+    seg_u = sk_g0 + slot * sk_base + min(slot, sk_rem);
+    seg_end = seg_u + sk_base + (slot < sk_rem ? 1 : 0);
   }
   // weight panels by LDS-DMA (dma_A_unit): the experiment of round 3 (+2 % on the tile-per-workgroup kernel, retired
   // there) -- and the form the stream-K variants use: it frees the eight staging registers of the panel unit, which is
@@ -708,8 +726,9 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
     } else if (c1 < nchunks) {
       // this workgroup began the tile: add the parts of the workgroups that follow it (their FIRST segments, finished
       // long before this one -- the last of this workgroup's range), in workgroup order (deterministic sum)
-      for (int w2 = pid + 1; w2 < A.n_blocks; ++w2) {
-        const int s2 = w2 * sk_base + min(w2, sk_rem);
+      const int qm = (1 << A.sk_qshift) - 1;
+      for (int w2 = pid + 1; (w2 & qm) != 0; ++w2) {          // (the group's last workgroup ends on a tile boundary)
+        const int s2 = sk_g0 + (w2 & qm) * sk_base + min(w2 & qm, sk_rem);
         if (s2 >= (tile + 1) * nchunks) break;
         if (tid == 0 && !(sk_abl & 4))
           while (__hip_atomic_load(flags + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
@@ -906,11 +925,20 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
     // form gains nothing for the step (measured: forward alone -1.7 %, whole step +-0.1 % with both directions in this
     // form, scripts/r4_sk_step_ab.py).  3 = both directions.
     const bool dir_ok = d->mode != DV3_EPI_DGRAD || g_pp2_sk >= 2;
-    if (ws_ok && dir_ok && g_pp2_sk && (S & (S - 1)) == 0 && (a.m_tiles & (a.m_tiles - 1)) == 0 && units >= 2 * P && (g_pp2_sk == 2 || sk * 100 < dp * g_pp2_sk_gain)) {
+    // per-XCD unit ranges: P / 8 workgroups (a power of two) per group, every group at least one tile
+    const int q = P / 8;
+    const bool grp_ok = (P % 8) == 0 && q > 0 && (q & (q - 1)) == 0 && nb >= 8;
+    if (ws_ok && dir_ok && grp_ok && g_pp2_sk && (S & (S - 1)) == 0 && (a.m_tiles & (a.m_tiles - 1)) == 0 && units >= 2 * P && (g_pp2_sk == 2 || sk * 100 < dp * g_pp2_sk_gain)) {
       a.sk_abl = g_pp2_sk_abl;
       a.sk_units = (int)units;
-      a.sk_base = (int)(units / P);
-      a.sk_rem = (int)(units % P);
+      a.sk_tg = (int)(nb / 8);
+      a.sk_tr = (int)(nb % 8);
+      a.sk_qshift = __builtin_ctz((unsigned)q);
+      const int64_t ub = (int64_t)(a.sk_tg + 1) * S, us = (int64_t)a.sk_tg * S;     // units of a group with / without the extra tile
+      a.sk_base = (int)(ub / q);
+      a.sk_rem = (int)(ub % q);
+      a.sk_base2 = (int)(us / q);
+      a.sk_rem2 = (int)(us % q);
       a.sk_shift = __builtin_ctz((unsigned)S);
       a.sk_mshift = __builtin_ctz((unsigned)a.m_tiles);
       a.n_blocks = P;

@@ -101,9 +101,31 @@ def _stream():
 
 
 stream_probe_log = []      # one record per concurrent_stream() call: bench.py prints them as `stream_queues`
+_hip_rt = None
 
 
-def concurrent_stream(avoid, tries=12, role="side", strict=None):
+def new_stream(priority="normal"):
+    """a HIP stream as a torch stream object.  priority "low": created with hipStreamCreateWithPriority at the device's
+    LEAST priority (torch itself only offers normal and high) and wrapped as an ExternalStream -- for work that should
+    yield compute units to the step stream whenever both have workgroups to place (the weight-gradient branch of
+    backward: profiles/r05_step_timeline.txt -- the input-gradient chain on the step stream is the critical path, the
+    weight-gradient queue is 68-84 % busy).  Never destroyed (a handful per process)."""
+    if priority != "low":
+        return torch.cuda.Stream()
+    import ctypes
+    global _hip_rt
+    if _hip_rt is None:
+        _hip_rt = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+    if _hip_rt.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0 or least.value == greatest.value:
+        return torch.cuda.Stream()
+    h = ctypes.c_void_p()
+    if _hip_rt.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(least.value)) != 0 or not h.value:   # 1 = non-blocking
+        return torch.cuda.Stream()
+    return torch.cuda.ExternalStream(h.value)
+
+
+def concurrent_stream(avoid, tries=12, role="side", strict=None, priority="normal"):
     """A torch stream whose work REALLY runs beside the work of every stream in `avoid`.  HIP multiplexes its streams onto a
     few hardware queues (GPU_MAX_HW_QUEUES, default 4): two streams that land on the same queue execute in issue order,
     whatever the events between them say -- the step's second backward stream then adds nothing (measured: the same
@@ -116,16 +138,16 @@ def concurrent_stream(avoid, tries=12, role="side", strict=None):
     (DV3_STRICT_STREAMS=1).  While a capture is active (no synchronize allowed) or with DV3_STREAM_PROBE=0: a plain
     stream, recorded as unprobed."""
     import warnings
-    rec = dict(role=role, avoid=len(avoid), probed=False, found=None, candidates=[])
+    rec = dict(role=role, avoid=len(avoid), probed=False, found=None, candidates=[], priority=priority)
     stream_probe_log.append(rec)
     if not avoid:
-        return torch.cuda.Stream()
+        return new_stream(priority)
     if strict is None:
         strict = _os.environ.get("DV3_STRICT_STREAMS", "") == "1"
     dev = avoid[0].device
     with torch.cuda.device(dev):
         if _os.environ.get("DV3_STREAM_PROBE", "1") in ("0", "") or torch.cuda.is_current_stream_capturing():
-            return torch.cuda.Stream()
+            return new_stream(priority)
         cycles = 200000
 
         def spin_pair(a, s):
@@ -146,12 +168,12 @@ def concurrent_stream(avoid, tries=12, role="side", strict=None):
             spin_pair(avoid[0], None)
             one = min(spin_pair(avoid[0], None) for _ in range(3))
         except Exception:      # no spin kernel in this build: take any stream
-            return torch.cuda.Stream()
+            return new_stream(priority)
         rec["probed"] = True
         want_shared = _os.environ.get("DV3_SIDE_STREAM_SAME_QUEUE", "") == "1"      # experiment: the opposite choice
         best, best_worst = None, None
         for _ in range(tries):
-            s = torch.cuda.Stream()
+            s = new_stream(priority)
             ratios = [round(min(spin_pair(a, s) for _ in range(3)) / one, 2) for a in avoid]
             rec["candidates"].append(ratios)
             worst = max(ratios)
@@ -681,9 +703,14 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
 
 
 # stream-K workspaces of the 256 x 256 tap-GEMM kernels (include/dv3hip.h: dv3_conv_desc.sk_ws), one per (device, stream):
-# launches that share one must be ordered, which launches on one stream are.  Allocated and zeroed on first use by the
-# stream that will use it (inside a graph capture: from the capture's pool, with the zeroing as a node).  DV3_STREAMK=0
-# turns the form off.
+# launches that share one must be ordered, which launches on one stream are.  Allocated and zeroed ONCE, eagerly, from the
+# ordinary allocator pool -- never inside a graph capture: a buffer taken from a capture's private pool dies with that
+# graph while this cache (keyed by the raw stream handle, which torch's stream pool hands out again) would go on serving
+# its address: flags that are no longer zero, partial sums read before they are written.  (Round 5: this made the
+# nyanko bf16 replay return NaN whenever a deepvoice3 f16x3 replay had run earlier in the process -- ADVICE r4.)  A
+# capture whose stream has no workspace yet therefore gets none (tile-per-workgroup form) unless its owner prepared one
+# first: train_step.GraphedTrainer calls prepare_streamk_ws(device, capture stream) before it begins to capture.
+# DV3_STREAMK=0 turns the form off.
 streamk = _os.environ.get("DV3_STREAMK", "1") not in ("0", "")     # "force": also with a forced tile (scripts)
 _sk_ws = {}
 
@@ -694,10 +721,20 @@ def _streamk_ws(device):
     key = (device.index, _stream())
     e = _sk_ws.get(key)
     if e is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
         n = int(_lib.lib().dv3_conv_streamk_ws_bytes())
         t = torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
         e = _sk_ws[key] = (t.data_ptr(), n, t)
     return e[0], e[1]
+
+
+def prepare_streamk_ws(device, stream):
+    """create (outside any capture) the stream-K workspace the launches captured on `stream` will use"""
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("prepare_streamk_ws: call before the capture begins")
+    with torch.cuda.stream(stream):
+        return _streamk_ws(device)
 
 
 def _conv_gemm_c8(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J, dil, padL, mode, Cg, bias, spk, spk_strides, r, r2,
@@ -1328,6 +1365,14 @@ class SpeakerBiasBlockFn(torch.autograd.Function):
             y.v, y.g, y.bias, y.out, y.C = v.data_ptr(), _ptr(g), _ptr(b), outs[l].data_ptr(), C
             c8g = ctx.holder.pop(l, None)      # a c8 layer left its pre-gate gradient here (ConvLayerC8Fn.backward)
             if c8g is not None:
+                # the real gradient travelled through the holder; what autograd delivers for this output must be the
+                # zero-stride stand-in of ConvLayerC8Fn.backward -- anything else is a SECOND consumer of the bias tensor
+                # (a hook, a regulariser) whose gradient would be dropped silently here
+                do = douts[l]
+                z = _spk_dummy.get(e.device)
+                if do is not None and not (z is not None and do.data_ptr() == z.data_ptr() and all(st == 0 for st in do.stride())):
+                    raise RuntimeError("speaker_bias_block: the bias of layer %d has a consumer besides its Conv1dGLU layer; "
+                                       "its gradient can not be combined with the c8 hand-over (set DV3_FUSED_SPK=0)" % l)
                 keep.append(c8g)
                 y.dout, y.dout_c8p = c8g.data_ptr(), c8g.shape[1]
             else:

@@ -212,7 +212,9 @@ class Trainer(object):
         self.side_stream = None
         if dev.type == "cuda" and os.environ.get("DV3_WGRAD_STREAM", "1") not in ("0", ""):
             with torch.cuda.device(dev):
-                self.side_stream = ops.concurrent_stream([torch.cuda.current_stream()], role="weight-gradient")
+                # DV3_SIDE_PRIORITY=low: the weight-gradient stream at the device's least stream priority (ops.new_stream)
+                self.side_stream = ops.concurrent_stream([torch.cuda.current_stream()], role="weight-gradient",
+                                                         priority=os.environ.get("DV3_SIDE_PRIORITY", "normal"))
         self.pg = process_group
         self.world = 1
         self.comm = None
@@ -589,7 +591,9 @@ class GraphedTrainer(object):
             # a process group brings its watchdog thread: its event queries must not invalidate this thread's capture
             mode = dict(capture_error_mode="thread_local") if trainer.comm is not None else {}
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, **mode):
+            cap = torch.cuda.Stream()
+            ops.prepare_streamk_ws(dev, cap)       # the captured stream-K launches' workspace: not from the graph's pool
+            with torch.cuda.graph(self.graph, stream=cap, **mode):
                 self.scal = self._body()
         else:
             self.graph = None
@@ -632,6 +636,7 @@ class GraphedTrainer(object):
         torch.cuda.synchronize()
         gc.collect()
         cap = torch.cuda.Stream()
+        ops.prepare_streamk_ws(t.device, cap)       # the captured stream-K launches' workspace: not from the graphs' pool
         cap.wait_stream(torch.cuda.current_stream())
         SS.split_capture, SS.split_on_fork = True, on_fork
         try:

@@ -328,6 +328,77 @@ def test_c8pp_kernel_is_bit_identical_to_the_planes_kernel(dev, modes, kind, C, 
         assert torch.equal(dp0[n], dp1[n]), n
 
 
+@pytest.mark.parametrize("d,causal", [(1, False), (27, True)])
+def test_north_star_c8pp_is_the_kernel_the_bench_times(dev, modes, d, causal):
+    """BASELINE.json's shape on the bf16 / c8 path: Conv1dGLU at B = 64 x 256 channels x T = 1024, k = 3 -- what
+    bench.py's `roofline_bf16_c8` times and what the nyanko / vctk steps dispatch wherever a grid has >= 128 tiles.  With
+    the DEFAULT dispatch (nothing forced):
+      * eval forward: served by conv_c8pp_kernel (variant 9101), every stored value within (1/2 + 1/16) bf16 ulp of the
+        oracle evaluated with the same roundings (bf16 operands from the HIP path's own weight image, fp32 accumulate and
+        tail), the boundary flips counted;
+      * training forward (keep-bytes, pre-gate save) + backward (input gradient, weight / gain / bias gradients): variant
+        9101 again, and bit-identical to the 128-row planes kernel at this very shape (dv3_debug_set(19, 0)), which the
+        small-shape tests above hold to the oracle -- both LOAD-phase orders of the kernel (dv3_debug_set(30, v))."""
+    ops = modes
+    from deepvoice3_pytorch_amd import modules, _lib
+    L = _lib.lib()
+    B, C, T, k = 64, 256, 1024, 3
+    torch.manual_seed(0)
+    layer = modules.Conv1dGLU(1, 16, C, C, k, dropout=0.05, dilation=d, causal=causal, residual=True).to(dev)
+    with torch.no_grad():
+        layer.conv.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(B, C, T, device=dev).to(torch.bfloat16).float()
+    ops.set_gemm_precision("bf16")
+    ops.bf16_storage = True
+    layer.eval()
+    with torch.no_grad():
+        y8 = layer(ops.to_c8(x))
+    assert L.dv3_debug_get(10) == 9101, L.dv3_debug_get(10)
+    got = ops.from_c8(y8).cpu().double()
+    v_, g_ = layer.conv.wn_params()
+    pk = ops.pack_weights(v_.detach(), g_.detach(), glu_cg=C, need_bwd=False, split_only=True)
+    kp = (C + 31) // 32 * 32
+    img = pk.fwd_s.view(torch.bfloat16)[: k * kp * pk.lda].view(k, kp // 8, pk.lda, 8).float().cpu()
+    w_hip = torch.empty(2 * C, C, k)
+    for o in range(2 * C):
+        col = o if o < C else pk.a_half + (o - C)
+        w_hip[o] = img[:, :, col, :].reshape(k, kp)[:, :C].t()
+    sd = {"l.conv.weight": w_hip, "l.conv.bias": layer.conv.bias.detach().cpu()}
+    O.set_operand_rounding("bf16")
+    try:
+        want = O.conv1d_glu(sd, "l", x.cpu(), k, d, causal, True).double()
+    finally:
+        O.set_operand_rounding(None)
+    ulp = _bf16_ulp(want)
+    slack = 2e-6 * float(want.abs().max())
+    excess = ((got - want).abs() - (0.5 + 1.0 / 16) * ulp - slack).max()
+    assert float(excess) <= 0.0, "variant 9101 leaves the half-ulp band of the same-rounding oracle by %.3e" % float(excess)
+    stored = want.float().to(torch.bfloat16).double()
+    flips = got != stored
+    assert float(flips.double().mean()) < 2e-2
+    del want, got, stored, flips, ulp
+    # training forward + backward: the benchmarked kernel against the planes kernel at the benchmarked shape
+    layer.train()
+    out = {}
+    try:
+        for tag, thr, rf in (("planes", 0, 1), ("c8pp", 128, 1), ("c8pp staging first", 128, 0)):
+            L.dv3_debug_set(19, thr)
+            L.dv3_debug_set(30, rf)
+            out[tag] = _run(layer, x, True, "bf16", ops)
+            assert L.dv3_debug_get(10) == (9101 if thr else L.dv3_debug_get(10)), (tag, L.dv3_debug_get(10))
+            assert (L.dv3_debug_get(10) // 1000 == 9) == bool(thr), (tag, L.dv3_debug_get(10))
+    finally:
+        L.dv3_debug_set(19, 128)
+        L.dv3_debug_set(30, 1)
+    y0, dx0, dp0 = out["planes"]
+    for tag in ("c8pp", "c8pp staging first"):
+        y1, dx1, dp1 = out[tag]
+        assert torch.equal(y0, y1), (tag, float((y0 - y1).abs().max()))
+        assert torch.equal(dx0, dx1), (tag, float((dx0 - dx1).abs().max()))
+        for n in dp0:
+            assert torch.equal(dp0[n], dp1[n]), (tag, n)
+
+
 def test_c8pp_plain_and_fp32_output_forms(dev, modes):
     """1 x 1 layers through the same kernel: c8 -> c8 with activation / residuals, c8 -> fp32 (513 rows: not a multiple
     of anything), and their input gradients -- bit-identical to the planes kernel"""

@@ -630,6 +630,57 @@ def test_256x256_k16_pingpong_tap_gemm_equals_the_128_wide_kernels(dev, gemm_mod
     assert torch.equal(dxs[0], dxs[1])
 
 
+def test_stream_k_workspace_never_comes_from_a_capture_pool(dev):
+    """ops._streamk_ws (round 5's NaN: the nyanko bf16 replay after deepvoice3 f16x3 replays in one process):
+    the workspace of a stream is allocated eagerly from the ordinary pool.  A launch captured on a stream that has none
+    gets NO workspace (tile-per-workgroup form, variant ...101) and caches nothing; once its owner has prepared one
+    (ops.prepare_streamk_ws, what GraphedTrainer does before it captures) the captured launch takes the stream-K form
+    (...102), replays give the eager result, and the buffer outlives the graph."""
+    from deepvoice3_pytorch_amd import ops, _lib
+    L = _lib.lib()
+    ops.set_gemm_precision("f16x3")
+    B, C, T, k = 64, 512, 150, 3                     # the encoder layer of the benchmark step: 152 tiles, stream-K by the rule
+    torch.manual_seed(0)
+    x = torch.randn(B, C, T, device=dev)
+    v = torch.randn(2 * C, C, k, device=dev) * math.sqrt(4.0 * 0.95 / (k * C))
+    g = v.reshape(2 * C, -1).norm(dim=1).view(-1, 1, 1).clone()
+    pk = ops.pack_weights(v, g, glu_cg=C, need_bwd=False)
+    kw = dict(B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=1, padL=1, mode=ops.EPI_GLU, Cg=C, r=x, residual=1, a_split=pk.fwd_s)
+    y_eager = torch.empty(B, C, T, device=dev)
+    ops.conv_gemm(x, None, pk.lda, pk.a_half, y=y_eager, **kw)
+    assert L.dv3_debug_get(10) % 1000 == 102            # eager on the current stream: stream-K form
+    torch.cuda.synchronize()
+    for prepared in (False, True):
+        cap = torch.cuda.Stream()
+        while (dev.index or 0, cap.cuda_stream) in ops._sk_ws:     # a pool stream nobody has used for this yet
+            cap = torch.cuda.Stream()
+        n_keys = len(ops._sk_ws)
+        if prepared:
+            assert ops.prepare_streamk_ws(dev, cap) is not None and len(ops._sk_ws) == n_keys + 1
+        y = torch.empty(B, C, T, device=dev)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=cap):
+            ops.conv_gemm(x, None, pk.lda, pk.a_half, y=y, **kw)
+            variant = L.dv3_debug_get(10) % 1000
+        assert variant == (102 if prepared else 101), (prepared, variant)
+        assert len(ops._sk_ws) == n_keys + (1 if prepared else 0)
+        for _ in range(3):
+            y.zero_()
+            gr.replay()
+            torch.cuda.synchronize()
+            if prepared:
+                assert torch.equal(y, y_eager)
+            else:
+                assert float((y - y_eager).abs().max()) < 2e-6 * float(y_eager.abs().max())
+        ptr = ops._sk_ws.get((dev.index or 0, cap.cuda_stream), (None,))[0]
+        del gr
+        torch.cuda.synchronize()
+        if prepared:      # still alive and still zeroed flags after the graph is gone
+            e = ops._sk_ws[(dev.index or 0, cap.cuda_stream)]
+            assert e[0] == ptr and int(e[2][:1024].abs().sum()) == 0
+
+
+
 @pytest.mark.parametrize("B,C,T,d,masked", [(64, 512, 150, 1, True), (64, 512, 150, 27, False), (48, 256, 201, 3, True),
                                             (24, 256, 410, 1, False)])
 def test_stream_k_form_of_the_256x256_tap_gemm(dev, gemm_mode, B, C, T, d, masked):
