@@ -110,11 +110,14 @@ def mfma_peak_tf(mode):
     return {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_16BIT_MFMA_TF}.get(mode, PEAK_16BIT_MFMA_TF / 3.0)
 
 
-def synth_batch(rng, B, Tt, n_frames, hp, fixed=True):
+def synth_batch(rng, B, Tt, n_frames, hp, fixed=True, lengths=None):
     """Synthetic LJSpeech-shaped items padded exactly as train.collate_fn does (train.py:293-360):
-    target length rounded up to r and downsample_step, plus b_pad*downsample_step leading frames."""
+    target length rounded up to r and downsample_step, plus b_pad*downsample_step leading frames.
+    lengths: (text_lens, frame_lens) of the B items (a batch drawn by a sampler)"""
     r, ds = hp["r"], hp["downsample_step"]
-    if fixed:
+    if lengths is not None:
+        text_lens, frame_lens = np.asarray(lengths[0], dtype=np.int64), np.asarray(lengths[1], dtype=np.int64)
+    elif fixed:
         text_lens = np.full(B, Tt)
         frame_lens = np.full(B, n_frames)
     else:
@@ -164,6 +167,8 @@ def _time_launches(launch, iters, settle=100, per_graph=25):
     s = torch.cuda.current_stream()      # the stream ops.* enqueue on
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     try:
+        if os.environ.get("DV3_BENCH_EAGER_TIMING", "") == "1":      # counter passes (scripts/pmc_r5.sh): one launch per dispatch
+            raise RuntimeError("eager timing requested")
         cap = torch.cuda.Stream()
         cap.wait_stream(s)
         g = torch.cuda.CUDAGraph()
@@ -183,7 +188,8 @@ def _time_launches(launch, iters, settle=100, per_graph=25):
         _time_launches.last_mode = "hipGraph of %d launches, %d replays" % (per_graph, replays)
         return e0.elapsed_time(e1) * 1e3 / (replays * per_graph)
     except Exception as e:      # noqa: a capture that fails must not void the line
-        sys.stderr.write("roofline timing: graph capture failed (%s: %s); eager launches\n" % (type(e).__name__, e))
+        if os.environ.get("DV3_BENCH_EAGER_TIMING", "") != "1":
+            sys.stderr.write("roofline timing: graph capture failed (%s: %s); eager launches\n" % (type(e).__name__, e))
         torch.cuda.synchronize()
     e0.record(s)
     for _ in range(iters):
@@ -201,7 +207,7 @@ def _traffic(kernel_key):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, calibrated as MI355X_MICROARCH.md
     prescribes), collected offline with rocprofv3 (scripts/pmc_hbm.sh; a counter pass can not run inside this
     process) and committed under profiles/ -- used only when the file was collected for THIS kernel."""
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):      # newest collection that holds THIS variant
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):      # newest collection that holds THIS variant
         try:
             hb = json.load(open(os.path.join(ROOT, "profiles", name)))
             ent = hb[kernel_key]
@@ -811,6 +817,56 @@ def side_config(dev, pg, rank, world, preset, gemm, args, steps, warmup, batch=N
                             allreduce_exposed_ms=m["allreduce_exposed_ms"]))
 
 
+def ragged_epoch_config(dev, preset, gemm, args, n_items=13100, n_batches=10):
+    """What an epoch over LJSpeech-shaped data costs: `n_items` item lengths from SURVEY 8d
+    cfg2's distribution, cut into mini-batches by data.LengthBucketedSampler -- the reference's
+    PartialyRandomizedSimilarTimeLengthSampler (train.py:195-239): sorted by length, shuffled inside groups of 32
+    batches, so a batch pads to the maximum of SIMILAR lengths -- and `n_batches` of them, spread over the epoch, run as
+    optimisation steps.  The padded shape changes every step: no replay (a hipGraph is captured for one shape), eager
+    launches, so the host's issue time is part of the number.  value = un-padded frames of those batches / wall time."""
+    from deepvoice3_pytorch_amd import data, train_step
+    rng = np.random.RandomState(4321)
+    frames = np.clip(rng.normal(566, 180, n_items), 120, 870).astype(np.int64)
+    text = np.clip(frames * (100.0 / 566.0) + rng.normal(0, 8, n_items), 20, 187).astype(np.int64)
+    sampler = data.LengthBucketedSampler(frames, batch_size=args.batch, seed=0)
+    batches = [b for b in sampler.epoch_batches() if len(b) == args.batch]
+    pick = [batches[i] for i in np.linspace(0, len(batches) - 1, n_batches).astype(int)]
+    run = TrainRun(dev, None, 0, 1, preset, gemm, args.batch, args.text_len, args.frames, graph=False)
+    try:
+        dev_batches, real, padded = [], 0, 0
+        for idx in pick:
+            bt = synth_batch(rng, len(idx), 0, 0, run.hp, lengths=(text[idx], frames[idx]))
+            dev_batches.append(train_step.Batch.from_collate(bt["text"], bt["input_lengths"], bt["mel"], bt["y"],
+                                                             bt["text_positions"], bt["frame_positions"], bt["done"],
+                                                             bt["target_lengths"], None, downsample_step=4, device=dev))
+            real += int(frames[idx].sum())
+            padded += int(bt["mel"].shape[0] * bt["mel"].shape[1])
+        for b in dev_batches:               # every shape once untimed (allocator, workspaces)
+            run.trainer.step(b)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in dev_batches:
+            scal = run.trainer.step(b)
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        loss = float(scal["loss"])
+        if not math.isfinite(loss):
+            raise RuntimeError("non-finite training loss in the ragged epoch")
+    finally:
+        run.close()
+    # the same items in arrival order (no length bucketing): what the padding would be
+    naive = [np.arange(i, i + args.batch) for i in np.linspace(0, n_items - args.batch, n_batches).astype(int)]
+    pad_naive = sum(int(args.batch * (frames[i].max() + 8)) for i in naive) / float(sum(int(frames[i].sum()) for i in naive))
+    return dict(value=round(real / dt, 1), unit="mel-frames/s", ms_per_step=round(dt / len(dev_batches) * 1e3, 3),
+                host_enqueue_ms_per_step=round(t_issue / len(dev_batches) * 1e3, 3), steps=len(dev_batches),
+                per_gpu_batch=args.batch, hipgraph=False,
+                real_frames=real, padded_frames=padded, padded_over_real=round(padded / float(real), 4),
+                padded_over_real_without_length_bucketing=round(pad_naive, 4), final_loss=round(loss, 5),
+                lengths="%d items, frames ~ clip(N(566,180),120,870); mini-batches by data.LengthBucketedSampler (train.py:195-239), "
+                        "%d of the epoch's %d batches, padded to the batch maximum as train.collate_fn does" % (n_items, len(dev_batches), len(batches)))
+
+
 def ddp_world1_config(dev, preset, gemm, args, no_group_ms, steps=12, warmup=4):
     """The data-parallel step with its gradient exchange ARMED, on the one GPU a bench box has: a world-size-1 "nccl"
     (RCCL) group, dist.BucketedAllReduce's notifications, bucketed all-reduces on the collective stream, clip with
@@ -1141,6 +1197,10 @@ def main():
                     cfgs[key] = side_config(dev, pg, rank, world, args.preset, gemm, args, 20, 8, **kw)
                 except Exception as e:
                     cfgs[key] = dict(error="%s: %s" % (type(e).__name__, e))
+            try:
+                cfgs["dv3lj_b64_ragged_epoch"] = ragged_epoch_config(dev, args.preset, gemm, args)
+            except Exception as e:
+                cfgs["dv3lj_b64_ragged_epoch"] = dict(error="%s: %s" % (type(e).__name__, e))
             try:
                 made = _world1_group()
                 import torch.distributed as tdist
