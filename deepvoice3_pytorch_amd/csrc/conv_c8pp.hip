@@ -29,9 +29,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace {
 
 constexpr int KB = 4, HALO_MAX = 64;
-constexpr int BM = 256, BMH = 128, BN = 256, NT = 512, MI = 2, NI = 2, WN = 4;
-constexpr int AU = KB * BM / NT;                            // weight-panel units per thread per step (2)
-static_assert(AU == 2, "two panel units per thread and step");
+constexpr int BM = 256, BMH = 128, MI = 2, NI = 2;
+// NW = 8 (rounds 4-5): one 8-wave workgroup per CU, 256 x 256 tile, the two waves of a SIMD half a step apart (ping-pong).
+// NW = 4 (round 5): a 4-wave workgroup on a 256 x 128 tile (2 x 2 waves of the same 128 x 64 wave tile), 57 KB of LDS, TWO
+// of them per CU: independent workgroups, so the prologue and the chip-wide tail burst of one run under the main loop of
+// the other (a third of the 8-wave launch is prologue + tail); inside a workgroup the four waves run the
+// LOAD / COMPUTE phases together (one barrier per step), the SIMD partner is a wave of the other workgroup.
+template <int NW> struct C8ppGeo {
+  static constexpr int NT = NW * 64, WN = NW / 2, BN = WN * NI * 32;
+  static constexpr int AU = KB * BM / NT;                   // weight-panel units per thread per step (2 / 4)
+};
 
 template <typename T>
 __device__ __forceinline__ T c8pp_ldg(const void* base, uint32_t byte_off) {
@@ -60,8 +67,10 @@ __device__ __forceinline__ bf16x8 c8pp_keep8(const bf16x8& v, uint32_t m) {
 // (raw, before the keep-bytes) are stored a second time into a 64 KB strip [16 channel groups][256 columns] behind the
 // tile buffers, and the tail reads the residual from there instead of fetching 33.5 MB (north star) from memory inside
 // the chip-wide tail burst.  Taken when the descriptor's residual tensor is the input tensor itself.
-template <int JT, bool MASK, int ABL = 0, bool RF = false, bool RL = false>
-__global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
+template <int JT, bool MASK, int ABL = 0, bool RF = false, bool RL = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_c8pp_kernel(const ConvArgs args) {
+  constexpr int NT = C8ppGeo<NW>::NT, WN = C8ppGeo<NW>::WN, BN = C8ppGeo<NW>::BN, AU = C8ppGeo<NW>::AU;
+  constexpr bool PP = NW == 8;               // ping-pong halves
   constexpr int XI = (KB * (BN + (JT > 1 ? HALO_MAX : 0)) + NT - 1) / NT;   // activation units per thread per chunk
   constexpr int XPS = XI * NT;                                              // units per tile buffer (padded: no store is predicated)
   static_assert(JT == 1 || JT == 3, "tap counts of the models' layers");
@@ -231,8 +240,15 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
   // LDS hazards: the panel of step s+1 is stored during the L phases of step s (intervals 2s, 2s+1) into the buffer last
   // read in the L phases of step s-1 (intervals 2s-2, 2s-1) and first read in L(s+1) (interval 2s+2); the tile of chunk
   // c+1 during the L phases of chunk c into the buffer last read in chunk c-1.  Every interval ends with a barrier.
-  const int late = wave >> 2;
+  const int late = PP ? (wave >> 2) : 0;
   if (late && ABL != 6) __syncthreads();
+  if constexpr (!PP) {
+    // the two workgroups of a CU start together: the odd one of a pair waits a little so that they do not run the
+    // same phase (args.stagger units of 64 cycles; which blocks share a CU is the dispatcher's business -- adjacent
+    // ones by observation)
+    if (args.stagger > 0 && (blockIdx.x & args.stagger_mask) != 0)
+      for (int i = 0; i < args.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   for (int c = 0; c < nchunks; ++c) {
     const bf16x8* XsC = Xs + (c & 1) * XPS;
     const int cx = min(c + 2, nchunks - 1);          // the chunk fetched during this one (the tail re-fetches the last)
@@ -332,7 +348,9 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
             acc[mi][1][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mi][1], fb[ks][ni], acc[mi][1][ni], 0, 0, 0);
           }
       __builtin_amdgcn_sched_barrier(0);
-      if (ABL != 6 && (!(last_chunk && j == JT - 1) || !late)) __syncthreads();
+      // (4-wave form: the barrier after the LOAD phase orders everything: the next LOAD's stores go to buffers whose last
+      //  reads are behind it, its reads to buffers whose stores are behind it)
+      if (PP && ABL != 6 && (!(last_chunk && j == JT - 1) || !late)) __syncthreads();
     }
   }
   if (ABL == 3 && acc[0][0][0][0] + acc[1][1][1][7] != 1.2345e30f) return;
@@ -371,12 +389,13 @@ __global__ __launch_bounds__(NT) void conv_c8pp_kernel(const ConvArgs args) {
   }
 }
 
-template <int JT, bool MASK, int ABL = 0, bool RF = false, bool RL = false>
+template <int JT, bool MASK, int ABL = 0, bool RF = false, bool RL = false, int NW = 8>
 int launch_c8pp(const ConvArgs& a, size_t lds, hipStream_t st) {
+  constexpr int NT = C8ppGeo<NW>::NT, BN = C8ppGeo<NW>::BN;
   if (RL) lds += (size_t)(BMH / 8) * BN * 16;      // the residual strip
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_c8pp_kernel<JT, MASK, ABL, RF, RL>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_c8pp_kernel<JT, MASK, ABL, RF, RL, NW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_c8pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -384,7 +403,7 @@ int launch_c8pp(const ConvArgs& a, size_t lds, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_c8pp_kernel<JT, MASK, ABL, RF, RL>), dim3(a.n_blocks), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL((conv_c8pp_kernel<JT, MASK, ABL, RF, RL, NW>), dim3(a.n_blocks), dim3(NT), lds, st, a);
   return dv3_check_launch("conv_c8pp");
 }
 
@@ -395,6 +414,8 @@ int launch_c8pp(const ConvArgs& a, size_t lds, hipStream_t st) {
 // (scripts/r5_ship_check.py, profiles/r05_c8pp_reads_first.txt: north star eval 63.9 -> 59.3 us, masked training forward
 // 77.4 -> 72.0 us, input gradient 58.5 -> 54.3 us; C = 512, T = 800: 201.5 -> 183.0 / 241.0 -> 209.0 / 186.0 -> 164.2 us)
 int g_c8pp_rf = 1;
+int g_c8pp_nw4 = 2;            // dv3_debug_set(34, v): two 4-wave workgroups per CU on 256 x 128 tiles (NW = 4): 0 never, 1 always, 2 by the rule in the dispatcher
+int g_c8pp_stagger = 0, g_c8pp_stagger_mask = 1;   // dv3_debug_set(35 / 36, v): start delay (x 64 cycles) of the blocks with (blockIdx & mask) != 0
 int g_c8pp_rl = 0;             // dv3_debug_set(32, v), experiment build: the residual of a gated layer read from LDS (RL instantiations)
 int g_c8pp_abl = 0;            // dv3_debug_set(21, v): timing-only ablations (EXP build)
 int g_c8pp_min_tiles = 128;   // dv3_debug_set(19, v): the 256 x 256 c8 kernel serves eligible shapes whose grid has at
@@ -411,8 +432,23 @@ int dv3_conv_c8pp_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   if (d->x_c8p != kp / 8) return 1;
   const int64_t ntot = (int64_t)d->B * d->Tout;
   const int64_t m_tiles = gated ? dv3_cdiv(d->Cg, BMH) : dv3_cdiv(d->M, BM);
+  constexpr int BN = C8ppGeo<8>::BN, NT = C8ppGeo<8>::NT;
   const int64_t nb = m_tiles * dv3_cdiv64(ntot, BN);
-  if (d->tile_hint != 40 && nb < g_c8pp_min_tiles) return 1;
+  // Which form (round 5, profiles/r05_c8pp_two_workgroups_per_cu.txt; one process, graph-timed, B = 64):
+  //   * 8 waves on 256 x 256 (NW = 8): eval forward and input gradients of grids that fill the chip (>= 256 tiles: the
+  //     4-wave form is 5-14 % slower there: in-phase SIMD partners, twice the weight-panel traffic per column);
+  //   * two 4-wave workgroups per CU on 256 x 128 (NW = 4): the masked training forward with its pre-gate save (three
+  //     times the tail stores: -4 ... -8 % at every size, -14 % at 100 tiles) and input gradients of grids that do NOT
+  //     fill the chip with 256 x 256 tiles (64 ... 255 of them: -21 ... -26 %; the 8-wave form leaves CUs idle there);
+  //   * below that the 128-row planes kernel (return 1).
+  const bool is_dgrad = d->mode == DV3_EPI_DGRAD;
+  const bool masked_fwd = d->xmask_c8 != nullptr && !is_dgrad;
+  bool use_nw4 = g_c8pp_nw4 == 1 || d->tile_hint == 41;
+  if (g_c8pp_nw4 == 2 && d->tile_hint != 40) {
+    if (masked_fwd) use_nw4 = nb >= 100;
+    else if (is_dgrad) use_nw4 = nb >= 64 && nb < 256;
+  }
+  if (d->tile_hint != 40 && !use_nw4 && nb < g_c8pp_min_tiles) return 1;
   const int XI = (KB * (BN + (d->J > 1 ? HALO_MAX : 0)) + NT - 1) / NT;
   const size_t lds = (size_t)(2 * KB * BM + 2 * XI * NT) * 16;
   ConvArgs a;
@@ -425,6 +461,21 @@ int dv3_conv_c8pp_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   a.n_blocks = (int)nb;
   g_dv3_last_conv = 9000 + 100 + 1;     // single-term c8, 256 x 256 tile, ping-pong
   const bool mask = d->xmask_c8 != nullptr;
+  if (use_nw4) {
+    // two 4-wave workgroups per CU on 256 x 128 tiles (NW = 4)
+    constexpr int BN4 = C8ppGeo<4>::BN, NT4 = C8ppGeo<4>::NT;
+    const int XI4 = (KB * (BN4 + (d->J > 1 ? HALO_MAX : 0)) + NT4 - 1) / NT4;
+    const size_t lds4 = (size_t)(2 * KB * BM + 2 * XI4 * NT4) * 16;
+    a.n_tiles = (int)dv3_cdiv64(ntot, BN4);
+    const int64_t nb4 = m_tiles * a.n_tiles;
+    DV3_REQUIRE(nb4 < (1ll << 31), "conv_c8pp: grid too large");
+    a.n_blocks = (int)nb4;
+    a.stagger = g_c8pp_stagger;
+    a.stagger_mask = g_c8pp_stagger_mask;
+    g_dv3_last_conv = 9000 + 110 + 1;   // ... 256 x 128 tile, two workgroups per CU
+    if (d->J == 3) return mask ? launch_c8pp<3, true, 0, true, false, 4>(a, lds4, st) : launch_c8pp<3, false, 0, true, false, 4>(a, lds4, st);
+    return mask ? launch_c8pp<1, true, 0, true, false, 4>(a, lds4, st) : launch_c8pp<1, false, 0, true, false, 4>(a, lds4, st);
+  }
 #ifdef DV3_EXPERIMENTS
   if (g_c8pp_abl && !mask && d->J == 3) {
     switch (g_c8pp_abl) {
@@ -461,5 +512,8 @@ int dv3_c8pp_debug_set(int what, int value) {
   if (what == 21) g_c8pp_abl = value;
   if (what == 30) g_c8pp_rf = value;
   if (what == 32) g_c8pp_rl = value;
+  if (what == 34) g_c8pp_nw4 = value;
+  if (what == 35) g_c8pp_stagger = value;
+  if (what == 36) g_c8pp_stagger_mask = value;
   return DV3_OK;
 }

@@ -11,7 +11,8 @@ struct ConvArgs {
   int m_tiles, n_tiles, n_blocks;
   int a_scalar;  // packed operand not 16-byte aligned (per-batch A = an activation): scalar staging
   int kp;        // bf16x3: K extent of the split weight image (Cin rounded up to 32)
-  int stagger;   // planes kernel: s_sleep(127) repeats before the second co-resident workgroup starts
+  int stagger;   // planes kernel: s_sleep(127) repeats before the second co-resident workgroup starts; conv_c8pp (NW = 4): s_sleep(1) repeats
+  int stagger_mask = 1;   // conv_c8pp (NW = 4): blocks with (blockIdx & mask) != 0 are the delayed ones
   int wide = 1;                    // 16-byte input-gradient epilogue through LDS (0 = off)
   uint32_t* range_ctr = nullptr;   // f16x3: sticky fp16-range event counter (common.h), NULL = do not count
   int prio = 0;  // ping-pong tap-GEMM: wave priority scheme (dv3_debug_set(14, v); 0 = none)

@@ -793,7 +793,7 @@ extern "C" int dv3_debug_set(int what, int value) {
               "debug_set(%d, %d): ablation variants are not in this build (make EXP=1)", what, value);
 #endif
   if (what >= 4 && what <= 8) return dv3_planes_debug_set(what, value);
-  if (what == 19 || what == 21 || what == 30 || what == 32) return dv3_c8pp_debug_set(what, value);
+  if (what == 19 || what == 21 || what == 30 || what == 32 || (what >= 34 && what <= 36)) return dv3_c8pp_debug_set(what, value);
   if (what == 20) g_wgrad_c8_pf2 = value;
   if (what == 9) g_x3_rel2 = value;
   if (what == 12) g_x3_pp2 = value;

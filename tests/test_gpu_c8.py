@@ -313,19 +313,24 @@ def test_c8pp_kernel_is_bit_identical_to_the_planes_kernel(dev, modes, kind, C, 
     x = torch.randn(B, C, T, device=dev)
     out = {}
     try:
-        for tag, thr in (("planes", 0), ("c8pp", 1)):
+        # planes kernel | 8 waves on 256 x 256 | two 4-wave workgroups per CU on 256 x 128 (round 5: dv3_debug_set(34, 1))
+        for tag, thr, nw4, want in (("planes", 0, 0, 8), ("c8pp", 1, 0, 9101), ("c8pp 4-wave", 1, 1, 9111)):
             L.dv3_debug_set(19, thr)
+            L.dv3_debug_set(34, nw4)
             out[tag] = _run(layer, x, True, "bf16", ops)
             # the last tap-GEMM of backward is the input gradient: served by the kernel under test
-            assert L.dv3_debug_get(10) // 1000 == (9 if thr else 8), (tag, L.dv3_debug_get(10))
+            v = L.dv3_debug_get(10)
+            assert (v // 1000 == want) if want < 10 else (v == want), (tag, v)
     finally:
         L.dv3_debug_set(19, 128)
+        L.dv3_debug_set(34, 2)
     y0, dx0, dp0 = out["planes"]
-    y1, dx1, dp1 = out["c8pp"]
-    assert torch.equal(y0, y1), float((y0 - y1).abs().max())
-    assert torch.equal(dx0, dx1), float((dx0 - dx1).abs().max())
-    for n in dp0:
-        assert torch.equal(dp0[n], dp1[n]), n
+    for tag in ("c8pp", "c8pp 4-wave"):
+        y1, dx1, dp1 = out[tag]
+        assert torch.equal(y0, y1), (tag, float((y0 - y1).abs().max()))
+        assert torch.equal(dx0, dx1), (tag, float((dx0 - dx1).abs().max()))
+        for n in dp0:
+            assert torch.equal(dp0[n], dp1[n]), (tag, n)
 
 
 @pytest.mark.parametrize("d,causal", [(1, False), (27, True)])
@@ -381,17 +386,24 @@ def test_north_star_c8pp_is_the_kernel_the_bench_times(dev, modes, d, causal):
     layer.train()
     out = {}
     try:
-        for tag, thr, rf in (("planes", 0, 1), ("c8pp", 128, 1), ("c8pp staging first", 128, 0)):
+        # (34: 0 = 8-wave form only, 1 = the 4-wave form everywhere, 2 = the dispatcher's rule -- what a training step runs:
+        #  masked forward on two 4-wave workgroups per CU, this 256-tile input gradient on the 8-wave form)
+        for tag, thr, rf, nw4 in (("planes", 0, 1, 0), ("c8pp", 128, 1, 0), ("c8pp staging first", 128, 0, 0),
+                                  ("c8pp 4-wave", 128, 1, 1), ("c8pp by the rule", 128, 1, 2)):
             L.dv3_debug_set(19, thr)
             L.dv3_debug_set(30, rf)
+            L.dv3_debug_set(34, nw4)
             out[tag] = _run(layer, x, True, "bf16", ops)
-            assert L.dv3_debug_get(10) == (9101 if thr else L.dv3_debug_get(10)), (tag, L.dv3_debug_get(10))
-            assert (L.dv3_debug_get(10) // 1000 == 9) == bool(thr), (tag, L.dv3_debug_get(10))
+            v = L.dv3_debug_get(10)
+            assert (v // 1000 == 9) == bool(thr), (tag, v)
+            if thr:
+                assert v == (9111 if nw4 == 1 else 9101), (tag, v)
     finally:
         L.dv3_debug_set(19, 128)
         L.dv3_debug_set(30, 1)
+        L.dv3_debug_set(34, 2)
     y0, dx0, dp0 = out["planes"]
-    for tag in ("c8pp", "c8pp staging first"):
+    for tag in ("c8pp", "c8pp staging first", "c8pp 4-wave", "c8pp by the rule"):
         y1, dx1, dp1 = out[tag]
         assert torch.equal(y0, y1), (tag, float((y0 - y1).abs().max()))
         assert torch.equal(dx0, dx1), (tag, float((dx0 - dx1).abs().max()))
