@@ -121,8 +121,10 @@ extern "C" int dv3_graph_destroy(void* exec) {
   return DV3_OK;
 }
 
+int dv3_conv_census_count();   // conv_gemm.hip
 extern "C" int dv3_debug_get(int what) {
   if (what == 10) return g_dv3_last_conv;
+  if (what == 40) return dv3_conv_census_count();
   if (what == 11) return g_dv3_last_wgrad;
   return 0;
 }

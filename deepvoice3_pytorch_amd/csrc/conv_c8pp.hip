@@ -439,14 +439,14 @@ int dv3_conv_c8pp_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   //     4-wave form is 5-14 % slower there: in-phase SIMD partners, twice the weight-panel traffic per column);
   //   * two 4-wave workgroups per CU on 256 x 128 (NW = 4): the masked training forward with its pre-gate save (three
   //     times the tail stores: -4 ... -8 % at every size, -14 % at 100 tiles) and input gradients of grids that do NOT
-  //     fill the chip with 256 x 256 tiles (64 ... 255 of them: -21 ... -26 %; the 8-wave form leaves CUs idle there);
+  //     fill the chip with 256 x 256 tiles (64 ... 191 of them: -21 ... -26 %; the 8-wave form leaves CUs idle there);
   //   * below that the 128-row planes kernel (return 1).
   const bool is_dgrad = d->mode == DV3_EPI_DGRAD;
   const bool masked_fwd = d->xmask_c8 != nullptr && !is_dgrad;
   bool use_nw4 = g_c8pp_nw4 == 1 || d->tile_hint == 41;
   if (g_c8pp_nw4 == 2 && d->tile_hint != 40) {
     if (masked_fwd) use_nw4 = nb >= 100;
-    else if (is_dgrad) use_nw4 = nb >= 64 && nb < 256;
+    else if (is_dgrad) use_nw4 = nb >= 64 && nb < 192;   // (201 tiles: 8-wave 49 us, 4-wave 55: profiles/r05_conv_census_nyanko_bf16_c8.txt)
   }
   if (d->tile_hint != 40 && !use_nw4 && nb < g_c8pp_min_tiles) return 1;
   const int XI = (KB * (BN + (d->J > 1 ? HALO_MAX : 0)) + NT - 1) / NT;

@@ -16,6 +16,8 @@ struct ConvArgs {
   int wide = 1;                    // 16-byte input-gradient epilogue through LDS (0 = off)
   uint32_t* range_ctr = nullptr;   // f16x3: sticky fp16-range event counter (common.h), NULL = do not count
   int prio = 0;  // ping-pong tap-GEMM: wave priority scheme (dv3_debug_set(14, v); 0 = none)
+  int ks = 0;    // 128 x 64 split tile: 2 = the k-split form (two wave groups per workgroup, halves of the chunk range)
+  int dp = 0;    // 128 x 64 split tile: deep-prefetch form with this compile-time tap count (1 or 3; 0 = the in-phase loop)
   // stream-K form of the 256 x 256 kernels: n_blocks = workgroups (one per CU), sk_units = tiles x chunks
   int sk_units = 0, sk_base = 0, sk_rem = 0, sk_shift = 0, sk_mshift = 0, sk_abl = 0;   // units; per-workgroup share and remainder (groups with the extra tile); log2(chunks per tile)
   int sk_base2 = 0, sk_rem2 = 0, sk_tg = 0, sk_tr = 0, sk_qshift = 0;                   // ... of the groups without it; tiles per XCD group, groups with one more; log2(workgroups per group)

@@ -17,6 +17,7 @@
 //   * fragment reads are ds_read_b32 with lanes along the contiguous axis: conflict-free,
 //     and at the fp32 MFMA rate (64 cycles per instruction) LDS bandwidth is <15% used.
 #include "conv_common.h"
+#include <string.h>
 
 namespace {
 
@@ -313,7 +314,38 @@ int launch_cfg(const ConvArgs& a, int bkc, size_t lds, hipStream_t st) {
 int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st);  // conv_gemm_bf16x3.hip
 int dv3_conv_planes_dispatch(const dv3_conv_desc* d, hipStream_t st);       // conv_planes.hip
 
+static int conv_gemm_dispatch(const dv3_conv_desc* d, void* stream);
+// Launch census (dv3_debug_set(40, 1) starts, (40, 0) stops, dv3_debug_get(40) = count, dv3_debug_read(40 / 41, ...) =
+// the descriptors / the kernel variant that served each): every tap-GEMM descriptor of a step, so that a script can
+// re-issue each launch of a REAL training step stand-alone and time it (scripts/r5_conv_census.py)
+namespace {
+constexpr int CENSUS_CAP = 2048;
+dv3_conv_desc g_census_desc[CENSUS_CAP];
+int g_census_variant[CENSUS_CAP];
+int g_census_n = 0;
+bool g_census_on = false;
+}  // namespace
+int dv3_conv_census_set(int on) {
+  if (on) g_census_n = 0;
+  g_census_on = on != 0;
+  return DV3_OK;
+}
+int dv3_conv_census_count() { return g_census_n; }
+int dv3_conv_census_read(int what, void* dst, int64_t bytes) {
+  const int64_t have = what == 40 ? (int64_t)g_census_n * (int64_t)sizeof(dv3_conv_desc) : (int64_t)g_census_n * (int64_t)sizeof(int);
+  DV3_REQUIRE(dst && bytes >= 0 && bytes <= have, "debug_read: the census holds %lld bytes", (long long)have);
+  memcpy(dst, what == 40 ? (const void*)g_census_desc : (const void*)g_census_variant, (size_t)bytes);
+  return DV3_OK;
+}
 extern "C" int dv3_conv_gemm_f32(const dv3_conv_desc* d, void* stream) {
+  const int rc = conv_gemm_dispatch(d, stream);
+  if (g_census_on && d && rc == DV3_OK && g_census_n < CENSUS_CAP) {
+    g_census_desc[g_census_n] = *d;
+    g_census_variant[g_census_n++] = g_dv3_last_conv;
+  }
+  return rc;
+}
+static int conv_gemm_dispatch(const dv3_conv_desc* d, void* stream) {
   DV3_REQUIRE(d && (d->x || d->x_planes) && (d->a || d->a_split) && d->y, "conv_gemm: null pointer");
   DV3_REQUIRE(d->B > 0 && d->Cin > 0 && d->Tin > 0 && d->M > 0 && d->Tout > 0, "conv_gemm: bad dims");
   DV3_REQUIRE(d->J >= 1 && d->J <= 16 && d->dil >= 1, "conv_gemm: bad taps J=%d dil=%d", d->J, d->dil);

@@ -77,28 +77,51 @@ __device__ __forceinline__ T ldg_off(const void* base, uint32_t byte_off) {
 constexpr int STAMP_SLOTS = 192;
 __device__ unsigned long long g_x3_stamps[8 * STAMP_SLOTS * 2];
 
-template <int WM, int WN, int NI, bool MASK, int ABL = 0, int TERMS = 3, int MI = 1, bool PP = false, bool F16 = false>
-__global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const ConvArgs args) {
+// DPJ (round 5, "deep prefetch"): 0 = the loops below; 1 / 3 = the tap count is this compile-time constant and the
+// global fetches run DA steps (weight panels) / DX chunks (activation tiles) ahead through register rings (see the
+// DPJ main loop).  For grids that leave a CU with one or two workgroups -- the decoder's T = 200 layers, every layer at
+// the preset's own batch 16 -- a step of the in-phase loop costs one exposed L2 / HBM round trip (its panel is fetched
+// at the top of the step that stores it); with the rings the round trip is paid once per tile.
+//
+// KS (round 5, "k-split"): 1 = one group of WM x WN waves; 2 = TWO such groups in one workgroup, each with its own LDS
+// buffers, staging the first / second half of the input-channel chunks of the SAME output tile; the second group's
+// accumulators go through LDS to the first, which adds them (first half + second half: a fixed order, a function of the
+// shape) and runs the tail.  For grids that leave a CU one workgroup (profiles/r05_conv_census_dv3lj_b16.txt: every
+// layer at the preset's batch 16) a lone wave per SIMD serialises fragment reads -> MFMAs -> stores -> barrier; the
+// second group is the second wave per SIMD that overlaps them, on a k-range half as long.
+template <int WM, int WN, int NI, bool MASK, int ABL = 0, int TERMS = 3, int MI = 1, bool PP = false, bool F16 = false, int DPJ = 0, int KS = 1>
+__global__ __launch_bounds__(WM* WN * 64 * KS) void conv_gemm_bf16x3_kernel(const ConvArgs args) {
   static_assert(!F16 || TERMS == 3, "the fp16 form is the three-term split");
+  static_assert(KS == 1 || (KS == 2 && !PP && DPJ == 0 && ABL == 0), "k-split: two groups on the in-phase loop");
+  static_assert(DPJ == 0 || (DPJ == 1 || DPJ == 3), "deep prefetch: 1 or 3 taps");
+  static_assert(DPJ == 0 || (!PP && MI == 1 && ABL == 0 && TERMS == 3), "deep prefetch: the in-phase three-term tiles");
+  // rings: weight panels in flight (steps) / activation tiles in flight (chunks).  One step of the 1-tap form issues
+  // 4 + 8 loads (+ 8 keep-bit words when masked): the masked ring is one step shorter to stay under the 63 loads vmcnt counts
+  constexpr int DA = DPJ == 0 ? 1 : (DPJ == 1 ? (MASK ? 3 : 4) : 3);
+  constexpr int DX = DPJ == 0 ? 1 : (DPJ == 1 ? (MASK ? 3 : 4) : 2);
   static_assert(!PP || (WM * WN == 8 && MI == 1 && (ABL == 0 || ABL >= 10)), "ping-pong: 8 waves, one row sub-tile per wave");
   constexpr int BM = WM * MI * 64, BMH = WM * MI * 32, BN = WN * NI * 32;
   constexpr int NT = WM * WN * 64;
   constexpr int AU = KB * BM / NT;                          // A units per plane per thread per step
-  constexpr int XI = (KB * (BN + HALO_MAX) + NT - 1) / NT;  // X items per thread per chunk
+  constexpr int XI = (KB * (BN + (DPJ == 1 ? 0 : HALO_MAX)) + NT - 1) / NT;  // X items per thread per chunk
   static_assert(KB * BM % NT == 0, "A panel must split evenly");
   const dv3_conv_desc& p = args.d;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int J = p.J, dil = p.dil;
+  const int J = DPJ ? DPJ : p.J, dil = p.dil;   // (the dispatcher launches a DPJ form only for that tap count)
   const int BNH = BN + (J - 1) * dil;
-  // [2 buffers] x { A hi [KB][BM], A lo [KB][BM] } then [2 buffers] x { X hi [KB][BNH], X lo }
-  bf16x8* const As = reinterpret_cast<bf16x8*>(smem_raw);
-  bf16x8* const Xs = As + 2 * 2 * KB * BM;
   const int xbuf = 2 * KB * BNH;  // units per X buffer (hi + lo)
+  // k-split: group index, and thread / wave index INSIDE the group (all staging and tile indexing below is per group)
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int grp = KS > 1 ? wave_all / (WM * WN) : 0;
+  const int grp_units = 2 * 2 * KB * BM + 2 * xbuf;   // 16-byte units of one group's buffers
+  // [2 buffers] x { A hi [KB][BM], A lo [KB][BM] } then [2 buffers] x { X hi [KB][BNH], X lo }
+  bf16x8* const As = reinterpret_cast<bf16x8*>(smem_raw) + grp * grp_units;
+  bf16x8* const Xs = As + 2 * 2 * KB * BM;
 
-  const int tid = threadIdx.x;
+  const int tid = (int)threadIdx.x - grp * NT;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave_all - grp * (WM * WN);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lhi = lane >> 5;
 
@@ -185,31 +208,35 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   }
 
   // ---- register staging ----
-  bf16x8 ra[2][AU];
-  float rx[XI][8];
-  uint32_t rm[MASK ? XI : 1][8];
+  bf16x8 ra[DA][2][AU];
+  float rx[DX][XI][8];
+  uint32_t rm[MASK ? DX : 1][MASK ? XI : 1][8];
 
-  const int nchunks = (Cin + BKC - 1) / BKC;
+  const int nchunks_all = (Cin + BKC - 1) / BKC;
+  const int nch_first = KS > 1 ? (nchunks_all + 1) / 2 : nchunks_all;      // k-split: the first group's share
+  const int c_base = grp * nch_first;                                      // this group's first chunk
+  const int nchunks = grp == 0 ? nch_first : nchunks_all - nch_first;      // ... and its number of chunks (local indices below)
 
-  auto load_A = [&](int chunk, int j) {
+  auto load_A = [&](int chunk_l, int j, int slot = 0) {
+    const int chunk = chunk_l + c_base;
     const bf16x8* srch = Wh + (int64_t)(j * k8_total + chunk * KB) * lda;  // uniform
     const bf16x8* srcl = srch + plane;
 #pragma unroll
     for (int u = 0; u < AU; ++u) {
-      ra[0][u] = ldg_off<bf16x8>(srch, aoff[u]);
-      if (TERMS == 3) ra[1][u] = ldg_off<bf16x8>(srcl, aoff[u]);
+      ra[slot][0][u] = ldg_off<bf16x8>(srch, aoff[u]);
+      if (TERMS == 3) ra[slot][1][u] = ldg_off<bf16x8>(srcl, aoff[u]);
     }
   };
-  auto write_A = [&](int buf) {
+  auto write_A = [&](int buf, int slot = 0) {
     bf16x8* dst = As + buf * (2 * KB * BM);
 #pragma unroll
     for (int u = 0; u < AU; ++u) {
-      dst[tid + u * NT] = ra[0][u];
-      if (TERMS == 3) dst[KB * BM + tid + u * NT] = ra[1][u];
+      dst[tid + u * NT] = ra[slot][0][u];
+      if (TERMS == 3) dst[KB * BM + tid + u * NT] = ra[slot][1][u];
     }
   };
-  auto load_X = [&](int chunk) {
-    const int c0 = chunk * BKC;
+  auto load_X = [&](int chunk_l, int slot = 0) {
+    const int c0 = (chunk_l + c_base) * BKC;
     if (c0 + BKC <= Cin) {
       // whole chunk in range (uniform): 8 uniform row bases + one loop-invariant per-thread offset
       // per item -> every load is the SGPR-base form with no address arithmetic
@@ -220,8 +247,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
           for (int i = 0; i < XI; ++i) {
-            rx[i][e] = __uint_as_float((uint32_t)ldg_off<uint16_t>(xb + (int64_t)e * x_rsb, xoff[i]) << 16);
-            if (MASK) rm[i][e] = ldg_off<uint32_t>(mb + (int64_t)e * m_rsb, xmo[i]);
+            rx[slot][i][e] = __uint_as_float((uint32_t)ldg_off<uint16_t>(xb + (int64_t)e * x_rsb, xoff[i]) << 16);
+            if (MASK) rm[slot][i][e] = ldg_off<uint32_t>(mb + (int64_t)e * m_rsb, xmo[i]);
           }
         }
       } else {
@@ -229,8 +256,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
           for (int i = 0; i < XI; ++i) {
-            rx[i][e] = ldg_off<float>(xb + (int64_t)e * x_rsb, xoff[i]);
-            if (MASK) rm[i][e] = ldg_off<uint32_t>(mb + (int64_t)e * m_rsb, xmo[i]);
+            rx[slot][i][e] = ldg_off<float>(xb + (int64_t)e * x_rsb, xoff[i]);
+            if (MASK) rm[slot][i][e] = ldg_off<uint32_t>(mb + (int64_t)e * m_rsb, xmo[i]);
           }
         }
       }
@@ -243,14 +270,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         for (int e = 0; e < 8; ++e) {
           // row relative to this item's k8 block (mod 2^32: may be "negative" when Cin < k8*8)
           const uint32_t dc = (uint32_t)(min(c0 + xk8[i] + e, Cin - 1) - xk8[i]);
-          rx[i][e] = xbf ? __uint_as_float((uint32_t)ldg_off<uint16_t>(p.x, xoff[i] + dc * x_rsb) << 16)
+          rx[slot][i][e] = xbf ? __uint_as_float((uint32_t)ldg_off<uint16_t>(p.x, xoff[i] + dc * x_rsb) << 16)
                          : ldg_off<float>(p.x, xoff[i] + dc * x_rsb);
-          if (MASK) rm[i][e] = ldg_off<uint32_t>(xmask, xmo[MASK ? i : 0] + dc * m_rsb);
+          if (MASK) rm[slot][i][e] = ldg_off<uint32_t>(xmask, xmo[MASK ? i : 0] + dc * m_rsb);
         }
       }
     }
   };
-  auto write_X = [&](int buf) {
+  auto write_X = [&](int buf, int slot = 0) {
     bf16x8* dst = Xs + buf * xbuf;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
@@ -259,8 +286,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          v[e] = rx[i][e];
-          if (MASK) v[e] *= ((rm[i][e] >> xsh[i]) & 1u) ? dscale : 0.f;
+          v[e] = rx[slot][i][e];
+          if (MASK) v[e] *= ((rm[slot][i][e] >> xsh[i]) & 1u) ? dscale : 0.f;
           else if (F16) v[e] *= xscale;
         }
         bf16x8 hi, lo;
@@ -285,11 +312,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
   const int a_off = wm * (MI * 32) + l31;
   const int x_off = wn * (NI * 32) + l31;
 
-  load_A(0, 0);
-  load_X(0);
-  write_A(0);
-  write_X(0);
-  __syncthreads();
+  if constexpr (DPJ == 0) {
+    load_A(0, 0);
+    load_X(0);
+    write_A(0);
+    write_X(0);
+    __syncthreads();
+  }
 
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -427,8 +456,112 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
       c = cn;
     }
     stamp();                       // slot 1 + 6*nsteps: main loop left
+  } else if constexpr (DPJ > 0) {
+    // ---- deep-prefetch main loop (in-phase tiles, compile-time tap count) ----
+    // Step s = (chunk s / J, tap s % J).  At its top the panel of step s + DA goes into ring slot s % DA (the panel that
+    // slot held was stored at the end of step s - 1) and, at a chunk's first tap, the activation tile of chunk c + DX into
+    // slot c % DX; at its end the panel of step s + 1 (fetched DA - 1 steps ago) and, at a chunk's last tap, the tile of
+    // chunk c + 1 (fetched (DX - 1) chunks ago) are stored into the other LDS buffer.  U steps are unrolled so that every
+    // ring index is a compile-time constant (U a multiple of DA and of DX * J; U and U / J even: the LDS buffer parities too).
+    // Same fragment images, same MFMA order as the loop below: bit-identical results.
+    //
+    // The loop starts U steps BEFORE step 0: the virtual steps run the same fetches and stores (indices clamped into
+    // the tile, so they re-fetch step 0's panel at worst) and stores, and skip only the fragment reads + MFMAs; so do the
+    // up to U - 1 steps behind the last one (the loop leaves at a round boundary only).  That fills the rings in consumption order with the loop's
+    // own instruction stream -- no separate prologue whose differently-ordered pending fetches the compiler would have
+    // to merge into the loop header's wait counts (a first version with a peeled prologue drained the rings to 11
+    // outstanding loads at the top of every U-th step) -- and every fetch and store is unconditional, so each
+    // s_waitcnt vmcnt(N) is exact.
+    constexpr int U = (DPJ == 1 && DA == 4) ? 4 : 6;
+    static_assert(U % DA == 0 && (U / DPJ) % DX == 0 && U % DPJ == 0 && U % 2 == 0 && (U / DPJ) % 2 == 0,
+                  "ring slots and LDS buffer parities must be compile-time");
+    const int last_step = nsteps - 1, last_chunk = nchunks - 1;
+#pragma unroll
+    for (int a = 0; a < DA; ++a)
+#pragma unroll
+      for (int u = 0; u < AU; ++u) ra[a][0][u] = ra[a][1][u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int x = 0; x < DX; ++x)
+#pragma unroll
+      for (int i = 0; i < XI; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          rx[x][i][e] = 0.f;
+          if (MASK) rm[x][i][e] = 0u;
+        }
+    int s_first = -U;
+    asm volatile("" : "+s"(s_first));   // opaque: keeps the compiler from peeling the virtual round into a prologue again
+    for (int s0 = s_first; s0 < nsteps; s0 += U) {
+#pragma unroll
+      for (int dd = 0; dd < U; ++dd) {
+        const int s = s0 + dd;
+        const int jj = dd % DPJ;                 // tap
+        const int cx = dd / DPJ;                 // chunk, relative to s0 / J (a multiple of DX)
+        {
+          const int sa = min(max(s + DA, 0), last_step);
+          load_A(sa / DPJ, sa % DPJ, dd % DA);
+        }
+        if (jj == 0) load_X(min(max(s0 / DPJ + cx + DX, 0), last_chunk), cx % DX);
+        if (s >= 0 && s < nsteps) {   // (no early exit from the round: the compiler funnels every loop exit through one
+                                      //  block with an edge back to the header, whose wait counts then assume the worst exit)
+          const bf16x8* AsH = As + (dd & 1) * (2 * KB * BM);
+          const bf16x8* AsL = AsH + KB * BM;
+          const bf16x8* XsH = Xs + (cx & 1) * xbuf;
+          const bf16x8* XsL = XsH + KB * BNH;
+          const bool fix = (need >> jj) & 1u;
+          const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int k8 = 2 * s2 + lhi;
+            const int ai = k8 * BM + a_off;
+            const bf16x8 ah0 = AsH[ai], ah1 = AsH[ai + BMH], al0 = AsL[ai], al1 = AsL[ai + BMH];
+            bf16x8 bh[NI], bl[NI];
+            const int xi = k8 * BNH + x_off + jj * dil;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              bh[ni] = XsH[xi + ni * 32];
+              bl[ni] = XsL[xi + ni * 32];
+            }
+            if (fix) {
+#pragma unroll
+              for (int ni = 0; ni < NI; ++ni) {
+                const bool ok = (vbits >> (jj * NI + ni)) & 1u;
+                bh[ni] = ok ? bh[ni] : zero8;
+                bl[ni] = ok ? bl[ni] : zero8;
+              }
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[0][0][ni] = mma16<F16>(al0, bh[ni], acc[0][0][ni]);
+              acc[0][1][ni] = mma16<F16>(al1, bh[ni], acc[0][1][ni]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[0][0][ni] = mma16<F16>(ah0, bl[ni], acc[0][0][ni]);
+              acc[0][1][ni] = mma16<F16>(ah1, bl[ni], acc[0][1][ni]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              acc[0][0][ni] = mma16<F16>(ah0, bh[ni], acc[0][0][ni]);
+              acc[0][1][ni] = mma16<F16>(ah1, bh[ni], acc[0][1][ni]);
+            }
+          }
+        }
+        // stores for step s + 1, unconditional like the fetches (a conditional store leaves "maybe still pending" marks
+        // on its ring slot at the join, which reach the loop header).  The last step stores into buffers nobody reads any
+        // more; the virtual steps before -1 store ring slots that are not fetched yet: zeros (see the initialisation
+        // above the loop -- the fp16 range guard must not see register garbage), into buffers overwritten before use.
+        write_A((dd & 1) ^ 1, (dd + 1) % DA);
+        if (jj == DPJ - 1) write_X((cx & 1) ^ 1, (cx + 1) % DX);
+        __syncthreads();
+      }
+    }
   } else
-  for (int step = 0; step < nsteps; ++step) {
+  for (int step = 0; step < (KS > 1 ? nch_first * J : nsteps); ++step) {
+    if (KS > 1 && step >= nsteps) {   // the second group of an odd chunk count: one chunk fewer, same number of barriers
+      __syncthreads();
+      continue;
+    }
     const int cur = step & 1;
     int jn = j + 1, cn = c;
     if (jn == J) { jn = 0; cn = c + 1; }
@@ -520,6 +653,33 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_bf16x3_kernel(const Con
     c = cn;
   }
 
+  if constexpr (KS > 1) {
+    // second group -> LDS (its own buffers: the main loop's last barrier is behind every read of them) -> first group
+    float* red = reinterpret_cast<float*>(reinterpret_cast<bf16x8*>(smem_raw) + grp_units);
+    constexpr int NR = MI * 2 * NI * 16;
+    static_assert((size_t)WM * WN * NR * 64 * 4 <= (size_t)(2 * 2 * KB * BM) * 16, "the accumulator image must fit one group's panels");
+    float* mine = red + (wave * NR) * 64 + lane;
+    if (grp == 1) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(((mi * 2 + h) * NI + ni) * 16 + r) * 64] = acc[mi][h][ni][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][h][ni][r] += mine[(((mi * 2 + h) * NI + ni) * 16 + r) * 64];
+  }
   // ABL 6: skip the epilogue but keep the accumulators live
   if ((ABL != 6 && ABL != 9) || acc[0][0][0][0] + acc[MI - 1][1][0][0] + acc[0][0][NI - 1][5] + acc[MI - 1][1][NI - 1][7] == 1.2345e30f) {
     static_assert(MI == 1 || MI == 2, "row sub-tiles per wave");
@@ -595,11 +755,18 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
   dst[n + idx] = lo;
 }
 
-template <int WM, int WN, int NI, bool MASK, int TERMS, int MI = 1, bool PP = false, bool F16 = false>
+#ifdef DV3_X3_ISA_ONLY   // scripts/x3_isa.sh: one instantiation only, for reading its ISA
+#ifndef DV3_X3_ISA_KS
+#define DV3_X3_ISA_KS 1
+#endif
+template __global__ void conv_gemm_bf16x3_kernel<2, 2, 1, DV3_X3_ISA_MASK, 0, 3, 1, false, DV3_X3_ISA_F16, DV3_X3_ISA_DPJ, DV3_X3_ISA_KS>(const ConvArgs);
+}  // namespace
+#else
+template <int WM, int WN, int NI, bool MASK, int TERMS, int MI = 1, bool PP = false, bool F16 = false, int DPJ = 0, int KS = 1>
 int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP, F16>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP, F16, DPJ, KS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_gemm_bf16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -607,8 +774,8 @@ int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
     }
     attr_set = true;
   }
-  dim3 grid(a.n_blocks), block(WM * WN * 64);
-  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP, F16>), grid, block, lds, st, a);
+  dim3 grid(a.n_blocks), block(WM * WN * 64 * KS);
+  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP, F16, DPJ, KS>), grid, block, lds * KS, st, a);
   return dv3_check_launch("conv_gemm_bf16x3");
 }
 int g_x3_ablate = 0;   // debug: dv3_debug_set(); ablation variants of the 128x128 unmasked tile
@@ -665,6 +832,28 @@ int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
     }
   }
 #endif
+  if constexpr (WM == 2 && WN == 2 && NI == 1) {
+    // k-split form of the 128 x 64 tile (kernel template KS = 2): chosen by the dispatcher (a.ks)
+    if (a.ks == 2 && a.d.split_terms != 1) {
+      const bool f16 = a.d.split_terms == DV3_SPLIT_F16X3, m = a.d.xmask != nullptr;
+      if (f16) return m ? launch_x3_m<2, 2, 1, true, 3, 1, false, true, 0, 2>(a, lds, st) : launch_x3_m<2, 2, 1, false, 3, 1, false, true, 0, 2>(a, lds, st);
+      return m ? launch_x3_m<2, 2, 1, true, 3, 1, false, false, 0, 2>(a, lds, st) : launch_x3_m<2, 2, 1, false, 3, 1, false, false, 0, 2>(a, lds, st);
+    }
+  }
+#ifdef DV3_EXPERIMENTS   // measured and retired (profiles/r05_deep_prefetch_rings.txt): experiment build only
+  if constexpr (WM == 2 && WN == 2 && NI == 1) {
+    // deep-prefetch form of the 128 x 64 tile (kernel template DPJ): chosen by the dispatcher (a.dp = 1 or 3 taps)
+    if (a.dp == 1 || a.dp == 3) {
+      const bool f16 = a.d.split_terms == DV3_SPLIT_F16X3, m = a.d.xmask != nullptr;
+      if (a.dp == 1) {
+        if (f16) return m ? launch_x3_m<2, 2, 1, true, 3, 1, false, true, 1>(a, lds, st) : launch_x3_m<2, 2, 1, false, 3, 1, false, true, 1>(a, lds, st);
+        return m ? launch_x3_m<2, 2, 1, true, 3, 1, false, false, 1>(a, lds, st) : launch_x3_m<2, 2, 1, false, 3, 1, false, false, 1>(a, lds, st);
+      }
+      if (f16) return m ? launch_x3_m<2, 2, 1, true, 3, 1, false, true, 3>(a, lds, st) : launch_x3_m<2, 2, 1, false, 3, 1, false, true, 3>(a, lds, st);
+      return m ? launch_x3_m<2, 2, 1, true, 3, 1, false, false, 3>(a, lds, st) : launch_x3_m<2, 2, 1, false, 3, 1, false, false, 3>(a, lds, st);
+    }
+  }
+#endif
   if (a.d.split_terms == DV3_SPLIT_F16X3)
     return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3, 1, false, true>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3, 1, false, true>(a, lds, st);
   if (a.d.split_terms == 1)
@@ -672,6 +861,14 @@ int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
   return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3>(a, lds, st);
 }
 
+int g_x3_ks = 0;        // dv3_debug_set(44, v): k-split form of the 128 x 64 tile: 0 never, 1 by the rule in the dispatcher, 2 wherever eligible
+int g_x3_ks_max_blocks = 320, g_x3_ks_min_chunks = 8;   // dv3_debug_set(45 / 46, v): the rule's bounds
+int g_x3_dp = 0;        // dv3_debug_set(43, v), experiment build: deep-prefetch form of the 128 x 64 tile: 0 never, 1 small grids, 2 always
+int g_x3_rel8 = 86;     // dv3_debug_set(42, v): relative cost (percent) of the 256 x 128 ping-pong tile in the picker below.  Rounds 2-4: 93
+                        // (north-star sweep).  Round 5's census of a real step (profiles/r05_conv_census_dv3lj_b64.txt) has it ahead
+                        // of the 128 x 256 tile stand-alone wherever the two tie on rounds (the encoder's input gradients, the
+                        // 1 x 1 layers at T = 804); whole steps at 86: 15.56 -> 15.45 ms at B = 64, 7.75 -> 7.71 at B = 16
+                        // (profiles/r05_rel8_step_ab.txt)
 int g_x3_j1_flat = 1;   // dv3_debug_set(27, v)
 int g_x3_rel2 = 112;   // dv3_debug_set(9, v): relative cost (percent) of the 128x64 tile in the picker below
 // bf16x3 tile choice: padded work over the FLAT column axis, weight-panel traffic penalised
@@ -697,7 +894,7 @@ const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
     // 8-wave 256-wide tiles (one workgroup per CU): less weight-panel traffic per MFMA; the
     // 128-row-per-wave tile (7, one wave per SIMD) measured slower everywhere: opt-in only (hint 27)
     static const double kRel[10] = {0, 1.0, 1.12, 2.0, 2.2, 1.8, 2.0, 9.9, 0.93, 0.87};
-    double rel = c.id == 2 ? g_x3_rel2 * 0.01 : kRel[c.id];
+    double rel = c.id == 2 ? g_x3_rel2 * 0.01 : c.id == 8 ? g_x3_rel8 * 0.01 : kRel[c.id];
     // 1 x 1 convolutions / Linear layers with K <= 512 (8-16 k32 steps per tile): prologue and tail dominate and the wide
     // tiles' staging advantage is gone -- measured per unit of modeled work the 128 x 64, 128 x 128, 256 x 128 and
     // 128 x 256 tiles cost the same (scripts/small_gemm_tiles.py: with the J = 3 weights the picker took the 128 x 256
@@ -765,8 +962,24 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   const int64_t nb = (int64_t)a.m_tiles * a.n_tiles;
   DV3_REQUIRE(nb < (1ll << 31), "conv_gemm: grid too large");
   a.n_blocks = (int)nb;
+  // k-split form (the 128 x 64 tile, three-term splits; 2 x 48 KB of LDS + halo): grids that leave a CU about one workgroup,
+  // k-ranges long enough to amortise the hand-over
+  a.ks = 0;
+  {
+    const int nch = (d->Cin + 31) / 32;
+    if (best->id == 2 && d->split_terms != 1 && g_x3_ks && nch >= 2 && 2 * lds <= 160 * 1024 &&
+        (g_x3_ks == 2 || (nb <= g_x3_ks_max_blocks && nch * d->J >= g_x3_ks_min_chunks)))
+      a.ks = 2;
+  }
+  // deep-prefetch form (the 128 x 64 tile, 1 or 3 taps, three-term splits): experiment build only, off by default
+  a.dp = 0;
+#ifdef DV3_EXPERIMENTS
+  if (best->id == 2 && d->split_terms != 1 && (d->J == 1 || d->J == 3) && g_x3_dp) {
+    if (g_x3_dp == 2 || nb <= 2 * 256) a.dp = d->J;
+  }
+#endif
   g_dv3_last_conv = (d->split_terms == 1 ? 4000 : d->split_terms == DV3_SPLIT_F16X3 ? 5000 : 3000) + best->id * 10 +
-                    ((best->id >= 8 && g_x3_pingpong) ? 1 : 0);
+                    ((best->id >= 8 && g_x3_pingpong) ? 1 : 0) + (a.dp ? 5 : 0) + (a.ks == 2 ? 2 : 0);
   switch (best->id) {
     case 1: return launch_x3<2, 2, 2>(a, lds, st);
     case 2: return launch_x3<2, 2, 1>(a, lds, st);
@@ -785,14 +998,16 @@ extern int g_wgrad_tile, g_wgrad_prio, g_wgrad_t2_abl, g_wgrad_taps2_default;   
 extern int g_wgrad_c8_pf2, g_spk_abl;                                                       // wgrad_c8.hip
 int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 int dv3_c8pp_debug_set(int what, int value);     // conv_c8pp.hip
+int dv3_conv_census_set(int on);                 // conv_gemm.hip
 extern "C" int dv3_debug_set(int what, int value) {
 #ifndef DV3_EXPERIMENTS
   // the timing-only ablation / stamp instantiations are compiled with `make EXP=1` only: say so instead of silently
   // timing the production kernel
-  DV3_REQUIRE(!(value != 0 && (what == 1 || what == 6 || what == 13 || what == 16 || what == 21 || what == 26 || what == 28 || what == 32)),
+  DV3_REQUIRE(!(value != 0 && (what == 1 || what == 6 || what == 13 || what == 16 || what == 21 || what == 26 || what == 28 || what == 32 || what == 43)),
               "debug_set(%d, %d): ablation variants are not in this build (make EXP=1)", what, value);
 #endif
   if (what >= 4 && what <= 8) return dv3_planes_debug_set(what, value);
+  if (what == 40) return dv3_conv_census_set(value);
   if (what == 19 || what == 21 || what == 30 || what == 32 || (what >= 34 && what <= 36)) return dv3_c8pp_debug_set(what, value);
   if (what == 20) g_wgrad_c8_pf2 = value;
   if (what == 9) g_x3_rel2 = value;
@@ -812,6 +1027,11 @@ extern "C" int dv3_debug_set(int what, int value) {
   if (what == 25) g_x3_pp2_sk_units = value;
   if (what == 26) g_pp2_sk_abl = value;
   if (what == 27) g_x3_j1_flat = value;
+  if (what == 43) g_x3_dp = value;
+  if (what == 42) g_x3_rel8 = value;
+  if (what == 44) g_x3_ks = value;
+  if (what == 45) g_x3_ks_max_blocks = value;
+  if (what == 46) g_x3_ks_min_chunks = value;
   if (what == 28) g_spk_abl = value;
   if (what == 14) g_x3_prio = value;
   if (what == 18) g_x3_wide = value;
@@ -826,7 +1046,9 @@ extern "C" int dv3_debug_set(int what, int value) {
 
 int dv3_pp2_read_stamps(void* dst, int64_t bytes);   // conv_gemm_pp2.hip
 int dv3_decode_read_stamps(void* dst, int64_t bytes);  // decode_step.hip
+int dv3_conv_census_read(int what, void* dst, int64_t bytes);   // conv_gemm.hip
 extern "C" int dv3_debug_read(int what, void* dst, int64_t bytes) {
+  if (what == 40 || what == 41) return dv3_conv_census_read(what, dst, bytes);
   if (what == 2 && dst) return dv3_pp2_read_stamps(dst, bytes);
   if (what == 3 && dst) return dv3_decode_read_stamps(dst, bytes);
   DV3_REQUIRE(what == 1 && dst && bytes > 0 && bytes <= (int64_t)sizeof(unsigned long long) * 8 * STAMP_SLOTS * 2,
@@ -851,3 +1073,4 @@ extern "C" int dv3_split_pack_bf16(const float* packed, uint16_t* out, int32_t J
                      dv3_range_ctr());
   return dv3_check_launch("split_pack_bf16");
 }
+#endif   // DV3_X3_ISA_ONLY

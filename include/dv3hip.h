@@ -41,10 +41,15 @@ int dv3_sizeof(const char* name);
  * what = 2: bf16x3 wgrad tile, 0 auto / 1 = 128x128 / 2 = 256x128; what = 3: 8-wave bf16x3
  * tap-GEMM tiles on the in-phase (0) or ping-pong (1, default) main loop; what = 4: tile of the planes
  * tap-GEMM, 0 auto / 1 = 128x128 (4 waves, two workgroups per CU) / 2 = 128x64 / 9 = 128x256 (8 waves);
- * what = 5: start-up stagger of the second co-resident workgroup, -1 auto / n = n sleeps of ~4 us). */
+ * what = 5: start-up stagger of the second co-resident workgroup, -1 auto / n = n sleeps of ~4 us;
+ * what = 34: conv_c8pp form, 0 = 8 waves on 256x256 only / 1 = two 4-wave workgroups per CU on 256x128 / 2 = by rule;
+ * what = 40: launch census of dv3_conv_gemm_f32, 1 = clear and record / 0 = stop; what = 42: relative cost (percent)
+ * of the 256x128 ping-pong tile in the split kernels' tile picker.  The full list: INTEGRATION.md, section 2). */
 int dv3_debug_set(int what, int value);
 /* what = 1: phase timestamps left by the last dv3_debug_set(1, 10) launch of the 128x256 bf16x3 tile
- * ([8 waves][192 slots][2] uint64, host pointer). */
+ * ([8 waves][192 slots][2] uint64, host pointer).  what = 40 / 41: the launch census -- the recorded dv3_conv_desc
+ * structs (bytes <= count * sizeof(dv3_conv_desc)) / the kernel variant (int32 each, encoded as dv3_debug_get(10))
+ * that served each; count = dv3_debug_get(40). */
 int dv3_debug_read(int what, void* dst, int64_t bytes);
 /* what = 10: which kernel the LAST dv3_conv_gemm_f32 call of this process launched, encoded
  * family * 1000 + tile_id * 10 + pingpong; family 1 = exact-fp32 streaming kernel, 2 = exact-fp32

@@ -722,7 +722,8 @@ def test_archived_bench_line_meets_the_contract():
     assert cb["kind"] in ("reference", "port")
     assert abs(d["value"] - d["config"]["global_batch"] * 800 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
     # round 3: the host's issue time and the launch-mode probe are reported for the headline and for every side config
-    for cfg in [d["config"]] + [c["config"] for k, c in d["configs"].items() if k not in ("synth_rtf", "ddp_world1")]:
+    flat = ("synth_rtf", "ddp_world1", "dv3lj_b64_ragged_epoch")
+    for cfg in [d["config"]] + [c["config"] for k, c in d["configs"].items() if k not in flat]:
         assert cfg["host_enqueue_ms_per_step"] > 0 and "hipgraph" in cfg and "launch_bound" in cfg
         assert cfg["launch_probe"] is None or {"eager_ms_per_step", "hipgraph_ms_per_step"} <= set(cfg["launch_probe"])
     assert "roofline_wgrad" in d and d["roofline_wgrad"]["alg_bytes"] > 2e8       # g + x + dW
@@ -731,6 +732,10 @@ def test_archived_bench_line_meets_the_contract():
     for k in ("dv3lj_b16", "dv3lj_b64_ragged", "dv3lj_b16_ragged"):
         assert d["configs"][k]["config"]["per_gpu_batch"] in (16, 64) and d["configs"][k]["value"] > 0
     assert d["configs"]["dv3lj_b64_ragged"]["config"]["lengths"].startswith("ragged")
+    # round 5: an epoch of LJSpeech-shaped lengths cut by the reference's length-bucketed sampler (eager: the shape changes)
+    ep = d["configs"].get("dv3lj_b64_ragged_epoch")
+    if ep is not None:
+        assert ep["value"] > 0 and ep["hipgraph"] is False and ep["real_frames"] > 0 and ep["host_enqueue_ms_per_step"] > 0
     w1 = d["configs"]["ddp_world1"]
     assert w1["backend"] == "nccl" and w1["rccl_ranks"] == 1
     for k, e in w1.items():

@@ -42,6 +42,10 @@ def dev():
     return torch.device("cuda:0")
 
 
+KS_DEFAULT = 0      # dv3_debug_set(44, v): the k-split form of the 128 x 64 tile (conv_gemm_bf16x3.hip): 0 off / 1 by rule
+DP_DEFAULT = 0      # dv3_debug_set(43, v): the deep-prefetch form of the 128 x 64 tile is off (conv_gemm_bf16x3.hip, experiment build)
+
+
 def _ops():
     from deepvoice3_pytorch_amd import ops
     return ops
@@ -628,6 +632,134 @@ def test_256x256_k16_pingpong_tap_gemm_equals_the_128_wide_kernels(dev, gemm_mod
         ops.conv_gemm(gm, None, pk.ldb, 0, y=dx, tile_hint=hint, **dkw)
         dxs.append(dx)
     assert torch.equal(dxs[0], dxs[1])
+
+
+@pytest.mark.parametrize("B,C,T,k,d,causal,masked", [(3, 64, 75, 3, 2, False, True), (2, 256, 150, 3, 27, False, False),
+                                                     (2, 128, 100, 3, 1, True, True), (5, 96, 61, 3, 9, False, True),
+                                                     (7, 32, 33, 3, 1, False, False), (4, 160, 201, 1, 1, False, False),
+                                                     (3, 24, 37, 1, 1, False, True), (2, 512, 150, 3, 3, False, True),
+                                                     (16, 256, 201, 1, 1, False, True), (1, 40, 17, 3, 27, True, False)])
+def test_deep_prefetch_form_of_the_128x64_tile_is_bit_identical(dev, gemm_mode, B, C, T, k, d, causal, masked):
+    """conv_gemm_bf16x3.hip, template DPJ (round 5; experiment build, dv3_debug_set(43, 0 | 1 | 2)): the 128 x 64 split tile with its
+    global fetches 3-4 steps ahead through register rings -- same fragment images, same MFMA order, so forward
+    (Conv1dGLU with the pre-gate save and keep-bits, modules.py:145-164), plain 1 x 1 / Linear and the input-gradient
+    form must agree BIT FOR BIT with the in-phase loop; covers 1 and 3 taps, partial chunks (C % 32 != 0), tiles shorter
+    than the rings (C = 24, 32, 40: one or two steps), columns across batch items, and the fp16 range guard staying
+    silent on the rings' virtual steps."""
+    if gemm_mode == "f32":
+        pytest.skip("split-operand kernel test")
+    from deepvoice3_pytorch_amd import ops, _lib
+    L = _lib.lib()
+    if L.dv3_debug_set(43, 2) != 0:
+        pytest.skip("the deep-prefetch form was measured and retired (profiles/r05_deep_prefetch_rings.txt): it is compiled "
+                    "into the experiment build only (make EXP=1, DV3_LIBPATH=.../libdv3hip_exp.so)")
+    L.dv3_debug_set(43, 0)
+    torch.manual_seed(C + T)
+    x = torch.randn(B, C, T, device=dev)
+    v = torch.randn(2 * C, C, k, device=dev) * math.sqrt(4.0 * 0.95 / (k * C))
+    g = v.reshape(2 * C, -1).norm(dim=1).view(-1, 1, 1).clone()
+    bias = torch.randn(2 * C, device=dev) * 0.1
+    pk = ops.pack_weights(v, g, glu_cg=C, need_bwd=True)
+    bits = rs = None
+    if masked:
+        ops.dropout_state.manual_seed(3)
+        bits, rs = ops.dropout_bits(B * C, T, 0.05, dev)
+    padL = (k - 1) * d if causal else (k - 1) // 2 * d
+    kw = dict(B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d, padL=padL, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x,
+              residual=1, a_split=pk.fwd_s, xmask=bits, xmask_rs=rs or 0, drop_scale=1 / 0.95 if masked else 1.0,
+              tile_hint=22)
+    gm = torch.randn(B, 2 * C, T, device=dev)
+    dres = torch.randn(B, C, T, device=dev)
+    dkw = dict(B=B, Cin=2 * C, Tin=T, M=C, Tout=T, J=k, dil=d, padL=(k - 1) * d - padL, mode=ops.EPI_DGRAD,
+               r=dres, ymask=bits, ymask_rs=rs or 0, drop_scale=1 / 0.95 if masked else 1.0, a_split=pk.bwd_s, tile_hint=22)
+    lkw = dict(B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d, padL=padL, mode=ops.EPI_RELU, bias=bias, a_split=pk.fwd_s,
+               tile_hint=22)
+    ev0 = ops.f16_range_events() if hasattr(ops, "f16_range_events") else None
+    outs = []
+    try:
+        for dp in (0, 2):
+            L.dv3_debug_set(43, dp)
+            y = torch.empty(B, C, T, device=dev)
+            ab = torch.empty(B, 2 * C, T, device=dev)
+            dx = torch.empty(B, C, T, device=dev)
+            z = torch.empty(B, 2 * C, T, device=dev)
+            ops.conv_gemm(x, None, pk.lda, pk.a_half, y=y, ab=ab, **kw)
+            v0 = L.dv3_debug_get(10)
+            ops.conv_gemm(gm, None, pk.ldb, 0, y=dx, **dkw)
+            v1 = L.dv3_debug_get(10)
+            ops.conv_gemm(x, None, pk.lda, pk.lda, y=z, **lkw)
+            v2 = L.dv3_debug_get(10)
+            assert (v0 % 10, v1 % 10, v2 % 10) == ((5, 5, 5) if dp else (0, 0, 0)), (dp, v0, v1, v2)
+            assert v0 % 1000 // 10 == 2 and v1 % 1000 // 10 == 2
+            outs.append((y, ab, dx, z))
+    finally:
+        L.dv3_debug_set(43, DP_DEFAULT)
+    for a, b, name in zip(outs[0], outs[1], ("y", "pre-gate", "dx", "relu")):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (name, float((a - b).abs().max()))
+    if ev0 is not None:
+        assert ops.f16_range_events() == ev0
+
+
+@pytest.mark.parametrize("B,C,T,k,d,causal,masked", [(3, 64, 75, 3, 2, False, True), (2, 256, 150, 3, 27, False, False),
+                                                     (2, 128, 100, 3, 1, True, True), (5, 96, 61, 3, 9, False, True),
+                                                     (4, 160, 201, 1, 1, False, False), (3, 40, 37, 1, 1, False, True),
+                                                     (2, 512, 150, 3, 3, False, True), (16, 256, 201, 1, 1, False, True),
+                                                     (1, 72, 17, 3, 27, True, False), (3, 24, 50, 3, 1, False, False)])
+def test_k_split_form_of_the_128x64_tile(dev, gemm_mode, B, C, T, k, d, causal, masked):
+    """conv_gemm_bf16x3.hip, template KS = 2 (round 5; dv3_debug_set(44, 0 | 1 | 2)): two wave groups of one workgroup
+    take the first / second half of the input-channel chunks of the same 128 x 64 tile and the second hands its
+    accumulators to the first through LDS.  The sum is (first half) + (second half) instead of one running sum:
+    not bit-identical to the one-group loop, but a fixed function of the shape -- checked: equal to the one-group
+    result to the kernel tolerance, REPEATABLE bit for bit, and anchored on the oracle (Conv1dGLU forward,
+    modules.py:145-164).  Covers odd chunk counts (C = 96, 160: the second group runs a chunk fewer), a partial last
+    chunk in the second group (C = 40, 72), 1 and 3 taps, keep-bits, the input-gradient form, and a single-chunk
+    layer (C = 24) that must stay on the one-group kernel."""
+    if gemm_mode == "f32":
+        pytest.skip("split-operand kernel test")
+    from deepvoice3_pytorch_amd import ops, _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(C + T + k)
+    sd = _glu_sd(C, k, rng)
+    x_cpu = torch.from_numpy(rng.randn(B, C, T).astype(np.float32))
+    x = x_cpu.to(dev)
+    bias = sd["l.conv.bias"].to(dev)
+    pk = ops.pack_weights(sd["l.conv.weight_v"].to(dev), sd["l.conv.weight_g"].to(dev), glu_cg=C, need_bwd=True)
+    bits = rs = None
+    if masked:
+        ops.dropout_state.manual_seed(3)
+        bits, rs = ops.dropout_bits(B * C, T, 0.05, dev)
+    padL = (k - 1) * d if causal else (k - 1) // 2 * d
+    kw = dict(B=B, Cin=C, Tin=T, M=2 * C, Tout=T, J=k, dil=d, padL=padL, mode=ops.EPI_GLU, Cg=C, bias=bias, r=x,
+              residual=1, a_split=pk.fwd_s, xmask=bits, xmask_rs=rs or 0, drop_scale=1 / 0.95 if masked else 1.0,
+              tile_hint=22)
+    torch.manual_seed(1)
+    gm = torch.randn(B, 2 * C, T, device=dev)
+    dres = torch.randn(B, C, T, device=dev)
+    dkw = dict(B=B, Cin=2 * C, Tin=T, M=C, Tout=T, J=k, dil=d, padL=(k - 1) * d - padL, mode=ops.EPI_DGRAD,
+               r=dres, ymask=bits, ymask_rs=rs or 0, drop_scale=1 / 0.95 if masked else 1.0, a_split=pk.bwd_s, tile_hint=22)
+    eligible = (C + 31) // 32 >= 2
+    outs = []
+    try:
+        for ks in (0, 2, 2):
+            L.dv3_debug_set(44, ks)
+            y = torch.empty(B, C, T, device=dev)
+            ab = torch.empty(B, 2 * C, T, device=dev)
+            dx = torch.empty(B, C, T, device=dev)
+            ops.conv_gemm(x, None, pk.lda, pk.a_half, y=y, ab=ab, **kw)
+            v0 = L.dv3_debug_get(10)
+            ops.conv_gemm(gm, None, pk.ldb, 0, y=dx, **dkw)
+            v1 = L.dv3_debug_get(10)
+            assert (v0 % 10, v1 % 10) == ((2, 2) if ks and eligible else (0, 2 if ks else 0)), (ks, v0, v1)
+            assert v0 % 1000 // 10 == 2 and v1 % 1000 // 10 == 2
+            outs.append((y, ab, dx))
+    finally:
+        L.dv3_debug_set(44, KS_DEFAULT)
+    tol = 5e-6 if gemm_mode == "f16x3" else KTOL
+    for a, b, c, name in zip(outs[0], outs[1], outs[2], ("y", "pre-gate", "dx")):
+        assert torch.equal(b.view(torch.int32), c.view(torch.int32)), name          # repeatable
+        assert rel_err(b.cpu(), a.cpu()) < tol, (name, rel_err(b.cpu(), a.cpu()))
+    if not masked:
+        assert rel_err(outs[1][0].cpu(), O.conv1d_glu(sd, "l", x_cpu, k, d, causal, True)) < KTOL
 
 
 def test_stream_k_workspace_never_comes_from_a_capture_pool(dev):

@@ -613,7 +613,7 @@ def test_north_star_conv1dglu_full_tensor(dev, d, causal, gemm_mode):
                 variant=variant)
         assert e < tol, (d, causal, training, e)
         # the kernel bench.py's roofline times
-        want_variant = {"f16x3": 5101, "bf16x3": 3101, "bf16": 4091}.get(gemm_mode)
+        want_variant = {"f16x3": 5101, "bf16x3": 3101, "bf16": 4081}.get(gemm_mode)   # (bf16 on fp32 tensors: the 256 x 128 ping-pong tile since round 5)
         if want_variant is not None:
             assert variant == want_variant, variant
         else:
