@@ -861,8 +861,8 @@ int launch_x3(const ConvArgs& a, size_t lds, hipStream_t st) {
   return a.d.xmask ? launch_x3_m<WM, WN, NI, true, 3>(a, lds, st) : launch_x3_m<WM, WN, NI, false, 3>(a, lds, st);
 }
 
-int g_x3_ks = 0;        // dv3_debug_set(44, v): k-split form of the 128 x 64 tile: 0 never, 1 by the rule in the dispatcher, 2 wherever eligible
-int g_x3_ks_max_blocks = 320, g_x3_ks_min_chunks = 8;   // dv3_debug_set(45 / 46, v): the rule's bounds
+int g_x3_ks = 1;        // dv3_debug_set(44, v): k-split form of the 128 x 64 tile: 0 never, 1 by the rule in the dispatcher, 2 wherever eligible
+int g_x3_ks_max_blocks = 256, g_x3_ks_min_steps = 8;   // dv3_debug_set(45 / 46, v): the rule's bounds
 int g_x3_dp = 0;        // dv3_debug_set(43, v), experiment build: deep-prefetch form of the 128 x 64 tile: 0 never, 1 small grids, 2 always
 int g_x3_rel8 = 86;     // dv3_debug_set(42, v): relative cost (percent) of the 256 x 128 ping-pong tile in the picker below.  Rounds 2-4: 93
                         // (north-star sweep).  Round 5's census of a real step (profiles/r05_conv_census_dv3lj_b64.txt) has it ahead
@@ -946,6 +946,20 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   // the flat column axis needs batch-strided tensors only through (b, t) addressing: fine for all
   const TileCfg* best = pick_tile_x3(d, gated, d->tile_hint > 20 ? d->tile_hint - 20 : 0);
   if (!best) return 1;
+  // k-split form (kernel template KS = 2, the 128 x 64 tile, three-term splits; 2 x (48 KB + halo) of LDS): grids of at most
+  // one 128 x 64 tile per CU, k-ranges of at least 8 steps (profiles/r05_k_split.txt: 0.76-0.94 x there, 1.15-2 x the
+  // time from 300 tiles up, nothing below 8 steps).  Where the picker went to a smaller tile for such a grid (64 x 64,
+  // 128 x 32: more, lonelier workgroups) the k-split 128 x 64 tile is the faster way to more waves per CU.
+  bool ks_ok = false;
+  if (g_x3_ks && d->split_terms != 1 && (d->tile_hint == 0 || d->tile_hint == 22)) {
+    const int64_t nb2 = (int64_t)(gated ? dv3_cdiv(d->Cg, 64) : dv3_cdiv(d->M, 128)) * dv3_cdiv64((int64_t)d->B * d->Tout, 64);
+    const int nch = (d->Cin + 31) / 32;
+    // (8 ... 15 k-steps: only grids of at most 160 tiles -- at B = 64 the 201-tile M = 80 layers measured 0.93-0.95 x
+    //  stand-alone and +0.3 % on the step, where they share the chip with the weight-gradient stream)
+    const int ksteps = nch * d->J;
+    ks_ok = nch >= 2 && (g_x3_ks == 2 || (ksteps >= g_x3_ks_min_steps && nb2 <= (ksteps >= 16 ? g_x3_ks_max_blocks : g_x3_ks_max_blocks * 5 / 8)));
+    if (ks_ok && d->tile_hint == 0 && (best->id == 4 || best->id == 6)) best = &kCfgs[1];
+  }
   const int BM = best->wm * best->mi * 64, BMH = best->wm * best->mi * 32, BN = best->wn * best->ni * 32;
   const int BNH = BN + (d->J - 1) * d->dil;
   const size_t lds = (size_t)(2 * 2 * KB * BM + 2 * 2 * KB * BNH) * 16;
@@ -962,15 +976,7 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   const int64_t nb = (int64_t)a.m_tiles * a.n_tiles;
   DV3_REQUIRE(nb < (1ll << 31), "conv_gemm: grid too large");
   a.n_blocks = (int)nb;
-  // k-split form (the 128 x 64 tile, three-term splits; 2 x 48 KB of LDS + halo): grids that leave a CU about one workgroup,
-  // k-ranges long enough to amortise the hand-over
-  a.ks = 0;
-  {
-    const int nch = (d->Cin + 31) / 32;
-    if (best->id == 2 && d->split_terms != 1 && g_x3_ks && nch >= 2 && 2 * lds <= 160 * 1024 &&
-        (g_x3_ks == 2 || (nb <= g_x3_ks_max_blocks && nch * d->J >= g_x3_ks_min_chunks)))
-      a.ks = 2;
-  }
+  a.ks = (ks_ok && best->id == 2 && 2 * lds <= 160 * 1024) ? 2 : 0;
   // deep-prefetch form (the 128 x 64 tile, 1 or 3 taps, three-term splits): experiment build only, off by default
   a.dp = 0;
 #ifdef DV3_EXPERIMENTS
@@ -1031,7 +1037,7 @@ extern "C" int dv3_debug_set(int what, int value) {
   if (what == 42) g_x3_rel8 = value;
   if (what == 44) g_x3_ks = value;
   if (what == 45) g_x3_ks_max_blocks = value;
-  if (what == 46) g_x3_ks_min_chunks = value;
+  if (what == 46) g_x3_ks_min_steps = value;
   if (what == 28) g_spk_abl = value;
   if (what == 14) g_x3_prio = value;
   if (what == 18) g_x3_wide = value;

@@ -44,7 +44,8 @@ int dv3_sizeof(const char* name);
  * what = 5: start-up stagger of the second co-resident workgroup, -1 auto / n = n sleeps of ~4 us;
  * what = 34: conv_c8pp form, 0 = 8 waves on 256x256 only / 1 = two 4-wave workgroups per CU on 256x128 / 2 = by rule;
  * what = 40: launch census of dv3_conv_gemm_f32, 1 = clear and record / 0 = stop; what = 42: relative cost (percent)
- * of the 256x128 ping-pong tile in the split kernels' tile picker.  The full list: INTEGRATION.md, section 2). */
+ * of the 256x128 ping-pong tile in the split kernels' tile picker; what = 44: k-split form of the 128x64 split tile,
+ * 0 never / 1 by rule (default) / 2 wherever eligible.  The full list: INTEGRATION.md, section 2). */
 int dv3_debug_set(int what, int value);
 /* what = 1: phase timestamps left by the last dv3_debug_set(1, 10) launch of the 128x256 bf16x3 tile
  * ([8 waves][192 slots][2] uint64, host pointer).  what = 40 / 41: the launch census -- the recorded dv3_conv_desc
@@ -54,7 +55,7 @@ int dv3_debug_read(int what, void* dst, int64_t bytes);
 /* what = 10: which kernel the LAST dv3_conv_gemm_f32 call of this process launched, encoded
  * family * 1000 + tile_id * 10 + pingpong; family 1 = exact-fp32 streaming kernel, 2 = exact-fp32
  * LDS-staged kernel, 3 = split-bf16 (3 MFMAs per product), 4 = bf16 (1 MFMA per product); tile ids as
- * dv3_conv_desc.tile_hint (9 = the 8-wave 128x256 tile).  what = 11: same for dv3_wgrad_gemm_f32
+ * dv3_conv_desc.tile_hint (9 = the 8-wave 128x256 tile); + 2 on the 128x64 split tile = its k-split form.  what = 11: same for dv3_wgrad_gemm_f32
  * (family 1 = exact fp32, 3 = split-bf16, 4 = bf16; tile 1 = 128x128, 2 = 256x128).  Tests use it to
  * assert that a shape was served by the kernel the benchmark times.  Returns the value (>= 0). */
 int dv3_debug_get(int what);

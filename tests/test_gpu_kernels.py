@@ -42,7 +42,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-KS_DEFAULT = 0      # dv3_debug_set(44, v): the k-split form of the 128 x 64 tile (conv_gemm_bf16x3.hip): 0 off / 1 by rule
+KS_DEFAULT = 1      # dv3_debug_set(44, v): the k-split form of the 128 x 64 tile (conv_gemm_bf16x3.hip): 0 off / 1 by rule / 2 wherever eligible
 DP_DEFAULT = 0      # dv3_debug_set(43, v): the deep-prefetch form of the 128 x 64 tile is off (conv_gemm_bf16x3.hip, experiment build)
 
 
@@ -627,11 +627,19 @@ def test_256x256_k16_pingpong_tap_gemm_equals_the_128_wide_kernels(dev, gemm_mod
     dkw = dict(B=B, Cin=2 * C, Tin=T, M=C, Tout=T, J=k, dil=d, padL=(k - 1) * d - padL, mode=ops.EPI_DGRAD,
                r=dres, ymask=bits, ymask_rs=rs or 0, drop_scale=1 / 0.95 if masked else 1.0, a_split=pk.bwd_s)
     dxs = []
-    for hint in (0, 30):
-        dx = torch.empty(B, C, T, device=dev)
-        ops.conv_gemm(gm, None, pk.ldb, 0, y=dx, tile_hint=hint, **dkw)
-        dxs.append(dx)
+    try:
+        # (the picker's kernel for these small grids is the k-split form since round 5 -- first half + second half of the
+        #  chunk range: compared with the running sum of the 256 x 256 kernel it is held to the tolerance, the one-group
+        #  loop bit for bit)
+        for hint, ks in ((0, 0), (30, 0), (0, KS_DEFAULT)):
+            _lib.lib().dv3_debug_set(44, ks)
+            dx = torch.empty(B, C, T, device=dev)
+            ops.conv_gemm(gm, None, pk.ldb, 0, y=dx, tile_hint=hint, **dkw)
+            dxs.append(dx)
+    finally:
+        _lib.lib().dv3_debug_set(44, KS_DEFAULT)
     assert torch.equal(dxs[0], dxs[1])
+    assert rel_err(dxs[2].cpu(), dxs[1].cpu()) < (5e-6 if gemm_mode == "f16x3" else KTOL)
 
 
 @pytest.mark.parametrize("B,C,T,k,d,causal,masked", [(3, 64, 75, 3, 2, False, True), (2, 256, 150, 3, 27, False, False),
@@ -654,6 +662,7 @@ def test_deep_prefetch_form_of_the_128x64_tile_is_bit_identical(dev, gemm_mode, 
         pytest.skip("the deep-prefetch form was measured and retired (profiles/r05_deep_prefetch_rings.txt): it is compiled "
                     "into the experiment build only (make EXP=1, DV3_LIBPATH=.../libdv3hip_exp.so)")
     L.dv3_debug_set(43, 0)
+    L.dv3_debug_set(44, 0)          # (the rule would give these small grids to the k-split form)
     torch.manual_seed(C + T)
     x = torch.randn(B, C, T, device=dev)
     v = torch.randn(2 * C, C, k, device=dev) * math.sqrt(4.0 * 0.95 / (k * C))
@@ -694,6 +703,7 @@ def test_deep_prefetch_form_of_the_128x64_tile_is_bit_identical(dev, gemm_mode, 
             outs.append((y, ab, dx, z))
     finally:
         L.dv3_debug_set(43, DP_DEFAULT)
+        L.dv3_debug_set(44, KS_DEFAULT)
     for a, b, name in zip(outs[0], outs[1], ("y", "pre-gate", "dx", "relu")):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (name, float((a - b).abs().max()))
     if ev0 is not None:
