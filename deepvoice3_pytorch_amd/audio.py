@@ -26,27 +26,35 @@ N_FFT = 1024
 N_BIN = N_FFT // 2 + 1
 
 
+def resolve_window_scale(window_scale, hop, fft_size=N_FFT):
+    """None / "hop_normalized" -> sqrt(2 hop / fft_size) (the default, see AudioConfig); else the positive number given"""
+    if window_scale is None or window_scale == "hop_normalized":
+        return float(np.sqrt(2.0 * hop / fft_size))
+    if not (isinstance(window_scale, (int, float)) and window_scale > 0):
+        raise ValueError("window_scale must be a positive number or 'hop_normalized'")
+    return float(window_scale)
+
+
 class AudioConfig(object):
     """The hparams audio.py reads (hparams.py:38-43,124)."""
 
     def __init__(self, fft_size=1024, hop_size=256, sample_rate=22050, preemphasis=0.97,
                  min_level_db=-100, ref_level_db=20, power=1.4, griffin_lim_iters=60, convention="lws",
-                 window_scale=1.0):
-        """window_scale (lws framing only): amplitude factor of the analysis window.  UNCONFIRMED CONSTANT of the third-party
-        package (audio): this repository restates `awin = sqrt(hann(fsize))` (window_scale 1.0); if
-        the package's integer-argument constructor instead builds `sqrt(hann(fsize) * 2 * fshift / fsize)` (sum of squares
-        normalised for the hop), the right value is "hop_normalized" = sqrt(2 * hop / 1024) (0.7071 at hop 256): every
-        magnitude is then 3.01 dB lower, i.e. every normalised [0, 1] feature 0.0301 lower -- the observable
-        tests/test_audio.py::test_window_scale_is_the_unconfirmed_constant pins.  Perfect reconstruction, the frame count
-        and Griffin-Lim's fixed points do not depend on it (the synthesis window carries the inverse factor)."""
+                 window_scale="hop_normalized"):
+        """window_scale (lws framing only): amplitude factor of the analysis window, the one constant of the third-party
+        package this repository holds by recollection only (audio).  "hop_normalized" (default since
+        round 6) = sqrt(2 * hop / 1024) (0.7071 at hop 256): `lws.lws(fsize, fshift)` with an integer first argument
+        builds `awin = sqrt(hann(fsize, symmetric) * 2 * fshift / fsize)` as two independent recollections of lws.pyx
+        have it.  1.0 = plain sqrt(hann) (rounds 4-5's default) stays selectable.  The two differ in ONE observable: every
+        magnitude by 3.01 dB, i.e. every normalised [0, 1] feature by 0.0301, and an inverted waveform's amplitude by the
+        inverse factor (tests/test_audio.py::test_window_scale_is_the_unconfirmed_constant); perfect reconstruction, the
+        frame count and Griffin-Lim's fixed points do not depend on it (the synthesis window carries the inverse factor).
+        tests/test_audio.py compares with the real package wherever it is importable."""
         if fft_size != N_FFT:
             raise ValueError("the HIP FFT kernels are built for fft_size=1024 (every reference preset)")
         if convention not in ("lws", "torch"):
             raise ValueError("convention must be 'lws' (the reference's framing) or 'torch'")
-        if window_scale == "hop_normalized":
-            window_scale = float(np.sqrt(2.0 * hop_size / fft_size))
-        if not (isinstance(window_scale, (int, float)) and window_scale > 0):
-            raise ValueError("window_scale must be a positive number or 'hop_normalized'")
+        window_scale = resolve_window_scale(window_scale, hop_size, fft_size)
         self.window_scale = float(window_scale)
         self.fft_size, self.hop_size, self.sample_rate = fft_size, hop_size, sample_rate
         self.preemphasis, self.min_level_db, self.ref_level_db = preemphasis, min_level_db, ref_level_db
@@ -57,11 +65,11 @@ class AudioConfig(object):
 # ---------------------------------------------------------------------------------------------
 # lws framing (audio.py:54-55): window tables, frame / sample counts
 # ---------------------------------------------------------------------------------------------
-def lws_windows_np(fsize=N_FFT, fshift=256, scale=1.0):
+def lws_windows_np(fsize=N_FFT, fshift=256, scale=None):
     """(awin, swin) of lws.lws(fsize, fshift) as float64 numpy: `scale` x sqrt of the symmetric Hann window, and the
     synthesis window awin / overlap-added(awin^2) that makes overlap-add reconstruct perfectly (lws.pyx: hann, synthwin)."""
     k = np.arange(fsize, dtype=np.float64)
-    awin = float(scale) * np.sqrt(0.5 * (1.0 - np.cos(2.0 * np.pi * k / (fsize - 1))))
+    awin = resolve_window_scale(scale, fshift, fsize) * np.sqrt(0.5 * (1.0 - np.cos(2.0 * np.pi * k / (fsize - 1))))
     Q = -(-fsize // fshift)
     w = np.concatenate([awin * awin, np.zeros(Q * fshift - fsize)]).reshape(Q, fshift).sum(0)
     w = np.tile(w, Q)[:fsize]
@@ -73,8 +81,9 @@ def lws_windows_np(fsize=N_FFT, fshift=256, scale=1.0):
 _WIN_CACHE = {}
 
 
-def lws_windows(device, hop, scale=1.0):
+def lws_windows(device, hop, scale=None):
     """the two tables as float32 device tensors (cached per device, hop and window scale)"""
+    scale = resolve_window_scale(scale, hop)
     key = (str(device), int(hop), float(scale))
     if key not in _WIN_CACHE:
         a, s = lws_windows_np(N_FFT, hop, scale)
@@ -102,7 +111,7 @@ def magnitudes(linear_outputs, cfg):
     return mag
 
 
-def istft(mag, phasor, hop, convention="torch", window_scale=1.0):
+def istft(mag, phasor, hop, convention="torch", window_scale=None):
     """mag (B,T,513), phasor (B,T,513,2) or None -> y (B, hop*(T-1)); lws framing: (B, (T+1)*hop - 1024)."""
     B, T, F = mag.shape
     assert F == N_BIN
@@ -121,7 +130,7 @@ def istft(mag, phasor, hop, convention="torch", window_scale=1.0):
     return y
 
 
-def stft(y, T, hop, want_phasor=True, want_spec=False, convention="torch", window_scale=1.0):
+def stft(y, T, hop, want_phasor=True, want_spec=False, convention="torch", window_scale=None):
     """y (B, hop*(T-1)) -> unit phasors and/or the complex STFT, each (B,T,513,2); lws framing: T = lws_num_frames(L)."""
     y = _c(_chk(y, "y"))
     B = y.shape[0]
@@ -216,7 +225,7 @@ def melspectrogram_batch(wav, cfg=None, num_mels=80, fmin=125.0, fmax=7600.0):
     return _db_norm(mel, cfg)
 
 
-def griffin_lim(mag, hop, n_iter, init_phasor=None, convention="torch", window_scale=1.0):
+def griffin_lim(mag, hop, n_iter, init_phasor=None, convention="torch", window_scale=None):
     """Griffin & Lim: alternate projections between the given magnitudes and consistent STFTs."""
     y = istft(mag, init_phasor, hop, convention, window_scale)
     B, T, _ = mag.shape

@@ -81,6 +81,49 @@ __device__ __forceinline__ void dv3_note_range(uint32_t* ctr, bool bad) {
 
 __device__ __forceinline__ float dv3_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// One element of the gate backward (autograd of modules.py:157-164 GLU, :224-226 highway): dy already scaled by the
+// layer's output factor (d = dy * sqrt(.5) for a residual GLU).  ONE definition for the stand-alone kernel
+// (elementwise.hip) and for the input-gradient tails that run it for their producer (conv_common.h), with the
+// contraction of its products switched off, so that the two routes agree bit for bit.  The sigmoid is the forward
+// tail's (v_exp_f32 + v_rcp_f32).
+__device__ __forceinline__ void dv3_gate_deriv(float d, float a, float g, float x, bool glu, float& va, float& vg, float& vr) {
+#pragma clang fp contract(off)
+  const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+  const float t = s * (1.0f - s);
+  va = d * s;
+  if (glu) {
+    vg = (d * a) * t;
+    vr = d;
+  } else {
+    vg = (d * (a - x)) * t;
+    vr = d * (1.0f - s);
+  }
+}
+
+// PAIR WORD of v (include/dv3hip.h, dv3_conv_desc.pg_pair): (bf16_rn(v) << 16) | bf16_rn(v - bf16_rn(v)) -- the hi / lo
+// operands split8() of the gradient GEMMs builds from v while staging, built once where v is produced.
+__device__ __forceinline__ uint32_t dv3_pair_word(float v) {
+  const __bf16 h = (__bf16)v;
+  const float r = v - (float)h;
+  const __bf16 l = (__bf16)r;
+  return ((uint32_t)__builtin_bit_cast(uint16_t, h) << 16) | (uint32_t)__builtin_bit_cast(uint16_t, l);
+}
+__device__ __forceinline__ float dv3_pair_value(uint32_t w) {   // hi + lo as fp32 (2^-17-class)
+  return __uint_as_float(w & 0xffff0000u) + __uint_as_float(w << 16);
+}
+// eight pair words -> the hi and lo 16-byte operand units (element e of a unit = word e): two v_perm_b32 per word pair
+__device__ __forceinline__ void dv3_pair_units(const uint32_t (&w)[8], dv3_bf16x8& hi, dv3_bf16x8& lo) {
+  typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+  u32x4_ h4, l4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h4[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x07060302u);
+    l4[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x05040100u);
+  }
+  hi = __builtin_bit_cast(dv3_bf16x8, h4);
+  lo = __builtin_bit_cast(dv3_bf16x8, l4);
+}
+
 // Bijective XCD-aware remap of a 1-D block id (MI355X: block b runs on XCD b % 8).  Gives each
 // XCD a contiguous chunk of the logical tile order so tiles sharing an operand panel hit the
 // same private L2.

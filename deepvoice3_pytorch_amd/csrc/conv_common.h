@@ -57,6 +57,123 @@ __device__ __forceinline__ void dv3_st_act(void* base, uint32_t byte_off, float 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the PRODUCER's gate backward inside the input-gradient tail (include/dv3hip.h: dv3_conv_desc.pg ...).
+// The value an input-gradient launch writes, y = dL/d(out of the layer that produced this layer's input), is all the
+// gate backward of that producer needs besides its saved pre-gate pair: the tail computes the pre-gate gradient on the
+// tile it holds (dv3_gate_deriv, common.h: the function the stand-alone kernel runs), writes it as fp32 or as the PAIR
+// WORDS the two gradient GEMMs of the producer stage without conversion, and leaves the bias partial sums per 32-column
+// block [2M][n_part].  y is written as always.
+// ---------------------------------------------------------------------------------------------------------------
+// N values per lane, L lanes (consecutive lane indices, j = index inside the group): halving butterfly -- after log2(L)
+// steps lane j holds, in v[0 .. N/L), the group's sums of the values j * (N/L) + [0, N/L).  N - N/L exchanges instead of
+// N * log2(L); the order of the additions is a function of (N, L) only.
+template <int N, int D>
+__device__ __forceinline__ void dv3_reduce_scatter_step(float* v, int j) {
+  if constexpr (D >= 1) {
+    constexpr int n2 = N / 2;
+    const bool up = (j & D) != 0;
+#pragma unroll
+    for (int i = 0; i < n2; ++i) {
+      const float keep = up ? v[i + n2] : v[i];
+      const float send = up ? v[i] : v[i + n2];
+      v[i] = keep + __shfl_xor(send, D, 64);
+    }
+    dv3_reduce_scatter_step<n2, D / 2>(v, j);
+  }
+}
+template <int N, int L>
+__device__ __forceinline__ void dv3_reduce_scatter(float (&v)[N], int j) {
+  static_assert(N % L == 0 && (L & (L - 1)) == 0, "reduce_scatter: N a multiple of L, L a power of two");
+  dv3_reduce_scatter_step<N, L / 2>(v, j);
+}
+__device__ __forceinline__ void dv3_st_u32(void* base, uint32_t byte_off, uint32_t v) {
+  *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// accumulator-order form (one frame per lane and column sub-tile): any Tout.  nblk0 = index of the wave's first
+// 32-column block of the flat (b, t) axis.  The kernels compile these tails into SEPARATE instantiations (template
+// parameter FG): as a run-time branch of the shared epilogue they cost every instantiation its spill-free tail.
+template <int BM, int BMH, int NI>
+__device__ __forceinline__ void conv_epilogue_dgrad_gate(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], int mt, int row0,
+                                                         int lhi, int l31, const int (&bcol)[NI], const int (&tcol)[NI],
+                                                         const bool (&okc)[NI], int nblk0) {
+  const float dscale = p.drop_scale;
+  const uint32_t Tout = (uint32_t)p.Tout, M = (uint32_t)p.M;
+  const uint32_t y_rs = (uint32_t)p.y_rs * 4u, r_rs = (uint32_t)p.r_rs * 4u, ym_rs = (uint32_t)p.ymask_rs * 4u;
+  const uint32_t px_rs = (uint32_t)p.pg_x_rs * 4u, g_rs = Tout * 4u;
+  const float rsc = p.r_scale != 0.f ? p.r_scale : 1.0f;
+  const bool glu = p.pg_mode == DV3_EPI_GLU;
+  const float k = (glu && p.pg_residual) ? 0.70710678118654752440f : 1.0f;
+  const bool pair = p.pg_pair != 0;
+  const int n_part = (int)(((int64_t)p.B * p.Tout + 31) >> 5);
+  uint32_t yb[NI], rbc[NI], ymb[NI], pgb[NI], pxb[NI], rsb[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const uint32_t b = okc[ni] ? (uint32_t)bcol[ni] : 0u, t = okc[ni] ? (uint32_t)tcol[ni] : 0u;
+    yb[ni] = (b * (uint32_t)p.y_bs + t) * 4u;
+    rbc[ni] = (b * (uint32_t)p.r_bs + t) * 4u;
+    ymb[ni] = (b * M * (uint32_t)p.ymask_rs + (t >> 5)) * 4u;
+    pgb[ni] = (b * 2u * M * Tout + t) * 4u;           // the pre-gate pair and its gradient: [B][2M][Tout]
+    pxb[ni] = (b * (uint32_t)p.pg_x_bs + t) * 4u;
+    rsb[ni] = (b * M * Tout + t) * 4u;                // dpg_res: [B][M][Tout]
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t rowb = (uint32_t)(mt * BM + h * BMH + row0 + 4 * lhi);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float v[32];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {       // four rows per batch of loads
+        uint32_t wv[4];
+        float rv[4], pa[4], pgt[4], px[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t m = rowb + (uint32_t)(e + 8 * rg);
+          const uint32_t mc = m < M ? m : M - 1;
+          wv[e] = p.ymask ? dv3_ld<uint32_t>(p.ymask, ymb[ni] + mc * ym_rs) : 0xffffffffu;
+          rv[e] = p.r ? dv3_ld<float>(p.r, rbc[ni] + mc * r_rs) : 0.f;
+          pa[e] = dv3_ld<float>(p.pg, pgb[ni] + mc * g_rs);
+          pgt[e] = dv3_ld<float>(p.pg, pgb[ni] + (M + mc) * g_rs);
+          px[e] = glu ? 0.f : dv3_ld<float>(p.pg_x, pxb[ni] + mc * px_rs);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rg + e;
+          const uint32_t m = rowb + (uint32_t)(e + 8 * rg);
+          float o = acc[h][ni][r];
+          if (p.ymask) o = ((wv[e] >> (tcol[ni] & 31)) & 1u) ? o * dscale : 0.f;
+          o = o + rsc * rv[e];
+          float va = 0.f, vg = 0.f, vr = 0.f;
+          if (okc[ni] && m < M) {
+            dv3_st(p.y, yb[ni] + m * y_rs, o);
+            dv3_gate_deriv(o * k, pa[e], pgt[e], px[e], glu, va, vg, vr);
+            const uint32_t oa = pgb[ni] + m * g_rs, og = pgb[ni] + (M + m) * g_rs;
+            if (pair) {
+              dv3_st_u32(p.dpg, oa, dv3_pair_word(va));
+              dv3_st_u32(p.dpg, og, dv3_pair_word(vg));
+            } else {
+              dv3_st(p.dpg, oa, va);
+              dv3_st(p.dpg, og, vg);
+            }
+            if (!glu && p.dpg_res) dv3_st(p.dpg_res, rsb[ni] + m * g_rs, vr);
+          }
+          v[r] = va;
+          v[16 + r] = vg;
+        }
+      }
+      // lane l31 ends with the block sum of value l31: the `a` row (l31 & 15) of this half for l31 < 16, else its gate row
+      dv3_reduce_scatter<32, 32>(v, l31);
+      const int r = l31 & 15;
+      const uint32_t m = rowb + (uint32_t)((r & 3) + 8 * (r >> 2));
+      const int blk = nblk0 + ni;
+      if (p.pg_part && m < M && blk < n_part)
+        p.pg_part[(size_t)((l31 >> 4) ? M + m : m) * (size_t)n_part + (size_t)blk] = v[0];
+    }
+  }
+}
+
 template <int BM, int BMH, int NI, int ABL = 0, bool IOB = false>
 __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], bool gated,
                                               int mt, int row0, int lhi, const int (&bcol)[NI],
@@ -238,6 +355,104 @@ __device__ __forceinline__ bool dv3_wide_epilogue_ok(const dv3_conv_desc& p, int
   if (!al(p.y, p.y_rs, p.y_bs) || !al(p.r, p.r_rs, p.r_bs)) return false;
   if (p.ymask && p.ymask_rs * 32 < p.Tout) return false;
   return true;
+}
+// ... and of the FG tails (the fused gate backward moves the producer's tensors 16 bytes at a time too)
+__device__ __forceinline__ bool dv3_wide_gate_ok(const dv3_conv_desc& p, int enable) {
+  if (!dv3_wide_epilogue_ok(p, enable)) return false;
+  if ((((uintptr_t)p.pg | (uintptr_t)p.dpg | (uintptr_t)p.dpg_res) & 15) != 0) return false;
+  if (p.pg_mode == DV3_EPI_HIGHWAY && ((((uintptr_t)p.pg_x) & 15) != 0 || (p.pg_x_rs & 3) != 0 || (p.pg_x_bs & 3) != 0)) return false;
+  return true;
+}
+
+// The same block with the producer's gate backward (dv3_conv_desc.pg, see conv_epilogue_dgrad_gate): a lane holds four
+// consecutive frames of eight rows, so the pre-gate pair is read and its gradient written 16 bytes at a time, and the
+// 32-column bias partial sums are a sum over four frames + a butterfly over the eight lanes of a block.
+template <int BM, int BMH>
+__device__ __forceinline__ void conv_epilogue_wide_block_gate(const dv3_conv_desc& p, const f32x16 (&acc0)[2], int mt, int row0,
+                                                              int half, int lane, int nw0, int Ntot, float* __restrict__ lds) {
+  typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const uint32_t T = (uint32_t)p.Tout, M = (uint32_t)p.M;
+  const int rr = lane >> 4, c4 = lane & 15;
+  const int n4 = nw0 + c4 * 4;
+  const bool okw = n4 < Ntot;
+  const uint32_t b4 = okw ? (uint32_t)n4 / T : 0u, t4 = okw ? (uint32_t)n4 - b4 * T : 0u;
+  const uint32_t rowb = (uint32_t)(mt * BM + half * BMH + row0);
+  const float dscale = p.drop_scale;
+  const float rsc = p.r_scale != 0.f ? p.r_scale : 1.0f;
+  const bool glu = p.pg_mode == DV3_EPI_GLU;
+  const float k = (glu && p.pg_residual) ? 0.70710678118654752440f : 1.0f;
+  const bool pair = p.pg_pair != 0;
+  const int n_part = (Ntot + 31) >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {       // accumulator order -> LDS [row][column]
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) lds[row * DV3_WIDE_LD + ni * 32 + l31] = acc0[ni][r];
+  }
+  float sv[16];
+#pragma unroll
+  for (int ig = 0; ig < 2; ++ig) {     // two batches of four rows: bounds the loads in flight beside the accumulators
+    f32x4 rv[4], pa[4], pgt[4], px[4];
+    uint32_t mw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t m = rowb + (uint32_t)(rr + 4 * (ig * 4 + q));
+      const uint32_t mc = m < M ? m : M - 1;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      rv[q] = (p.r && okw) ? *reinterpret_cast<const f32x4*>(p.r + (size_t)b4 * p.r_bs + (size_t)mc * p.r_rs + t4) : z4;
+      mw[q] = (p.ymask && okw) ? p.ymask[((size_t)b4 * M + mc) * (size_t)p.ymask_rs + (t4 >> 5)] : 0xffffffffu;
+      pa[q] = okw ? *reinterpret_cast<const f32x4*>(p.pg + ((size_t)b4 * 2u * M + mc) * T + t4) : z4;
+      pgt[q] = okw ? *reinterpret_cast<const f32x4*>(p.pg + ((size_t)b4 * 2u * M + M + mc) * T + t4) : z4;
+      px[q] = (!glu && okw) ? *reinterpret_cast<const f32x4*>(p.pg_x + (size_t)b4 * p.pg_x_bs + (size_t)mc * p.pg_x_rs + t4) : z4;
+    }
+    if (ig == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = ig * 4 + q;
+      const uint32_t m = rowb + (uint32_t)(rr + 4 * i);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(lds + (rr + 4 * i) * DV3_WIDE_LD + c4 * 4);
+      const bool live = okw && m < M;
+      f32x4 o, da = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f}, dr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = w[e];
+        if (p.ymask) a = ((mw[q] >> ((t4 & 31) + e)) & 1u) ? a * dscale : 0.f;
+        o[e] = a + rsc * rv[q][e];
+        float va, vg, vr;
+        dv3_gate_deriv(o[e] * k, pa[q][e], pgt[q][e], px[q][e], glu, va, vg, vr);
+        da[e] = live ? va : 0.f;
+        dg[e] = live ? vg : 0.f;
+        dr[e] = vr;
+      }
+      if (live) {
+        *reinterpret_cast<f32x4*>(p.y + (size_t)b4 * p.y_bs + (size_t)m * p.y_rs + t4) = o;
+        float* const oa = p.dpg + ((size_t)b4 * 2u * M + m) * T + t4;
+        float* const og = oa + (size_t)M * T;
+        if (pair) {
+          *reinterpret_cast<u32x4_*>(oa) = u32x4_{dv3_pair_word(da[0]), dv3_pair_word(da[1]), dv3_pair_word(da[2]), dv3_pair_word(da[3])};
+          *reinterpret_cast<u32x4_*>(og) = u32x4_{dv3_pair_word(dg[0]), dv3_pair_word(dg[1]), dv3_pair_word(dg[2]), dv3_pair_word(dg[3])};
+        } else {
+          *reinterpret_cast<f32x4*>(oa) = da;
+          *reinterpret_cast<f32x4*>(og) = dg;
+        }
+        if (!glu && p.dpg_res) *reinterpret_cast<f32x4*>(p.dpg_res + ((size_t)b4 * M + m) * T + t4) = dr;
+      }
+      sv[2 * i] = (da[0] + da[1]) + (da[2] + da[3]);
+      sv[2 * i + 1] = (dg[0] + dg[1]) + (dg[2] + dg[3]);
+    }
+  }
+  // eight lanes (c4 & 7) share a 32-column block: lane j ends with the `a` and gate sums of row rr + 4 j
+  dv3_reduce_scatter<16, 8>(sv, c4 & 7);
+  {
+    const uint32_t m = rowb + (uint32_t)(rr + 4 * (c4 & 7));
+    const int blk = (nw0 >> 5) + (c4 >> 3);
+    if (p.pg_part && m < M && blk < n_part) {
+      p.pg_part[(size_t)m * (size_t)n_part + (size_t)blk] = sv[0];
+      p.pg_part[(size_t)(M + m) * (size_t)n_part + (size_t)blk] = sv[1];
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done before the next block overwrites the rows
 }
 
 // One 32-row block of a wave (rows row0 + [0, 32) of half `half` of the tile), 64 columns starting at flat column nw0:

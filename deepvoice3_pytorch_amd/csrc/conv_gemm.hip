@@ -388,6 +388,23 @@ static int conv_gemm_dispatch(const dv3_conv_desc* d, void* stream) {
   DV3_REQUIRE(!d->xmask_c8 || d->mode != DV3_EPI_DGRAD, "conv_gemm: xmask_c8 masks the input of a forward layer");
   DV3_REQUIRE(!d->xmask_c8 || (d->x_planes && d->split_terms == 1) || (!d->x_planes && d->xmask && d->a_split),
               "conv_gemm: xmask_c8 needs a c8 input, or an fp32 input with its keep-bits and a split weight image");
+  // round 6: the producer's gate backward in the input-gradient tail / pair-word input (include/dv3hip.h)
+  if (d->pg) {
+    DV3_REQUIRE(d->mode == DV3_EPI_DGRAD && d->store_mode == DV3_STORE_BCT && d->io_bf16 == 0 && !d->x_planes,
+                "conv_gemm: pg rides on an fp32 (B, C, T) input-gradient launch");
+    DV3_REQUIRE(d->a_split && d->split_terms != 1 && (d->tile_hint == 0 || d->tile_hint > 20),
+                "conv_gemm: pg is served by the three-term split kernels");
+    DV3_REQUIRE(d->pg_mode == DV3_EPI_GLU || d->pg_mode == DV3_EPI_HIGHWAY, "conv_gemm: pg_mode must be GLU or HIGHWAY");
+    DV3_REQUIRE(d->dpg, "conv_gemm: pg without dpg");
+    DV3_REQUIRE(d->pg_mode != DV3_EPI_HIGHWAY || (d->pg_x && d->dpg_res), "conv_gemm: a highway producer needs pg_x and dpg_res");
+    DV3_REQUIRE((int64_t)d->B * 2 * d->M * d->Tout < (1ll << 30) &&
+                (!d->pg_x || (int64_t)d->B * d->pg_x_bs + (int64_t)d->M * d->pg_x_rs < (1ll << 30)),
+                "conv_gemm: the producer's pre-gate pair exceeds the 4 GB the epilogue can address");
+  }
+  if (d->x_pair)
+    DV3_REQUIRE(d->a_split && (d->split_terms == 0 || d->split_terms == 3) && !d->xmask && !d->xmask_c8 && !d->x_planes &&
+                d->io_bf16 == 0 && (d->tile_hint == 0 || d->tile_hint > 20),
+                "conv_gemm: pair-word input is read by the bf16-pair split kernels, without dropout");
   // both operands pre-split: the persistent planes kernel.  No silent fallback: the planes carry the dropout
   // mask of the consuming layer, which the other kernels would have to be handed separately.
   if (d->x_planes) {
@@ -403,6 +420,8 @@ static int conv_gemm_dispatch(const dv3_conv_desc* d, void* stream) {
     const int rc = dv3_conv_gemm_bf16x3_dispatch(d, (hipStream_t)stream);
     if (rc != 1) return rc;
   }
+  DV3_REQUIRE(!d->pg && !d->x_pair, "conv_gemm: shape not eligible for the split kernels, which alone run the fused gate "
+                                     "backward / read pair words (Tin == Tout, (J-1)*dil <= 64, no per-batch operand)");
   DV3_REQUIRE(d->io_bf16 == 0, "conv_gemm: shape not eligible for the split kernels, which alone take bf16 activations "
                                "(Tin == Tout, (J-1)*dil <= 64, no per-batch operand)");
   DV3_REQUIRE(d->tile_hint <= 20, "conv_gemm: tile_hint %d needs split-bf16 operands", d->tile_hint);

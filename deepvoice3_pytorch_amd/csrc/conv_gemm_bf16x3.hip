@@ -89,8 +89,11 @@ __device__ unsigned long long g_x3_stamps[8 * STAMP_SLOTS * 2];
 // shape) and runs the tail.  For grids that leave a CU one workgroup (profiles/r05_conv_census_dv3lj_b16.txt: every
 // layer at the preset's batch 16) a lone wave per SIMD serialises fragment reads -> MFMAs -> stores -> barrier; the
 // second group is the second wave per SIMD that overlaps them, on a k-range half as long.
-template <int WM, int WN, int NI, bool MASK, int ABL = 0, int TERMS = 3, int MI = 1, bool PP = false, bool F16 = false, int DPJ = 0, int KS = 1>
+// FG (round 6): an input-gradient launch whose tail also runs the gate backward of the layer that PRODUCED this layer's
+// input (dv3_conv_desc.pg; conv_common.h) -- separate instantiations (bf16 pair, no dropout) that contain that tail only.
+template <int WM, int WN, int NI, bool MASK, int ABL = 0, int TERMS = 3, int MI = 1, bool PP = false, bool F16 = false, int DPJ = 0, int KS = 1, bool FG = false>
 __global__ __launch_bounds__(WM* WN * 64 * KS) void conv_gemm_bf16x3_kernel(const ConvArgs args) {
+  static_assert(!FG || (!MASK && !F16 && TERMS == 3 && ABL == 0 && DPJ == 0), "fused gate backward: the unmasked bf16-pair forms");
   static_assert(!F16 || TERMS == 3, "the fp16 form is the three-term split");
   static_assert(KS == 1 || (KS == 2 && !PP && DPJ == 0 && ABL == 0), "k-split: two groups on the in-phase loop");
   static_assert(DPJ == 0 || (DPJ == 1 || DPJ == 3), "deep prefetch: 1 or 3 taps");
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(WM* WN * 64 * KS) void conv_gemm_bf16x3_kernel(cons
   // fp16 form: the activation scale 2^DV3_F16_ACT_SHIFT rides on the dropout scale (or is applied alone)
   const float xscale = F16 ? (float)(1 << DV3_F16_ACT_SHIFT) : 1.0f;
   const float dscale = p.drop_scale * xscale;
+  const bool xpw = !MASK && !F16 && TERMS == 3 && p.x_pair != 0;   // round 6: x holds pair words (include/dv3hip.h)
 
   // ---- this lane's output columns: (batch, time) and per-tap validity of the shifted read ----
   uint32_t vbits = 0;  // bit j*NI+ni: the tap-j input of column ni lies inside its batch item
@@ -291,7 +295,15 @@ __global__ __launch_bounds__(WM* WN * 64 * KS) void conv_gemm_bf16x3_kernel(cons
           else if (F16) v[e] *= xscale;
         }
         bf16x8 hi, lo;
-        if constexpr (F16) dv3_note_range(args.range_ctr, dv3_split8_f16(v, hi, lo)); else split8(v, hi, lo);
+        if constexpr (F16) dv3_note_range(args.range_ctr, dv3_split8_f16(v, hi, lo));
+        else if constexpr (!MASK && TERMS == 3) {
+          if (xpw) {      // pair words (dv3_conv_desc.x_pair, wave-uniform): the pair is already there
+            uint32_t w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(rx[slot][i][e]);
+            dv3_pair_units(w, hi, lo);
+          } else split8(v, hi, lo);
+        } else split8(v, hi, lo);
         dst[idx] = hi;
         if (TERMS == 3) dst[KB * BNH + idx] = lo;
       }
@@ -707,6 +719,26 @@ __global__ __launch_bounds__(WM* WN * 64 * KS) void conv_gemm_bf16x3_kernel(cons
       bcol[ni] = n / T;
       tcol[ni] = n - bcol[ni] * T;
     }
+    if constexpr (FG) {
+      const int nw0 = n0e + wn * (NI * 32);
+      bool wide_done = false;
+      if constexpr (NI == 2) {
+        if (dv3_wide_gate_ok(p, args.wide) && (size_t)(WM * WN) * DV3_WIDE_LDS <= (size_t)(2 * 2 * KB * BM + 2 * xbuf) * 16) {
+          float* wl = reinterpret_cast<float*>(smem_raw) + wave * (DV3_WIDE_LDS / 4);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int row0 = wm * (MI * 32) + mi * 32;
+            conv_epilogue_wide_block_gate<BM, BMH>(p, acc[mi][0], mt, row0, 0, lane, nw0, Ntot, wl);
+            conv_epilogue_wide_block_gate<BM, BMH>(p, acc[mi][1], mt, row0, 1, lane, nw0, Ntot, wl);
+          }
+          wide_done = true;
+        }
+      }
+      if (!wide_done) {
+        conv_epilogue_dgrad_gate<BM, BMH, NI>(p, acc[0], mt, wm * (MI * 32), lhi, l31, bcol, tcol, okc, nw0 >> 5);
+        if (MI == 2) conv_epilogue_dgrad_gate<BM, BMH, NI>(p, acc[MI - 1], mt, wm * (MI * 32) + 32, lhi, l31, bcol, tcol, okc, nw0 >> 5);
+      }
+    } else
     if (TERMS == 1 && (p.io_bf16 & DV3_IO_OUT_C8)) {   // bf16 storage: channel-blocked y / ab / residuals
       conv_epilogue_c8<BM, BMH, NI>(p, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
       if (MI == 2) conv_epilogue_c8<BM, BMH, NI>(p, acc[MI - 1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
@@ -762,11 +794,11 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 template __global__ void conv_gemm_bf16x3_kernel<2, 2, 1, DV3_X3_ISA_MASK, 0, 3, 1, false, DV3_X3_ISA_F16, DV3_X3_ISA_DPJ, DV3_X3_ISA_KS>(const ConvArgs);
 }  // namespace
 #else
-template <int WM, int WN, int NI, bool MASK, int TERMS, int MI = 1, bool PP = false, bool F16 = false, int DPJ = 0, int KS = 1>
+template <int WM, int WN, int NI, bool MASK, int TERMS, int MI = 1, bool PP = false, bool F16 = false, int DPJ = 0, int KS = 1, bool FG = false>
 int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;  // raise the dynamic-LDS cap once per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP, F16, DPJ, KS>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP, F16, DPJ, KS, FG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_gemm_bf16x3: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -775,7 +807,7 @@ int launch_x3_m(const ConvArgs& a, size_t lds, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(a.n_blocks), block(WM * WN * 64 * KS);
-  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP, F16, DPJ, KS>), grid, block, lds * KS, st, a);
+  hipLaunchKernelGGL((conv_gemm_bf16x3_kernel<WM, WN, NI, MASK, 0, TERMS, MI, PP, F16, DPJ, KS, FG>), grid, block, lds * KS, st, a);
   return dv3_check_launch("conv_gemm_bf16x3");
 }
 int g_x3_ablate = 0;   // debug: dv3_debug_set(); ablation variants of the 128x128 unmasked tile
@@ -879,6 +911,7 @@ const TileCfg* pick_tile_x3(const dv3_conv_desc* d, bool gated, int want_tile) {
   const int64_t ntot = (int64_t)d->B * d->Tout;
   for (const TileCfg& c : kCfgs) {
     if (want_tile && c.id != want_tile) continue;
+    if (d->pg && !(c.id == 1 || c.id == 2 || c.id == 8 || c.id == 9)) continue;   // the tiles with a fused-gate-backward tail
     const int BM = c.wm * c.mi * 64, BMH = c.wm * c.mi * 32, BN = c.wn * c.ni * 32;
     const int64_t mt = gated ? dv3_cdiv(d->Cg, BMH) : dv3_cdiv(d->M, BM);
     const int64_t ntl = dv3_cdiv64(ntot, BN);
@@ -986,6 +1019,19 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
 #endif
   g_dv3_last_conv = (d->split_terms == 1 ? 4000 : d->split_terms == DV3_SPLIT_F16X3 ? 5000 : 3000) + best->id * 10 +
                     ((best->id >= 8 && g_x3_pingpong) ? 1 : 0) + (a.dp ? 5 : 0) + (a.ks == 2 ? 2 : 0);
+  if (d->pg) {
+    // round 6: the fused gate backward lives in its own instantiations (bf16 pair, no dropout) of four tiles
+    if (d->xmask || d->split_terms == DV3_SPLIT_F16X3 || d->split_terms == 1) return 1;
+    g_dv3_last_conv += 600;            // 36xx: fused gate backward in the tail
+    switch (best->id) {
+      case 1: return launch_x3_m<2, 2, 2, false, 3, 1, false, false, 0, 1, true>(a, lds, st);
+      case 2: return a.ks == 2 ? launch_x3_m<2, 2, 1, false, 3, 1, false, false, 0, 2, true>(a, lds, st)
+                               : launch_x3_m<2, 2, 1, false, 3, 1, false, false, 0, 1, true>(a, lds, st);
+      case 8: return launch_x3_m<4, 2, 2, false, 3, 1, true, false, 0, 1, true>(a, lds, st);
+      case 9: return launch_x3_m<2, 4, 2, false, 3, 1, true, false, 0, 1, true>(a, lds, st);
+    }
+    return 1;
+  }
   switch (best->id) {
     case 1: return launch_x3<2, 2, 2>(a, lds, st);
     case 2: return launch_x3<2, 2, 1>(a, lds, st);

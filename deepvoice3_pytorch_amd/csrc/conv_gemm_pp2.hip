@@ -89,8 +89,17 @@ __device__ unsigned long long g_pp2_stamps[8 * PP2_STAMPS * 2];
 //  64  the activation items are converted and stored in COMPUTE phases, between the MFMAs, instead of in LOAD phases
 //   4  the tile's residual rows are touched (one 4-byte load per 128-byte line) during the last chunk of the main loop, so
 //      that the tail reads them from L2 while the chip-wide tail burst only writes
-template <bool MASK, bool F16, int ABL = 0, bool SK = false, int ORD = 0>
+//  PW (round 6): the activation tensor holds PAIR WORDS (include/dv3hip.h: dv3_conv_desc.x_pair) -- the bf16 hi / lo pair of
+//      every element, built once by the kernel that produced the tensor: an item is staged with eight v_perm_b32 instead
+//      of the fp32 -> pair conversion (bf16-pair instantiations without dropout: the input gradient of a gated layer)
+//  FG (round 6): an input-gradient launch whose tail also runs the gate backward of the layer that PRODUCED this layer's
+//      input (dv3_conv_desc.pg; conv_common.h: conv_epilogue_dgrad_gate / conv_epilogue_wide_block_gate).  A separate
+//      instantiation that contains that tail and no other: as a run-time branch of the shared tail it cost every
+//      instantiation of this kernel its spill-free register allocation.
+template <bool MASK, bool F16, int ABL = 0, bool SK = false, int ORD = 0, bool PW = false, bool FG = false>
 __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) {
+  static_assert(!PW || (!MASK && !F16 && !SK), "pair words: the unmasked bf16-pair tile-per-workgroup form");
+  static_assert(!FG || (!MASK && !F16 && !SK), "fused gate backward: the unmasked bf16-pair tile-per-workgroup form");
   const dv3_conv_desc& p = args.d;
   int n_stamp = 0;
   auto stamp = [&]() {
@@ -356,7 +365,12 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
       else if (F16) v[e] *= xscale;
     }
     bf16x8 hi, lo;
-    if constexpr (F16 && LEAN) {
+    if constexpr (PW) {
+      uint32_t w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(rx[i][e]);
+      dv3_pair_units(w, hi, lo);
+    } else if constexpr (F16 && LEAN) {
       // the range test first (it is made anyway); a wave whose eight values all sit inside the fp16 range -- every wave of
       // a healthy run -- builds the pair without the clamps (identity there) and takes the residual as one fused
       // multiply-add per element: a - hi is exact in fp32 either way, so the pair is bit-identical to dv3_split8_f16's
@@ -419,7 +433,12 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
       } else if (F16) v[e] *= xscale;
     }
     bf16x8 hi, lo;
-    if constexpr (F16) {
+    if constexpr (PW) {
+      uint32_t w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(rx[i][e]);
+      dv3_pair_units(w, hi, lo);
+    } else if constexpr (F16) {
       const bool bad = dv3_split8_f16(v, hi, lo);
       sbad += (uint32_t)__builtin_popcountll(__ballot(bad));
     } else {
@@ -796,6 +815,21 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
       bcol[ni] = n / T;
       tcol[ni] = n - bcol[ni] * T;
     }
+    if constexpr (FG) {
+      const int nw0 = n0e + wn * (NI * 32);
+      if (dv3_wide_gate_ok(pt, AT.wide)) {
+        float* wl = reinterpret_cast<float*>(smem_raw) + wave * (DV3_WIDE_LDS / 4);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int row0 = wm * (MI * 32) + mi * 32;
+          conv_epilogue_wide_block_gate<BM, BMH>(pt, acc[mi][0], mt, row0, 0, lane, nw0, Ntot, wl);
+          conv_epilogue_wide_block_gate<BM, BMH>(pt, acc[mi][1], mt, row0, 1, lane, nw0, Ntot, wl);
+        }
+      } else {
+        conv_epilogue_dgrad_gate<BM, BMH, NI>(pt, acc[0], mt, wm * (MI * 32), lhi, l31, bcol, tcol, okc, nw0 >> 5);
+        conv_epilogue_dgrad_gate<BM, BMH, NI>(pt, acc[1], mt, wm * (MI * 32) + 32, lhi, l31, bcol, tcol, okc, nw0 >> 5);
+      }
+    } else
     if (ABL != 10 && dv3_wide_epilogue_ok(pt, AT.wide)) {
       // 16-byte epilogue through LDS (conv_common.h): every LDS read of the main loop is behind the last barrier this
       // wave passed, so the whole allocation is free; each wave transposes in its own 8.5 KB
@@ -828,12 +862,12 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
 }
 
 #ifndef DV3_PP2_ISA_ONLY   // (developer: compile one instantiation for ISA inspection, scripts/pp2_isa.sh)
-template <bool MASK, bool F16, int ABL = 0, bool SK = false, int ORD = 0>
+template <bool MASK, bool F16, int ABL = 0, bool SK = false, int ORD = 0, bool PW = false, bool FG = false>
 int launch_pp2(const ConvArgs& a, size_t lds, hipStream_t st) {
-  if ((ORD & 4) != 0 && lds + 8 * 256 > 160 * 1024) return launch_pp2<MASK, F16, ABL, SK, (ORD & ~4)>(a, lds, st);
+  if ((ORD & 4) != 0 && lds + 8 * 256 > 160 * 1024) return launch_pp2<MASK, F16, ABL, SK, (ORD & ~4), PW, FG>(a, lds, st);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_pp2_kernel<MASK, F16, ABL, SK, ORD>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_pp2_kernel<MASK, F16, ABL, SK, ORD, PW, FG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("conv_gemm_pp2: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -843,7 +877,7 @@ int launch_pp2(const ConvArgs& a, size_t lds, hipStream_t st) {
   }
   if ((ORD & 4) != 0) lds += 8 * 256;   // the prefetch strip
   else if ((ORD & 64) != 0) lds += 32;   // two spare units behind the activation buffers
-  hipLaunchKernelGGL((conv_gemm_pp2_kernel<MASK, F16, ABL, SK, ORD>), dim3(a.n_blocks), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_pp2_kernel<MASK, F16, ABL, SK, ORD, PW, FG>), dim3(a.n_blocks), dim3(NT), lds, st, a);
   return dv3_check_launch("conv_gemm_pp2");
 }
 
@@ -915,6 +949,15 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   a.n_blocks = (int)nb;
   g_dv3_last_conv = (f16 ? 5000 : 3000) + 100 + 1;     // tile id 10, ping-pong
   const bool mask = d->xmask_c8 != nullptr;
+  if (d->x_pair || d->pg) {
+    // round 6: pair-word input and / or the producer's gate backward in the tail: the bf16-pair kernel without dropout,
+    // tile per workgroup, the default LOAD-phase structure (ORD 81)
+    if (mask || f16) return 1;
+    g_dv3_last_conv += (d->x_pair ? 5 : 0) + (d->pg ? 10 : 0);   // ...106 pair-word staging, 111 fused gate backward, 116 both
+    if (d->pg) return d->x_pair ? launch_pp2<false, false, 0, false, 81, true, true>(a, lds, st)
+                                : launch_pp2<false, false, 0, false, 81, false, true>(a, lds, st);
+    return launch_pp2<false, false, 0, false, 81, true>(a, lds, st);
+  }
   {
     const int P = pp2_cu_count(), S = d->Cin / BKC;
     const int64_t units = nb * S;

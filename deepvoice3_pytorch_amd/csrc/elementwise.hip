@@ -33,17 +33,9 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
     float* dres = p.dres ? p.dres + row * T : nullptr;
     const bool glu = p.mode == DV3_EPI_GLU;
     // one element: (dy, a, g, x) -> (da, dg, dres)
+    // (common.h: the same function runs inside the input-gradient tails that take this kernel's place, round 6)
     auto elem = [&](float dyv, float av, float gv, float xv, float& va, float& vg, float& vr) {
-      const float d = dyv * k;
-      const float s = 1.0f / (1.0f + expf(-gv));
-      va = d * s;
-      if (glu) {
-        vg = d * av * s * (1.0f - s);
-        vr = d;
-      } else {
-        vg = d * (av - xv) * s * (1.0f - s);
-        vr = d * (1.0f - s);
-      }
+      dv3_gate_deriv(dyv * k, av, gv, xv, glu, va, vg, vr);
     };
     if (VEC4) {
       // rows are 16-byte aligned and T % 4 == 0 (checked by the launcher): 16 bytes per lane and access
@@ -76,8 +68,14 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
           sa += va;
           sg += vg;
         }
-        da4[q] = oa;
-        dg4[q] = og;
+        if (p.dab_pair) {      // (uniform) the pre-gate gradient as the bf16 hi / lo pair its consumers would build from it
+          typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+          reinterpret_cast<u32x4_*>(da)[q] = u32x4_{dv3_pair_word(oa[0]), dv3_pair_word(oa[1]), dv3_pair_word(oa[2]), dv3_pair_word(oa[3])};
+          reinterpret_cast<u32x4_*>(dg)[q] = u32x4_{dv3_pair_word(og[0]), dv3_pair_word(og[1]), dv3_pair_word(og[2]), dv3_pair_word(og[3])};
+        } else {
+          da4[q] = oa;
+          dg4[q] = og;
+        }
         if (dres) dres4[q] = orr;
       }
     } else {
@@ -87,8 +85,13 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
         const float gt = ab16 ? __uint_as_float((uint32_t)g16[t] << 16) : g[t];
         elem(dy[t], at, gt, glu ? 0.f : x[t], va, vg, vr);
         if (dres) dres[t] = vr;
-        da[t] = va;
-        dg[t] = vg;
+        if (p.dab_pair) {
+          reinterpret_cast<uint32_t*>(da)[t] = dv3_pair_word(va);
+          reinterpret_cast<uint32_t*>(dg)[t] = dv3_pair_word(vg);
+        } else {
+          da[t] = va;
+          dg[t] = vg;
+        }
         sa += va;
         sg += vg;
       }
@@ -668,6 +671,7 @@ extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
   // 16 bytes per lane when every row starts 16-byte aligned (gated modes; the others are small)
   const uintptr_t ptrs = (uintptr_t)d->dy | (uintptr_t)d->ab_or_y | (uintptr_t)d->dab | (uintptr_t)d->x | (uintptr_t)d->dres;
   DV3_REQUIRE(!d->ab_bf16 || gated, "gate_bwd: ab_bf16 is for the gated modes");
+  DV3_REQUIRE(!d->dab_pair || (gated && !d->c8), "gate_bwd: pair words are written by the gated modes on fp32 tensors");
   if (gated && (d->T & 3) == 0 && (ptrs & 15) == 0)
     hipLaunchKernelGGL(gate_bwd_kernel<true>, dim3((unsigned)dv3_cdiv64(rows, 4)), dim3(256), 0,
                        (hipStream_t)stream, *d);

@@ -268,6 +268,14 @@ __device__ __forceinline__ void wn_bwd_row(const dv3_wn_bwd_desc& p, const int r
   if (p.bias_part && p.dbias) {
     for (int o = r; o < O; o += nrows) {
       float bs = 0.f;
+      if (p.bias_part_t) {   // [O][n_part] (the input-gradient tail's 32-column partial sums): contiguous per channel
+        const float* __restrict__ bp = p.bias_part + (int64_t)o * p.n_part;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        int k = threadIdx.x;
+        for (; k + 768 < p.n_part; k += 1024) { b0 += bp[k]; b1 += bp[k + 256]; b2 += bp[k + 512]; b3 += bp[k + 768]; }
+        for (; k < p.n_part; k += 256) b0 += bp[k];
+        bs = (b0 + b1) + (b2 + b3);
+      } else
       for (int k = threadIdx.x; k < p.n_part; k += 256) bs += p.bias_part[(int64_t)k * O + o];
       bs = dv3_wave_sum(bs);
       __syncthreads();

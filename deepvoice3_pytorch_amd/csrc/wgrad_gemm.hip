@@ -129,10 +129,12 @@ extern "C" int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream) {
   a.d = *d;
   const bool small = (d->M <= 64 && d->Cin <= 64);
   DV3_REQUIRE(!d->k_split || (d->split_bf16 && !small), "wgrad_gemm: k_split needs the split-bf16 kernel");
+  DV3_REQUIRE(!d->g_pair || (d->split_bf16 == 1 && !small), "wgrad_gemm: pair-word g needs the three-term split kernels (M or Cin > 64)");
   if (d->split_bf16 && !small) {
     const int rc = dv3_wgrad_gemm_bf16x3_dispatch(d, st);
     if (rc != 1) return rc;
   }
+  DV3_REQUIRE(!d->g_pair, "wgrad_gemm: shape not eligible for the split kernels, which alone read pair words");
   g_dv3_last_wgrad = 1000 + (small ? 0 : 10);
   if (small) {
     a.m_tiles = dv3_cdiv(d->M, 64);

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
   const int shift = j * p.dil - p.padL;
   const int T = p.T, Tin = p.Tin, M = p.M, Cin = p.Cin;
 
+  const bool gpw = TERMS == 3 && p.g_pair != 0;
   // this thread's staging units: (row, k8) -- 4 consecutive lanes cover one row's 32 time steps
   int grow[GU], gk8[GU], xrow[XU], xk8[XU];
 #pragma unroll
@@ -204,7 +205,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wgrad_gemm_bf16x3_kernel(const
     for (int u = 0; u < GU; ++u) {
       if (__any((gval[S][u] & 0xffu) != 0xffu)) mask8(rg[S][u], gval[S][u]);   // rare: row tails
       bf16x8 hi, lo;
-      split8(rg[S][u], hi, lo);
+      if (TERMS == 3 && gpw) {     // pair words (dv3_wgrad_desc.g_pair, uniform): the pair is already there
+        uint32_t w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(rg[S][u][e]);
+        dv3_pair_units(w, hi, lo);
+      } else split8(rg[S][u], hi, lo);
       const int o = gk8[u] * LDM + grow[u];
       dst[o] = hi;
       if (TERMS == 3) dst[KB * LDM + o] = lo;
@@ -394,7 +400,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_taps_kernel(const WgradArgs args
     {
       if (__any((gval[S] & 0xffu) != 0xffu)) mask8(rg[S], gval[S]);
       bf16x8 hi, lo;
-      split8(rg[S], hi, lo);
+      if (TERMS == 3 && p.g_pair != 0) {
+        uint32_t w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(rg[S][e]);
+        dv3_pair_units(w, hi, lo);
+      } else split8(rg[S], hi, lo);
       const int o = uk8 * LDM + urow;
       dst[o] = hi;
       if (TERMS == 3) dst[KB * LDM + o] = lo;

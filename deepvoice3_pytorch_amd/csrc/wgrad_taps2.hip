@@ -85,7 +85,9 @@ __device__ __forceinline__ void wt2_realign(float (&v)[8], int sh) {
   for (int e = 0; e < 8; ++e) v[e] = w[e];
 }
 
-template <bool MASK, int ABL = 0>
+// GP (round 6): g holds PAIR WORDS (include/dv3hip.h: dv3_wgrad_desc.g_pair) -- its unit is staged with eight v_perm_b32
+// instead of the fp32 -> bf16-pair conversion (the validity masks and the re-alignment act on whole words either way)
+template <bool MASK, int ABL = 0, bool GP = false>
 __global__ __launch_bounds__(NT) void wgrad_taps2_kernel(const WgradT2Args args) {
   const dv3_wgrad_desc& p = args.d;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_t2[];
@@ -161,7 +163,12 @@ __global__ __launch_bounds__(NT) void wgrad_taps2_kernel(const WgradT2Args args)
       if (__any(sh != 0)) wt2_realign(rg[S], sh);
       if (__any(vm != 0xffu)) wt2_mask8(rg[S], vm);
       bf16x8 hi, lo;
-      wt2_split8(rg[S], hi, lo);
+      if constexpr (GP) {
+        uint32_t w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(rg[S][e]);
+        dv3_pair_units(w, hi, lo);
+      } else wt2_split8(rg[S], hi, lo);
       const int o = uk8 * LDM + urow;
       dst[o] = hi;
       dst[KB * LDM + o] = lo;
@@ -268,12 +275,12 @@ __global__ __launch_bounds__(NT) void wgrad_taps2_kernel(const WgradT2Args args)
   }
 }
 
-template <bool MASK, int ABL = 0>
+template <bool MASK, int ABL = 0, bool GP = false>
 int launch_wgrad_taps2(const WgradT2Args& a, int64_t nb, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * BUF * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_taps2_kernel<MASK, ABL>,
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_taps2_kernel<MASK, ABL, GP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("wgrad_taps2: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -281,7 +288,7 @@ int launch_wgrad_taps2(const WgradT2Args& a, int64_t nb, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_taps2_kernel<MASK, ABL>), dim3((unsigned)nb), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL((wgrad_taps2_kernel<MASK, ABL, GP>), dim3((unsigned)nb), dim3(NT), lds, st, a);
   return dv3_check_launch("wgrad_taps2");
 }
 
@@ -307,5 +314,9 @@ int dv3_wgrad_taps2_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
     }
   }
 #endif
+  if (d->g_pair) {
+    g_dv3_last_wgrad += 1;                       // ...41: pair-word g operand
+    return d->xmask ? launch_wgrad_taps2<true, 0, true>(a, nb, st) : launch_wgrad_taps2<false, 0, true>(a, nb, st);
+  }
   return d->xmask ? launch_wgrad_taps2<true>(a, nb, st) : launch_wgrad_taps2<false>(a, nb, st);
 }

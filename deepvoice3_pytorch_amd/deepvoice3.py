@@ -94,6 +94,8 @@ def _run_stack(modules, x, speaker_embed_btc, first=0, keep_c8=False):
         if isinstance(f, Conv1dGLU):
             x = f(x, speaker_embed_btc)
             C = f.conv.out_channels // 2
+            if i + 1 < n:
+                ops.mark_sole_consumer(x)      # the next layer of the stack is x's only consumer (ops.GateFuse)
         elif isinstance(f, _conv.Conv1d):
             relu = i + 1 < n and isinstance(modules[i + 1], nn.ReLU)
             last = (i + (2 if relu else 1) >= n) and not keep_c8
@@ -739,6 +741,8 @@ class Converter(nn.Module):
             last = (i == n - 1)
             if isinstance(f, Conv1dGLU):
                 x = f(x, speaker_embed_btc)
+                if not last:
+                    ops.mark_sole_consumer(x)  # the next layer of the stack is x's only consumer (ops.GateFuse)
             elif isinstance(f, _conv.Conv1d):
                 if last:
                     x = _conv1d_c8(f, x, True, mode=ops.EPI_SIGMOID)      # torch.sigmoid(x) of deepvoice3.py:604, fused

@@ -47,6 +47,7 @@ class BucketedAllReduce(object):
         self.side = None
         self.async_issue = False
         self._works = []
+        self._sync_issued = False
         if arena.grad.is_cuda:
             from . import ops as _ops
             if issue_stream is not None:
@@ -205,6 +206,7 @@ class BucketedAllReduce(object):
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
+            self._sync_issued = True      # no handle: join() has to make the step stream wait for the issuing stream
 
     def join(self, cur=None):
         """the step stream waits for the collectives (timed when exposed_events is a list)"""
@@ -220,8 +222,13 @@ class BucketedAllReduce(object):
             with torch.cuda.stream(cur):
                 for w in works:
                     w.wait()                 # the CURRENT stream waits for the communicator stream's end-of-collective event
-        if not self.async_issue:
+        #  a collective issued synchronously on the issuing stream -- the non-async mode, and EVERY collective
+        # issued inside a capture, e.g. the buckets finish() launches for parameters that got no gradient, after
+        # SideStream.join() has already re-joined the side stream -- left no handle: without this wait a single-graph
+        # capture would end with the issuing stream forked and unjoined, or clip + Adam would read un-reduced gradients
+        if not self.async_issue or self._sync_issued or torch.cuda.is_current_stream_capturing():
             cur.wait_stream(self.side)
+        self._sync_issued = False
         if timed:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record(cur)

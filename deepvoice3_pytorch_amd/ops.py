@@ -623,15 +623,49 @@ def mask_bits_to_c8(bits, bits_rs, B, C, T):
 # ----------------------------------------------------------------------------------------------
 # raw kernel wrappers
 # ----------------------------------------------------------------------------------------------
+class GateFuse(object):
+    """Round 6: the gate backward of a Conv1dGLU / HighwayConv1d (autograd of modules.py:157-164, 224-226) run by the
+    input-gradient launch of the layer that CONSUMES its output (include/dv3hip.h: dv3_conv_desc.pg ...): that launch
+    holds dL/d(out) of the producer in registers, so the stand-alone pass over (B, 3C, T) (dv3_gate_bwd_f32: a read of dy
+    and of the saved pre-gate pair, a write of the pre-gate gradient, on the queue of backward that has no slack) becomes
+    part of its tail.  Request: the producer's saved pair `ab`, its mode / residual flag, its input `x` (highway), `pair`
+    = write the pre-gate gradient as pair words (the producer's two gradient GEMMs then stage it without conversion).
+    Result (after conv_gemm): dab (B, 2C, T), dres (highway) and the bias partial sums part [2C][n_part]."""
+    __slots__ = ("ab", "mode", "residual", "x", "pair", "dab", "dres", "part", "n_part")
+
+    def __init__(self, ab, mode, residual, x=None, pair=False):
+        self.ab, self.mode, self.residual, self.x, self.pair = ab, mode, int(residual), x, bool(pair)
+        self.dab = self.dres = self.part = None
+        self.n_part = 0
+
+    def attach(self, d, B, C, T, device):
+        ab = self.ab
+        if ab.dtype != torch.float32 or tuple(ab.shape) != (B, 2 * C, T) or not ab.is_contiguous():
+            raise RuntimeError("GateFuse: the producer's pre-gate pair must be a contiguous fp32 (B, 2C, T) tensor")
+        self.n_part = (B * T + 31) // 32
+        self.dab = torch.empty((B, 2 * C, T), dtype=torch.float32, device=device)
+        self.part = torch.empty((2 * C, self.n_part), dtype=torch.float32, device=device)
+        d.pg, d.dpg, d.pg_part = ab.data_ptr(), self.dab.data_ptr(), self.part.data_ptr()
+        d.pg_mode, d.pg_residual, d.pg_pair = self.mode, self.residual, int(self.pair)
+        if self.mode == EPI_HIGHWAY:
+            x = self.x
+            if x is None or x.dtype != torch.float32 or tuple(x.shape) != (B, C, T) or x.stride(2) != 1:
+                raise RuntimeError("GateFuse: a highway producer needs its fp32 (B, C, T) input")
+            self.dres = torch.empty((B, C, T), dtype=torch.float32, device=device)
+            d.pg_x, d.pg_x_bs, d.pg_x_rs, d.dpg_res = x.data_ptr(), x.stride(0), x.stride(1), self.dres.data_ptr()
+
+
 def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mode=EPI_LINEAR,
               Cg=0, bias=None, spk=None, spk_strides=(0, 0, 0), r=None, r2=None, residual=0,
               y=None, y_rs=None, ab=None, xmask=None, xmask_rs=0, ymask=None, ymask_rs=0,
               drop_scale=1.0, a_bs=0, store_mode=STORE_BCT, x_bs=None, x_rs=None, tile_hint=0,
               a_split=None, x_planes=None, r_scale=0.0, out_dtype=torch.float32, x_c8=None, out_c8=False,
-              xmask_c8=None, ymask_c8=None):
+              xmask_c8=None, ymask_c8=None, gate=None, x_pair=False):
     """dv3_conv_gemm_f32.  x: [B][Cin][Tin] (strides overridable); returns y.  x_planes: the input already
     split into operand planes (split_planes; x may then be None).  bf16 storage: x_c8 = the input as a c8 tensor
-    (with its keep-bytes xmask_c8), out_c8 = y / ab written and r / r2 read in c8 (ymask_c8 for DGRAD)."""
+    (with its keep-bytes xmask_c8), out_c8 = y / ab written and r / r2 read in c8 (ymask_c8 for DGRAD).
+    gate (a GateFuse, DGRAD launches of the split kernels): the tail also runs the gate backward of the layer that
+    produced this layer's input and fills gate.dab / .dres / .part; x_pair: x holds pair words (include/dv3hip.h)."""
     gated = mode in (EPI_GLU, EPI_HIGHWAY)
     Cout = Cg if gated else (M // 2 if store_mode == STORE_INTERLEAVE2 else M)
     To = 2 * Tout if store_mode == STORE_INTERLEAVE2 else Tout
@@ -694,7 +728,13 @@ def conv_gemm(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J=1, dil=1, padL=0, mo
         # the image carries its operand type (split_pack / pack_weights tag it): scaled fp16 hi/lo or bf16
         d.split_terms = CONSTS["DV3_SPLIT_F16X3"] if getattr(a_split, "_dv3_f16", False) else \
             (1 if _gemm_mode == "bf16" else 0)
-    if a_split is not None and J == 3 and d.split_terms != 1 and (tile_hint == 0 or streamk == "force"):
+    d.x_pair = int(bool(x_pair))
+    if gate is not None:
+        if mode != EPI_DGRAD or a_split is None or d.split_terms == 1:
+            raise RuntimeError("conv_gemm: the fused gate backward rides on a split-kernel input-gradient launch")
+        gate.attach(d, B, M, Tout, y.device)
+    if a_split is not None and J == 3 and d.split_terms != 1 and (tile_hint == 0 or streamk == "force") and \
+            gate is None and not x_pair:
         ws = _streamk_ws(y.device)
         if ws is not None:
             d.sk_ws, d.sk_ws_bytes = ws
@@ -820,8 +860,8 @@ def gate_bwd_c8(dy, ab_or_y, x, *, B, C, T, mode, residual=0, alpha=1.0, want_dr
 
 def wgrad_gemm(g, x, *, B, M, Cin, T, Tin, J=1, dil=1, padL=0, n_slabs=1, xmask=None, xmask_rs=0,
                drop_scale=1.0, out=None, ldo=None, g_bs=None, g_rs=None, x_bs=None, x_rs=None,
-               split_bf16=False, k_split=False, rows_of_slabs=False):
-    """dv3_wgrad_gemm_f32 -> out [S][J][M][ldo].
+               split_bf16=False, k_split=False, rows_of_slabs=False, g_pair=False):
+    """dv3_wgrad_gemm_f32 -> out [S][J][M][ldo].  g_pair: g holds pair words (GateFuse(pair=True)).
     rows_of_slabs: the K-split partial sums as [J][M][S][ldo] instead -- the S partial rows of one weight row lie back
     to back (S * ldo contiguous floats), which is how the weight-norm backward reads them (round 3 read S slabs
     1.5 MB apart per element: 36 us per layer at 1.4 TB/s).  Same kernels: only the descriptor's slab stride (ldo) and
@@ -846,13 +886,15 @@ def wgrad_gemm(g, x, *, B, M, Cin, T, Tin, J=1, dil=1, padL=0, n_slabs=1, xmask=
     d.B, d.M, d.Cin, d.T, d.Tin, d.J, d.dil, d.padL, d.n_slabs = B, M, Cin, T, Tin, J, dil, padL, n_slabs
     d.split_bf16 = (2 if _gemm_mode == "bf16" else 1) if split_bf16 else 0
     d.k_split = int(bool(k_split))
+    d.g_pair = int(bool(g_pair))
     _lib.call("dv3_wgrad_gemm_f32", ctypes.byref(d), _stream())
     return out
 
 
 def gate_bwd(dy, ab_or_y, x, *, B, C, T, mode, residual=0, alpha=1.0, want_dres=False,
-             want_dpre=True):
-    """dv3_gate_bwd_f32 -> (dab_or_dpre, dres, bias_part)."""
+             want_dpre=True, pair=False):
+    """dv3_gate_bwd_f32 -> (dab_or_dpre, dres, bias_part).  pair (gated modes): dab as pair words (include/dv3hip.h) -- for
+    conv_gemm(x_pair=True) / wgrad_gemm(g_pair=True)."""
     gated = mode in (EPI_GLU, EPI_HIGHWAY)
     dev = dy.device
     rows = 2 * C if gated else C
@@ -865,12 +907,13 @@ def gate_bwd(dy, ab_or_y, x, *, B, C, T, mode, residual=0, alpha=1.0, want_dres=
     d.alpha = alpha
     d.B, d.C, d.T, d.mode, d.residual = B, C, T, mode, residual
     d.ab_bf16 = int(gated and ab_or_y is not None and ab_or_y.dtype == torch.bfloat16)
+    d.dab_pair = int(bool(pair) and gated)
     _lib.call("dv3_gate_bwd_f32", ctypes.byref(d), _stream())
     return dab, dres, part
 
 
 def weight_norm_bwd(slabs, n_slabs, ldo, v, g, scale, bias_part, n_part, O, I, J, transposed=False,
-                    want_bias=True, into=None, rows_of_slabs=False):
+                    want_bias=True, into=None, rows_of_slabs=False, part_t=False):
     """into = (dv, dg, dbias) gradient buffers to ACCUMULATE into (the parameters' own .grad views in
     the trainer's flat arena) instead of fresh tensors.  rows_of_slabs: the layout wgrad_gemm(rows_of_slabs=True)
     wrote."""
@@ -893,6 +936,7 @@ def weight_norm_bwd(slabs, n_slabs, ldo, v, g, scale, bias_part, n_part, O, I, J
     d.bias_part, d.n_part, d.dbias = _ptr(bias_part) if dbias is not None else None, n_part, _ptr(dbias)
     d.O, d.I, d.J, d.transposed = O, I, J, int(transposed)
     d.accumulate = int(into is not None)
+    d.bias_part_t = int(bool(part_t))          # [O][n_part]: the layout GateFuse.part has
     if into is not None and WnBwdBatch.active:
         WnBwdBatch.add(d, I if transposed else O, (slabs, v, g, scale, bias_part, dv, dg, dbias))
         return dv, dg, dbias
@@ -1120,6 +1164,47 @@ class SideStream(object):
 SideStream._section = SideStream._Section()
 
 
+# Round 6: the gate backward of a gated layer runs in the tail of its consumer's input-gradient launch (GateFuse) when the
+# caller marked the layer's output as having no other consumer (`y._dv3_sole = True`: the stack runners of deepvoice3.py /
+# nyanko.py do).  DV3_FUSE_GATE=0 restores the stand-alone dv3_gate_bwd_f32 launches (A/B runs).
+fuse_gate_bwd = _os.environ.get("DV3_FUSE_GATE", "1") not in ("0", "")
+# ... where it pays.  Measured per launch (scripts/r6_gate_fuse_kernels.py, profiles/r06_gate_fuse_kernels.txt): the tail
+# costs what the stand-alone kernel costs once that kernel is bandwidth-bound (B = 64: 59 us stand-alone at 5.6 TB/s
+# against +73 us of tail at the north-star shape; break-even at 64 x 512 x 150), and half of it where the stand-alone
+# launch is latency-bound (B = 16, 256 x 804: 12.3 us against +6.4 us).  Elements (B * C * T) up to which a producer offers
+# its gate backward to its consumer (DV3_FUSE_GATE_MAX; 0 = never, a huge value = always):
+fuse_gate_max_elems = int(_os.environ.get("DV3_FUSE_GATE_MAX", str(4 << 20)))
+# the pre-gate gradient as pair words for the layer's own gradient GEMMs (DV3_PAIR_WORDS=0: fp32, A/B runs)
+pair_words = _os.environ.get("DV3_PAIR_WORDS", "1") not in ("0", "")
+gate_fuse_stats = {"fused": 0, "standalone": 0}     # gated-layer backwards served either way (tests, bench)
+
+
+class _GateToken(object):
+    """what a gated layer leaves on its output for the consumer's backward (see GateFuse)"""
+    __slots__ = ("ab", "mode", "residual", "x", "C", "pair")
+
+    def __init__(self, ab, mode, residual, x, C, pair):
+        self.ab, self.mode, self.residual, self.x, self.C, self.pair = ab, mode, residual, x, C, pair
+
+
+class _GateResult(object):
+    """rides on the gradient tensor the consumer's backward returns; the producer's backward takes it only if that very
+    tensor -- unmodified -- is what autograd hands it (another consumer of the producer's output would make autograd sum
+    the gradients into a different tensor, or bump this one's version)"""
+    __slots__ = ("tok", "dab", "dres", "part", "n_part", "pair", "version")
+
+    def __init__(self, tok, gate, version):
+        self.tok, self.dab, self.dres, self.part, self.n_part = tok, gate.dab, gate.dres, gate.part, gate.n_part
+        self.pair, self.version = gate.pair, version
+
+
+def mark_sole_consumer(y):
+    """the caller's promise that exactly one conv layer consumes y (and nothing else does)"""
+    if fuse_gate_bwd and getattr(y, "_dv3_tok", None) is not None:
+        y._dv3_sole = True
+    return y
+
+
 class ConvLayerFn(torch.autograd.Function):
     """y = layer(x; v, g, bias[, spk][, r][, r2]).  See LayerCfg.  `packed` may carry a cached
     Packed (eval mode); spk is the additive per-(b,channel[,t]) term on the `a` half (already
@@ -1128,6 +1213,7 @@ class ConvLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, v, g, bias, spk, r, r2, cfg, packed):
         _chk(x, "x")
+        x_in = x
         x = _c(x)
         B, Cin, T = x.shape
         mode = cfg.mode
@@ -1204,6 +1290,27 @@ class ConvLayerFn(torch.autograd.Function):
             ctx.has_r, ctx.has_r2 = (r is not None), (r2 is not None)
             ctx.has_bias = bias is not None
             ctx.save_for_backward(x, v, g, ab if gated else y)
+            # round 6 (GateFuse).  As a producer: leave on y what the consumer's input-gradient launch needs to run this
+            # layer's gate backward.  As a consumer: remember the producer of x when the caller marked x accordingly.
+            ctx.tok = ctx.prod = None
+            split_modes = _gemm_mode in ("f16x3", "bf16x3")
+            # pair words (include/dv3hip.h): this layer's pre-gate gradient can go to its two gradient GEMMs as the bf16
+            # hi / lo pairs they would otherwise build while staging (both on the three-term split kernels, no per-frame
+            # speaker-bias gradient reading the tensor as fp32)
+            ctx.pair_ok = bool(gated and pair_words and split_modes and not use_planes and pk.bwd_s is not None and
+                               split_only and ab.dtype == torch.float32 and (spk is None or spk.dim() == 2) and
+                               not (M <= 64 and Cin <= 64))
+            if fuse_gate_bwd and split_modes and not use_planes and pk.bwd_s is not None:
+                Jd = 1 if cfg.transposed else J
+                if gated and ab.dtype == torch.float32 and spk is None and split_only and \
+                        B * Cg * T <= fuse_gate_max_elems:
+                    ctx.tok = _GateToken(ab, mode, int(cfg.residual), x if mode == EPI_HIGHWAY else None, Cg,
+                                         pair=ctx.pair_ok)
+                    y._dv3_tok = ctx.tok
+                prod = getattr(x_in, "_dv3_tok", None) if (x_in is x and getattr(x_in, "_dv3_sole", False)) else None
+                if prod is not None and prod.C == Cin and ctx.needs_input_grad[0] and Tout == T and \
+                        (Jd - 1) * cfg.dil <= 64 and Jd <= 16:
+                    ctx.prod = prod
         return y
 
     @staticmethod
@@ -1217,11 +1324,23 @@ class ConvLayerFn(torch.autograd.Function):
         rs2 = math.sqrt(0.5)
         dr = dr2 = dspk = None
         r_scale = 0.0
+        n_part, g_pair, part_t = B, False, False
         if gated:
             # the skip path of a residual GLU passes sqrt(.5) * dy: the DGRAD epilogue reads dy itself
             glu_skip = mode == EPI_GLU and cfg.residual
-            dab, dres, part = gate_bwd(dy, saved, x if mode == EPI_HIGHWAY else None, B=B, C=Cg, T=T,
-                                       mode=mode, residual=int(cfg.residual), want_dres=(mode == EPI_HIGHWAY))
+            fused = getattr(dy, "_dv3_gate", None)
+            if fused is not None and ctx.tok is not None and fused.tok is ctx.tok and dy._version == fused.version:
+                # the consumer's input-gradient launch already ran this layer's gate backward (GateFuse)
+                dab, dres, part = fused.dab, fused.dres, fused.part
+                n_part, g_pair, part_t = fused.n_part, fused.pair, True
+                dy._dv3_gate = None
+                gate_fuse_stats["fused"] += 1
+            else:
+                g_pair = ctx.pair_ok
+                dab, dres, part = gate_bwd(dy, saved, x if mode == EPI_HIGHWAY else None, B=B, C=Cg, T=T,
+                                           mode=mode, residual=int(cfg.residual), want_dres=(mode == EPI_HIGHWAY),
+                                           pair=g_pair)
+                gate_fuse_stats["standalone"] += 1
             if glu_skip:
                 dres, r_scale = dy, rs2
             if ctx.spk_dim == 2:
@@ -1263,10 +1382,16 @@ class ConvLayerFn(torch.autograd.Function):
             gp = None
             if use_planes and pk.bwd_s is not None and planes_eligible(Jd, cfg.dil, Tg, T):
                 gp = split_planes(gmat, f16=False)
+            gate = None
+            if ctx.prod is not None and gp is None:
+                t_ = ctx.prod
+                gate = GateFuse(t_.ab, t_.mode, t_.residual, t_.x, pair=t_.pair)
             dx = conv_gemm(gmat, pk.bwd, pk.ldb, 0, B=B, Cin=Mg, Tin=Tg, M=Cin, Tout=T, J=Jd, x_planes=gp,
                            dil=cfg.dil, padL=(Jd - 1) * cfg.dil - padL, mode=EPI_DGRAD, r=dres, r_scale=r_scale,
                            ymask=ctx.bits, ymask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
-                           a_split=pk.bwd_s if _gemm_mode != "f32" else None)
+                           a_split=pk.bwd_s if _gemm_mode != "f32" else None, gate=gate, x_pair=g_pair)
+            if gate is not None:
+                dx._dv3_gate = _GateResult(ctx.prod, gate, dx._version)
         if ctx.needs_input_grad[1]:
             Jd = 1 if cfg.transposed else J
             tiles = ((Mg + 127) // 128) * ((Cin + 127) // 128) * Jd
@@ -1285,13 +1410,14 @@ class ConvLayerFn(torch.autograd.Function):
             with side:
                 slabs = wgrad_gemm(gmat, x, B=B, M=Mg, Cin=Cin, T=Tg, Tin=T, J=Jd, dil=cfg.dil, padL=padL,
                                    n_slabs=S, xmask=ctx.bits, xmask_rs=ctx.bits_rs, drop_scale=ctx.dscale,
-                                   split_bf16=x3, k_split=x3, rows_of_slabs=slab_rows)
+                                   split_bf16=x3, k_split=x3, rows_of_slabs=slab_rows, g_pair=g_pair)
                 if ctx.inplace:
                     pv, pg, pb = ctx.leaves
-                    weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None, pk.scale, part, B,
+                    weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None, pk.scale, part, n_part,
                                     pk.O, pk.I, pk.J, cfg.transposed, want_bias=ctx.has_bias,
                                     into=(pv.grad, pg.grad if pg is not None else None,
-                                          pb.grad if pb is not None else None), rows_of_slabs=slab_rows)
+                                          pb.grad if pb is not None else None), rows_of_slabs=slab_rows,
+                                    part_t=part_t)
                     if SideStream.stream is not None:
                         SideStream.retain(slabs)
                     pv._dv3_pending -= 1
@@ -1302,8 +1428,8 @@ class ConvLayerFn(torch.autograd.Function):
                 dv = dg = dbias = None
             else:
                 dv, dg, dbias = weight_norm_bwd(slabs, S, Cin, _c(v3), _c(g) if g is not None else None,
-                                                pk.scale, part, B, pk.O, pk.I, pk.J, cfg.transposed,
-                                                want_bias=ctx.has_bias, rows_of_slabs=slab_rows)
+                                                pk.scale, part, n_part, pk.O, pk.I, pk.J, cfg.transposed,
+                                                want_bias=ctx.has_bias, rows_of_slabs=slab_rows, part_t=part_t)
                 dv = dv.view_as(v)
         return dx, dv, dg, dbias, dspk, dr, dr2, None, None
 

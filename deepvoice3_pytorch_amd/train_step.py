@@ -31,7 +31,7 @@ class TrainConfig(object):
                  guided_attention_sigma=0.2, clip_thresh=0.1, adam_beta1=0.5, adam_beta2=0.9,
                  adam_eps=1e-6, weight_decay=0.0, initial_learning_rate=5e-4,
                  lr_schedule="noam_learning_rate_decay", lr_schedule_kwargs=None, max_positions=512,
-                 range_check_every=0):
+                 range_check_every=0, amsgrad=False):
         self.outputs_per_step = outputs_per_step
         self.downsample_step = downsample_step
         self.masked_loss_weight = masked_loss_weight
@@ -43,6 +43,13 @@ class TrainConfig(object):
         self.clip_thresh = clip_thresh
         self.adam_beta1, self.adam_beta2, self.adam_eps = adam_beta1, adam_beta2, adam_eps
         self.weight_decay = weight_decay
+        # hparams.py:103 / train.py:975-979 hand `amsgrad` to optim.Adam (False in every preset).  The fused clip + Adam
+        # launch keeps no running maximum of the second moment: accepted so that the reference's hparams can be forwarded
+        # unchanged, refused explicitly when set
+        if amsgrad:
+            raise ValueError("amsgrad=True is not supported by the fused clip + Adam step (every reference preset uses "
+                             "amsgrad=False, hparams.py:103)")
+        self.amsgrad = False
         self.initial_learning_rate = initial_learning_rate
         self.lr_schedule = lr_schedule
         self.lr_schedule_kwargs = lr_schedule_kwargs or {}

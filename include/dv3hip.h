@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 38
+#define DV3_ABI_VERSION 39
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -154,6 +154,28 @@ typedef struct dv3_conv_desc {
                                                 stream).  NULL = one tile per workgroup.  Results differ between the
                                                 two forms by fp32 summation order only.                              */
   int64_t sk_ws_bytes;
+  /* ---- round 6: the producer's gate backward inside the input-gradient tail (split kernels, DV3_EPI_DGRAD) ----------
+   * The output y of an input-gradient launch is dL/d(out) of the layer that PRODUCED this layer's input.  When that
+   * producer is a Conv1dGLU / HighwayConv1d whose output has no other consumer, its gate backward (autograd of
+   * modules.py:157-164, 224-226; stand-alone: dv3_gate_bwd_f32) runs here, on the tile the tail already holds:
+   *   pg       the producer's saved pre-gate pair [B][2M][Tout] (its `ab`), fp32; NULL = plain tail
+   *   pg_x     HIGHWAY: the producer's input [B][M][Tout] (pg_x_bs / pg_x_rs element strides)
+   *   dpg      out: the producer's pre-gate gradient [B][2M][Tout] (what gate_bwd writes as `dab`)
+   *   dpg_res  out, HIGHWAY: the gradient of its skip path [B][M][Tout] (`dres`); GLU: the skip gradient is
+   *            sqrt(.5) * y, which the producer's own DGRAD launch reads through r / r_scale as before
+   *   pg_part  out: bias partial sums, TRANSPOSED [2M][n_part], n_part = ceil(B * Tout / 32): entry (row, k) = the sum
+   *            of dpg[row] over the flat (b, t) columns [32 k, 32 k + 32) -- deterministic, summed by
+   *            dv3_weight_norm_bwd_f32 (bias_part_t = 1)
+   *   pg_mode  DV3_EPI_GLU or DV3_EPI_HIGHWAY; pg_residual as the producer's `residual`
+   *   pg_pair  1: dpg is written as PAIR WORDS (below) instead of fp32
+   * y itself is written as always (it is the gradient autograd is handed).
+   * PAIR WORDS: a 32-bit word (bf16_rn(v) << 16) | bf16_rn(v - bf16_rn(v)) in the place of the fp32 value v -- the two
+   * bf16 operands the gradient GEMMs (this entry point in DGRAD form, dv3_wgrad_gemm_f32) would otherwise build from v
+   * while staging, computed once by the producer of the tensor.  Same shape, strides and bytes as the fp32 tensor.
+   *   x_pair   1: x holds pair words (split_terms == 3 or 0 with a_split: the bf16-pair kernels; no xmask)        */
+  const float* pg; const float* pg_x; int64_t pg_x_bs, pg_x_rs;
+  float* dpg; float* dpg_res; float* pg_part;
+  int32_t pg_mode, pg_residual, pg_pair, x_pair;
 } dv3_conv_desc;
 #define DV3_IO_IN_BF16 1
 #define DV3_IO_OUT_BF16 2
@@ -300,6 +322,8 @@ typedef struct dv3_wgrad_desc {
                                                 Cin channels; the stride fields are unused): the bf16-storage form --
                                                 split_bf16 == 2, k_split, T == Tin, J in {1, 3}                     */
   const uint8_t* xmask_c8;                   /* c8: dropout keep-bytes over x [B][round_up(Cin,32)/8][Tin], or NULL   */
+  int32_t g_pair;                            /* 1 (split_bf16 == 1): g holds PAIR WORDS (dv3_conv_desc: pg_pair), staged
+                                                without conversion                                                     */
 } dv3_wgrad_desc;
 int dv3_wgrad_gemm_f32(const dv3_wgrad_desc* d, void* stream);
 
@@ -394,6 +418,7 @@ typedef struct dv3_wn_bwd_desc {
   int32_t accumulate;                        /* 1: dv, dg, dbias += (gradient buffers that are zeroed once
                                                 per step and shared by every use of the parameter);
                                                 0: overwrite                                          */
+  int32_t bias_part_t;                       /* 0: bias_part is [n_part][O]; 1: [O][n_part] (dv3_conv_desc.pg_part) */
 } dv3_wn_bwd_desc;
 int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream);
 /* The same for n <= DV3_WN_BWD_MULTI_MAX layers in ONE launch: one workgroup per normalised row of every layer.  A
@@ -420,6 +445,9 @@ typedef struct dv3_gate_bwd_desc {
   int32_t ab_bf16;                           /* gated modes: ab_or_y is a bf16 tensor (DV3_IO_AB_BF16 / _OUT_BF16)  */
   int32_t c8;                                /* every activation tensor (dy, ab_or_y, x, dab, dres) is channel-blocked
                                                 bf16 (DV3_IO_OUT_C8 layout; C % 8 == 0); bias_part stays fp32        */
+  int32_t dab_pair;                          /* gated modes, fp32 tensors: dab is written as PAIR WORDS (dv3_conv_desc:
+                                                pg_pair) -- the layer's two gradient GEMMs stage it without conversion
+                                                (dv3_conv_desc.x_pair, dv3_wgrad_desc.g_pair)                        */
 } dv3_gate_bwd_desc;
 int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream);
 

@@ -139,8 +139,10 @@ def melspectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97, 
 # (`.istft`, audio.py:42).  The package (Jonathan Le Roux, github.com/Jonathan-LeRoux/lws, pinned by setup.py:87 as
 # "lws <= 1.0"; python/lws.pyx) is not vendored and cannot be installed here (no network), so what follows restates its
 # PUBLISHED conventions -- README "Additional options" and lws.pyx: hann / synthwin / stft / istft -- not its output:
-#   * analysis window  = sqrt of a SYMMETRIC Hann window (lws.pyx: `awin = np.sqrt(hann(fsize, symmetric=True,
-#     use_offset=False))`, hann(n) = 0.5 - 0.5 cos(2 pi k / (n - 1)));
+#   * analysis window  = sqrt of a SYMMETRIC Hann window, normalised for the hop (lws.pyx, integer-argument constructor:
+#     `awin = np.sqrt(hann(fsize, symmetric=True, use_offset=False) * 2 * fshift / fsize)`, hann(n) = 0.5 - 0.5 cos(2 pi
+#     k / (n - 1))) -- the factor sqrt(2 fshift / fsize) is the one constant of this restatement that is held by
+#     recollection only (lws_scale below);
 #   * synthesis window = the analysis window divided by the overlap-added product awin * swin over the Q = ceil(fsize /
 #     fshift) frame positions (lws.pyx: synthwin), so that overlap-add reconstructs perfectly;
 #   * perfectrec=True (the default): the signal is padded with fsize - fshift ZEROS on both sides (and with zeros on the
@@ -157,11 +159,22 @@ def lws_hann(n, symmetric=True):
     return 0.5 * (1.0 - np.cos(2.0 * np.pi * k / ((n - 1) if symmetric else n)))
 
 
-def lws_windows(fsize=1024, fshift=256, scale=1.0):
+def lws_scale(scale=None, fsize=1024, fshift=256):
+    """amplitude factor of the analysis window.  None / "hop_normalized" (the default since round 6): sqrt(2 fshift / fsize)
+    -- lws.pyx's integer-argument constructor as two independent recollections of the source have it,
+    `awin = np.sqrt(hann(fsize, symmetric) * 2 * fshift / fsize)` (0.7071 at hop 256); 1.0 = plain sqrt(hann), rounds 4-5's
+    default.  Still NOT confirmed against a run of the package (none can be installed here): tests/test_audio.py compares
+    with the real `lws` wherever it is importable, and scripts/pin_audio_oracle.py writes tests/golden/audio_lws.npz on
+    any box that has it."""
+    if scale is None or scale == "hop_normalized":
+        return float(np.sqrt(2.0 * fshift / fsize))
+    return float(scale)
+
+
+def lws_windows(fsize=1024, fshift=256, scale=None):
     """-> (awin, swin): lws.lws(fsize, fshift).awin and the synthwin(awin, fshift) perfect-reconstruction synthesis window.
-    `scale`: amplitude factor of the analysis window -- the constant this restatement can NOT confirm offline (1.0 = plain
-    sqrt(hann); sqrt(2 fshift / fsize) if the package normalises the window's sum of squares for the hop)"""
-    awin = float(scale) * np.sqrt(lws_hann(fsize, True))
+    `scale`: see lws_scale"""
+    awin = lws_scale(scale, fsize, fshift) * np.sqrt(lws_hann(fsize, True))
     Q = int(np.ceil(fsize * 1.0 / fshift))
     twin = awin * awin
     w = np.concatenate([twin, np.zeros(Q * fshift - fsize)]).reshape(Q, fshift).sum(0)
@@ -176,7 +189,7 @@ def lws_num_frames(length, fsize=1024, fshift=256):
     return -(-(length + 2 * pad - fsize) // fshift) + 1
 
 
-def lws_stft(x, fsize=1024, fshift=256, scale=1.0):
+def lws_stft(x, fsize=1024, fshift=256, scale=None):
     """lws.lws(fsize, fshift).stft(x): (L,) or (B, L) real -> (..., M, fsize / 2 + 1) complex"""
     x = np.asarray(x, dtype=np.float64)
     if x.ndim == 2:
@@ -190,7 +203,7 @@ def lws_stft(x, fsize=1024, fshift=256, scale=1.0):
     return np.fft.rfft(frames, axis=-1)
 
 
-def lws_istft(S, fshift=256, scale=1.0):
+def lws_istft(S, fshift=256, scale=None):
     """lws.lws(fsize, fshift).istft(S): (..., M, fsize / 2 + 1) complex -> (..., (M - 1) fshift + fsize - 2 (fsize - fshift))"""
     S = np.asarray(S)
     if S.ndim == 3:
@@ -205,27 +218,27 @@ def lws_istft(S, fshift=256, scale=1.0):
     return yp[pad:len(yp) - pad]
 
 
-def lws_griffin_lim(mag, n_iter, fshift=256, init_phasor=None):
+def lws_griffin_lim(mag, n_iter, fshift=256, init_phasor=None, scale=None):
     """Griffin-Lim on the lws framing: mag real (B, M, 513) -> (B, L)"""
     mag = np.asarray(mag, dtype=np.float64)
     ph = np.ones(mag.shape, dtype=np.complex128) if init_phasor is None else np.asarray(init_phasor, dtype=np.complex128)
     fsize = 2 * (mag.shape[-1] - 1)
-    y = lws_istft(mag * ph, fshift)
+    y = lws_istft(mag * ph, fshift, scale)
     for _ in range(n_iter):
-        Z = lws_stft(y, fsize, fshift)
+        Z = lws_stft(y, fsize, fshift, scale)
         ph = Z / np.maximum(np.abs(Z), 1e-8)
-        y = lws_istft(mag * ph, fshift)
+        y = lws_istft(mag * ph, fshift, scale)
     return y
 
 
-def lws_spectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97, scale=1.0):
+def lws_spectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97, scale=None):
     """audio.spectrogram (audio.py:31-35) on the lws framing: (B, L) -> (B, 513, M)"""
     D = np.abs(lws_stft(preemphasis(wav, coef), 1024, hop, scale)).transpose(0, 2, 1)
     return normalize(amp_to_db(D, min_level_db) - ref_level_db, min_level_db)
 
 
-def lws_melspectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97, **mel_kw):
+def lws_melspectrogram(wav, hop=256, min_level_db=-100, ref_level_db=20, coef=0.97, scale=None, **mel_kw):
     """audio.melspectrogram (audio.py:46-51) on the lws framing: (B, L) -> (B, 80, M)"""
-    D = np.abs(lws_stft(preemphasis(wav, coef), 1024, hop)).transpose(0, 2, 1)
+    D = np.abs(lws_stft(preemphasis(wav, coef), 1024, hop, scale)).transpose(0, 2, 1)
     M = np.einsum("mf,bft->bmt", slaney_mel_basis(**mel_kw), D)
     return normalize(amp_to_db(M, min_level_db) - ref_level_db, min_level_db)

@@ -66,7 +66,10 @@ def test_oracle_lws_framing_published_properties():
     lws_num_frames / lws_pad_lr helpers compute); the product's host-side tables are the oracle's."""
     aw, sw = A.lws_windows(1024, 256)
     assert aw[0] == 0.0 and np.allclose(aw, aw[::-1]) and abs(aw[511] - aw[512]) < 1e-12       # symmetric, n - 1 denominator
-    assert np.allclose(aw ** 2, 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1024) / 1023.0))
+    # the default since round 6: the hop-normalised window, sqrt(hann * 2 * fshift / fsize)
+    assert np.allclose(aw ** 2, (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1024) / 1023.0)) * 2 * 256 / 1024)
+    a1, _ = A.lws_windows(1024, 256, 1.0)
+    assert np.allclose(a1 ** 2, 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(1024) / 1023.0))
     ola = np.zeros(1024 + 3 * 256)
     for q in range(4):
         ola[q * 256:q * 256 + 1024] += aw * sw
@@ -97,8 +100,9 @@ def test_oracle_lws_framing_published_properties():
 
 def test_window_scale_is_the_unconfirmed_constant():
     """The one number of the lws framing this repository cannot confirm offline (audio): the amplitude of the
-    analysis window.  sqrt(hann) (window_scale 1.0, the default) against sqrt(hann * 2 * fshift / fsize)
-    ("hop_normalized" = 0.7071 at hop 256) differ in exactly one observable: every STFT magnitude by the factor itself,
+    analysis window.  sqrt(hann) (window_scale 1.0, rounds 4-5's default) against sqrt(hann * 2 * fshift / fsize)
+    ("hop_normalized" = 0.7071 at hop 256, the default since round 6: what two independent recollections of lws.pyx's
+    integer-argument constructor say) differ in exactly one observable: every STFT magnitude by the factor itself,
     i.e. the normalised [0, 1] spectrogram of audio.spectrogram (audio.py:31-35) by 20 log10(0.7071) / 100 = -0.0301
     wherever it is not clipped -- here the peak of a -40 dBFS sine.  Everything the other tests check (perfect
     reconstruction, frame counts, Griffin-Lim's convergence) holds for both, which is why they cannot tell them apart;
@@ -107,7 +111,9 @@ def test_window_scale_is_the_unconfirmed_constant():
     hop = 256
     s2 = float(np.sqrt(2.0 * hop / 1024))
     cfg2 = audio.AudioConfig(window_scale="hop_normalized")
-    assert abs(cfg2.window_scale - s2) < 1e-15 and audio.AudioConfig().window_scale == 1.0
+    assert abs(cfg2.window_scale - s2) < 1e-15 and audio.AudioConfig().window_scale == cfg2.window_scale
+    assert audio.AudioConfig(window_scale=1.0).window_scale == 1.0            # rounds 4-5's value stays selectable
+    assert A.lws_scale() == A.lws_scale("hop_normalized") == cfg2.window_scale and A.lws_scale(1.0) == 1.0
     with pytest.raises(ValueError):
         audio.AudioConfig(window_scale=0.0)
     n = np.arange(256 * 40)
@@ -123,11 +129,64 @@ def test_window_scale_is_the_unconfirmed_constant():
         y = A.lws_istft(A.lws_stft(x, 1024, hop, sc), hop, sc)
         assert np.abs(y[:3000] - x).max() < 1e-12
     a1, w1 = audio.lws_windows_np(1024, hop, 1.0)
-    a2, w2 = audio.lws_windows_np(1024, hop, s2)
+    a2, w2 = audio.lws_windows_np(1024, hop)                                  # the default
     assert np.allclose(a2, s2 * a1) and np.allclose(w2, w1 / s2)
     # ... and the frame count is the documented ceil for any hop (hop 300, 1200 samples -> 7 frames)
     assert audio.lws_num_frames(1200, 300) == 7 == A.lws_num_frames(1200, 1024, 300)
     assert [audio.lws_num_frames(L, 256) for L in (256, 2560, 1000, 1)] == [4, 13, 7, 4]
+
+
+# ------------------------------------------------------------------------------------------------
+# The automatic pin: wherever the real packages can be imported, the restatement is compared with them;
+# and once scripts/pin_audio_oracle.py has been run on such a box, with the vectors it wrote.  Neither package is in the
+# build image (no network): these tests SKIP there and rows a16 / f2 stay "parity unpinned" until one of them runs.
+# ------------------------------------------------------------------------------------------------
+def _pin_signals():
+    rng = np.random.RandomState(1234)
+    return [rng.randn(L) * 0.1 for L in (2560, 256 * 37, 5000, 1000)]
+
+
+def test_oracle_lws_framing_against_the_real_package():
+    lws = pytest.importorskip("lws")
+    proc = lws.lws(1024, 256, mode="speech")            # reference audio.py:54-55
+    for x in _pin_signals():
+        S = proc.stft(x)
+        want = A.lws_stft(x)
+        assert S.shape == want.shape, (S.shape, want.shape)
+        assert np.abs(S - want).max() < 1e-9 * np.abs(want).max()
+        y = proc.istft(S)
+        mine = A.lws_istft(S)
+        n = min(len(y), len(mine))
+        assert abs(len(y) - len(mine)) <= 1024 and np.abs(y[:n] - mine[:n]).max() < 1e-9
+
+
+def test_oracle_mel_basis_against_librosa():
+    librosa = pytest.importorskip("librosa")
+    W = librosa.filters.mel(sr=22050, n_fft=1024, n_mels=80, fmin=125, fmax=7600)     # reference audio.py:74-76, hparams.py:32-37
+    assert np.abs(W - A.slaney_mel_basis()).max() < 1e-6 * W.max()
+
+
+def test_oracle_lws_framing_against_pinned_vectors():
+    """tests/golden/audio_lws.npz, written by scripts/pin_audio_oracle.py on a box that has `lws` (and optionally
+    `librosa`): inputs + the package's own stft / istft / awin (+ the mel basis).  Absent until someone runs it."""
+    import os
+    from tests.util import GOLDEN
+    path = os.path.join(GOLDEN, "audio_lws.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/audio_lws.npz not generated yet (scripts/pin_audio_oracle.py needs the lws package)")
+    z = np.load(path, allow_pickle=False)
+    awin, _ = A.lws_windows(1024, 256)
+    assert np.abs(z["awin"] - awin).max() < 1e-12, "the analysis window (its hop normalisation) is not the package's"
+    for i in range(int(z["n"])):
+        x, S = z["x%d" % i], z["S%d" % i]
+        want = A.lws_stft(x)
+        assert S.shape == want.shape and np.abs(S - want).max() < 1e-9 * np.abs(want).max()
+        y = z["y%d" % i]
+        mine = A.lws_istft(S)
+        n = min(len(y), len(mine))
+        assert np.abs(y[:n] - mine[:n]).max() < 1e-9
+    if "mel" in z.files:
+        assert np.abs(z["mel"] - A.slaney_mel_basis()).max() < 1e-6 * z["mel"].max()
 
 
 def test_oracle_inv_preemphasis_inverts_preemphasis():
