@@ -590,7 +590,10 @@ class _PowerSampler(object):
 class TrainRun(object):
     """model + trainer + resident batch of one (preset, gemm mode); .measure() = the contract's timed loop"""
 
-    def __init__(self, dev, pg, rank, world, preset, gemm, batch, text_len, frames, graph, ragged=False):
+    def __init__(self, dev, pg, rank, world, preset, gemm, batch, text_len, frames, graph, ragged=False, standin=None,
+                 trainer_kw=None):
+        """standin: a dist.RingStandin in the process group's place (one GPU, no group): the data-parallel step's bucket
+        schedule with a measurement stand-in for the ring kernels (configs.ddp_standin)"""
         from deepvoice3_pytorch_amd import builder, train_step, ops
         self.ops, self.train_step = ops, train_step
         self.prev_mode = ops.set_gemm_precision(gemm)
@@ -601,7 +604,8 @@ class TrainRun(object):
         torch.manual_seed(0)            # identical initial weights on every rank
         self.model = getattr(builder, bname)(**self.hp).to(dev)
         cfg = train_step.TrainConfig(max_positions=self.hp["max_positions"], guided_attention_sigma=ga_sigma)
-        self.trainer = train_step.Trainer(self.model, cfg, process_group=pg)
+        self.trainer = train_step.Trainer(self.model, cfg, process_group=standin if standin is not None else pg,
+                                          **(trainer_kw or {}))
         rng = np.random.RandomState(1234 + rank)
         self.bt = synth_batch(rng, batch, text_len, frames, self.hp, fixed=not ragged)
         self.spk = torch.from_numpy(rng.randint(0, self.hp["n_speakers"], batch)) if self.hp["n_speakers"] > 1 else None
@@ -916,6 +920,41 @@ def ddp_world1_config(dev, preset, gemm, args, no_group_ms, steps=12, warmup=4):
     return out
 
 
+def ddp_standin_config(dev, preset, gemm, batch, args, no_group_ms, world=8, channels=16, threads=256, busbw_gbps=150.0,
+                       steps=12, warmup=4, bucket_mb=None):
+    """What ONE GPU can measure about the collective of an 8-GPU step: the data-parallel
+    step's bucket schedule with dist.RingStandin in the communicator's place -- `channels` persistent workgroups that
+    stream 2 (n - 1) / n of every bucket through HBM at the pace an n-rank xGMI ring would set (busbw), issued where the
+    bucket all-reduces are issued, awaited where they are awaited.  Reports the stretch of the step beside such a third
+    tenant of the CUs, the time the step stream waits for the last buckets, and the 8-GPU weak-scaling efficiency the two
+    predict: no_group_ms / standin_ms (every rank does the same work; the collective's wire time is in the stand-in's
+    pace).  Segmented replay, like the headline."""
+    from deepvoice3_pytorch_amd import dist as _dist
+    sd = _dist.RingStandin(world=world, channels=channels, threads=threads, busbw_gbps=busbw_gbps, device=dev)
+    kw = dict(bucket_mb=float(bucket_mb)) if bucket_mb is not None else None
+    run = TrainRun(dev, None, 0, 1, preset, gemm, batch, args.text_len, args.frames, graph=True, standin=sd, trainer_kw=kw)
+    try:
+        if not run.use_graph:
+            return dict(error=run.graph_error or "capture failed")
+        m = run.measure(steps, warmup, settle_s=args.settle)
+        comm = run.trainer.comm
+        sizes = [(hi - lo) * 4 for lo, hi, _ in comm.buckets]
+        wire = [sd.ideal_ms(b) for b in sizes]
+        seg = getattr(run.runner, "seg_buckets", None)
+        out = dict(ms_per_step=m["ms_per_step"], no_group_ms_per_step=no_group_ms,
+                   step_inflation=round(m["ms_per_step"] / no_group_ms, 4) if no_group_ms else None,
+                   allreduce_exposed_ms=m["allreduce_exposed_ms"],
+                   predicted_weak_scaling_efficiency=round(no_group_ms / m["ms_per_step"], 4) if no_group_ms else None,
+                   per_gpu_batch=batch, ranks_modelled=world, channels=channels, threads=threads, busbw_gbps=busbw_gbps,
+                   bucket_mb=[round(b / 2 ** 20, 2) for b in sizes],
+                   wire_ms_per_bucket=[round(w, 3) for w in wire], wire_ms_per_step=round(sum(wire), 3),
+                   buckets_issued_after_segment=[[int(b) for b in bs] for bs in seg] if seg is not None else None,
+                   host_enqueue_ms_per_step=m["host_enqueue_ms_per_step"])
+        return out
+    finally:
+        run.close()
+
+
 def _world1_group():
     """a world-size-1 "nccl" group in this process (no launcher): RCCL loads and runs its collectives on one device"""
     import torch.distributed as tdist
@@ -1201,6 +1240,20 @@ def main():
                 cfgs["dv3lj_b64_ragged_epoch"] = ragged_epoch_config(dev, args.preset, gemm, args)
             except Exception as e:
                 cfgs["dv3lj_b64_ragged_epoch"] = dict(error="%s: %s" % (type(e).__name__, e))
+            try:
+                # what one GPU can measure about the 8-GPU step's collective: a ring stand-in beside backward
+                ds = dict(note="dist.RingStandin (csrc/standin.hip) in the communicator's place: 16 persistent workgroups x 256 "
+                               "threads streaming 2*(7/8) of every gradient bucket at an assumed all-reduce busbw of 150 GB/s, "
+                               "issued / awaited where the bucket all-reduces are; nothing is reduced (one GPU). "
+                               "predicted_weak_scaling_efficiency = step without a group / step beside the stand-in; "
+                               "sweeps of channels / busbw / bucket size: profiles/r06_collective_standin.txt")
+                ds["dv3lj_" + gemm] = ddp_standin_config(dev, args.preset, gemm, args.batch, args, m["ms_per_step"])
+                ds["dv3lj_b16"] = ddp_standin_config(dev, args.preset, gemm, 16, args, cfgs.get("dv3lj_b16", {}).get("ms_per_step"))
+                ds["nyanko_bf16"] = ddp_standin_config(dev, "nyanko_ljspeech", "bf16", args.batch, args, cfgs["nyanko_bf16"]["ms_per_step"])
+                ds["vctk_bf16"] = ddp_standin_config(dev, "deepvoice3_vctk", "bf16", args.batch, args, cfgs["vctk_bf16"]["ms_per_step"])
+                cfgs["ddp_standin"] = ds
+            except Exception as e:
+                cfgs["ddp_standin"] = dict(error="%s: %s" % (type(e).__name__, e))
             try:
                 made = _world1_group()
                 import torch.distributed as tdist

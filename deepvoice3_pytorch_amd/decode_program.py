@@ -234,3 +234,45 @@ class StepProgram(object):
                 elif t > max_steps:
                     break
         return t
+
+
+class StepTrace(object):
+    """Per-step results of the module-by-module decode loops (the configurations the step program does not take):
+    each step's (B, 1, .) tensors are copied into stacked (B, capacity, .) buffers that double when full -- the host-side
+    shape of what the step program writes on the device -- so the loops end with three slices instead of three lists of
+    per-step tensors to squeeze, stack and transpose.  `stop` is the reference's rule (deepvoice3.py:469-473)."""
+
+    def __init__(self, min_steps, max_steps, teacher_forced):
+        self.min_steps, self.max_steps, self.teacher_forced = min_steps, max_steps, teacher_forced
+        self.n = 0
+        self.dones = []
+        self._bufs = None
+
+    def _room(self, parts):
+        if self._bufs is None:
+            cap = 64
+            self._bufs = [p.new_empty((p.size(0), cap) + tuple(p.shape[2:])) for p in parts]
+        elif self.n == self._bufs[0].size(1):
+            self._bufs = [torch.cat((b, torch.empty_like(b)), dim=1) for b in self._bufs]
+
+    def push(self, output, alignment, state, done):
+        parts = (output, alignment, state)
+        self._room(parts)
+        for b, p in zip(self._bufs, parts):
+            b[:, self.n:self.n + 1].copy_(p)
+        self.dones.append(done)
+        self.n += 1
+
+    @property
+    def last_output(self):
+        return self._bufs[0][:, self.n - 1:self.n].contiguous()
+
+    def stop(self, done):
+        """after push: the free-running loop ends once every item signalled done past min_steps, or past max_steps"""
+        if self.teacher_forced:
+            return False
+        return bool((done > 0.5).all() and self.n > self.min_steps) or self.n > self.max_steps
+
+    def result(self):
+        out, ali, st = (b[:, :self.n] for b in self._bufs)
+        return out.contiguous(), ali, self.dones, st.contiguous()

@@ -20,6 +20,7 @@ from . import ops
 from .modules import Conv1d, ConvTranspose1d, Embedding, Linear
 from .modules import key_lengths_i32, get_mask_from_lengths, SinusoidalEncoding, Conv1dGLU
 from . import conv as _conv
+from .decode_program import StepTrace
 
 
 def expand_speaker_embed(inputs_btc, speaker_embed=None, tdim=1):
@@ -417,7 +418,7 @@ class Decoder(nn.Module):
             v = att.value_projection.forward_bct(values_bct) if att.value_projection is not None else values_bct
             proj.append((k, v))
 
-        decoder_states, outputs, alignments, dones = [], [], [], []
+        trace = StepTrace(self.min_decoder_steps, self.max_decoder_steps, test_inputs is not None)
         last_attended = [torch.zeros(1, dtype=torch.int32, device=dev) if v else None
                          for v in self.force_monotonic_attention]
         num_attention_layers = sum([layer is not None for layer in self.attention])
@@ -463,13 +464,12 @@ class Decoder(nn.Module):
             step_pos = torch.ones((B, 1), dtype=torch.long, device=dev)
             graph, gout = None, None
         current_input = initial_input
-        while True:
-            if test_inputs is not None:
-                if t >= test_inputs.size(1):
-                    break
-                current_input = test_inputs[:, t, :].unsqueeze(1)
+        n_forced = test_inputs.size(1) if test_inputs is not None else None
+        while n_forced is None or t < n_forced:
+            if n_forced is not None:
+                current_input = test_inputs[:, t:t + 1, :]
             elif t > 0 and not graphed:
-                current_input = outputs[-1]
+                current_input = trace.last_output
 
             if not graphed:
                 frame_pos = torch.full((B, 1), t + 1, dtype=torch.long, device=dev)
@@ -488,27 +488,13 @@ class Decoder(nn.Module):
                             step_pos.add_(1)
                     graph.replay()
                     res = gout
-                output, done, decoder_state, ave_alignment = [r.clone() for r in res]
+                output, done, decoder_state, ave_alignment = res[0], res[1].clone(), res[2], res[3]
 
-            decoder_states += [decoder_state]
-            outputs += [output]
-            alignments += [ave_alignment]
-            dones += [done]
-
+            trace.push(output, ave_alignment, decoder_state, done)      # (copies: the graph's outputs are reused)
             t += 1
-            if test_inputs is None:
-                if (done > 0.5).all() and t > self.min_decoder_steps:
-                    break
-                elif t > self.max_decoder_steps:
-                    break
-
-        alignments = list(map(lambda x: x.squeeze(1), alignments))
-        decoder_states = list(map(lambda x: x.squeeze(1), decoder_states))
-        outputs = list(map(lambda x: x.squeeze(1), outputs))
-        alignments = torch.stack(alignments).transpose(0, 1)
-        decoder_states = torch.stack(decoder_states).transpose(0, 1).contiguous()
-        outputs = torch.stack(outputs).transpose(0, 1).contiguous()
-        return outputs, alignments, dones, decoder_states
+            if trace.stop(done):
+                break
+        return trace.result()
 
     def _fast_decode_eligible(self, Tk):
         """What the fused step program (csrc/decode_step.hip) takes; anything else runs the module-by-module

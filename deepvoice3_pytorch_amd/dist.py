@@ -41,7 +41,8 @@ class BucketedAllReduce(object):
         deepvoice3_vctk replay +16 % under a world-1 group on the driver's box, +1.4 % on another).  None: a collective
         stream of this object's own, picked to run beside `beside` (rounds 2-4)."""
         self.arena = arena
-        self.pg = process_group
+        self.standin = process_group if getattr(process_group, "is_standin", False) else None
+        self.pg = None if self.standin is not None else process_group
         # the collective stream: one whose work really overlaps with the streams backward runs on (`beside`; see
         # ops.concurrent_stream -- HIP streams share a few hardware queues)
         self.side = None
@@ -202,7 +203,13 @@ class BucketedAllReduce(object):
         """current stream = the issuing stream.  async_issue: the call returns a handle and the issuing stream is NOT made
         to wait for the collective (its next kernels -- the following layers' weight gradients -- run beside it); join()
         makes the step stream wait.  Inside a capture (single-graph replay) the call stays synchronous."""
-        if self.async_issue and not torch.cuda.is_current_stream_capturing():
+        if self.standin is not None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("RingStandin: the stand-in collectives are issued from the host (segmented replay or eager)")
+            self._works.append(self.standin.all_reduce(view))
+            if not self.async_issue:
+                self._sync_issued = True
+        elif self.async_issue and not torch.cuda.is_current_stream_capturing():
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
@@ -268,6 +275,58 @@ class BucketedAllReduce(object):
         synchronize); clears the record"""
         ev, self.exposed_events = self.exposed_events or [], []
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
+
+
+class RingStandin(object):
+    """An n-rank RCCL ring all-reduce as ONE GPU sees it -- a MEASUREMENT stand-in, not a collective (csrc/standin.hip):
+    `channels` persistent workgroups of `threads` threads that stream 2 (n - 1) / n x S bytes through HBM at the pace the
+    links would set (2 (n - 1) / n x S / busbw), on a communicator stream of its own that waits for the issuing stream's
+    position -- c10d's stream discipline.  Pass it to `train_step.Trainer(process_group=RingStandin(...))`: the bucket
+    schedule, the notifications and the issue points are the data-parallel step's; the gradients stay the single-GPU
+    step's (nothing is summed; world = 1 in the update).  What it measures: how much a step stretches when a third tenant
+    (after the input-gradient and weight-gradient queues) holds CUs and memory bandwidth while backward runs, and how
+    long the step stream waits for the last buckets (`allreduce_exposed_ms`).
+
+    busbw_gbps: the all-reduce "bus bandwidth" (rccl-tests' busbw = S / t x 2 (n - 1) / n) assumed for the node's xGMI
+    ring(s); MI355X: 7 links x ~153 GB/s per GPU, a ring is bound by one link per direction, RCCL runs several rings."""
+    is_standin = True
+
+    def __init__(self, world=8, channels=16, threads=256, busbw_gbps=150.0, device=None, avoid=()):
+        from . import ops as _ops
+        self.world, self.channels, self.threads, self.busbw_gbps = int(world), int(channels), int(threads), float(busbw_gbps)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(self.device):
+            self.stream = _ops.concurrent_stream(list(avoid), role="communicator stand-in") if avoid else torch.cuda.Stream()
+        self.scratch = torch.empty(32 << 20, dtype=torch.uint8, device=self.device)
+        self.launches, self.bytes = 0, 0
+
+    class _Work(object):
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):                      # c10d Work.wait(): the CURRENT stream waits for the collective's end
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def all_reduce(self, view):
+        """current stream = the issuing stream: the communicator stream waits for its position, runs the stand-in, and the
+        returned handle's wait() makes a stream wait for its end"""
+        from . import _lib
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+        n = view.numel() * view.element_size()
+        moved = int(2 * (self.world - 1) * n // self.world)
+        _lib.call("dv3_ring_standin", view.data_ptr(), n, self.scratch.data_ptr(), self.scratch.numel(), moved,
+                  self.channels, self.threads, self.busbw_gbps * 1e3, self.stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        self.launches += 1
+        self.bytes += moved
+        return RingStandin._Work(done)
+
+    def ideal_ms(self, n_bytes):
+        """duration the links alone give an all-reduce of n_bytes"""
+        return 2.0 * (self.world - 1) / self.world * n_bytes / (self.busbw_gbps * 1e9) * 1e3
 
 
 def init_from_env(backend=None, allow_single=False):

@@ -15,6 +15,7 @@ from .modules import Embedding, Linear, Conv1d, ConvTranspose1d
 from .modules import HighwayConv1d, get_mask_from_lengths, key_lengths_i32
 from .modules import position_encoding_init
 from .deepvoice3 import AttentionLayer, _c8_enter, _c8_leave, _conv1d_c8
+from .decode_program import StepTrace
 
 
 def _run_seq(mods, x):
@@ -44,6 +45,8 @@ def _run_seq(mods, x):
             x = _c8_enter(f(_c8_leave(x, f.in_channels)))
         else:
             x = f(x)
+            if isinstance(f, HighwayConv1d) and i + 1 < n:
+                ops.mark_sole_consumer(x)      # the next layer of the sequence is x's only consumer (ops.GateFuse)
         i += 1
     return _c8_leave(x, C)
 
@@ -295,21 +298,18 @@ class Decoder(nn.Module):
         k = att.key_projection.forward_bct(keys_bct) if att.key_projection is not None else keys_bct
         v = att.value_projection.forward_bct(values_bct) if att.value_projection is not None else values_bct
 
-        decoder_states, outputs, alignments, dones = [], [], [], []
+        trace = StepTrace(self.min_decoder_steps, self.max_decoder_steps, test_inputs is not None)
         last_attended = torch.zeros(1, dtype=torch.int32, device=dev) if self.force_monotonic_attention else None
-        t = 0
         if initial_input is None:
             initial_input = keys.new_zeros(B, 1, self.in_dim * self.r)
-        current_input = initial_input
-        while True:
+        n_forced = test_inputs.size(1) if test_inputs is not None else None
+        t = 0
+        while n_forced is None or t < n_forced:
             frame_pos = torch.full((B, 1), t + 1, dtype=torch.long, device=dev)
-            if test_inputs is not None:
-                if t >= test_inputs.size(1):
-                    break
-                current_input = test_inputs[:, t, :].unsqueeze(1)
+            if n_forced is not None:
+                current_input = test_inputs[:, t:t + 1, :]
             else:
-                if t > 0:
-                    current_input = outputs[-1]
+                current_input = trace.last_output if t > 0 else initial_input
             x = _run_seq_incremental(self.audio_encoder_modules, current_input)      # (B, 1, D)
             Q = x
             xq = ops.add_position_encoding(x.transpose(1, 2).contiguous(), frame_pos,
@@ -325,39 +325,19 @@ class Decoder(nn.Module):
             x = _run_seq_incremental(self.audio_decoder_modules, x)
             decoder_state = x
             x = self.last_conv.incremental_forward(x)
-            output = torch.sigmoid(x)
             done = torch.sigmoid(self.fc(x))
-            decoder_states += [decoder_state]
-            outputs += [output]
-            alignments += [alignment]
-            dones += [done]
+            trace.push(torch.sigmoid(x), alignment, decoder_state, done)
             t += 1
-            if test_inputs is None:
-                if (done > 0.5).all() and t > self.min_decoder_steps:
-                    break
-                elif t > self.max_decoder_steps:
-                    break
-
-        alignments = list(map(lambda x: x.squeeze(1), alignments))
-        decoder_states = list(map(lambda x: x.squeeze(1), decoder_states))
-        outputs = list(map(lambda x: x.squeeze(1), outputs))
-        alignments = torch.stack(alignments).transpose(0, 1)
-        decoder_states = torch.stack(decoder_states).transpose(0, 1).contiguous()
-        outputs = torch.stack(outputs).transpose(0, 1).contiguous()
-        return outputs, alignments, dones, decoder_states
+            if trace.stop(done):
+                break
+        return trace.result()
 
     def start_fresh_sequence(self):
-        _clear_modules(self.audio_encoder_modules)
-        _clear_modules(self.audio_decoder_modules)
-        self.last_conv.clear_buffer()
-
-
-def _clear_modules(modules):
-    for m in modules:
-        try:
+        """forget the incremental state of every layer that keeps one (nyanko.py:340-343)"""
+        stateful = [m for seq in (self.audio_encoder_modules, self.audio_decoder_modules) for m in seq
+                    if hasattr(m, "clear_buffer")] + [self.last_conv]
+        for m in stateful:
             m.clear_buffer()
-        except AttributeError:
-            pass
 
 
 class Converter(nn.Module):

@@ -227,7 +227,9 @@ class Trainer(object):
         self.comm = None
         if process_group is not None:
             from . import dist as _dist
-            self.world = torch.distributed.get_world_size(process_group)
+            # (a dist.RingStandin measures a ring's footprint on one GPU: the bucket schedule is the data-parallel step's,
+            # the arithmetic the single-GPU step's)
+            self.world = 1 if getattr(process_group, "is_standin", False) else torch.distributed.get_world_size(process_group)
             # the speaker table receives a gradient from every layer of every module: a bucket of its own
             shared = set(id(p) for n, p in model.named_parameters() if n.split(".")[-2:-1] == ["embed_speakers"])
             isolate = [i for i, p in enumerate(self.arena.params) if id(p) in shared]

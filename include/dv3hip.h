@@ -60,6 +60,13 @@ int dv3_debug_read(int what, void* dst, int64_t bytes);
  * assert that a shape was served by the kernel the benchmark times.  Returns the value (>= 0). */
 int dv3_debug_get(int what);
 
+/* Measurement stand-in for an n-rank RCCL ring all-reduce on ONE GPU (csrc/standin.hip; dist.RingStandin): `channels`
+ * persistent workgroups of `threads` (256 | 512) threads copy `bytes` (= 2 (n-1)/n x the bucket) from `src` (read only,
+ * wrapped) into `scratch` (wrapped) at `bytes_per_us` for all workgroups together (the links' pace, kept by spinning on
+ * the 100 MHz wall clock).  Reduces nothing.  Not on the product path.                                            */
+int dv3_ring_standin(const void* src, int64_t src_bytes, void* scratch, int64_t scratch_bytes, int64_t bytes,
+                     int32_t channels, int32_t threads, float bytes_per_us, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Epilogue modes of the tap-GEMM (dv3_conv_gemm_f32).
  * ------------------------------------------------------------------------------------ */

@@ -411,6 +411,78 @@ def test_north_star_c8pp_is_the_kernel_the_bench_times(dev, modes, d, causal):
             assert torch.equal(dp0[n], dp1[n]), (tag, n)
 
 
+@pytest.mark.parametrize("d,causal", [(1, False), (27, True)])
+def test_north_star_c8_training_pass_against_the_same_rounding_oracle(dev, modes, d, causal):
+    """The hop test_north_star_c8pp_is_the_kernel_the_bench_times leaves to the planes kernel: at
+    BASELINE's shape (B = 64 x 256 x 1024) the c8 TRAINING forward (keep-bytes, pre-gate save) and every gradient
+    DIRECTLY against the oracle evaluated with the same operand rounding (bf16 conv inputs incl. the weight-normed
+    weights -- so weight-norm packing is inside the comparison --, fp32 accumulate and tail) and the same dropout
+    decisions.  The full tensors are too slow for the host oracle's autograd: the loss weights are zero outside every
+    16th batch item, so the HIP path runs the benchmarked shape on the benchmarked kernels (variant 9101 asserted) while
+    the oracle differentiates only the sampled items (dx, dW, dg, dbias of a loss that touches nothing else are sums
+    over those items only)."""
+    ops = modes
+    from deepvoice3_pytorch_amd import modules, _lib
+    L = _lib.lib()
+    B, C, T, k, p = 64, 256, 1024, 3, 0.05
+    items = list(range(0, B, 16))
+    torch.manual_seed(0)
+    layer = modules.Conv1dGLU(1, 16, C, C, k, dropout=p, dilation=d, causal=causal, residual=True).to(dev).train()
+    layer._dv3_site = "l"
+    with torch.no_grad():
+        layer.conv.bias.uniform_(-0.1, 0.1)
+    x = torch.randn(B, C, T, device=dev).to(torch.bfloat16).float()
+    ops.set_gemm_precision("bf16")
+    ops.bf16_storage = True
+    for q in layer.parameters():
+        q.grad = None
+    xin = x.clone().requires_grad_(True)
+    w = torch.zeros(B, C, T, device=dev)
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    w_s = torch.randn(len(items), C, T, generator=gen)
+    w[items] = w_s.to(dev)
+    rec = {}
+    ops.dropout_state.manual_seed(3)
+    ops.dropout_state.record = rec
+    try:
+        y = ops.from_c8(layer(ops.to_c8(xin)))
+        v_fwd = L.dv3_debug_get(10)
+        (y * w).sum().backward()
+        v_bwd = L.dv3_debug_get(10)
+    finally:
+        ops.dropout_state.record = None
+    assert v_fwd in (9101, 9111) and v_bwd == 9101, (v_fwd, v_bwd)     # masked forward: 4-wave form by the rule; dgrad: 9101
+    bits, rows, Tm = rec["l"]
+    keep = torch.from_numpy(O.unpack_keep_bits(bits.cpu().numpy().view(np.uint32), rows, (Tm + 31) // 32, Tm)).float()
+    keep = keep.view(B, C, T)[items]
+
+    def drop(site, t, p_, layout):
+        return t * keep / (1 - p_)
+    sd = {"l.conv." + n: t.detach().cpu().clone().requires_grad_(True) for n, t in layer.conv.state_dict().items()}
+    xs = x[items].cpu().clone().requires_grad_(True)
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, prev_threads))
+    O.set_operand_rounding("bf16")
+    try:
+        want = O.conv1d_glu(sd, "l", xs, k, d, causal, True, p=p, drop=drop)
+        (want * w_s).sum().backward()
+    finally:
+        O.set_operand_rounding(None)
+        torch.set_num_threads(prev_threads)
+    # forward: a stored bf16 value against the fp32 tail of the same arithmetic -- half an ulp of the value, i.e. at most
+    # 2^-9 of the tensor's range (+ dropout scale placement: the HIP path scales the accumulators, the oracle the operand)
+    e_y = rel_err(y.detach()[items].cpu(), want.detach())
+    e_dx = rel_err(xin.grad[items].cpu(), xs.grad)
+    assert float(xin.grad[[i for i in range(B) if i not in items]].abs().max()) == 0.0
+    errs = dict(y=e_y, dx=e_dx)
+    for n, q in layer.conv.named_parameters():
+        errs[n] = rel_err(q.grad.cpu(), sd["l.conv." + n].grad)
+    assert e_y < 6e-3, errs
+    assert e_dx < 2e-2, errs
+    for n in ("weight_v", "weight_g", "bias"):
+        assert errs[n] < 2e-2, errs
+
+
 def test_c8pp_plain_and_fp32_output_forms(dev, modes):
     """1 x 1 layers through the same kernel: c8 -> c8 with activation / residuals, c8 -> fp32 (513 rows: not a multiple
     of anything), and their input gradients -- bit-identical to the planes kernel"""
