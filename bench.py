@@ -1248,7 +1248,10 @@ def main():
                                "predicted_weak_scaling_efficiency = step without a group / step beside the stand-in; "
                                "sweeps of channels / busbw / bucket size: profiles/r06_collective_standin.txt")
                 ds["dv3lj_" + gemm] = ddp_standin_config(dev, args.preset, gemm, args.batch, args, m["ms_per_step"])
-                ds["dv3lj_b16"] = ddp_standin_config(dev, args.preset, gemm, 16, args, cfgs.get("dv3lj_b16", {}).get("ms_per_step"))
+                # (per-GPU batch 16: 8 MB buckets throughout -- measured x1.056 against x1.090 with the 25 MB default,
+                #  profiles/r06_collective_standin.txt: a 25 MB bucket's wire time is 5 % of so short a step)
+                ds["dv3lj_b16"] = ddp_standin_config(dev, args.preset, gemm, 16, args, cfgs.get("dv3lj_b16", {}).get("ms_per_step"),
+                                                     bucket_mb=8.0)
                 ds["nyanko_bf16"] = ddp_standin_config(dev, "nyanko_ljspeech", "bf16", args.batch, args, cfgs["nyanko_bf16"]["ms_per_step"])
                 ds["vctk_bf16"] = ddp_standin_config(dev, "deepvoice3_vctk", "bf16", args.batch, args, cfgs["vctk_bf16"]["ms_per_step"])
                 cfgs["ddp_standin"] = ds

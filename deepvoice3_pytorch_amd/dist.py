@@ -43,6 +43,8 @@ class BucketedAllReduce(object):
         self.arena = arena
         self.standin = process_group if getattr(process_group, "is_standin", False) else None
         self.pg = None if self.standin is not None else process_group
+        if self.standin is not None and self.standin.stream is None and arena.grad.is_cuda:
+            self.standin.bind(list(beside) + [issue_stream])
         # the collective stream: one whose work really overlaps with the streams backward runs on (`beside`; see
         # ops.concurrent_stream -- HIP streams share a few hardware queues)
         self.side = None
@@ -295,10 +297,24 @@ class RingStandin(object):
         from . import ops as _ops
         self.world, self.channels, self.threads, self.busbw_gbps = int(world), int(channels), int(threads), float(busbw_gbps)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        with torch.cuda.device(self.device):
-            self.stream = _ops.concurrent_stream(list(avoid), role="communicator stand-in") if avoid else torch.cuda.Stream()
+        self.stream = None
+        if avoid:
+            self.bind(avoid)
         self.scratch = torch.empty(32 << 20, dtype=torch.uint8, device=self.device)
         self.launches, self.bytes = 0, 0
+
+    def bind(self, avoid):
+        """pick the communicator stream: one whose kernels really run BESIDE the streams backward runs on (HIP maps its
+        streams onto a few hardware queues, ops.concurrent_stream) -- a stand-in that shares a queue with the step stream
+        would measure that serialisation, not a ring's footprint (first sweep of round 6: step inflation 1.03 .. 1.29 for
+        one configuration, depending on which pool stream torch handed out)"""
+        from . import ops as _ops
+        with torch.cuda.device(self.device):
+            uniq = []
+            for st in avoid:
+                if st is not None and all(st != u for u in uniq):
+                    uniq.append(st)
+            self.stream = _ops.concurrent_stream(uniq, role="communicator stand-in")
 
     class _Work(object):
         def __init__(self, ev):
@@ -311,6 +327,8 @@ class RingStandin(object):
         """current stream = the issuing stream: the communicator stream waits for its position, runs the stand-in, and the
         returned handle's wait() makes a stream wait for its end"""
         from . import _lib
+        if self.stream is None:
+            self.bind([torch.cuda.current_stream()])
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.stream.wait_event(ev)

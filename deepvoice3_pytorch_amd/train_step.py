@@ -575,6 +575,7 @@ class GraphedTrainer(object):
             split_streams = trainer.side_stream is not None and os.environ.get("DV3_SPLIT_GRAPH", "1") not in ("0", "")
         self.split = bool(split_streams) and trainer.side_stream is not None
         self.chunk = int(chunk or os.environ.get("DV3_SPLIT_CHUNK", "0"))      # 0: chosen after the warm-up steps
+        self.cut_on_bucket = os.environ.get("DV3_CUT_ON_BUCKET", "1") not in ("0", "")
         self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
         self._prev_offset = ops.dropout_state.dev_offset        # restored by close()
         ops.dropout_state.dev_offset = self.seed_offset
@@ -638,7 +639,12 @@ class GraphedTrainer(object):
 
         def on_fork():
             st["forks"] += 1
-            if st["forks"] % self.chunk == 0:
+            # data parallel (round 6): a bucket that became complete inside this segment ends it -- its all-reduce is
+            # issued from the host right after the segment it closes, not `chunk` layers later (nyanko's encoder, 49 MB in
+            # five buckets, used to be final only with the last segment: 0.66 ms of exposed wait beside a ring stand-in,
+            # profiles/r06_collective_standin.txt)
+            bucket_done = t.comm is not None and bool(t.comm._completed) and self.cut_on_bucket
+            if st["forks"] % self.chunk == 0 or bucket_done:
                 end_seg()
                 begin_seg()
 

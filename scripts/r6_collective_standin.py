@@ -31,7 +31,7 @@ for preset, gemm, B in CASES:
     print("%s %s B=%d: no group %.3f ms/step" % (preset, gemm, B, base), flush=True)
     points = [dict()]
     if not quick:
-        points += [dict(channels=c) for c in (4, 8, 32)] + [dict(busbw_gbps=b) for b in (75.0, 300.0)] + \
+        points += [dict(channels=c) for c in (4, 8, 32, 64)] + [dict(busbw_gbps=b) for b in (75.0, 300.0)] + \
                   [dict(bucket_mb=m) for m in (8.0, 50.0)] + [dict(threads=512)]
     for kw in points:
         r = bench.ddp_standin_config(dev, preset, gemm, B, args, base, **kw)
