@@ -87,8 +87,41 @@ __device__ __forceinline__ void wt2_realign(float (&v)[8], int sh) {
 
 // GP (round 6): g holds PAIR WORDS (include/dv3hip.h: dv3_wgrad_desc.g_pair) -- its unit is staged with eight v_perm_b32
 // instead of the fp32 -> bf16-pair conversion (the validity masks and the re-alignment act on whole words either way)
-template <bool MASK, int ABL = 0, bool GP = false>
+//
+// DIL (round 6, "one window for the three taps"): 0 = the form above (per tap: two 16-byte loads of the 8 shifted
+// elements, their keep-bits, one fp32 -> pair conversion -- 24 conversions per x unit, three quarters of the vector work
+// of a step, which is what keeps this kernel at a third of its roof: all eight waves convert at the same time and the
+// matrix pipe waits).  1 / 3 = the dilation is this compile-time constant (every layer of the three presets whose grid
+// matters: the converter's and the decoder's d = 1 and 3 layers): the three taps of a unit read the overlapping windows
+// [t - padL + j d, + 8), so ONE window of 8 + 2 d elements is fetched (three / four 16-byte loads instead of six),
+// masked (one pair of keep-bit words instead of three) and converted ONCE (10 / 14 conversions instead of 24), and the
+// three shifted units are cut out of the converted window: dwords as they are for an even element shift, one
+// v_alignbit_b32 per dword for an odd one.  The same pair per element as the per-tap form: bit-identical slabs.
+template <int N>
+__device__ __forceinline__ void wt2_realign_n(float (&v)[N], int sh) {
+  asm volatile("" : "+v"(sh));        // (see wt2_realign: keep the select chains inside the rare branch)
+  float w[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    float x = 0.f;
+#pragma unroll
+    for (int q = 0; q < N; ++q) x = (e + sh == q) ? v[q] : x;
+    w[e] = x;
+  }
+#pragma unroll
+  for (int e = 0; e < N; ++e) v[e] = w[e];
+}
+// bit e set <=> 0 <= t + e < len, e < n
+__device__ __forceinline__ uint32_t wt2_valid_n(int t, int len, int n) {
+  const int elo = max(0, -t), ehi = min(n, len - t);
+  return ehi > elo ? (((1u << ehi) - 1u) & ~((1u << elo) - 1u)) : 0u;
+}
+template <bool MASK, int ABL = 0, bool GP = false, int DIL = 0>
 __global__ __launch_bounds__(NT) void wgrad_taps2_kernel(const WgradT2Args args) {
+  static_assert(DIL == 0 || DIL == 1 || DIL == 3, "window form: d = 1 or 3");
+  constexpr int WLEN = 8 + 2 * DIL;                 // elements of the window of one unit
+  constexpr int NW4 = (WLEN + 3) / 4;               // 16-byte loads per window
+  constexpr int WL = DIL > 0 ? 4 * NW4 : 1;
   const dv3_wgrad_desc& p = args.d;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_t2[];
   bf16x8* const smem = reinterpret_cast<bf16x8*>(smem_raw_t2);       // [2 buffers][G hi, G lo | 3 x (X hi, X lo)]
@@ -108,8 +141,9 @@ __global__ __launch_bounds__(NT) void wgrad_taps2_kernel(const WgradT2Args args)
   const int urow = tid >> 2, uk8 = tid & 3;
   // the two register sets hold RAW fetched data only (32 + 6 registers each); validity masks, clamp distances and the
   // dropout word alignment are recomputed from the step index when the set is converted
-  float rg[2][8], rx[2][JT][8];
-  uint32_t mlo[MASK ? 2 : 1][JT], mhi[MASK ? 2 : 1][JT];
+  float rg[2][8], rx[2][DIL > 0 ? 1 : JT][DIL > 0 ? 1 : 8];
+  float rw[2][WL];                                  // window form: the raw window of each register set
+  uint32_t mlo[MASK ? 2 : 1][DIL > 0 ? 1 : JT], mhi[MASK ? 2 : 1][DIL > 0 ? 1 : JT];
   const int n_tc = (T + BKT - 1) / BKT;
   int nsteps, step0 = 0;
   {
@@ -134,6 +168,22 @@ __global__ __launch_bounds__(NT) void wgrad_taps2_kernel(const WgradT2Args args)
     const int t0 = tc * BKT;
     const int gb = b * (int)p.g_bs + t0, xb = b * (int)p.x_bs + t0;
     (void)wt2_load8(p.g, gb + grow_off, g_total, rg[S]);
+    if constexpr (DIL > 0) {
+      const int woff = xb + xrow_off - p.padL;
+      const int offc = min(max(woff, 0), x_total - WL);
+#pragma unroll
+      for (int q = 0; q < NW4; ++q) {
+        const f32x4u a = wt2_ldg<f32x4u>(p.x, (uint32_t)(offc + 4 * q) * 4u);
+        rw[S][4 * q] = a[0]; rw[S][4 * q + 1] = a[1]; rw[S][4 * q + 2] = a[2]; rw[S][4 * q + 3] = a[3];
+      }
+      if constexpr (MASK) {
+        const int tx = t0 + uk8 * 8 - p.padL;
+        const uint32_t mo = (uint32_t)(b * Cin * p.xmask_rs + xm_off);
+        const int w0 = min(max(tx, 0) >> 5, wl);
+        mlo[S][0] = wt2_ldg<uint32_t>(p.xmask, (mo + (uint32_t)w0) * 4u);
+        mhi[S][0] = wt2_ldg<uint32_t>(p.xmask, (mo + (uint32_t)min(w0 + 1, wl)) * 4u);
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
       const int shift = j * p.dil - p.padL;
@@ -173,6 +223,59 @@ __global__ __launch_bounds__(NT) void wgrad_taps2_kernel(const WgradT2Args args)
       dst[o] = hi;
       dst[KB * LDM + o] = lo;
     }
+    if constexpr (DIL > 0) {
+      const int woff = xb + xrow_off - p.padL;
+      const int sh = woff - min(max(woff, 0), x_total - WL);
+      const int tx = t0 + uk8 * 8 - p.padL;                          // time of the window's element 0
+      constexpr uint32_t FULL = (1u << WLEN) - 1u;
+      uint32_t xm = FULL;
+      const bool x_edge = t0 - p.padL < 0 || t0 + BKT - p.padL + 2 * DIL > Tin;   // (uniform)
+      if (x_edge) xm = wt2_valid_n(tx, Tin, WLEN);
+      if (!xrow_ok) xm = 0u;
+      if constexpr (MASK) {
+        uint32_t bits = __builtin_amdgcn_alignbit(mhi[S][0], mlo[S][0], (uint32_t)(max(tx, 0) & 31));
+        if (x_edge && tx < 0) bits = (-tx < 32) ? bits << (-tx) : 0u;
+        xm &= bits;
+      }
+      if (__any(sh != 0)) wt2_realign_n<WL>(rw[S], sh);
+      if (MASK || __any(xm != FULL)) {
+#pragma unroll
+        for (int e = 0; e < WLEN; ++e)
+          rw[S][e] = __uint_as_float(__float_as_uint(rw[S][e]) & (uint32_t)__builtin_amdgcn_sbfe((int)xm, e, 1));
+      }
+      // the window as bf16 pairs, two elements per dword and plane
+      uint32_t hw[WLEN / 2], lw[WLEN / 2];
+#pragma unroll
+      for (int k = 0; k < WLEN / 2; ++k) {
+        const f32x2 f = {rw[S][2 * k], rw[S][2 * k + 1]};
+        const bf16x2 h = __builtin_convertvector(f, bf16x2);
+        const f32x2 r = f - __builtin_convertvector(h, f32x2);
+        const bf16x2 l = __builtin_convertvector(r, bf16x2);
+        hw[k] = __builtin_bit_cast(uint32_t, h);
+        lw[k] = __builtin_bit_cast(uint32_t, l);
+      }
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        constexpr int dummy = 0; (void)dummy;
+        const int e0 = j * DIL;                                      // element of the window the tap's unit starts at
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        u32x4_ h4, l4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if ((e0 & 1) == 0) {
+            h4[i] = hw[e0 / 2 + i];
+            l4[i] = lw[e0 / 2 + i];
+          } else {
+            h4[i] = __builtin_amdgcn_alignbit(hw[(e0 + 1) / 2 + i], hw[(e0 - 1) / 2 + i], 16u);
+            l4[i] = __builtin_amdgcn_alignbit(lw[(e0 + 1) / 2 + i], lw[(e0 - 1) / 2 + i], 16u);
+          }
+        }
+        bf16x8* dx = dst + GBUF + j * XTAP;
+        const int o = uk8 * LDN + urow;
+        dx[o] = __builtin_bit_cast(bf16x8, h4);
+        dx[KB * LDN + o] = __builtin_bit_cast(bf16x8, l4);
+      }
+    } else
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
       bf16x8* dx = dst + GBUF + j * XTAP;
@@ -275,12 +378,12 @@ __global__ __launch_bounds__(NT) void wgrad_taps2_kernel(const WgradT2Args args)
   }
 }
 
-template <bool MASK, int ABL = 0, bool GP = false>
+template <bool MASK, int ABL = 0, bool GP = false, int DIL = 0>
 int launch_wgrad_taps2(const WgradT2Args& a, int64_t nb, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * BUF * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_taps2_kernel<MASK, ABL, GP>,
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_taps2_kernel<MASK, ABL, GP, DIL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("wgrad_taps2: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -288,12 +391,13 @@ int launch_wgrad_taps2(const WgradT2Args& a, int64_t nb, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_taps2_kernel<MASK, ABL, GP>), dim3((unsigned)nb), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL((wgrad_taps2_kernel<MASK, ABL, GP, DIL>), dim3((unsigned)nb), dim3(NT), lds, st, a);
   return dv3_check_launch("wgrad_taps2");
 }
 
 }  // namespace
 
+int g_wgrad_t2_window = 1;   // dv3_debug_set(47, v): the one-window-for-three-taps form of d = 1 / 3 launches (0 = the per-tap form)
 int g_wgrad_t2_abl = 0;   // dv3_debug_set(16, v): timing-only ablations (1 no MFMAs, 2 no staging, 6 k16 blocks not pinned apart)
 
 // three taps, three-term split, K split over contiguous ranges (called by dv3_wgrad_gemm_bf16x3_dispatch)
@@ -314,9 +418,13 @@ int dv3_wgrad_taps2_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
     }
   }
 #endif
-  if (d->g_pair) {
-    g_dv3_last_wgrad += 1;                       // ...41: pair-word g operand
-    return d->xmask ? launch_wgrad_taps2<true, 0, true>(a, nb, st) : launch_wgrad_taps2<false, 0, true>(a, nb, st);
-  }
-  return d->xmask ? launch_wgrad_taps2<true>(a, nb, st) : launch_wgrad_taps2<false>(a, nb, st);
+  // window form (kernel template DIL): d = 1 or 3, a tensor long enough for the window's loads
+  const int win = (g_wgrad_t2_window && (d->dil == 1 || d->dil == 3) &&
+                   (int64_t)(d->B - 1) * d->x_bs + (int64_t)(d->Cin - 1) * d->x_rs + d->Tin >= 16) ? d->dil : 0;
+  g_dv3_last_wgrad += (d->g_pair ? 1 : 0) + (win ? 2 : 0);     // ...41 pair-word g, 42 window form, 43 both
+#define DV3_T2(M, G) \
+  (win == 1 ? launch_wgrad_taps2<M, 0, G, 1>(a, nb, st) : win == 3 ? launch_wgrad_taps2<M, 0, G, 3>(a, nb, st) : launch_wgrad_taps2<M, 0, G, 0>(a, nb, st))
+  if (d->g_pair) return d->xmask ? DV3_T2(true, true) : DV3_T2(false, true);
+  return d->xmask ? DV3_T2(true, false) : DV3_T2(false, false);
+#undef DV3_T2
 }

@@ -823,6 +823,16 @@ def _conv_gemm_c8(x, a, lda, a_half, *, B, Cin, Tin, M, Tout, J, dil, padL, mode
     return y
 
 
+def pair_words_of(x):
+    """fp32 tensor -> the same-shape tensor of PAIR WORDS (include/dv3hip.h: (bf16_rn(v) << 16) | bf16_rn(v - bf16_rn(v)),
+    stored in an fp32-typed tensor), computed with torch ops: what dv3_gate_bwd_f32(dab_pair) / the fused tails write.
+    For tests and micro-benchmarks that need a pair-word operand without running a gate backward."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    w = (hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xffff)
+    return w.view(torch.float32)
+
+
 def wgrad_gemm_c8(g8, x8, *, B, M, Cin, T, J, dil, padL, n_slabs, xmask_c8=None, drop_scale=1.0, rows_of_slabs=False):
     """dv3_wgrad_gemm_f32, c8 form: g8 (B, M/8.., T, 8), x8 (B, Cin/8.., T, 8) -> out [S][J][M][Cin]
     (rows_of_slabs: [J][M][S][Cin], see wgrad_gemm)"""

@@ -550,14 +550,22 @@ def test_fused_attention_forward_equals_unfused(dev, gemm_mode, B, E, Tq, Tk, p)
 @pytest.mark.parametrize("mode", ["f16x3", "bf16x3"])
 @pytest.mark.parametrize("B,M,C,T,d,masked,S", [(3, 128, 64, 75, 2, False, 2), (2, 512, 256, 150, 27, True, 3),
                                                (4, 96, 200, 61, 9, True, 5), (5, 256, 128, 800, 1, True, 7),
-                                               (2, 130, 130, 33, 3, True, 2), (6, 72, 64, 100, 1, False, 19)])
+                                               (2, 130, 130, 33, 3, True, 2), (6, 72, 64, 100, 1, False, 19),
+                                               (3, 128, 96, 50, -1, True, 3), (2, 256, 64, 804, -3, True, 4),
+                                               (1, 70, 70, 9, 3, True, 1), (2, 128, 128, 16, -3, False, 2),
+                                               (4, 512, 256, 201, 3, False, 6)])
 def test_two_steps_ahead_wgrad_equals_the_all_taps_wgrad(dev, mode, B, M, C, T, d, masked, S):
     """wgrad_taps2_kernel (csrc/wgrad_taps2.hip, the default weight-gradient kernel: operand units of the NEXT two steps
     in flight as raw registers) against wgrad_taps_kernel: the K-slab partial sums are bit-identical (same tile, slab
     and accumulation order), ragged channel counts, dilations up to 27 and masked operands included; the variant each
-    call served is read back (dv3_debug_get(11))."""
+    call served is read back (dv3_debug_get(11)).  Round 6: for d = 1 and 3 the default is the WINDOW form (one window of
+    8 + 2 d elements per unit fetched, masked and converted once for the three taps: variant ...42): bit-identical to the
+    per-tap form (dv3_debug_set(47, 0)) and to the all-taps kernel, same-padded (d > 0 here) and causal (d < 0: padL = 2 |d|),
+    sequences shorter than a window included."""
     from deepvoice3_pytorch_amd import ops, _lib
     L = _lib.lib()
+    causal, d = d < 0, abs(d)
+    padL = 2 * d if causal else d
     prev = ops.set_gemm_precision(mode)
     try:
         torch.manual_seed(1)
@@ -568,16 +576,21 @@ def test_two_steps_ahead_wgrad_equals_the_all_taps_wgrad(dev, mode, B, M, C, T, 
             ops.dropout_state.manual_seed(3)
             bits, rs = ops.dropout_bits(B * C, T, 0.05, dev)
         outs = []
-        for tile in (3, 4):         # dv3_debug_set(2, .): 3 = all-taps kernel, 4 = two-steps-ahead kernel
+        # dv3_debug_set(2, .): 3 = all-taps kernel, 4 = two-steps-ahead kernel; (47, .): its window form on / off
+        for tile, win in ((3, 1), (4, 1), (4, 0)):
             L.dv3_debug_set(2, tile)
-            o = ops.wgrad_gemm(g, x, B=B, M=M, Cin=C, T=T, Tin=T, J=3, dil=d, padL=d, n_slabs=S, xmask=bits,
+            L.dv3_debug_set(47, win)
+            o = ops.wgrad_gemm(g, x, B=B, M=M, Cin=C, T=T, Tin=T, J=3, dil=d, padL=padL, n_slabs=S, xmask=bits,
                                xmask_rs=rs or 0, drop_scale=1 / 0.95 if masked else 1.0, split_bf16=True, k_split=True)
             outs.append((o.clone(), L.dv3_debug_get(11)))
     finally:
         L.dv3_debug_set(2, 0)
+        L.dv3_debug_set(47, 1)
         ops.set_gemm_precision(prev)
-    assert outs[0][1] % 1000 == 30 and outs[1][1] % 1000 == 40, (outs[0][1], outs[1][1])
+    windowed = d in (1, 3) and (B - 1) * C * T + (C - 1) * T + T >= 16
+    assert outs[0][1] % 1000 == 30 and outs[1][1] % 1000 == (42 if windowed else 40) and outs[2][1] % 1000 == 40, [o[1] for o in outs]
     assert torch.equal(outs[0][0], outs[1][0]), float((outs[0][0] - outs[1][0]).abs().max())
+    assert torch.equal(outs[0][0], outs[2][0]), float((outs[0][0] - outs[2][0]).abs().max())
 
 
 @pytest.mark.parametrize("B,C,T,d,causal,masked", [(3, 64, 75, 2, False, True), (2, 256, 150, 27, False, False),
