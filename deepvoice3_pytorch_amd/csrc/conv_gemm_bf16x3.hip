@@ -1046,7 +1046,7 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   return 1;
 }
 
-extern int g_wgrad_tile, g_wgrad_prio, g_wgrad_t2_abl, g_wgrad_taps2_default, g_wgrad_t2_window;   // wgrad_gemm_bf16x3.hip, wgrad_taps2.hip
+extern int g_wgrad_tile, g_wgrad_prio, g_wgrad_t2_abl, g_wgrad_taps2_default, g_wgrad_t2_window, g_wgrad_t2_il;   // wgrad_gemm_bf16x3.hip, wgrad_taps2.hip
 extern int g_wgrad_c8_pf2, g_spk_abl;                                                       // wgrad_c8.hip
 int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 int dv3_c8pp_debug_set(int what, int value);     // conv_c8pp.hip
@@ -1091,6 +1091,7 @@ extern "C" int dv3_debug_set(int what, int value) {
   if (what == 16) g_wgrad_t2_abl = value;
   if (what == 17) g_wgrad_taps2_default = value;
   if (what == 47) g_wgrad_t2_window = value;
+  if (what == 48) g_wgrad_t2_il = value;
   if (what == 1) g_x3_ablate = value;
   if (what == 2) g_wgrad_tile = value;
   if (what == 3) g_x3_pingpong = value;

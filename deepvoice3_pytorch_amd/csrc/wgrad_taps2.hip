@@ -116,9 +116,19 @@ __device__ __forceinline__ uint32_t wt2_valid_n(int t, int len, int n) {
   const int elo = max(0, -t), ehi = min(n, len - t);
   return ehi > elo ? (((1u << ehi) - 1u) & ~((1u << elo) - 1u)) : 0u;
 }
-template <bool MASK, int ABL = 0, bool GP = false, int DIL = 0>
+// IL (window forms): the staging of the NEXT step's tile -- masking, conversion, cutting, LDS stores: ~100 vector
+// instructions that touch nothing the current step's MFMAs read -- is issued BETWEEN those MFMAs
+// (__builtin_amdgcn_sched_group_barrier: a few vector instructions behind each matrix instruction) instead of after them.
+// All eight waves run in phase here, so "after" means every wave converts while the matrix pipes of the CU idle; the
+// matrix pipe takes one instruction per 32 cycles from a wave, the conversion rides in the issue slots it leaves.  What
+// makes it possible: the window form's register set (186-202 against the per-tap form's 214-230; round 5's attempt needed
+// ~246 and spilled).  The rare paths that branch (re-alignment at the tensor's two ends, the validity mask of a g unit
+// in a row tail) run BEFORE the interleaved region -- a branch would cut the scheduling region -- and the x window's
+// validity / keep mask is applied unconditionally (it is two instructions per element).  Same values: bit-identical slabs.
+template <bool MASK, int ABL = 0, bool GP = false, int DIL = 0, bool IL = false>
 __global__ __launch_bounds__(NT) void wgrad_taps2_kernel(const WgradT2Args args) {
   static_assert(DIL == 0 || DIL == 1 || DIL == 3, "window form: d = 1 or 3");
+  static_assert(!IL || (DIL > 0 && ABL == 0), "interleaved staging: the window forms");
   constexpr int WLEN = 8 + 2 * DIL;                 // elements of the window of one unit
   constexpr int NW4 = (WLEN + 3) / 4;               // 16-byte loads per window
   constexpr int WL = DIL > 0 ? 4 * NW4 : 1;
@@ -335,9 +345,169 @@ __global__ __launch_bounds__(NT) void wgrad_taps2_kernel(const WgradT2Args args)
       }
     }
   };
+  // ---- IL: the step's pieces as separate lambdas ----
+  uint32_t xrow_bits = xrow_ok ? 0xffffffffu : 0u;
+  asm volatile("" : "+v"(xrow_bits));          // opaque: keeps the compiler from turning the AND back into a branch on xrow_ok
+  auto step_coords = [&](int step, int& t0, int& gb, int& xb) __attribute__((always_inline)) {
+    const int gs = step0 + min(step, nsteps - 1);
+    const int b = gs / n_tc, tc = gs - b * n_tc;
+    t0 = tc * BKT;
+    gb = b * (int)p.g_bs + t0;
+    xb = b * (int)p.x_bs + t0;
+  };
+  // rare, branching fix-ups of register set S (the tile of `step`): before the interleaved region
+  auto fix_step = [&](int step, auto set_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_c)::value;
+    int t0, gb, xb;
+    step_coords(step, t0, gb, xb);
+    {
+      const int off = gb + grow_off;
+      const int sh = off - min(max(off, 0), g_total - 8);
+      uint32_t vm = 0xffu;
+      if (t0 + BKT > T) vm = wt2_valid8(t0 + uk8 * 8, T);
+      if (!grow_ok) vm = 0u;
+      if (__any(sh != 0)) wt2_realign(rg[S], sh);
+      if (__any(vm != 0xffu)) wt2_mask8(rg[S], vm);
+    }
+    if constexpr (DIL > 0) {
+      const int woff = xb + xrow_off - p.padL;
+      const int sh = woff - min(max(woff, 0), x_total - WL);
+      if (__any(sh != 0)) wt2_realign_n<WL>(rw[S], sh);
+    }
+  };
+  // vector part 1: the g unit's pair, the x window masked and converted (hw / lw: the window as bf16 pairs)
+  auto conv_part1 = [&](int step, auto set_c, bf16x8& ghi, bf16x8& glo, uint32_t (&hw)[WLEN / 2], uint32_t (&lw)[WLEN / 2]) __attribute__((always_inline)) {
+    constexpr int S = decltype(set_c)::value;
+    int t0, gb, xb;
+    step_coords(step, t0, gb, xb);
+    if constexpr (GP) {
+      uint32_t w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(rg[S][e]);
+      dv3_pair_units(w, ghi, glo);
+    } else wt2_split8(rg[S], ghi, glo);
+    const int tx = t0 + uk8 * 8 - p.padL;
+    uint32_t xm = wt2_valid_n(tx, Tin, WLEN) & xrow_bits;      // (no control flow: a branch would cut the scheduling region)
+    if constexpr (MASK) {
+      uint32_t bits = __builtin_amdgcn_alignbit(mhi[S][0], mlo[S][0], (uint32_t)(max(tx, 0) & 31));
+      const uint32_t shifted = (-tx < 32) ? bits << ((-tx) & 31) : 0u;
+      bits = tx < 0 ? shifted : bits;
+      xm &= bits;
+    }
+#pragma unroll
+    for (int k = 0; k < WLEN / 2; ++k) {
+      const float a0 = __uint_as_float(__float_as_uint(rw[S][2 * k]) & (uint32_t)__builtin_amdgcn_sbfe((int)xm, 2 * k, 1));
+      const float a1 = __uint_as_float(__float_as_uint(rw[S][2 * k + 1]) & (uint32_t)__builtin_amdgcn_sbfe((int)xm, 2 * k + 1, 1));
+      const f32x2 f = {a0, a1};
+      const bf16x2 h = __builtin_convertvector(f, bf16x2);
+      const f32x2 r = f - __builtin_convertvector(h, f32x2);
+      const bf16x2 l = __builtin_convertvector(r, bf16x2);
+      hw[k] = __builtin_bit_cast(uint32_t, h);
+      lw[k] = __builtin_bit_cast(uint32_t, l);
+    }
+  };
+  // vector part 2 + the eight LDS stores
+  auto conv_part2 = [&](int buf, const bf16x8& ghi, const bf16x8& glo, const uint32_t (&hw)[WLEN / 2], const uint32_t (&lw)[WLEN / 2]) __attribute__((always_inline)) {
+    bf16x8* dst = smem + buf * BUF;
+    {
+      const int o = uk8 * LDM + urow;
+      dst[o] = ghi;
+      dst[KB * LDM + o] = glo;
+    }
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      constexpr int dummy = 0; (void)dummy;
+      const int e0 = j * DIL;
+      typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+      u32x4_ h4, l4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((e0 & 1) == 0) {
+          h4[i] = hw[e0 / 2 + i];
+          l4[i] = lw[e0 / 2 + i];
+        } else {
+          h4[i] = __builtin_amdgcn_alignbit(hw[(e0 + 1) / 2 + i], hw[(e0 - 1) / 2 + i], 16u);
+          l4[i] = __builtin_amdgcn_alignbit(lw[(e0 + 1) / 2 + i], lw[(e0 - 1) / 2 + i], 16u);
+        }
+      }
+      bf16x8* dx = dst + GBUF + j * XTAP;
+      const int o = uk8 * LDN + urow;
+      dx[o] = __builtin_bit_cast(bf16x8, h4);
+      dx[KB * LDN + o] = __builtin_bit_cast(bf16x8, l4);
+    }
+  };
+  // one k16 block of the current tile: ten fragment reads, eighteen MFMAs
+  auto mfma_ks = [&](int cur, auto ks_c) __attribute__((always_inline)) {
+    constexpr int ks = decltype(ks_c)::value;
+    const bf16x8* GsH = smem + cur * BUF;
+    const bf16x8* GsL = GsH + KB * LDM;
+    const int k8 = 2 * ks + lhi;
+    const int ai = k8 * LDM + wm * 64 + l31;
+    const bf16x8 ah0 = GsH[ai], ah1 = GsH[ai + 32];
+    const bf16x8 al0 = GsL[ai], al1 = GsL[ai + 32];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const bf16x8* XsH = GsH + GBUF + j * XTAP;
+      const int xi = k8 * LDN + wc * 32 + l31;
+      const bf16x8 bh = XsH[xi];
+      const bf16x8 bl = XsH[KB * LDN + xi];
+      acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, acc[j][0], 0, 0, 0);
+      acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc[j][1], 0, 0, 0);
+      acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, acc[j][0], 0, 0, 0);
+      acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc[j][1], 0, 0, 0);
+      acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[j][0], 0, 0, 0);
+      acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[j][1], 0, 0, 0);
+    }
+  };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
 
+  if constexpr (IL) {
+    if (nsteps > 0) {
+      load_step(0, S0{});
+      load_step(1, S1{});
+      write_step(0, 0, S0{});
+      load_step(2, S0{});
+      __syncthreads();
+      auto step = [&](int st, auto set_c) __attribute__((always_inline)) {
+        fix_step(st + 1, set_c);
+        bf16x8 ghi, glo;
+        uint32_t hw[WLEN / 2], lw[WLEN / 2];
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_ks(st & 1, std::integral_constant<int, 0>{});
+        conv_part1(st + 1, set_c, ghi, glo, hw, lw);
+        // (the address arithmetic of the fragment reads and the reads themselves head the pipeline: left unconstrained,
+        //  the solver hands those vector instructions to the first MFMA's group, finds no valid order and drops the lot)
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int m = 0; m < 18; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five VALU
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_ks(st & 1, std::integral_constant<int, 1>{});
+        conv_part2((st + 1) & 1, ghi, glo, hw, lw);
+#pragma unroll
+        for (int m = 0; m < 10; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // one DS write
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_step(st + 3, set_c);
+        __syncthreads();
+      };
+      for (int st = 0; st < nsteps; st += 2) {
+        step(st, S1{});
+        if (st + 1 < nsteps) step(st + 1, S0{});
+      }
+    }
+  } else
   if (nsteps > 0) {
     // ---- prologue: tile 0 -> buffer 0 (all waves); set 1 <- step 1, set 0 <- step 2 ----
     load_step(0, S0{});
@@ -378,12 +548,12 @@ __global__ __launch_bounds__(NT) void wgrad_taps2_kernel(const WgradT2Args args)
   }
 }
 
-template <bool MASK, int ABL = 0, bool GP = false, int DIL = 0>
+template <bool MASK, int ABL = 0, bool GP = false, int DIL = 0, bool IL = false>
 int launch_wgrad_taps2(const WgradT2Args& a, int64_t nb, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * BUF * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_taps2_kernel<MASK, ABL, GP, DIL>,
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_taps2_kernel<MASK, ABL, GP, DIL, IL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("wgrad_taps2: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -391,12 +561,13 @@ int launch_wgrad_taps2(const WgradT2Args& a, int64_t nb, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_taps2_kernel<MASK, ABL, GP, DIL>), dim3((unsigned)nb), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL((wgrad_taps2_kernel<MASK, ABL, GP, DIL, IL>), dim3((unsigned)nb), dim3(NT), lds, st, a);
   return dv3_check_launch("wgrad_taps2");
 }
 
 }  // namespace
 
+int g_wgrad_t2_il = 1;       // dv3_debug_set(48, v): the window forms stage the next tile between the MFMAs (0 = after them)
 int g_wgrad_t2_window = 1;   // dv3_debug_set(47, v): the one-window-for-three-taps form of d = 1 / 3 launches (0 = the per-tap form)
 int g_wgrad_t2_abl = 0;   // dv3_debug_set(16, v): timing-only ablations (1 no MFMAs, 2 no staging, 6 k16 blocks not pinned apart)
 
@@ -421,9 +592,12 @@ int dv3_wgrad_taps2_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
   // window form (kernel template DIL): d = 1 or 3, a tensor long enough for the window's loads
   const int win = (g_wgrad_t2_window && (d->dil == 1 || d->dil == 3) &&
                    (int64_t)(d->B - 1) * d->x_bs + (int64_t)(d->Cin - 1) * d->x_rs + d->Tin >= 16) ? d->dil : 0;
-  g_dv3_last_wgrad += (d->g_pair ? 1 : 0) + (win ? 2 : 0);     // ...41 pair-word g, 42 window form, 43 both
+  const bool il = win && g_wgrad_t2_il;
+  g_dv3_last_wgrad += (d->g_pair ? 1 : 0) + (win ? 2 : 0) + (il ? 4 : 0);   // ...41 pair-word g, 42 window form, 43 both; +4 interleaved staging
 #define DV3_T2(M, G) \
-  (win == 1 ? launch_wgrad_taps2<M, 0, G, 1>(a, nb, st) : win == 3 ? launch_wgrad_taps2<M, 0, G, 3>(a, nb, st) : launch_wgrad_taps2<M, 0, G, 0>(a, nb, st))
+  (win == 1 ? (il ? launch_wgrad_taps2<M, 0, G, 1, true>(a, nb, st) : launch_wgrad_taps2<M, 0, G, 1>(a, nb, st)) \
+   : win == 3 ? (il ? launch_wgrad_taps2<M, 0, G, 3, true>(a, nb, st) : launch_wgrad_taps2<M, 0, G, 3>(a, nb, st)) \
+   : launch_wgrad_taps2<M, 0, G, 0>(a, nb, st))
   if (d->g_pair) return d->xmask ? DV3_T2(true, true) : DV3_T2(false, true);
   return d->xmask ? DV3_T2(true, false) : DV3_T2(false, false);
 #undef DV3_T2

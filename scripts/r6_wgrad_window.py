@@ -21,9 +21,10 @@ for B, C, T, d in SHAPES:
     tiles = ((2 * C + 127) // 128) * ((C + 127) // 128)
     S = ops._ksplit_count(B * ((T + 31) // 32), tiles, slots=256)
     res, ref = {}, None
-    for win in (0, 1):
+    for win, il in ((0, 0), (1, 0), (1, 1)):
         for pair in (False, True):
             L.dv3_debug_set(47, win)
+            L.dv3_debug_set(48, il)
             f = lambda: ops.wgrad_gemm(gp if pair else g, x, B=B, M=2 * C, Cin=C, T=T, Tin=T, J=3, dil=d, padL=d, n_slabs=S,
                                        xmask=bits, xmask_rs=rs, drop_scale=1 / 0.95, split_bf16=True, k_split=True,
                                        rows_of_slabs=True, g_pair=pair)
@@ -32,8 +33,9 @@ for B, C, T, d in SHAPES:
             if ref is None:
                 ref = o.clone()
             same = torch.equal(o, ref)
-            res["%s%s (%d)" % ("window" if win else "per-tap", " + pair g" if pair else "", v)] = (graph_time(f), same)
+            res["%s%s (%d)" % ("window, interleaved" if il else "window" if win else "per-tap", " + pair g" if pair else "", v)] = (graph_time(f), same)
     L.dv3_debug_set(47, 1)
+    L.dv3_debug_set(48, 1)
     fl = 2.0 * B * T * 2 * C * 3 * C
     print("B=%d C=%d T=%d d=%d S=%d:" % (B, C, T, d, S),
           "  ".join("%s %.1f us%s" % (k, t, "" if ok else " DIFFERS") for k, (t, ok) in res.items()),

@@ -163,7 +163,8 @@ def test_fused_gate_backward_matches_standalone_and_oracle(dev, gemm_mode, pkind
 
 
 def test_fused_gate_backward_serves_the_kernels_it_names(dev, gemm_mode):
-    """variant ids: 256 x 256 kernel 3111 (fused tail) / 3116 (+ pair-word input), 128-wide tiles 36xx; wgrad 3041"""
+    """variant ids: 256 x 256 kernel 3111 (fused tail) / 3116 (+ pair-word input), 128-wide tiles 36xx; wgrad 3047 (pair-word g,
+    one window for the three taps, staging between the MFMAs) / 3046 (fp32 g)"""
     from deepvoice3_pytorch_amd import ops, _lib
     h = _lib.lib()
     rng = np.random.RandomState(5)
@@ -204,7 +205,7 @@ def test_fused_gate_backward_serves_the_kernels_it_names(dev, gemm_mode):
     # (pair words from layer 2's tail; fused tail for layer 0), layer 0 (pair words from layer 1's tail)
     assert [s[1] for s in dg] == [3116, 3116, 3106], dg
     assert [s[2:] for s in dg] == [(True, True), (True, True), (False, True)], dg
-    assert [s[1:] for s in wg] == [(3041, True)] * 3, wg
+    assert [s[1:] for s in wg] == [(3047, True)] * 3, wg
     # ... and with pair words off the fp32 forms
     prev, ops.pair_words = ops.pair_words, False
     try:
@@ -221,7 +222,7 @@ def test_fused_gate_backward_serves_the_kernels_it_names(dev, gemm_mode):
         ops.conv_gemm, ops.wgrad_gemm = real_conv, real_wgrad
         ops.pair_words = prev
     assert [s[1:] for s in seen if s[0] == "dgrad"] == [(3111, True, False), (3111, True, False), (3101, False, False)], seen
-    assert [s[1:] for s in seen if s[0] == "wgrad"] == [(3040, False)] * 3, seen
+    assert [s[1:] for s in seen if s[0] == "wgrad"] == [(3046, False)] * 3, seen
 
 
 def test_pair_words_are_the_operands_the_gradient_gemms_build_themselves(dev, gemm_mode):
