@@ -576,6 +576,8 @@ class GraphedTrainer(object):
         self.split = bool(split_streams) and trainer.side_stream is not None
         self.chunk = int(chunk or os.environ.get("DV3_SPLIT_CHUNK", "0"))      # 0: chosen after the warm-up steps
         self.cut_on_bucket = os.environ.get("DV3_CUT_ON_BUCKET", "1") not in ("0", "")
+        self.tail_fine = int(os.environ.get("DV3_SPLIT_TAIL", "6"))     # the last N fork points end a segment each (0 = off)
+        self.n_forks = 0
         self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
         self._prev_offset = ops.dropout_state.dev_offset        # restored by close()
         ops.dropout_state.dev_offset = self.seed_offset
@@ -597,6 +599,7 @@ class GraphedTrainer(object):
             # 10 (10.80 vs 10.90 ms), batch 16 the same at both
             n = ops.SideStream.forks_last if warmup > 0 else 0
             self.chunk = 4 if 0 < n < 52 else 10
+        self.n_forks = ops.SideStream.forks_last if warmup > 0 else 0
         if not self.split:
             # a process group brings its watchdog thread: its event queries must not invalidate this thread's capture
             mode = dict(capture_error_mode="thread_local") if trainer.comm is not None else {}
@@ -644,7 +647,12 @@ class GraphedTrainer(object):
             # five buckets, used to be final only with the last segment: 0.66 ms of exposed wait beside a ring stand-in,
             # profiles/r06_collective_standin.txt)
             bucket_done = t.comm is not None and bool(t.comm._completed) and self.cut_on_bucket
-            if st["forks"] % self.chunk == 0 or bucket_done:
+            # the LAST forks one per segment (round 6): side segment j starts when step segment j has run to its end, so the
+            # weight-gradient branch of the last segment has nothing left to run beside -- the step stream sat idle for
+            # 0.46 ms before clip + Adam while the last four layers' weight gradients ran (profiles/r06a timeline); with
+            # one-layer segments at the end only the last layer's is exposed
+            tail = self.n_forks > 0 and self.n_forks - st["forks"] < self.tail_fine
+            if st["forks"] % self.chunk == 0 or bucket_done or tail:
                 end_seg()
                 begin_seg()
 
