@@ -155,6 +155,18 @@ def synth_batch(rng, B, Tt, n_frames, hp, fixed=True, lengths=None):
 # -------------------------------------------------------------------------------------------------
 # kernel rooflines (HIP events on the launch stream)
 # -------------------------------------------------------------------------------------------------
+_CAP_STREAM = {}
+
+
+def _capture_stream():
+    """ONE capture stream per device for every roofline capture of this process (each torch.cuda.Stream() would pin a
+    67 MB stream-K workspace of its own in ops._sk_ws)"""
+    d = torch.cuda.current_device()
+    if d not in _CAP_STREAM:
+        _CAP_STREAM[d] = torch.cuda.Stream()
+    return _CAP_STREAM[d]
+
+
 def _time_launches(launch, iters, settle=100, per_graph=25):
     """us per launch, HIP events on the stream the launches run on.  Round 5: the launches are captured into one hipGraph
     (`per_graph` of them) and the REPLAYS are timed -- eager launches through ctypes cost the host 30-120 us each
@@ -169,8 +181,12 @@ def _time_launches(launch, iters, settle=100, per_graph=25):
     try:
         if os.environ.get("DV3_BENCH_EAGER_TIMING", "") == "1":      # counter passes (scripts/pmc_r5.sh): one launch per dispatch
             raise RuntimeError("eager timing requested")
-        cap = torch.cuda.Stream()
+        cap = _capture_stream()
         cap.wait_stream(s)
+        #  the launches captured here must be the variants the training step runs: a capture on a stream that
+        # has no stream-K workspace gets the tile-per-workgroup form (ops._streamk_ws never allocates inside a capture)
+        from deepvoice3_pytorch_amd import ops as _ops
+        _ops.prepare_streamk_ws(s.device, cap)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=cap):
             for _ in range(per_graph):

@@ -444,7 +444,7 @@ int dv3_conv_c8pp_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   const bool is_dgrad = d->mode == DV3_EPI_DGRAD;
   const bool masked_fwd = d->xmask_c8 != nullptr && !is_dgrad;
   bool use_nw4 = g_c8pp_nw4 == 1 || d->tile_hint == 41;
-  if (g_c8pp_nw4 == 2 && d->tile_hint != 40) {
+  if (g_c8pp_nw4 == 2 && d->tile_hint != 40 && d->tile_hint != 41) {   // (a forcing hint survives the size rule: ADVICE r5)
     if (masked_fwd) use_nw4 = nb >= 100;
     else if (is_dgrad) use_nw4 = nb >= 64 && nb < 192;   // (201 tiles: 8-wave 49 us, 4-wave 55: profiles/r05_conv_census_nyanko_bf16_c8.txt)
   }

@@ -530,6 +530,22 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         return n
 
 
+_CAPTURE_STREAMS = {}
+
+
+def _capture_stream(device):
+    """ONE capture stream per device for every GraphedTrainer of the process: ops._sk_ws keeps a permanent
+    67 MB stream-K workspace per (device, stream) -- a fresh torch.cuda.Stream() per capture cycled through torch's 32
+    pool streams and pinned up to 2 GB, and a pool handle shared with an unrelated eager user would have shared the
+    workspace's flags with a replaying graph.  Captures are sequential, replays run on the caller's stream."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _CAPTURE_STREAMS.get(key)
+    if st is None:
+        with torch.cuda.device(key):
+            st = _CAPTURE_STREAMS[key] = torch.cuda.Stream()
+    return st
+
+
 class GraphedTrainer(object):
     """Whole-step hipGraph replay: forward + losses + backward + (bucketed all-reduce) + clip/Adam captured once per
     batch shape and replayed -- removes the per-kernel host launch cost (~330 launches/step: 5-16 ms of host time,
@@ -581,7 +597,7 @@ class GraphedTrainer(object):
         self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
         self._prev_offset = ops.dropout_state.dev_offset        # restored by close()
         ops.dropout_state.dev_offset = self.seed_offset
-        s = torch.cuda.Stream()
+        s = _capture_stream(dev)           # (the warm-up steps' stream-K launches take their workspace per stream too)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):      # real optimisation steps (lr / bias corrections set first)
@@ -604,7 +620,7 @@ class GraphedTrainer(object):
             # a process group brings its watchdog thread: its event queries must not invalidate this thread's capture
             mode = dict(capture_error_mode="thread_local") if trainer.comm is not None else {}
             self.graph = torch.cuda.CUDAGraph()
-            cap = torch.cuda.Stream()
+            cap = _capture_stream(self.t.device)
             ops.prepare_streamk_ws(dev, cap)       # the captured stream-K launches' workspace: not from the graph's pool
             with torch.cuda.graph(self.graph, stream=cap, **mode):
                 self.scal = self._body()
@@ -658,7 +674,7 @@ class GraphedTrainer(object):
 
         torch.cuda.synchronize()
         gc.collect()
-        cap = torch.cuda.Stream()
+        cap = _capture_stream(self.t.device)
         ops.prepare_streamk_ws(t.device, cap)       # the captured stream-K launches' workspace: not from the graphs' pool
         cap.wait_stream(torch.cuda.current_stream())
         SS.split_capture, SS.split_on_fork = True, on_fork
@@ -848,14 +864,28 @@ def _load_file(path, unsafe=False):
         return torch.load(path, map_location="cpu", weights_only=False)
 
 
-def load_checkpoint(path_or_dict, trainer, reset_optimizer=False, unsafe=False):
+def load_checkpoint(path_or_dict, trainer, reset_optimizer=False, unsafe=False, module=None):
     """train.load_checkpoint (train.py:852-867): model weights, (unless reset_optimizer) the Adam
     moments, and the two counters.  Returns global_epoch.  Accepts files written by the reference:
-    its optimizer enumerates get_trainable_parameters() in the same order the arena does."""
+    its optimizer enumerates get_trainable_parameters() in the same order the arena does.
+
+    module: the sub-module the file's weights belong to -- the reference loads its `_seq2seq` / `_postnet`
+    checkpoints into model.seq2seq / model.postnet while training the WHOLE model (train.py:986-990).  None: the
+    trainer's own checkpoint module, or, when the file's keys are exactly those of model.seq2seq or model.postnet, that
+    sub-module.  The optimizer state of such a partial file covers its own parameters only: the moments of the others
+    stay as they are, and since one `adam_step` serves the whole arena the file's step count is taken only when
+    EVERY parameter of the arena got a state (otherwise the moments are loaded and the bias corrections keep the
+    trainer's own count: pass reset_optimizer=True for the reference's behaviour of a fresh optimizer)."""
     ck = path_or_dict if isinstance(path_or_dict, dict) else _load_file(path_or_dict, unsafe)
     a = trainer.arena
     with torch.no_grad():     # copy INTO the arena views (load_state_dict would keep them too; be explicit)
-        own = trainer.checkpoint_module().state_dict()
+        target = module if module is not None else trainer.checkpoint_module()
+        if module is None and target is trainer.model:
+            keys = set(ck["state_dict"])
+            for sub in (trainer.model.seq2seq, trainer.model.postnet):
+                if keys == set(sub.state_dict()):
+                    target = sub
+        own = target.state_dict()
         missing = [k for k in own if k not in ck["state_dict"]]
         unexpected = [k for k in ck["state_dict"] if k not in own]
         if missing or unexpected:
@@ -868,6 +898,7 @@ def load_checkpoint(path_or_dict, trainer, reset_optimizer=False, unsafe=False):
             raise RuntimeError("optimizer state does not match get_trainable_parameters()")
         steps = set()
         slot = {id(p): (o, n) for o, n, p in zip(a.offsets, a.sizes, a.params)}
+        loaded = 0
         for i, p in enumerate(trainer.optimizer_order):
             st = opt["state"].get(i)
             if st is None or id(p) not in slot:      # (a split-mode trainer keeps the moments of its own part only)
@@ -876,9 +907,12 @@ def load_checkpoint(path_or_dict, trainer, reset_optimizer=False, unsafe=False):
             a.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
             a.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
             steps.add(int(float(st["step"])))
+            loaded += 1
         if len(steps) > 1:
             raise RuntimeError("per-parameter Adam step counts differ: %s" % sorted(steps))
-        trainer.adam_step = steps.pop() if steps else 0
+        if loaded == len(a.params):
+            trainer.adam_step = steps.pop() if steps else 0
+        # (a partial state -- a sub-module's checkpoint under a joint trainer: see the docstring)
     trainer.global_step = int(ck["global_step"])
     return int(ck.get("global_epoch", 0))
 
