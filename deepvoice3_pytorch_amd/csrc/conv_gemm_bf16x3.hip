@@ -1047,7 +1047,7 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
 }
 
 extern int g_wgrad_tile, g_wgrad_prio, g_wgrad_t2_abl, g_wgrad_taps2_default, g_wgrad_t2_window, g_wgrad_t2_il;   // wgrad_gemm_bf16x3.hip, wgrad_taps2.hip
-extern int g_wgrad_c8_pf2, g_spk_abl;                                                       // wgrad_c8.hip
+extern int g_wgrad_c8_pf2, g_wgrad_c8_il, g_spk_abl;                                                       // wgrad_c8.hip
 int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 int dv3_c8pp_debug_set(int what, int value);     // conv_c8pp.hip
 int dv3_conv_census_set(int on);                 // conv_gemm.hip
@@ -1062,6 +1062,7 @@ extern "C" int dv3_debug_set(int what, int value) {
   if (what == 40) return dv3_conv_census_set(value);
   if (what == 19 || what == 21 || what == 30 || what == 32 || (what >= 34 && what <= 36)) return dv3_c8pp_debug_set(what, value);
   if (what == 20) g_wgrad_c8_pf2 = value;
+  if (what == 49) g_wgrad_c8_il = value;
   if (what == 9) g_x3_rel2 = value;
   if (what == 12) g_x3_pp2 = value;
   if (what == 13) g_pp2_abl = value;

@@ -38,8 +38,13 @@ __device__ __forceinline__ T ldg_off(const void* base, uint32_t byte_off) {
 // it).  Every load is unconditional (frames clamped into the row), validity is recomputed from the step index when the
 // set is transposed, the tail re-fetches the last step.  Same tile, LDS image and accumulation order: bit-identical
 // slabs.  One workgroup per CU either way (the grid is sized to the chip), so the kernel takes the 256-register budget.
-template <int JT, bool MASK, bool PF2>
+// IL (round 6, three-tap PF2 form): the staging of the next step's tile (zero padding, keep masks, the 8 x 4 transposes,
+// eight LDS stores: ~70 vector instructions per thread that touch nothing the current step's twelve MFMAs read) is issued
+// BETWEEN those MFMAs (__builtin_amdgcn_sched_group_barrier) instead of after them -- all eight waves run in phase, so
+// "after" leaves the matrix pipes idle while every wave transposes (wgrad_taps2.hip, IL).  Same values: bit-identical.
+template <int JT, bool MASK, bool PF2, bool IL = false>
 __global__ __launch_bounds__(512) void wgrad_c8_kernel(const WgradC8Args args) {
+  static_assert(!IL || (PF2 && JT == 3), "interleaved staging: the three-tap two-steps-ahead form (every thread stages)");
   constexpr int BM = 128, BN = 128;
   constexpr int LDM = BM + PAD, LDN = BN + PAD;
   constexpr int GBUF = KB * LDM, XTAP = KB * LDN, BUF = GBUF + JT * XTAP;   // 16-byte units per buffer
@@ -111,7 +116,9 @@ __global__ __launch_bounds__(512) void wgrad_c8_kernel(const WgradC8Args args) {
   };
   auto write_step = [&](int step, int buf, auto set_c) __attribute__((always_inline)) {
     constexpr int S = decltype(set_c)::value;
-    if (!stager) return;
+    if constexpr (NSTG < 512) {      // (JT == 3: every thread stages -- and a branch would cut IL's scheduling region)
+      if (!stager) return;
+    }
     const int gs = step0 + min(step, nsteps - 1);
     const int t0 = (gs % n_tc) * BKT + tq;
     const u32x4 zero = {0u, 0u, 0u, 0u};
@@ -170,9 +177,78 @@ __global__ __launch_bounds__(512) void wgrad_c8_kernel(const WgradC8Args args) {
       load_step(2, S0{});
       __syncthreads();
       // steps in pairs so the register-set index is static: step st + 1 is staged from set (st + 1) & 1
+      // IL: the step as six fenced segments -- [two MFMAs of one (k16 block, tap)] [the fragment reads of the next
+      // segment] [a sixth of the next tile's staging] -- in source order (sched_barrier(0) between segments: the
+      // compiler's own pipeline solver did not take this kernel's staging apart).  Per accumulator the k16 blocks are
+      // added in the order of mfma_step: bit-identical.
+      auto stage_unit = [&](int t0, auto set_c, auto ic) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value, i = decltype(ic)::value;
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        const int t = t0 + i;
+        if (!(grp_ok && t >= 0 && t < T)) ru[S][i] = zero;
+        if constexpr (MASK) ru[S][i] &= lut[rkeep[S][i]];
+      };
+      auto store_half = [&](int buf, auto set_c, auto hc) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value, h = decltype(hc)::value;
+        bf16x8* dst = smem + buf * BUF + (is_g ? 0 : GBUF + (panel - 1) * XTAP) + k8 * (is_g ? LDM : LDN) + grp * 8;
+#pragma unroll
+        for (int e = 4 * h; e < 4 * h + 4; ++e) {
+          const int q = e >> 1;
+          const uint32_t sel = (e & 1) ? 0x07060302u : 0x05040100u;
+          u32x2 o;
+          o[0] = __builtin_amdgcn_perm(ru[S][1][q], ru[S][0][q], sel);
+          o[1] = __builtin_amdgcn_perm(ru[S][3][q], ru[S][2][q], sel);
+          reinterpret_cast<u32x2*>(dst + e)[hsel] = o;
+        }
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      using I3 = std::integral_constant<int, 3>;
       auto step = [&](int st, auto set_c) __attribute__((always_inline)) {
-        mfma_step(st & 1);
-        write_step(st + 1, (st + 1) & 1, set_c);     // past the end: a re-fetched tile into the buffer nobody reads
+        if constexpr (!IL) {
+          mfma_step(st & 1);
+          write_step(st + 1, (st + 1) & 1, set_c);     // past the end: a re-fetched tile into the buffer nobody reads
+        } else {
+          const bf16x8* Gs = smem + (st & 1) * BUF;
+          const int gs = step0 + min(st + 1, nsteps - 1);
+          const int t0 = (gs % n_tc) * BKT + tq;
+          const int nbuf = (st + 1) & 1;
+          const int ai0 = lhi * LDM + wm * 64 + l31, ai1 = (2 + lhi) * LDM + wm * 64 + l31;
+          const int xi0 = GBUF + lhi * LDN + wc * 32 + l31, xi1 = GBUF + (2 + lhi) * LDN + wc * 32 + l31;
+          __builtin_amdgcn_sched_barrier(0);
+          bf16x8 a0 = Gs[ai0], a1 = Gs[ai0 + 32], b = Gs[xi0];
+          __builtin_amdgcn_sched_barrier(0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[0][1], 0, 0, 0);
+          bf16x8 b1 = Gs[xi0 + XTAP];
+          stage_unit(t0, set_c, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+          b = Gs[xi0 + 2 * XTAP];
+          stage_unit(t0, set_c, I1{});
+          __builtin_amdgcn_sched_barrier(0);
+          acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[2][0], 0, 0, 0);
+          acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[2][1], 0, 0, 0);
+          a0 = Gs[ai1]; a1 = Gs[ai1 + 32]; b1 = Gs[xi1];
+          stage_unit(t0, set_c, I2{});
+          __builtin_amdgcn_sched_barrier(0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[0][1], 0, 0, 0);
+          b = Gs[xi1 + XTAP];
+          stage_unit(t0, set_c, I3{});
+          __builtin_amdgcn_sched_barrier(0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[1][1], 0, 0, 0);
+          b1 = Gs[xi1 + 2 * XTAP];
+          store_half(nbuf, set_c, I0{});
+          __builtin_amdgcn_sched_barrier(0);
+          acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[2][0], 0, 0, 0);
+          acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[2][1], 0, 0, 0);
+          store_half(nbuf, set_c, I1{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
         load_step(st + 3, set_c);
         __syncthreads();
       };
@@ -212,13 +288,13 @@ __global__ __launch_bounds__(512) void wgrad_c8_kernel(const WgradC8Args args) {
   }
 }
 
-template <int JT, bool MASK, bool PF2>
+template <int JT, bool MASK, bool PF2, bool IL = false>
 int launch_c8(const WgradC8Args& a, int64_t nb, hipStream_t st) {
   constexpr int LDM = 128 + PAD;
   constexpr size_t lds = (size_t)2 * (KB * LDM + JT * KB * LDM) * 16 + 256 * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)wgrad_c8_kernel<JT, MASK, PF2>,
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad_c8_kernel<JT, MASK, PF2, IL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       dv3_set_error("wgrad_c8: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -226,12 +302,13 @@ int launch_c8(const WgradC8Args& a, int64_t nb, hipStream_t st) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_c8_kernel<JT, MASK, PF2>), dim3((unsigned)nb), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((wgrad_c8_kernel<JT, MASK, PF2, IL>), dim3((unsigned)nb), dim3(512), lds, st, a);
   return dv3_check_launch("wgrad_c8");
 }
 
 }  // namespace
 
+int g_wgrad_c8_il = 1;    // dv3_debug_set(49, v): the three-tap form stages the next tile between the MFMAs (0 = after them)
 int g_wgrad_c8_pf2 = 1;   // dv3_debug_set(20, v): 1 = operands fetched two steps ahead (default), 0 = the round-2 one-step form
 
 // called by dv3_wgrad_gemm_f32 (wgrad_gemm.hip) when d->c8 is set
@@ -252,6 +329,10 @@ int dv3_wgrad_c8_dispatch(const dv3_wgrad_desc* d, hipStream_t st) {
   DV3_REQUIRE(nb < (1ll << 31), "wgrad_gemm: grid too large");
   if (g_wgrad_c8_pf2) {
     g_dv3_last_wgrad = 5000 + 20 + d->J;
+    if (d->J == 3 && g_wgrad_c8_il) {
+      g_dv3_last_wgrad += 40;            // 5063: staging between the MFMAs
+      return d->xmask_c8 ? launch_c8<3, true, true, true>(a, nb, st) : launch_c8<3, false, true, true>(a, nb, st);
+    }
     if (d->J == 3) return d->xmask_c8 ? launch_c8<3, true, true>(a, nb, st) : launch_c8<3, false, true>(a, nb, st);
     return d->xmask_c8 ? launch_c8<1, true, true>(a, nb, st) : launch_c8<1, false, true>(a, nb, st);
   }

@@ -108,7 +108,7 @@ def test_c8_gated_layers_forward_backward(dev, modes, kind, C, k, d, causal, T, 
     rec = {}
     y8, dx8, dp8 = _run(layer, x, True, "bf16", ops, record=rec)
     assert _lib.lib().dv3_debug_get(10) // 1000 == 8            # the planes kernel, single-term bf16
-    assert _lib.lib().dv3_debug_get(11) in (5001, 5003, 5021, 5023)         # the c8 wgrad kernel (+20: two-steps-ahead fetch)
+    assert _lib.lib().dv3_debug_get(11) in (5001, 5003, 5021, 5023, 5063)   # the c8 wgrad kernel (+20: two-steps-ahead fetch, +40: staging between the MFMAs)
     # forward against the oracle with the recorded keep-bits
     bits, rows, Tm = rec["l"]
     keep = torch.from_numpy(O.unpack_keep_bits(bits.cpu().numpy().view(np.uint32), rows, (Tm + 31) // 32, Tm)).float()
@@ -541,11 +541,15 @@ def test_wgrad_c8_two_steps_ahead_is_bit_identical(dev, modes, kind, C, k, d, ca
     x = torch.randn(B, C, T, device=dev)
     out = {}
     try:
-        for pf2 in (0, 1):
+        # one step ahead | two steps ahead, staging after the MFMAs | ... between them (round 6, three taps: variant 5063)
+        for tag, pf2, il in ((0, 0, 0), (1, 1, 0), (2, 1, 1)):
             L.dv3_debug_set(20, pf2)
-            out[pf2] = _run(layer, x, True, "bf16", ops)
-            assert L.dv3_debug_get(11) == 5000 + 20 * pf2 + k
+            L.dv3_debug_set(49, il)
+            out[tag] = _run(layer, x, True, "bf16", ops)
+            assert L.dv3_debug_get(11) == 5000 + 20 * pf2 + k + (40 if (il and pf2 and k == 3) else 0)
     finally:
         L.dv3_debug_set(20, 1)
-    for n in out[0][2]:
-        assert torch.equal(out[0][2][n], out[1][2][n]), n
+        L.dv3_debug_set(49, 1)
+    for tag in (1, 2):
+        for n in out[0][2]:
+            assert torch.equal(out[0][2][n], out[tag][2][n]), (tag, n)
