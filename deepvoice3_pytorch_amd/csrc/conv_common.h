@@ -16,6 +16,7 @@ struct ConvArgs {
   int wide = 1;                    // 16-byte input-gradient epilogue through LDS (0 = off)
   uint32_t* range_ctr = nullptr;   // f16x3: sticky fp16-range event counter (common.h), NULL = do not count
   int prio = 0;  // ping-pong tap-GEMM: wave priority scheme (dv3_debug_set(14, v); 0 = none)
+  int fast_tail = 0;   // 256 x 256 kernel: interior sub-tiles of a gated launch take conv_epilogue_glu_interior (dv3_debug_set(50, v))
   int ks = 0;    // 128 x 64 split tile: 2 = the k-split form (two wave groups per workgroup, halves of the chunk range)
   int dp = 0;    // 128 x 64 split tile: deep-prefetch form with this compile-time tap count (1 or 3; 0 = the in-phase loop)
   // stream-K form of the 256 x 256 kernels: n_blocks = workgroups (one per CU), sk_units = tiles x chunks
@@ -174,6 +175,17 @@ __device__ __forceinline__ void conv_epilogue_dgrad_gate(const dv3_conv_desc& p,
   }
 }
 
+// The gate's output (modules.py:162-164 GLU: (a * sigmoid(g) [+ x]) * sqrt(.5 | 1); :224-226 highway: s a + (1 - s) x) as ONE
+// explicitly contracted expression shared by every fp32 tail of this header: left to the compiler, the guarded tail and
+// the straight-line tail of round 6 contracted `a * s + x` differently (a one-ulp difference between the interior and
+// the edge sub-tiles of one launch, and between kernels that are tested to agree bit for bit).
+__device__ __forceinline__ float dv3_gate_out(float a, float s, float x, float oscale, bool glu) {
+#pragma clang fp contract(off)
+  if (glu) return __builtin_fmaf(a, s, x) * oscale;
+  const float t = (1.0f - s) * x;
+  return __builtin_fmaf(s, a, t);
+}
+
 template <int BM, int BMH, int NI, int ABL = 0, bool IOB = false>
 __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], bool gated,
                                               int mt, int row0, int lhi, const int (&bcol)[NI],
@@ -242,7 +254,7 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
         }
         const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
         // GLU: (a*s [+ x]) * (sqrt(.5) | 1)      HIGHWAY: s*a + (1-s)*x
-        const float y = glu ? (a * s + xr[r][ni]) * oscale : s * a + (1.0f - s) * xr[r][ni];
+        const float y = dv3_gate_out(a, s, xr[r][ni], oscale, glu);
         if (ABL != 8 || y == 1.2345e30f) dv3_st_act(p.y, yb[ni] + ch * y_rs, y, outb);
       }
     }
@@ -328,6 +340,74 @@ __device__ __forceinline__ void conv_epilogue(const dv3_conv_desc& p, f32x16 (&a
         dv3_st_act(p.y, yb[ni] + mo * y_rs + (odd ? osz : 0u), v, outb);
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 6: the Conv1dGLU / HighwayConv1d tail of an INTERIOR 32-row sub-tile -- every row below Cg, every column inside
+// the tensor, fp32 tensors, no speaker bias: what all but the edge sub-tiles of a launch are.  conv_epilogue() above
+// guards each of its 16 x NI elements with per-lane tests (row < Cg, column valid) and re-tests the launch-uniform
+// switches (pre-gate save, speaker bias, GLU / highway) per element: ~950 branches in the 256 x 256 kernel's tails
+// (13 of the tail's 26 us are neither loads nor stores).  Here the caller makes the tests ONCE per wave
+// (they are wave-uniform) and this function is straight-line code, specialised on the two launch-uniform switches.
+// Same operations per element in the same order as conv_epilogue(): bit-identical.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BMH, int NI, bool AB, bool GLU>
+__device__ __forceinline__ void conv_epilogue_glu_interior_t(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], int mt, int row0, int lhi,
+                                                             const int (&bcol)[NI], const int (&tcol)[NI]) {
+  const uint32_t Tout = (uint32_t)p.Tout, M = (uint32_t)p.M, Cg = (uint32_t)p.Cg;
+  const bool has_r = !GLU || p.residual;
+  const float oscale = (GLU && p.residual) ? 0.70710678118654752440f : 1.0f;
+  const uint32_t y_rs = (uint32_t)p.y_rs * 4u, r_rs = (uint32_t)p.r_rs * 4u, g_rs = Tout * 4u;
+  uint32_t yb[NI], rb[NI], abb[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const uint32_t b = (uint32_t)bcol[ni], t = (uint32_t)tcol[ni];
+    yb[ni] = (b * (uint32_t)p.y_bs + t) * 4u;
+    rb[ni] = (b * (uint32_t)p.r_bs + t) * 4u;
+    abb[ni] = (b * M * Tout + t) * 4u;
+  }
+  const uint32_t ch0 = (uint32_t)(mt * BMH + row0 + 4 * lhi);
+  float xr[16][NI], ba[16], bg[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t ch = ch0 + (uint32_t)((r & 3) + 8 * (r >> 2));
+    ba[r] = bg[r] = 0.f;
+    if (p.bias) {
+      ba[r] = p.bias[ch];
+      bg[r] = p.bias[Cg + ch];
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) xr[r][ni] = has_r ? dv3_ld<float>(p.r, rb[ni] + ch * r_rs) : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t ch = ch0 + (uint32_t)((r & 3) + 8 * (r >> 2));
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const float a = acc[0][ni][r] + ba[r];
+      const float g = acc[1][ni][r] + bg[r];
+      if constexpr (AB) {
+        const uint32_t o = abb[ni] + ch * g_rs;
+        dv3_st(p.ab, o, a);
+        dv3_st(p.ab, o + Cg * g_rs, g);
+      }
+      const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-g));
+      const float y = dv3_gate_out(a, s, xr[r][ni], oscale, GLU);
+      dv3_st(p.y, yb[ni] + ch * y_rs, y);
+    }
+  }
+}
+template <int BMH, int NI>
+__device__ __forceinline__ void conv_epilogue_glu_interior(const dv3_conv_desc& p, f32x16 (&acc)[2][NI], int mt, int row0, int lhi,
+                                                           const int (&bcol)[NI], const int (&tcol)[NI]) {
+  const bool glu = p.mode == DV3_EPI_GLU;
+  if (p.ab) {
+    if (glu) conv_epilogue_glu_interior_t<BMH, NI, true, true>(p, acc, mt, row0, lhi, bcol, tcol);
+    else conv_epilogue_glu_interior_t<BMH, NI, true, false>(p, acc, mt, row0, lhi, bcol, tcol);
+  } else {
+    if (glu) conv_epilogue_glu_interior_t<BMH, NI, false, true>(p, acc, mt, row0, lhi, bcol, tcol);
+    else conv_epilogue_glu_interior_t<BMH, NI, false, false>(p, acc, mt, row0, lhi, bcol, tcol);
   }
 }
 
@@ -617,7 +697,7 @@ __device__ __forceinline__ void conv_epilogue_glu_wide(const dv3_conv_desc& p, f
       for (int e = 0; e < 4; ++e) {
         const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-g[e]));
         const float x = xr[k][ni][e];
-        y4[e] = glu ? (a[e] * s + x) * oscale : s * a[e] + (1.0f - s) * x;
+        y4[e] = dv3_gate_out(a[e], s, x, oscale, glu);
       }
       if (ABL != 13 || y4[0] == 1.2345e30f) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(p.y) + yo[ni] + ch * y_rs) = y4;
     }

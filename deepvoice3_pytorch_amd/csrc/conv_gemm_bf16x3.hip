@@ -948,7 +948,7 @@ int g_x3_pp2 = 128;  // dv3_debug_set(12, v): the 256 x 256 k16 ping-pong kernel
                      // whose grid has at least v tiles (0 = never).  Measured at B=64 over the presets' conv shapes
                      // (scripts/pp2_sweep.py, profiles/r03_pp2_sweep.txt): 0.73-0.88 of the 128 x 256 / 128 x 64 kernels'
                      // time from 152 tiles up, 1.3-1.9 x at 50-100 tiles (half the chip idle).
-extern int g_pp2_ord, g_pp2_ord_u, g_pp2_ord_m, g_pp2_abl, g_pp2_sk, g_pp2_sk_overhead, g_pp2_sk_gain, g_pp2_sk_abl;
+extern int g_pp2_ord, g_pp2_ord_u, g_pp2_ord_m, g_pp2_abl, g_pp2_sk, g_pp2_sk_overhead, g_pp2_sk_gain, g_pp2_sk_abl, g_pp2_fast_tail;
 int g_x3_pp2_sk_units = 8;   // measured (scripts/pp2_sk_check.py): at 9.5 units per CU (the encoder layers: 152 / 76 tiles) the
                              // stream-K form beats the 128-wide kernels by 6-8 %, at 6.3 (101 tiles x 16) it loses to them
 int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st);   // conv_gemm_pp2.hip
@@ -1074,6 +1074,7 @@ extern "C" int dv3_debug_set(int what, int value) {
     if (what == 29) { g_pp2_ord_u = ship ? value : 0; g_pp2_ord = ship ? 0 : value; }
     else g_pp2_ord_m = ship ? value : 0;
   }
+  if (what == 50) g_pp2_fast_tail = value;
   if (what == 22) g_pp2_sk = value;
   if (what == 23) g_pp2_sk_overhead = value;
   if (what == 24) g_pp2_sk_gain = value;

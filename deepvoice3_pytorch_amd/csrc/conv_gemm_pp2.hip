@@ -849,8 +849,21 @@ __global__ __launch_bounds__(NT) void conv_gemm_pp2_kernel(const ConvArgs args) 
       conv_epilogue_glu_wide<BMH, NI, TA>(pt, acc[1], mt, wm * (MI * 32) + 32, lane, nw0, Ntot);
     } else {
       constexpr int TA = ABL == 12 ? 7 : ABL == 13 ? 8 : 0;     // experiment build: 12 = no residual load, 13 = no stores
-      conv_epilogue<BM, BMH, NI, TA, false>(pt, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
-      conv_epilogue<BM, BMH, NI, TA, false>(pt, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+      // round 6: a wave whose 64 rows and 64 columns all lie inside the tensor takes the straight-line gated tail
+      // (conv_common.h: conv_epilogue_glu_interior; every test below is wave-uniform)
+      // (not in the stream-K instantiations: their tail sits inside the segment loop and any addition to it costs the
+      //  main loop its registers -- 70 -> 2 500 spills with this one)
+      bool interior = false;
+      if constexpr (!SK)
+        interior = TA == 0 && AT.fast_tail && gated && !pt.spk && pt.store_mode == DV3_STORE_BCT &&
+                   mt * BMH + wm * (MI * 32) + MI * 32 <= pt.Cg && n0e + wn * (NI * 32) + NI * 32 <= Ntot;
+      if (!SK && interior) {
+        conv_epilogue_glu_interior<BMH, NI>(pt, acc[0], mt, wm * (MI * 32), lhi, bcol, tcol);
+        conv_epilogue_glu_interior<BMH, NI>(pt, acc[1], mt, wm * (MI * 32) + 32, lhi, bcol, tcol);
+      } else {
+        conv_epilogue<BM, BMH, NI, TA, false>(pt, acc[0], gated, mt, wm * (MI * 32), lhi, bcol, tcol, okc);
+        conv_epilogue<BM, BMH, NI, TA, false>(pt, acc[1], gated, mt, wm * (MI * 32) + 32, lhi, bcol, tcol, okc);
+      }
     }
   }
   stamp();                               // tail stores issued
@@ -897,6 +910,7 @@ int g_pp2_ord = 0;   // experiment build: dv3_debug_set(29, v) with v outside {0
 // training forward 169.8 -> 166.9 us, bf16-pair input gradient 134.3 -> 132.3 us.  The masked bf16-pair instantiation
 // (legacy bf16x3 mode) keeps ORD 0: there the compiler contracts the mask multiply differently in the two forms.
 int g_pp2_ord_u = 81, g_pp2_ord_m = 81;
+int g_pp2_fast_tail = 1;   // dv3_debug_set(50, v): interior sub-tiles of a gated launch take the straight-line tail (0 = the guarded tail everywhere)
 int g_pp2_abl = 0;   // dv3_debug_set(13, v): timing-only ablations of the unmasked kernel (1 no MFMAs, 2 no staging, 3 no tail)
 
 // Stream-K (round 4).  A 256 x 256 tile grid rarely divides the 256 CUs: the encoder layers of the benchmark step are 152
@@ -940,6 +954,7 @@ int dv3_conv_gemm_pp2_dispatch(const dv3_conv_desc* d, hipStream_t st) {
   a.d = *d;
   a.a_scalar = 0;
   a.wide = g_x3_wide;
+  a.fast_tail = g_pp2_fast_tail;
   a.range_ctr = f16 ? dv3_range_ctr() : nullptr;
   a.kp = (d->Cin + 31) / 32 * 32;
   a.m_tiles = gated ? dv3_cdiv(d->Cg, BMH) : dv3_cdiv(d->M, BM);
