@@ -223,7 +223,7 @@ def _traffic(kernel_key):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, calibrated as MI355X_MICROARCH.md
     prescribes), collected offline with rocprofv3 (scripts/pmc_hbm.sh; a counter pass can not run inside this
     process) and committed under profiles/ -- used only when the file was collected for THIS kernel."""
-    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):      # newest collection that holds THIS variant
+    for name in ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):      # newest collection that holds THIS variant
         try:
             hb = json.load(open(os.path.join(ROOT, "profiles", name)))
             ent = hb[kernel_key]
