@@ -582,6 +582,41 @@ __global__ __launch_bounds__(256) void sincos_pos_bwd_kernel(const int64_t* __re
   if (threadIdx.x == 0) dw[b] = red[0] + red[1] + red[2] + red[3];
 }
 
+// two-stage form: chunk `blockIdx.y` of batch item `blockIdx.x` (a contiguous range of the flat (c, t) index)
+__global__ __launch_bounds__(256) void sincos_pos_bwd_part_kernel(const int64_t* __restrict__ pos, const float* __restrict__ table,
+                                                                  const float* __restrict__ w, int w_per_batch,
+                                                                  const float* __restrict__ dout, float* __restrict__ partial,
+                                                                  int T, int C, int n_pos) {
+  const int b = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
+  const float rate = w[w_per_batch ? b : 0];
+  const int total = C * T, per = (total + nch - 1) / nch;
+  const int lo = ch * per, hi = min(total, lo + per);
+  float s = 0.f;
+  for (int idx = lo + threadIdx.x; idx < hi; idx += 256) {
+    const int c = idx / T, t = idx - c * T;
+    int64_t p = pos[(int64_t)b * T + t];
+    p = p < 0 ? 0 : (p >= n_pos ? n_pos - 1 : p);
+    const float a = table[p * C + c];
+    const float d = dout[((int64_t)b * C + c) * T + t];
+    float de;
+    if (p == 0) de = a;
+    else de = (c & 1) ? -sinf(rate * a) * a : cosf(rate * a) * a;
+    s += d * de;
+  }
+  __shared__ float red[4];
+  s = dv3_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(int64_t)b * nch + ch] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sincos_pos_bwd_finish_kernel(const float* __restrict__ partial, int nch, float* __restrict__ dw, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int k = 0; k < nch; ++k) s += partial[(int64_t)b * nch + k];
+  dw[b] = s;
+}
+
 // dtable[p][c] = sum over the (b, t) with pos[b][t] == p of dout[b][c][t] * d enc / d table   (p >= 1; row 0 is the
 // padding row, F.embedding(padding_idx=0) gives it no gradient: modules.py:45-64 with trainable position tables).
 // One workgroup per table row, lanes over channels, a fixed (b, t) scan order: deterministic, no atomics.
@@ -636,6 +671,17 @@ extern "C" int dv3_sincos_pos_bwd_f32(const int64_t* pos, const float* table, co
   hipLaunchKernelGGL(sincos_pos_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pos, table, w,
                      w_per_batch, dout, dw, T, C, n_pos);
   return dv3_check_launch("sincos_pos_bwd_f32");
+}
+
+extern "C" int dv3_sincos_pos_bwd2_f32(const int64_t* pos, const float* table, const float* w, int32_t w_per_batch,
+                                       const float* dout, float* partial, int32_t n_chunks, float* dw, int32_t B, int32_t T,
+                                       int32_t C, int32_t n_pos, void* stream) {
+  DV3_REQUIRE(pos && table && w && dout && dw && partial && B > 0 && T > 0 && C > 0 && n_pos > 0, "sincos_pos_bwd2: bad args");
+  DV3_REQUIRE(n_chunks >= 1 && n_chunks <= 1024, "sincos_pos_bwd2: 1..1024 chunks");
+  hipLaunchKernelGGL(sincos_pos_bwd_part_kernel, dim3(B, n_chunks), dim3(256), 0, (hipStream_t)stream, pos, table, w,
+                     w_per_batch, dout, partial, T, C, n_pos);
+  hipLaunchKernelGGL(sincos_pos_bwd_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, n_chunks, dw, B);
+  return dv3_check_launch("sincos_pos_bwd2_f32");
 }
 
 extern "C" int dv3_sincos_pos_table_bwd_f32(const int64_t* pos, const float* table, const float* w, int32_t w_per_batch,

@@ -2007,8 +2007,12 @@ class _PosEncFn(torch.autograd.Function):
             wt = _c(w.detach().float().view(-1))
             per_batch = 1 if wt.numel() > 1 else 0
             dwb = torch.empty(B, dtype=torch.float32, device=dout.device)
-            _lib.call("dv3_sincos_pos_bwd_f32", _c(pos.long()).data_ptr(), _c(table).data_ptr(), wt.data_ptr(),
-                      per_batch, dout_c.data_ptr(), dwb.data_ptr(), B, T, C, table.shape[0], _stream())
+            # two deterministic stages: enough workgroups for the chip (the one-workgroup-per-item form took 160 us per call
+            # in the deepvoice3_vctk step: 64 workgroups of 200 dependent sinf / cosf iterations)
+            nch = max(1, min(32, (C * T) // 4096))
+            part = torch.empty((B, nch), dtype=torch.float32, device=dout.device)
+            _lib.call("dv3_sincos_pos_bwd2_f32", _c(pos.long()).data_ptr(), _c(table).data_ptr(), wt.data_ptr(),
+                      per_batch, dout_c.data_ptr(), part.data_ptr(), nch, dwb.data_ptr(), B, T, C, table.shape[0], _stream())
             dw = (dwb if per_batch else dwb.sum(0, keepdim=True)).view(ctx.w_shape)
         return (dout if ctx.has_base else None), None, dtable, dw, None
 

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 39
+#define DV3_ABI_VERSION 40
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -565,6 +565,12 @@ int dv3_sincos_pos_table_bwd_f32(const int64_t* pos, const float* table, const f
 int dv3_sincos_pos_bwd_f32(const int64_t* pos, const float* table, const float* w,
                            int32_t w_per_batch, const float* dout, float* dw, int32_t B, int32_t T,
                            int32_t C, int32_t n_pos, void* stream);
+/* The same in two deterministic stages (round 6; ABI 40): `n_chunks` workgroups per batch item leave partial sums in
+ * `partial` [B][n_chunks], a second launch adds each item's in index order -- the one-workgroup-per-item form above is
+ * 64 workgroups of 200 dependent sinf / cosf iterations on a 256-CU part (160 us per call in the deepvoice3_vctk step). */
+int dv3_sincos_pos_bwd2_f32(const int64_t* pos, const float* table, const float* w,
+                            int32_t w_per_batch, const float* dout, float* partial, int32_t n_chunks, float* dw,
+                            int32_t B, int32_t T, int32_t C, int32_t n_pos, void* stream);
 /* Incremental-conv window (conv.py:34-46): buf [rows][L] shifts left one frame and takes
  * x[row * x_stride] as its newest; in place, static addresses (hipGraph-capturable decode step) */
 int dv3_shift_append_f32(float* buf, const float* x, int64_t rows, int32_t L, int64_t x_stride,

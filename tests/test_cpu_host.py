@@ -722,7 +722,7 @@ def test_archived_bench_line_meets_the_contract():
     assert cb["kind"] in ("reference", "port")
     assert abs(d["value"] - d["config"]["global_batch"] * 800 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
     # round 3: the host's issue time and the launch-mode probe are reported for the headline and for every side config
-    flat = ("synth_rtf", "ddp_world1", "dv3lj_b64_ragged_epoch")
+    flat = ("synth_rtf", "ddp_world1", "dv3lj_b64_ragged_epoch", "ddp_standin")
     for cfg in [d["config"]] + [c["config"] for k, c in d["configs"].items() if k not in flat]:
         assert cfg["host_enqueue_ms_per_step"] > 0 and "hipgraph" in cfg and "launch_bound" in cfg
         assert cfg["launch_probe"] is None or {"eager_ms_per_step", "hipgraph_ms_per_step"} <= set(cfg["launch_probe"])
@@ -736,6 +736,16 @@ def test_archived_bench_line_meets_the_contract():
     ep = d["configs"].get("dv3lj_b64_ragged_epoch")
     if ep is not None:
         assert ep["value"] > 0 and ep["hipgraph"] is False and ep["real_frames"] > 0 and ep["host_enqueue_ms_per_step"] > 0
+    # round 6: the data-parallel step beside a ring stand-in (dist.RingStandin): step inflation, exposed wait, the bucket
+    # schedule and the weak-scaling efficiency they predict, for the three presets and the preset's own batch
+    sd = d["configs"].get("ddp_standin")
+    if sd is not None:
+        for k, e in sd.items():
+            if isinstance(e, dict):
+                assert e["ranks_modelled"] == 8 and e["channels"] >= 1 and e["busbw_gbps"] > 0
+                assert e["ms_per_step"] >= 0.98 * e["no_group_ms_per_step"] and 0.5 < e["predicted_weak_scaling_efficiency"] < 1.05
+                assert e["allreduce_exposed_ms"] is not None and len(e["bucket_mb"]) >= 2
+                assert abs(e["wire_ms_per_step"] - sum(e["wire_ms_per_bucket"])) < 0.01
     w1 = d["configs"]["ddp_world1"]
     assert w1["backend"] == "nccl" and w1["rccl_ranks"] == 1
     for k, e in w1.items():
@@ -780,3 +790,85 @@ def test_bench_self_launches_its_ranks_dry(n):
     assert out["dry_launch"] is True and out["buckets"] >= 2
     if not torch.cuda.is_available():
         assert out["backend"] == "gloo"
+
+
+def test_step_trace_collects_the_decode_loop_outputs():
+    """decode_program.StepTrace (round 6: the module-by-module decode loops write into stacked buffers): growth past
+    the initial capacity, the reference's stop rule (deepvoice3.py:469-473), the result shapes"""
+    from deepvoice3_pytorch_amd.decode_program import StepTrace
+    B, F, Tk, C = 3, 5, 7, 4
+    tr = StepTrace(min_steps=2, max_steps=100, teacher_forced=False)
+    outs = []
+    for t in range(150):
+        o = torch.full((B, 1, F), float(t))
+        done = torch.full((B, 1, 1), 0.9 if t >= 120 else 0.1)
+        tr.push(o, torch.full((B, 1, Tk), t + 0.5), torch.full((B, 1, C), -float(t)), done)
+        outs.append(o)
+        assert torch.equal(tr.last_output, o)
+        if tr.stop(done):
+            break
+    assert tr.n == 101                                  # max_steps: t > max_decoder_steps ends the loop
+    out, ali, dones, st = tr.result()
+    assert out.shape == (B, 101, F) and ali.shape == (B, 101, Tk) and st.shape == (B, 101, C) and len(dones) == 101
+    assert torch.equal(out, torch.cat(outs, 1)) and float(ali[0, 70, 0]) == 70.5 and float(st[2, 100, 3]) == -100.0
+    # every item signals done past min_steps: stop; teacher forcing never stops by itself
+    tr = StepTrace(2, 100, False)
+    for t in range(5):
+        done = torch.full((B, 1, 1), 0.9)
+        tr.push(torch.zeros(B, 1, F), torch.zeros(B, 1, Tk), torch.zeros(B, 1, C), done)
+        if tr.stop(done):
+            break
+    assert tr.n == 3
+    tf = StepTrace(2, 3, True)
+    tf.push(torch.zeros(B, 1, F), torch.zeros(B, 1, Tk), torch.zeros(B, 1, C), torch.ones(B, 1, 1))
+    assert not tf.stop(torch.ones(B, 1, 1))
+
+
+def test_round6_host_switches():
+    """TrainConfig accepts the reference's amsgrad=False and refuses True explicitly (train.py:975-979); the audio default
+    is the hop-normalised lws window in product and oracle; the ring stand-in's wire time"""
+    from deepvoice3_pytorch_amd import train_step, audio, dist
+    from oracle import audio_oracle as A
+    assert train_step.TrainConfig(amsgrad=False).amsgrad is False
+    with pytest.raises(ValueError):
+        train_step.TrainConfig(amsgrad=True)
+    assert abs(audio.AudioConfig().window_scale - np.sqrt(0.5)) < 1e-12 and audio.AudioConfig(window_scale=1.0).window_scale == 1.0
+    assert abs(audio.AudioConfig().window_scale - A.lws_scale()) < 1e-15
+    # 2 (n - 1) / n x S / busbw: 25 MiB over an 8-rank ring at 150 GB/s
+    ms = dist.RingStandin.ideal_ms(type("S", (), dict(world=8, busbw_gbps=150.0))(), 25 << 20)
+    assert abs(ms - 2 * 7 / 8 * (25 << 20) / 150e9 * 1e3) < 1e-9
+
+
+def test_sub_module_checkpoint_loads_under_a_joint_trainer():
+    """the reference loads its `_seq2seq` / `_postnet` checkpoints into model.seq2seq / model.postnet while
+    training the whole model (train.py:986-990): load_checkpoint finds the sub-module by the file's keys (or takes
+    module=), loads its moments and leaves the others' and the joint step count alone"""
+    from deepvoice3_pytorch_amd import builder, train_step
+    hp = dict(n_vocab=20, embed_dim=16, mel_dim=8, linear_dim=9, r=1, downsample_step=4, padding_idx=0, dropout=0.0,
+              kernel_size=3, encoder_channels=16, decoder_channels=16, converter_channels=16, max_positions=32)
+    torch.manual_seed(0)
+    src = train_step.Trainer(builder.deepvoice3(**hp), train_step.TrainConfig(max_positions=32), global_step=9,
+                             train_seq2seq=False, train_postnet=True)
+    src.adam_step = 4
+    src.arena.exp_avg.copy_(torch.randn_like(src.arena.exp_avg))
+    src.arena.exp_avg_sq.copy_(torch.rand_like(src.arena.exp_avg_sq))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = train_step.save_checkpoint(src, td, global_epoch=1)
+        assert path.endswith("_postnet.pth")
+        torch.manual_seed(1)
+        joint = train_step.Trainer(builder.deepvoice3(**hp), train_step.TrainConfig(max_positions=32))
+        joint.adam_step = 11
+        before = joint.arena.exp_avg.clone()
+        assert train_step.load_checkpoint(path, joint, unsafe=True) == 1
+    for (k, v), (k2, v2) in zip(joint.model.postnet.state_dict().items(), src.model.postnet.state_dict().items()):
+        assert k == k2 and torch.equal(v, v2)
+    assert joint.adam_step == 11 and joint.global_step == 9          # a partial optimizer state keeps the joint count
+    slot = {id(p): (o, n) for o, n, p in zip(joint.arena.offsets, joint.arena.sizes, joint.arena.params)}
+    post = set(id(p) for p in joint.model.postnet.parameters())
+    touched = sum(1 for p in joint.arena.params if id(p) in post and not torch.equal(
+        joint.arena.exp_avg[slot[id(p)][0]:slot[id(p)][0] + slot[id(p)][1]], before[slot[id(p)][0]:slot[id(p)][0] + slot[id(p)][1]]))
+    untouched = all(torch.equal(joint.arena.exp_avg[slot[id(p)][0]:slot[id(p)][0] + slot[id(p)][1]],
+                                before[slot[id(p)][0]:slot[id(p)][0] + slot[id(p)][1]])
+                    for p in joint.arena.params if id(p) not in post)
+    assert touched > 0 and untouched
