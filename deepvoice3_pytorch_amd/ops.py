@@ -1012,8 +1012,22 @@ def axpby(a, b, alpha):
     return out
 
 
+# K steps a weight-gradient workgroup gets at least.  0 = the measured rule: 8 for short reductions (B=16: more slabs
+# fill the chip), rising with the reduction length to 32 (fp32-storage kernels) / 20 (channel-blocked bf16 kernel) for the
+# B=64 ones, where fewer, longer workgroups write fewer partial slabs for the weight-norm backward to read
+# (profiles/r06_ksplit_min_steps_ab.txt: -1.3 % / -1.5 % / -0.8 % on the B=64 / B=32 / vctk-bf16 steps; 20 forced at B=16
+# costs +1.8 %, 56 at B=64 +7 %, 32 on the bf16 kernel +2 %).
+ksplit_min_steps = int(_os.environ.get("DV3_KSPLIT_MIN_STEPS", "0"))
+
+
+def _ksplit_count(total_steps, tiles, slots=512, min_steps=None, c8=False):
+    if min_steps is None:
+        min_steps = ksplit_min_steps or (max(8, min(20, total_steps // 22)) if c8 else max(8, min(32, total_steps // 14)))
+    return _ksplit_count_c(total_steps, tiles, slots, min_steps)
+
+
 @functools.lru_cache(maxsize=None)
-def _ksplit_count(total_steps, tiles, slots=512, min_steps=8):
+def _ksplit_count_c(total_steps, tiles, slots, min_steps):
     """Split-K factor for the bf16x3 wgrad: the grid (tiles x S workgroups) should fill the chip's
     2 x 256 workgroup slots a whole number of times, with at least `min_steps` K steps each."""
     s_max = max(1, total_steps // min_steps)
@@ -1708,7 +1722,7 @@ class ConvLayerC8Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             tiles = ((M + 127) // 128) * ((Cin + 127) // 128)
             v3 = v if v.dim() == 3 else v.unsqueeze(-1)
-            S = _ksplit_count(B * ((T + 31) // 32), tiles, slots=256)
+            S = _ksplit_count(B * ((T + 31) // 32), tiles, slots=256, c8=True)
             slab_rows = slab_rows_default and S > 1
             side = SideStream.fork(g8, x, ctx.bits, ctx.keep8, part, dy) if (ctx.inplace and SideStream.stream is not None) \
                 else contextlib.nullcontext()
