@@ -1047,7 +1047,8 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
 }
 
 extern int g_wgrad_tile, g_wgrad_prio, g_wgrad_t2_abl, g_wgrad_taps2_default, g_wgrad_t2_window, g_wgrad_t2_il;   // wgrad_gemm_bf16x3.hip, wgrad_taps2.hip
-extern int g_wgrad_c8_pf2, g_wgrad_c8_il, g_spk_abl;                                                       // wgrad_c8.hip
+extern int g_wn_bwd_vec4;                                                                                  // weight_norm.hip
+extern int g_wgrad_c8_pf2, g_wgrad_c8_il, g_wgrad_c8_tr, g_spk_abl;                                                       // wgrad_c8.hip
 int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
 int dv3_c8pp_debug_set(int what, int value);     // conv_c8pp.hip
 int dv3_conv_census_set(int on);                 // conv_gemm.hip
@@ -1075,6 +1076,8 @@ extern "C" int dv3_debug_set(int what, int value) {
     else g_pp2_ord_m = ship ? value : 0;
   }
   if (what == 50) g_pp2_fast_tail = value;
+  if (what == 51) g_wn_bwd_vec4 = value;
+  if (what == 52) g_wgrad_c8_tr = value;
   if (what == 22) g_pp2_sk = value;
   if (what == 23) g_pp2_sk_overhead = value;
   if (what == 24) g_pp2_sk_gain = value;

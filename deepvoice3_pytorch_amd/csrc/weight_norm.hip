@@ -7,6 +7,8 @@
 //   ConvTranspose1d      v [I][O][J]  norm per INPUT channel i (dim 0 of its weight)
 #include "common.h"
 
+int g_wn_bwd_vec4 = 1;     // dv3_debug_set(51, v): 0 = the 4-byte gather everywhere (A/B, bit-identity tests)
+
 namespace {
 
 // scale[r] = 1/||v[r]||  (1 when g == NULL: plain weight).  One block per row.
@@ -218,13 +220,49 @@ __global__ void zero_kernel(float* p, int64_t n) {
 // ---- backward ------------------------------------------------------------------------
 // one block per normalised row r (o, or i when transposed).  dW row gathered from the slabs
 // into LDS, dot with v, then dv / dg.
-__device__ __forceinline__ void wn_bwd_row(const dv3_wn_bwd_desc& p, const int r, const int nrows, float* dw, float* red) {
+__device__ __forceinline__ void wn_bwd_row(const dv3_wn_bwd_desc& p, const int r, const int nrows, float* dw, float* red,
+                                           const int vec4_ok) {
   const int O = p.O, I = p.I, J = p.J;
   const int len = p.transposed ? O * J : I * J;
   const float* vrow = p.v + (int64_t)r * len;
   float dot = 0.f;
   // gather: walk the slabs in THEIR order (for a Conv1d row: J runs of I contiguous floats), several slab
   // loads in flight per thread; the row lands in LDS in the parameter's (i, j) order
+  // 16-byte form (round 6): a thread sums four consecutive i of every slab, so a 768 / 1536-long row is one trip with all
+  // its slab loads in flight instead of three / six dependent trips of 4-byte loads.  Per element the order of the
+  // additions is the scalar loop's (partial k goes to accumulator k % 8; the same tree at the end): the same bits.
+  const bool vec4 = !p.transposed && (I & 3) == 0 && (p.ldo & 3) == 0 && (p.slab_ss & 3) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(p.slabs) & 15) == 0) && vec4_ok;
+  if (vec4) {
+    const int I4 = I >> 2;
+    for (int q = threadIdx.x; q < J * I4; q += 256) {
+      const int j = q / I4, i4 = q - j * I4;
+      const f32x4* __restrict__ sp = reinterpret_cast<const f32x4*>(p.slabs + ((int64_t)j * O + r) * p.ldo) + i4;
+      const int64_t ss4 = p.slab_ss >> 2;
+      f32x4 s[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int k = 0;
+      for (; k + 8 <= p.n_slabs; k += 8) {
+        f32x4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = sp[(int64_t)(k + u) * ss4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += a[u];
+      }
+      for (; k + 4 <= p.n_slabs; k += 4) {
+        f32x4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = sp[(int64_t)(k + u) * ss4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] += a[u];
+      }
+      for (; k < p.n_slabs; ++k) s[0] += sp[(int64_t)k * ss4];
+      const f32x4 tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dw[(i4 * 4 + e) * J + j] = tot[e];
+    }
+  } else
   for (int q = threadIdx.x; q < len; q += 256) {
     int64_t off;
     int idx;
@@ -303,10 +341,10 @@ __device__ __forceinline__ void wn_bwd_row(const dv3_wn_bwd_desc& p, const int r
   }
 }
 
-__global__ __launch_bounds__(256) void wn_bwd_kernel(const dv3_wn_bwd_desc p) {
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const dv3_wn_bwd_desc p, const int vec4_ok) {
   extern __shared__ float dw[];  // [len]
   __shared__ float red[4];
-  wn_bwd_row(p, blockIdx.x, gridDim.x, dw, red);
+  wn_bwd_row(p, blockIdx.x, gridDim.x, dw, red, vec4_ok);
 }
 
 // several layers in one launch: block -> (layer, row); the descriptors are kernel arguments (include/dv3hip.h)
@@ -314,6 +352,7 @@ struct WnBwdMultiArgs {
   dv3_wn_bwd_desc d[DV3_WN_BWD_MULTI_MAX];
   int32_t first_row[DV3_WN_BWD_MULTI_MAX + 1];
   int32_t n;
+  int32_t vec4_ok;
 };
 __global__ __launch_bounds__(256) void wn_bwd_multi_kernel(const WnBwdMultiArgs a) {
   extern __shared__ float dw[];
@@ -324,7 +363,7 @@ __global__ __launch_bounds__(256) void wn_bwd_multi_kernel(const WnBwdMultiArgs 
   for (int k = 1; k < DV3_WN_BWD_MULTI_MAX; ++k)
     if (k < a.n && a.first_row[k] <= blk) l = k;
   // (uniform per workgroup: the descriptor is read from the argument segment with scalar loads)
-  wn_bwd_row(a.d[l], blk - a.first_row[l], a.first_row[l + 1] - a.first_row[l], dw, red);
+  wn_bwd_row(a.d[l], blk - a.first_row[l], a.first_row[l + 1] - a.first_row[l], dw, red, a.vec4_ok);
 }
 
 // dbias[o] = sum_p part[p][o]
@@ -430,13 +469,14 @@ extern "C" int dv3_weight_norm_bwd_f32(const dv3_wn_bwd_desc* d, void* stream) {
   size_t lds = 0;
   const int rc = wn_bwd_check(d, &rows, &lds);
   if (rc != DV3_OK) return rc;
-  hipLaunchKernelGGL(wn_bwd_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, *d);
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(rows), dim3(256), lds, (hipStream_t)stream, *d, g_wn_bwd_vec4);
   return dv3_check_launch("weight_norm_bwd_f32");
 }
 
 extern "C" int dv3_weight_norm_bwd_multi(const dv3_wn_bwd_desc* descs, int32_t n, void* stream) {
   DV3_REQUIRE(descs && n > 0 && n <= DV3_WN_BWD_MULTI_MAX, "wn_bwd_multi: 1..%d descriptors", DV3_WN_BWD_MULTI_MAX);
   WnBwdMultiArgs a;
+  a.vec4_ok = g_wn_bwd_vec4;
   size_t lds_max = 0;
   int total = 0;
   for (int l = 0; l < n; ++l) {

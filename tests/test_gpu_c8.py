@@ -108,7 +108,8 @@ def test_c8_gated_layers_forward_backward(dev, modes, kind, C, k, d, causal, T, 
     rec = {}
     y8, dx8, dp8 = _run(layer, x, True, "bf16", ops, record=rec)
     assert _lib.lib().dv3_debug_get(10) // 1000 == 8            # the planes kernel, single-term bf16
-    assert _lib.lib().dv3_debug_get(11) in (5001, 5003, 5021, 5023, 5063)   # the c8 wgrad kernel (+20: two-steps-ahead fetch, +40: staging between the MFMAs)
+    # the c8 wgrad kernel (+20: two-steps-ahead fetch, +40: staging between the MFMAs; 51xx / 53xx: the transposing-read forms)
+    assert _lib.lib().dv3_debug_get(11) in (5001, 5003, 5021, 5023, 5063, 5101, 5103, 5143, 5301, 5303, 5343)
     # forward against the oracle with the recorded keep-bits
     bits, rows, Tm = rec["l"]
     keep = torch.from_numpy(O.unpack_keep_bits(bits.cpu().numpy().view(np.uint32), rows, (Tm + 31) // 32, Tm)).float()
@@ -541,15 +542,23 @@ def test_wgrad_c8_two_steps_ahead_is_bit_identical(dev, modes, kind, C, k, d, ca
     x = torch.randn(B, C, T, device=dev)
     out = {}
     try:
-        # one step ahead | two steps ahead, staging after the MFMAs | ... between them (round 6, three taps: variant 5063)
-        for tag, pf2, il in ((0, 0, 0), (1, 1, 0), (2, 1, 1)):
+        # register-transposing forms: one step ahead | two steps ahead, staging after the MFMAs | ... between them (three
+        # taps: variant 5063); transposing-read forms (round 6, dv3_debug_set(52, v)): plain 51xx | staging between the
+        # MFMAs 5143 | one barrier per two K steps 53xx | both 5343 (the default)
+        for tag, tr, pf2, il in ((0, 0, 0, 0), (1, 0, 1, 0), (2, 0, 1, 1), (3, 1, 1, 1), (4, 2, 1, 1), (5, 3, 1, 1), (6, 4, 1, 1)):
+            L.dv3_debug_set(52, tr)
             L.dv3_debug_set(20, pf2)
             L.dv3_debug_set(49, il)
             out[tag] = _run(layer, x, True, "bf16", ops)
-            assert L.dv3_debug_get(11) == 5000 + 20 * pf2 + k + (40 if (il and pf2 and k == 3) else 0)
+            if tr == 0:
+                want = 5000 + 20 * pf2 + k + (40 if (il and pf2 and k == 3) else 0)
+            else:
+                want = 5100 + k + (40 if (tr in (2, 4) and k == 3) else 0) + (200 if tr in (3, 4) else 0)
+            assert L.dv3_debug_get(11) == want, (tag, L.dv3_debug_get(11), want)
     finally:
         L.dv3_debug_set(20, 1)
         L.dv3_debug_set(49, 1)
-    for tag in (1, 2):
+        L.dv3_debug_set(52, 4)
+    for tag in range(1, 7):
         for n in out[0][2]:
             assert torch.equal(out[0][2][n], out[tag][2][n]), (tag, n)

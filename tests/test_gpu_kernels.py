@@ -889,3 +889,38 @@ def test_stream_k_form_of_the_256x256_tap_gemm(dev, gemm_mode, B, C, T, d, maske
         assert torch.equal(y1, sks[0][0]) and torch.equal(ab1, sks[0][1]) and torch.equal(dx1, sks[0][2])
     for a, b in ((y0, sks[0][0]), (ab0, sks[0][1]), (dx0, sks[0][2])):
         assert float((a - b).abs().max()) < 2e-6 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("O_,I,J,S,rows", [(512, 256, 3, 14, True), (1024, 512, 3, 32, True), (256, 256, 1, 5, True),
+                                           (96, 64, 5, 9, False), (513, 512, 1, 3, True), (64, 36, 3, 17, True)])
+def test_weight_norm_backward_16_byte_gather_is_the_4_byte_one(dev, O_, I, J, S, rows):
+    """dv3_weight_norm_bwd_f32 sums the K-split partial slabs four columns per thread (round 6) with the scalar loop's
+    order of additions per element: dv, dg and dbias must be the same bits as with dv3_debug_set(51, 0)."""
+    from deepvoice3_pytorch_amd import ops, _lib
+    rng = np.random.RandomState(O_ + I + J + S)
+    ldo = I
+    slabs = torch.from_numpy(rng.randn(*((J, O_, S, ldo) if rows else (S, J, O_, ldo))).astype(np.float32)).to(dev)
+    v = torch.from_numpy(rng.randn(O_, I, J).astype(np.float32) * 0.1).to(dev)
+    g = torch.from_numpy(rng.uniform(0.5, 1.5, (O_, 1, 1)).astype(np.float32)).to(dev)
+    scale = 1.0 / v.reshape(O_, -1).norm(dim=1)
+    part = torch.from_numpy(rng.randn(7, O_).astype(np.float32)).to(dev)
+    outs = []
+    for sw in (0, 1):
+        _lib.lib().dv3_debug_set(51, sw)
+        try:
+            outs.append(ops.weight_norm_bwd(slabs, S, ldo, v, g, scale, part, 7, O_, I, J, rows_of_slabs=rows))
+        finally:
+            _lib.lib().dv3_debug_set(51, 1)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # and it is the weight-norm backward: dW = sum of the slabs, dg = <dW, v> / |v|, dv = g / |v| (dW - <dW, v> v / |v|^2)
+    dW = (slabs.sum(2) if rows else slabs.sum(0)).permute(1, 2, 0).double()          # [O][I][J]
+    vd = v.double()
+    nrm = vd.reshape(O_, -1).norm(dim=1).view(O_, 1, 1)
+    dot = (dW * vd).reshape(O_, -1).sum(1).view(O_, 1, 1)
+    dg_ref = dot / nrm
+    dv_ref = g.double() / nrm * (dW - dot * vd / nrm ** 2)
+    dv, dg, dbias = outs[1]
+    assert rel_err(dv.cpu().numpy(), dv_ref.cpu().numpy()) < 2e-5
+    assert rel_err(dg.cpu().numpy(), dg_ref.cpu().numpy()) < 2e-5
+    assert rel_err(dbias.cpu().numpy(), part.double().sum(0).cpu().numpy()) < 2e-5
