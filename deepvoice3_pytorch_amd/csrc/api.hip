@@ -167,6 +167,7 @@ extern "C" int dv3_sizeof(const char* name) {
   DV3_SZ(dv3_attn_fwd_desc);
   DV3_SZ(dv3_spk_layer);
   DV3_SZ(dv3_spk_desc);
+  DV3_SZ(dv3_dropout_site);
 #undef DV3_SZ
   return -1;
 }

@@ -262,16 +262,16 @@ __global__ __launch_bounds__(256) void dropout_bits_kernel(uint32_t* __restrict_
 // The same keep decisions written straight as keep-BYTES of the channel-blocked layout ([B][C8][T], bit e of byte
 // (b, g, t) = channel 8g+e; include/dv3hip.h "c8") -- what dv3_dropout_bits followed by dv3_mask_bits_to_c8 produce,
 // in one launch.  One thread per (b, group, 32-frame word): eight Philox words, an 8 x 32 bit transpose, 32 bytes.
-__global__ __launch_bounds__(256) void dropout_keep_c8_kernel(uint8_t* __restrict__ out, int B, int C, int T, int rs,
-                                                              int c8p, uint32_t thr, uint64_t seed, uint64_t site,
-                                                              const uint64_t* __restrict__ dev_off,
-                                                              uint32_t* __restrict__ bits_out) {
+__device__ __forceinline__ void dropout_keep_c8_block(uint8_t* __restrict__ out, int B, int C, int T, int rs,
+                                                      int c8p, uint32_t thr, uint64_t seed, uint64_t site,
+                                                      const uint64_t* __restrict__ dev_off,
+                                                      uint32_t* __restrict__ bits_out, uint32_t block,
+                                                      uint32_t (*words)[9]) {
   // a workgroup = 32 entries (b, group, 32-frame word) x 8 channels: one Philox word per thread, the 8 x 32 bit
   // transpose through LDS, then thread (entry, q) writes bytes 4q .. 4q+3 of its entry (a wave covers 8 entries =
   // 256 contiguous bytes when T is a multiple of 32)
-  __shared__ uint32_t words[32][9];
   const uint32_t n_ent = (uint32_t)B * (uint32_t)c8p * (uint32_t)rs;             // < 2^31 (host-checked)
-  const uint32_t ent = blockIdx.x * 32u + (threadIdx.x >> 3);                      // ((b * c8p) + g) * rs + wi
+  const uint32_t ent = block * 32u + (threadIdx.x >> 3);                           // ((b * c8p) + g) * rs + wi
   const uint32_t e = threadIdx.x & 7;
   if (dev_off) seed += dev_off[0];
   uint32_t wi = 0, bg = 0;
@@ -299,6 +299,34 @@ __global__ __launch_bounds__(256) void dropout_keep_c8_kernel(uint8_t* __restric
     for (int c = 0; c < 8; ++c) m |= ((w[c] >> (4 * q + i)) & 1u) << c;
     o[i] = (uint8_t)m;
   }
+}
+__global__ __launch_bounds__(256) void dropout_keep_c8_kernel(uint8_t* __restrict__ out, int B, int C, int T, int rs,
+                                                              int c8p, uint32_t thr, uint64_t seed, uint64_t site,
+                                                              const uint64_t* __restrict__ dev_off,
+                                                              uint32_t* __restrict__ bits_out) {
+  __shared__ uint32_t words[32][9];
+  dropout_keep_c8_block(out, B, C, T, rs, c8p, thr, seed, site, dev_off, bits_out, blockIdx.x, words);
+}
+// several dropout sites in ONE launch (round 6: a step's ~25-35 mask launches, 6 us each on the forward's single queue):
+// block -> (site, block of the site); the table is a kernel argument.  Per site the decisions of the single-site kernel.
+struct DropoutMultiArgs {
+  dv3_dropout_site s[DV3_DROPOUT_MULTI_MAX];
+  uint32_t first_block[DV3_DROPOUT_MULTI_MAX + 1];
+  uint32_t thr[DV3_DROPOUT_MULTI_MAX];
+  int32_t n;
+  uint64_t seed;
+  const uint64_t* dev_off;
+};
+__global__ __launch_bounds__(256) void dropout_keep_c8_multi_kernel(const DropoutMultiArgs a) {
+  __shared__ uint32_t words[32][9];
+  const uint32_t blk = blockIdx.x;
+  int l = 0;
+#pragma unroll 8
+  for (int k = 1; k < DV3_DROPOUT_MULTI_MAX; ++k)
+    if (k < a.n && a.first_block[k] <= blk) l = k;
+  const dv3_dropout_site& e = a.s[l];
+  dropout_keep_c8_block(e.keep, e.B, e.C, e.T, (e.T + 31) / 32, (e.C + 31) / 32 * 4, a.thr[l], a.seed, e.site, a.dev_off, e.bits,
+                        blk - a.first_block[l], words);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -759,6 +787,29 @@ static int dropout_keep_launch(uint8_t* out, uint32_t* bits, int32_t B, int32_t 
   hipLaunchKernelGGL(dropout_keep_c8_kernel, dim3((unsigned)dv3_cdiv64(n, 32)), dim3(256), 0, (hipStream_t)stream, out,
                      B, C, T, rs, c8p, thr, seed, site, dev_seed_offset, bits);
   return dv3_check_launch("dropout_keep_c8");
+}
+
+extern "C" int dv3_dropout_keep_c8_multi(const dv3_dropout_site* sites, int32_t n, uint64_t seed,
+                                         const uint64_t* dev_seed_offset, void* stream) {
+  DV3_REQUIRE(sites && n > 0 && n <= DV3_DROPOUT_MULTI_MAX, "dropout_keep_c8_multi: 1..%d sites", DV3_DROPOUT_MULTI_MAX);
+  DropoutMultiArgs a;
+  int64_t total = 0;
+  for (int l = 0; l < n; ++l) {
+    const dv3_dropout_site& e = sites[l];
+    DV3_REQUIRE(e.keep && e.B > 0 && e.C > 0 && e.T > 0, "dropout_keep_c8_multi: bad site %d", l);
+    DV3_REQUIRE(e.p >= 0.f && e.p < 1.f, "dropout_keep_c8_multi: p out of range (site %d)", l);
+    const int rs = (e.T + 31) / 32, c8p = (e.C + 31) / 32 * 4;
+    DV3_REQUIRE((int64_t)e.B * c8p * e.T < (1ll << 31), "dropout_keep_c8_multi: mask %d exceeds the 2 GB the kernel can address", l);
+    a.s[l] = e;
+    a.thr[l] = (uint32_t)(e.p * 65536.0f + 0.5f);
+    a.first_block[l] = (uint32_t)total;
+    total += dv3_cdiv64((int64_t)e.B * c8p * rs, 32);
+  }
+  DV3_REQUIRE(total < (1ll << 31), "dropout_keep_c8_multi: grid too large");
+  for (int l = n; l <= DV3_DROPOUT_MULTI_MAX; ++l) a.first_block[l] = (uint32_t)total;
+  a.n = n; a.seed = seed; a.dev_off = dev_seed_offset;
+  hipLaunchKernelGGL(dropout_keep_c8_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
+  return dv3_check_launch("dropout_keep_c8_multi");
 }
 
 extern "C" int dv3_dropout_apply_f32(const float* x, const uint32_t* bits, int32_t bits_rs,

@@ -581,6 +581,68 @@ def from_c8(xc8, C=None):
     return _FromC8Fn.apply(xc8, _c8_C(xc8, C))
 
 
+class MaskPlan(object):
+    """A training step's dropout masks in ONE launch (dv3_dropout_keep_c8_multi).  Every Conv1dGLU / HighwayConv1d draws
+    its mask when its forward runs (dropout_keep_c8 / dropout_bits_keep below: one ~6 us launch each, 25-35 per step on
+    the forward's only queue).  A mask depends on (seed, site number, step counter) only, and the site number is the
+    position of the call in the step -- so once two consecutive steps have drawn the same list of (position, kind, shape,
+    p), the next step draws the whole list at its start (Trainer.forward_backward -> begin_step) and the layers take
+    their masks from it: the same bits the single launches write (tests/test_gpu_model.py).  A call that does not match
+    the list falls back to its own launch (same site number), and a step whose list differs from the previous one
+    switches the plan off until two steps agree again (ragged eager epochs never plan)."""
+    enabled = bool(int(_os.environ.get("DV3_MASK_PLAN", "1")))
+
+    def __init__(self):
+        self.plan = None         # tuple of (site offset, kind, B, C, T, p) two consecutive steps agreed on
+        self.last = None         # the previous step's list
+        self.rec = None          # this step's list (None outside a step)
+        self.s0 = 0
+        self.ready = {}          # site offset -> (signature, masks)
+        self.stats = dict(batched_launches=0, planned=0, single=0)
+
+    def begin_step(self, device):
+        st = dropout_state
+        if st.seed is None:
+            st.manual_seed(torch.initial_seed())
+        self.rec, self.s0, self.ready = [], st.site, {}
+        if not (self.enabled and self.plan) or st.record is not None:
+            return
+        MAX = CONSTS["DV3_DROPOUT_MULTI_MAX"]
+        Site = STRUCTS["dv3_dropout_site"]
+        for i in range(0, len(self.plan), MAX):
+            part = self.plan[i:i + MAX]
+            arr = (Site * len(part))()
+            for e, sig in zip(arr, part):
+                off, kind, B, C, T, p = sig
+                keep = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=device)
+                bits = torch.empty(B * C * ((T + 31) // 32), dtype=torch.int32, device=device) if kind == "both" else None
+                e.keep, e.bits, e.B, e.C, e.T, e.p, e.site = keep.data_ptr(), _ptr(bits), B, C, T, p, self.s0 + off
+                self.ready[off] = (sig, keep if bits is None else (bits, (T + 31) // 32, keep))
+            _lib.call("dv3_dropout_keep_c8_multi", arr, len(part), st.seed, _ptr(st.dev_offset), _stream())
+            self.stats["batched_launches"] += 1
+
+    def take(self, kind, B, C, T, p):
+        """after dropout_state.next_site(): the planned masks of this call, or None (the caller launches for itself)"""
+        if self.rec is None:
+            return None
+        sig = (dropout_state.site - self.s0, kind, B, C, T, float(p))
+        self.rec.append(sig)
+        hit = self.ready.pop(sig[0], None)
+        if hit is not None and hit[0] == sig:
+            self.stats["planned"] += 1
+            return hit[1]
+        self.stats["single"] += 1
+        return None
+
+    def end_step(self):
+        rec, self.rec, self.ready = tuple(self.rec or ()), None, {}
+        self.plan = rec if (rec and rec == self.last) else None
+        self.last = rec
+
+
+mask_plan = MaskPlan()
+
+
 def dropout_keep_c8(B, C, T, p, device, name=None):
     """keep-bytes [B][C8][T] of a dropout site over a c8 tensor -- the decisions dropout_bits(B*C, T, ...) draws for
     the same site.  When a test records masks the bits are generated too (and converted), so the record holds the
@@ -588,8 +650,11 @@ def dropout_keep_c8(B, C, T, p, device, name=None):
     if dropout_state.record is not None and name is not None:
         bits, rs = dropout_bits(B * C, T, p, device, name)
         return mask_bits_to_c8(bits, rs, B, C, T)
-    out = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=device)
     site = dropout_state.next_site()
+    hit = mask_plan.take("keep", B, C, T, p)
+    if hit is not None:
+        return hit
+    out = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=device)
     _lib.call("dv3_dropout_keep_c8", out.data_ptr(), B, C, T, float(p), dropout_state.seed, site,
               _ptr(dropout_state.dev_offset), _stream())
     return out
@@ -598,9 +663,12 @@ def dropout_keep_c8(B, C, T, p, device, name=None):
 def dropout_bits_keep(B, C, T, p, device, name=None):
     """one dropout site in both forms, one launch: -> (keep-bits int32 [B*C][rs], rs, keep-bytes uint8 [B][C8][T])"""
     rs = (T + 31) // 32
+    site = dropout_state.next_site()
+    hit = mask_plan.take("both", B, C, T, p) if (dropout_state.record is None or name is None) else None
+    if hit is not None:
+        return hit
     bits = torch.empty(B * C * rs, dtype=torch.int32, device=device)
     keep = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=device)
-    site = dropout_state.next_site()
     _lib.call("dv3_dropout_bits_keep", bits.data_ptr(), keep.data_ptr(), B, C, T, float(p), dropout_state.seed, site,
               _ptr(dropout_state.dev_offset), _stream())
     if dropout_state.record is not None and name is not None:

@@ -326,6 +326,7 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
             p._dv3_pending = 0
         self.model.train()
         ops.prepacked = self._prepack_all()
+        ops.mask_plan.begin_step(self.device)      # the step's dropout masks in one launch once its list of sites repeats
         s2s, pn = self.train_seq2seq, self.train_postnet
         try:
             if s2s and pn:
@@ -345,6 +346,7 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
                 mel_out = attn = done_hat = None
         finally:
             ops.prepacked = None
+            ops.mask_plan.end_step()
         if not (s2s and pn):
             return self._split_losses_backward(batch, mel_out, lin_out, attn, done_hat)
         wm, w = c.masked_loss_weight, c.binary_divergence_weight

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 40
+#define DV3_ABI_VERSION 41
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -478,6 +478,19 @@ int dv3_dropout_bits_keep(uint32_t* bits, uint8_t* keep, int32_t B, int32_t C, i
                           uint64_t site, const uint64_t* dev_seed_offset, void* stream);
 int dv3_dropout_keep_c8(uint8_t* out, int32_t B, int32_t C, int32_t T, float p, uint64_t seed, uint64_t site,
                         const uint64_t* dev_seed_offset, void* stream);
+
+/* Several dropout sites in ONE launch (ABI 41): site l gets exactly what dv3_dropout_bits_keep(bits, keep, B, C, T, p, seed,
+ * site, ...) (bits != NULL) or dv3_dropout_keep_c8(keep, ...) (bits == NULL) writes.  A training step draws 25-35 masks
+ * (one per Conv1dGLU / HighwayConv1d: modules.py:147,210), each a ~6 us launch on the forward's only queue; the host side
+ * (ops.MaskPlan) issues them together at the start of the step once the step's list of sites has repeated.        */
+#define DV3_DROPOUT_MULTI_MAX 48
+typedef struct dv3_dropout_site {
+  uint8_t* keep;  uint32_t* bits;      /* keep-bytes [B][round_up(C,32)/8][T]; keep-bits [B*C][ceil(T/32)] or NULL */
+  int32_t B, C, T;  float p;
+  uint64_t site;
+} dv3_dropout_site;
+int dv3_dropout_keep_c8_multi(const dv3_dropout_site* sites, int32_t n, uint64_t seed,
+                              const uint64_t* dev_seed_offset, void* stream);
 
 /* out[row][t] = x[row][t] * keep(bits,row,t) * scale -- a standalone F.dropout for the few
  * sites whose dropped tensor is shared by several consumers (deepvoice3.py:78-80,290,321:

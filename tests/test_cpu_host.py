@@ -872,3 +872,40 @@ def test_sub_module_checkpoint_loads_under_a_joint_trainer():
                                 before[slot[id(p)][0]:slot[id(p)][0] + slot[id(p)][1]])
                     for p in joint.arena.params if id(p) not in post)
     assert touched > 0 and untouched
+
+
+def test_mask_plan_state_machine():
+    """ops.MaskPlan (host side of dv3_dropout_keep_c8_multi): a plan exists only after two consecutive steps drew the same
+    list of (position, kind, shape, p); a step that differs drops it; outside begin_step / end_step nothing is recorded"""
+    from deepvoice3_pytorch_amd import ops
+    st, plan = ops.dropout_state, ops.MaskPlan()
+    st.manual_seed(5)
+
+    def step(shapes):
+        plan.rec, plan.s0, plan.ready = [], st.site, {}          # begin_step without the launch (no GPU here)
+        for kind, shape in shapes:
+            st.next_site()
+            assert plan.take(kind, *shape, 0.05) is None          # nothing was pre-drawn
+        plan.end_step()
+    a = [("both", (2, 64, 50)), ("keep", (2, 64, 50)), ("keep", (2, 128, 25))]
+    assert plan.take("keep", 2, 64, 50, 0.05) is None and plan.rec is None
+    step(a)
+    assert plan.plan is None and len(plan.last) == 3
+    step(a)
+    assert plan.plan == plan.last and [s[0] for s in plan.plan] == [1, 2, 3]
+    step(a[:2])
+    assert plan.plan is None
+    step(a[:2])
+    assert plan.plan is not None and len(plan.plan) == 2
+    step([])
+    assert plan.plan is None
+    # a pre-drawn mask is handed out once, to the call at its position with its signature only
+    plan.rec, plan.s0 = [], st.site
+    sig = (1, "keep", 2, 64, 50, 0.05)
+    plan.ready = {1: (sig, "mask")}
+    st.next_site()
+    assert plan.take("keep", 2, 64, 51, 0.05) is None
+    plan.ready = {2: ((2,) + sig[1:], "mask")}
+    st.next_site()
+    assert plan.take("keep", 2, 64, 50, 0.05) == "mask" and not plan.ready
+    plan.end_step()

@@ -899,3 +899,71 @@ def test_priority_freq_weight_and_trainable_position_tables(dev, gemm_mode):
         assert rel_err(p.grad.cpu(), gc) < 5e-4, k
     for k in ("seq2seq.decoder.embed_query_positions.weight", "seq2seq.decoder.embed_keys_positions.weight"):
         assert float(sdc[k].grad.abs().max()) > 0 and float(dict(model.named_parameters())[k].grad[0].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_dropout_sites_in_one_launch_draw_the_single_launch_masks(dev):
+    """dv3_dropout_keep_c8_multi: site l = what dv3_dropout_bits_keep / dv3_dropout_keep_c8 write for the same seed, site
+    number and step offset (the keep decisions of F.dropout's replacement, modules.py:147,210)"""
+    import ctypes
+    from deepvoice3_pytorch_amd import ops, _lib
+    sites = [("both", 3, 64, 77, 0.05, 11), ("keep", 2, 72, 150, 0.1, 12), ("both", 4, 256, 33, 0.05, 14), ("keep", 1, 8, 5, 0.5, 20)]
+    off = torch.tensor([12345], dtype=torch.int64, device=dev)
+    Site = ops.STRUCTS["dv3_dropout_site"]
+    arr, outs = (Site * len(sites))(), []
+    for e, (kind, B, C, T, p, site) in zip(arr, sites):
+        keep = torch.zeros((B, ops.c8_groups(C), T), dtype=torch.uint8, device=dev)
+        bits = torch.zeros(B * C * ((T + 31) // 32), dtype=torch.int32, device=dev) if kind == "both" else None
+        e.keep, e.bits, e.B, e.C, e.T, e.p, e.site = keep.data_ptr(), (bits.data_ptr() if bits is not None else None), B, C, T, p, site
+        outs.append((keep, bits))
+    _lib.call("dv3_dropout_keep_c8_multi", arr, len(sites), 777, off.data_ptr(), ops._stream())
+    for (kind, B, C, T, p, site), (keep, bits) in zip(sites, outs):
+        k1 = torch.zeros_like(keep)
+        if kind == "both":
+            b1 = torch.zeros_like(bits)
+            _lib.call("dv3_dropout_bits_keep", b1.data_ptr(), k1.data_ptr(), B, C, T, p, 777, site, off.data_ptr(), ops._stream())
+            assert torch.equal(b1, bits)
+        else:
+            _lib.call("dv3_dropout_keep_c8", k1.data_ptr(), B, C, T, p, 777, site, off.data_ptr(), ops._stream())
+        assert torch.equal(k1, keep), (kind, B, C, T)
+        assert 0 < int(keep.count_nonzero())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode", [("dv3_preset_like", "f16x3"), ("nyanko_tiny", "bf16")])
+def test_planned_masks_train_the_same_steps(dev, name, mode):
+    """ops.MaskPlan: from the third step on the trainer draws a step's masks in one launch; five steps must end in the same
+    parameters bit for bit as with every mask drawn by its own launch (DV3_MASK_PLAN=0), and the plan must have been used"""
+    from deepvoice3_pytorch_amd import builder, ops, train_step
+    prev = ops.set_gemm_precision(mode)
+    prev_storage, ops.bf16_storage = ops.bf16_storage, mode == "bf16"
+    try:
+        fx, b, hp, sd, x, _ = _build(name, dev)
+        xg = _to(x, dev)
+        B, Td = x["mel"].shape[0], x["mel"].shape[1]
+        r = hp.get("r", 1) if "r" in hp else 1
+        rng = np.random.RandomState(1)
+        batch = train_step.Batch(xg["text"], xg["text_positions"], xg["frame_positions"], xg["mel"],
+                                 torch.from_numpy(rng.rand(B, Td * 4, hp["linear_dim"]).astype(np.float32)).to(dev),
+                                 torch.zeros(B, Td, 1, device=dev), x["input_lengths"].numpy(),
+                                 np.full(B, Td * 4 - 4), xg.get("speaker_ids"), 1, 4, dev)
+        cfg = train_step.TrainConfig(max_positions=hp.get("max_positions", 512), initial_learning_rate=2e-3)
+        res = {}
+        for planned in (False, True):
+            ops.mask_plan.__init__()
+            ops.MaskPlan.enabled = planned
+            m = getattr(builder, b)(**hp)
+            m.load_state_dict(sd)
+            t = train_step.Trainer(m.to(dev), cfg)
+            ops.dropout_state.manual_seed(4242)
+            losses = [float(t.step(batch)["loss"]) for _ in range(5)]
+            res[planned] = (losses, [v.clone() for v in t.model.state_dict().values()], dict(ops.mask_plan.stats))
+    finally:
+        ops.MaskPlan.enabled = True
+        ops.mask_plan.__init__()
+        ops.bf16_storage = prev_storage
+        ops.set_gemm_precision(prev)
+    assert res[True][2]["batched_launches"] >= 3 and res[True][2]["planned"] > 0 and res[False][2]["batched_launches"] == 0
+    assert res[True][0] == res[False][0]
+    for a, c in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, c)
