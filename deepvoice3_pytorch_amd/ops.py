@@ -497,7 +497,8 @@ bf16_storage = _os.environ.get("DV3_BF16_STORAGE", "1") not in ("0", "")
 
 
 def zero_(t):
-    """t.zero_() through the library (hipMemsetAsync on the op stream) -- no torch fill kernel"""
+    """t.zero_() through the library: a fill kernel on the op stream (NOT hipMemsetAsync: its node in a captured step
+    replayed with a corrupt fill pattern, csrc/elementwise.hip dv3_memset_b8)"""
     _lib.call("dv3_memset_b8", t.data_ptr(), 0, t.numel() * t.element_size(), _stream())
     return t
 
@@ -598,6 +599,7 @@ class MaskPlan(object):
         self.rec = None          # this step's list (None outside a step)
         self.s0 = 0
         self.ready = {}          # site offset -> (signature, masks)
+        self.static = None       # GraphedTrainer's segmented capture: masks in buffers IT fills before each replay
         self.stats = dict(batched_launches=0, planned=0, single=0)
 
     def begin_step(self, device):
@@ -607,8 +609,17 @@ class MaskPlan(object):
         self.rec, self.s0, self.ready = [], st.site, {}
         if not (self.enabled and self.plan) or st.record is not None:
             return
+        if self.static is not None:          # drawn by the owner of `static` (its site numbers start at this s0 too)
+            self.ready = dict(self.static)
+            return
+        self.ready, tables = self.build(device, self.s0)
+        self.draw(tables, st.dev_offset)
+
+    def build(self, device, s0):
+        """mask tensors + descriptor tables of the plan with site numbers from s0 -> ({offset: (sig, masks)}, [tables])"""
         MAX = CONSTS["DV3_DROPOUT_MULTI_MAX"]
         Site = STRUCTS["dv3_dropout_site"]
+        ready, tables = {}, []
         for i in range(0, len(self.plan), MAX):
             part = self.plan[i:i + MAX]
             arr = (Site * len(part))()
@@ -616,9 +627,15 @@ class MaskPlan(object):
                 off, kind, B, C, T, p = sig
                 keep = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=device)
                 bits = torch.empty(B * C * ((T + 31) // 32), dtype=torch.int32, device=device) if kind == "both" else None
-                e.keep, e.bits, e.B, e.C, e.T, e.p, e.site = keep.data_ptr(), _ptr(bits), B, C, T, p, self.s0 + off
-                self.ready[off] = (sig, keep if bits is None else (bits, (T + 31) // 32, keep))
-            _lib.call("dv3_dropout_keep_c8_multi", arr, len(part), st.seed, _ptr(st.dev_offset), _stream())
+                e.keep, e.bits, e.B, e.C, e.T, e.p, e.site = keep.data_ptr(), _ptr(bits), B, C, T, p, s0 + off
+                ready[off] = (sig, keep if bits is None else (bits, (T + 31) // 32, keep))
+            tables.append(arr)
+        return ready, tables
+
+    def draw(self, tables, dev_offset, stream=None):
+        for arr in tables:
+            _lib.call("dv3_dropout_keep_c8_multi", arr, len(arr), dropout_state.seed, _ptr(dev_offset),
+                      _stream() if stream is None else stream)
             self.stats["batched_launches"] += 1
 
     def take(self, kind, B, C, T, p):

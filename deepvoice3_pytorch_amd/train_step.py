@@ -628,7 +628,26 @@ class GraphedTrainer(object):
                 self.scal = self._body()
         else:
             self.graph = None
-            self._capture_segments()
+            # the step's dropout masks (ops.MaskPlan: one launch per step once the list of sites repeats) are NOT part of
+            # the segments: they depend on (seed, site, step counter) only, so the replay draws step k + 1's on the second
+            # stream while step k's clip + Adam runs on the first (an integer-multiply-bound ~0.1 ms kernel beside an
+            # HBM-bound one) -- into buffers of this object, which the captured layers read
+            self._mask_tables, self._mask_event, self.mask_offset = None, None, None
+            mp = ops.mask_plan
+            if mp.enabled and mp.plan and ops.dropout_state.record is None and \
+                    os.environ.get("DV3_MASK_PREDRAW", "1") not in ("0", ""):
+                mp.static, self._mask_tables = mp.build(dev, site0)
+                self._mask_buffers = mp.static            # (this object keeps the buffers alive: the replays read them)
+            try:
+                self._capture_segments()
+            finally:
+                mp.static = None
+            if self._mask_tables is not None:
+                torch.cuda.synchronize()
+                self.mask_offset = self.seed_offset.clone()      # the counter value the first replay runs under
+                mp.draw(self._mask_tables, self.mask_offset)
+                self._mask_event, self._mask_join = torch.cuda.Event(), torch.cuda.Event()
+                self._mask_event.record(torch.cuda.current_stream())
         ops.dropout_state.site = site0
 
     def _capture_segments(self):
@@ -765,6 +784,8 @@ class GraphedTrainer(object):
             cur, side = torch.cuda.current_stream(), self.t.side_stream
             side_raw = side.cuda_stream
             comm = self.t.comm
+            if self._mask_tables is not None:
+                cur.wait_event(self._mask_event)            # this step's masks (drawn beside the previous step's tail)
             for j, ((g, ex), ev) in enumerate(zip(self.segs, self._seg_events)):
                 g.replay()
                 if ex is not None:        # side segment j reads what step segment j wrote: an ordinary event orders them
@@ -779,6 +800,14 @@ class GraphedTrainer(object):
                 if self.rest_buckets:
                     comm.launch_after(self.rest_buckets, (cur,))
                 comm.join(cur)
+            if self._mask_tables is not None:
+                # backward has read this step's masks (both streams are joined here): the next step's, on the second stream
+                self._mask_join.record(cur)
+                side.wait_event(self._mask_join)
+                with torch.cuda.stream(side):
+                    self.mask_offset.add_(1)
+                    ops.mask_plan.draw(self._mask_tables, self.mask_offset)
+                    self._mask_event.record(side)
             self.graph2.replay()
         ops.bump_param_epoch()           # the replayed clip/Adam wrote the parameters
         self.t.global_step += 1

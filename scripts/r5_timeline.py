@@ -65,7 +65,12 @@ if len(qs) >= 2:
     print("idle gaps between consecutive launches on the main queue: total %.3f ms; largest:" % (tot / 1e6))
     for g, a, b in gaps[-6:][::-1]:
         print("      %.1f us between %s -> %s" % (g / 1e3, a[:40], b[:40]))
-    if len(sys.argv) > 2 and sys.argv[2] == "dump":     # every launch of the overlap window: start us, length us, queue, kernel
+    if len(sys.argv) > 2 and sys.argv[2] == "dumpall":  # ... and of the stretch before it
+        print("launches before the window (us from the step's start | length | kernel):")
+        for s, e, q, n in S:
+            if e <= w0:
+                print("  %9.1f %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, n[:90]))
+    if len(sys.argv) > 2 and sys.argv[2] in ("dump", "dumpall"):     # every launch of the overlap window: start us, length us, queue, kernel
         print("launches of the step from the window's start (us from the step's start | length | queue | kernel):")
         for s, e, q, n in S:
             if e > w0:

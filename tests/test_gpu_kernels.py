@@ -924,3 +924,20 @@ def test_weight_norm_backward_16_byte_gather_is_the_4_byte_one(dev, O_, I, J, S,
     assert rel_err(dv.cpu().numpy(), dv_ref.cpu().numpy()) < 2e-5
     assert rel_err(dg.cpu().numpy(), dg_ref.cpu().numpy()) < 2e-5
     assert rel_err(dbias.cpu().numpy(), part.double().sum(0).cpu().numpy()) < 2e-5
+
+
+def test_memset_is_a_fill_kernel_with_exact_extent(dev):
+    """dv3_memset_b8 (ops.zero_: the gradient arena, padded c8 tensors) fills exactly [p, p + bytes) for every alignment of
+    both ends -- it is a kernel since round 6 (the runtime's memset node replayed with a corrupt pattern inside a captured
+    step: profiles/r06_memset_node.txt)"""
+    from deepvoice3_pytorch_amd import ops, _lib
+    buf = torch.empty(1 << 16, dtype=torch.uint8, device=dev)
+    for start, n, val in [(0, 65536, 0), (1, 17, 7), (3, 40000, 255), (16, 16, 1), (15, 1, 9), (5, 0, 3), (32, 4097, 0), (7, 31, 5)]:
+        buf.fill_(0xAB)
+        _lib.call("dv3_memset_b8", buf.data_ptr() + start, val, n, ops._stream())
+        want = torch.full_like(buf, 0xAB)
+        want[start:start + n] = val
+        assert torch.equal(buf, want), (start, n, val)
+    big = torch.full((25_000_001,), 3.0, device=dev)
+    ops.zero_(big)
+    assert float(big.abs().max()) == 0.0

@@ -429,14 +429,16 @@ def test_graphed_train_step_matches_reference_golden(dev):
     assert ops.dropout_state.dev_offset is None      # the process-wide dropout state is handed back
 
 
-@pytest.mark.parametrize("B,Tt,frames", [(4, 40, 120), (32, 100, 400)])
-def test_split_stream_graph_replay_is_bit_identical(dev, gemm_mode, B, Tt, frames):
+@pytest.mark.parametrize("B,Tt,frames,warm", [(4, 40, 120, 1), (32, 100, 400, 1), (4, 40, 120, 3)])
+def test_split_stream_graph_replay_is_bit_identical(dev, gemm_mode, B, Tt, frames, warm):
     """GraphedTrainer(split_streams=True): the weight-gradient branch of backward captured into its OWN hipGraphs and
     replayed on the real second stream (segments ordered by host-issued events) must give, replay after replay, the
     bits of the single whole-step graph and of eager launches -- same kernels, same order per stream; a wait that saw
     a stale record, or an operand whose memory was reused too early, would show here (the first form of the split,
     event NODES between two graphs, passed at the small size and produced NaN at the benchmark's: hence the second
-    size).  Preset channel counts, dropout on (the device-side seed offset advances per replay)."""
+    size).  Preset channel counts, dropout on (the device-side seed offset advances per replay).  With three warm-up
+    steps the step's list of dropout sites has repeated when it is captured: the single graph then draws its masks in
+    one launch, the segmented replay draws step k + 1's beside step k's clip + Adam (ops.MaskPlan) -- the same masks."""
     if gemm_mode == "f32" or (gemm_mode == "bf16x3" and B > 4):
         pytest.skip("one fp32-class mode is enough for the launch plumbing")
     import bench
@@ -453,6 +455,7 @@ def test_split_stream_graph_replay_is_bit_identical(dev, gemm_mode, B, Tt, frame
                                               bt["frame_positions"], bt["done"], bt["target_lengths"], None,
                                               downsample_step=4, device=dev)
         ops.dropout_state.manual_seed(11)
+        ops.mask_plan.__init__()
         norms = []
         if kind == "eager":
             # a GraphedTrainer draws its masks from (seed, site, device offset): the warm-up step uses the first N sites
@@ -460,17 +463,21 @@ def test_split_stream_graph_replay_is_bit_identical(dev, gemm_mode, B, Tt, frame
             off = torch.zeros(1, dtype=torch.int64, device=dev)
             prev, ops.dropout_state.dev_offset = ops.dropout_state.dev_offset, off
             try:
-                tr.step(batch)
+                for _ in range(warm):            # (a GraphedTrainer's warm-up steps advance the counter too)
+                    tr.step(batch)
+                    off.add_(1)
                 site_n = ops.dropout_state.site
                 for _ in range(steps - 1):
-                    off.add_(1)
                     ops.dropout_state.site = site_n
                     norms.append(float(tr.step(batch)["grad_norm"]))
+                    off.add_(1)
             finally:
                 ops.dropout_state.dev_offset = prev
         else:
-            g = train_step.GraphedTrainer(tr, batch, warmup=1, split_streams=(kind == "split"))
+            g = train_step.GraphedTrainer(tr, batch, warmup=warm, split_streams=(kind == "split"))
             assert g.split == (kind == "split")
+            if kind == "split":
+                assert (g._mask_tables is not None) == (warm >= 2)
             for _ in range(steps - 1):
                 norms.append(float(g.step()["grad_norm"]))
             g.close()
