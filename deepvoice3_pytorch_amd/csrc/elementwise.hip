@@ -867,6 +867,30 @@ __global__ __launch_bounds__(256) void fill_bytes_kernel(unsigned char* __restri
   if (i < tail) p[head + n16 * 16 + i] = (unsigned char)word;
 }
 }  // namespace
+namespace {
+__global__ __launch_bounds__(256) void fill_rows_kernel(unsigned char* __restrict__ p, uint32_t word, int64_t rows, int64_t row16,
+                                                        int64_t stride16) {
+  typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+  const u32x4_ v = {word, word, word, word};
+  u32x4_* const q = reinterpret_cast<u32x4_*>(p);
+  const int64_t n = rows * row16;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+    const int64_t r = k / row16, c = k - r * row16;
+    q[r * stride16 + c] = v;
+  }
+}
+}  // namespace
+extern "C" int dv3_memset_rows_b8(void* p, int32_t value, int64_t rows, int64_t row_bytes, int64_t row_stride_bytes, void* stream) {
+  DV3_REQUIRE(p && rows >= 0 && row_bytes >= 0 && row_stride_bytes >= row_bytes, "memset_rows: bad args");
+  DV3_REQUIRE((((uintptr_t)p | (uintptr_t)row_bytes | (uintptr_t)row_stride_bytes) & 15) == 0, "memset_rows: 16-byte units");
+  if (rows == 0 || row_bytes == 0) return DV3_OK;
+  const uint32_t word = ((uint32_t)value & 0xffu) * 0x01010101u;
+  int64_t blocks = (rows * (row_bytes >> 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char*)p, word, rows,
+                     row_bytes >> 4, row_stride_bytes >> 4);
+  return dv3_check_launch("memset_rows_b8");
+}
 extern "C" int dv3_memset_b8(void* p, int32_t value, int64_t bytes, void* stream) {
   DV3_REQUIRE(p && bytes >= 0, "memset: bad args");
   if (bytes == 0) return DV3_OK;

@@ -595,6 +595,7 @@ class GraphedTrainer(object):
         self.chunk = int(chunk or os.environ.get("DV3_SPLIT_CHUNK", "0"))      # 0: chosen after the warm-up steps
         self.cut_on_bucket = os.environ.get("DV3_CUT_ON_BUCKET", "1") not in ("0", "")
         self.tail_fine = int(os.environ.get("DV3_SPLIT_TAIL", "6"))     # the last N fork points end a segment each (0 = off)
+        self.head_fine = int(os.environ.get("DV3_SPLIT_HEAD", "0"))     # ... and the first N (0 = off)
         self.n_forks = 0
         self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
         self._prev_offset = ops.dropout_state.dev_offset        # restored by close()
@@ -689,7 +690,12 @@ class GraphedTrainer(object):
             # 0.46 ms before clip + Adam while the last four layers' weight gradients ran (profiles/r06a timeline); with
             # one-layer segments at the end only the last layer's is exposed
             tail = self.n_forks > 0 and self.n_forks - st["forks"] < self.tail_fine
-            if st["forks"] % self.chunk == 0 or bucket_done or tail:
+            # ... and the FIRST forks one per segment (round 6): segment 0 holds the whole forward, and side segment 0 starts
+            # when it ends -- with `chunk` layers of backward inside it the weight gradients of the model's LAST layers (the
+            # converter's: the largest of the step) waited for those layers' input-gradient chain to finish, 1.3-1.5 ms in
+            # which the step stream ran alone (profiles/r06_split_head.txt)
+            head = st["forks"] <= self.head_fine
+            if st["forks"] % self.chunk == 0 or bucket_done or tail or head:
                 end_seg()
                 begin_seg()
 

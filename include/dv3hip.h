@@ -549,9 +549,13 @@ int dv3_axpby_f32(const float* a, const float* b, float* out, int64_t n, float a
                   void* stream);
 /* out[0] = a[0] + b[0] (+ c[0]) (+ d[0]): the total of the loss terms (train.py:728-740); c, d may be NULL  */
 int dv3_sum_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out, void* stream);
-/* bytes of device memory to `value` (hipMemsetAsync on the caller's stream): the gradient arena before backward
- * (optimizer.zero_grad(), train.py:683), the padding channels of a c8 tensor                                   */
+/* bytes of device memory to `value` -- a fill KERNEL on the caller's stream, not hipMemsetAsync (a captured memset node
+ * replayed with a corrupt pattern: DESIGN.md 3.7): the gradient arena before backward (optimizer.zero_grad(),
+ * train.py:683)                                                                                                 */
 int dv3_memset_b8(void* p, int32_t value, int64_t bytes, void* stream);
+/* `rows` runs of row_bytes each, row_stride_bytes apart (all multiples of 16, p 16-byte aligned): the padding groups of a
+ * channel-blocked tensor whose channel count is not a multiple of 32 (ops._c8_empty), one launch.                    */
+int dv3_memset_rows_b8(void* p, int32_t value, int64_t rows, int64_t row_bytes, int64_t row_stride_bytes, void* stream);
 /* Embedding gather into BCT with optional dropout: out[b][c][t] = W[idx[b][t]][c]
  * (deepvoice3.py:74-75, nyanko.py:63).  Backward: dense scatter-add into dW.           */
 int dv3_embedding_bct_f32(const int64_t* idx, const float* w, float* out,

@@ -941,3 +941,12 @@ def test_memset_is_a_fill_kernel_with_exact_extent(dev):
     big = torch.full((25_000_001,), 3.0, device=dev)
     ops.zero_(big)
     assert float(big.abs().max()) == 0.0
+    # dv3_memset_rows_b8: runs a stride apart -- the padding groups of a c8 tensor (ops._c8_empty: 513 channels -> groups 64..67)
+    buf.fill_(0xAB)
+    _lib.call("dv3_memset_rows_b8", buf.data_ptr() + 64, 0, 5, 48, 1024, ops._stream())
+    want = torch.full_like(buf, 0xAB)
+    for r in range(5):
+        want[64 + r * 1024:64 + r * 1024 + 48] = 0
+    assert torch.equal(buf, want)
+    t = ops._c8_empty(3, 513, 77, dev)
+    assert t.shape == (3, 68, 77, 8) and float(t[:, 64:].float().abs().max()) == 0.0
