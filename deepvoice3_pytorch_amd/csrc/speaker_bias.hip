@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NT) void spk_fwd_kernel(const SpkArgs a) {
 // partial dW tiles go through the gp tile's own storage once it has been consumed: 53 KB, three workgroups per CU.
 constexpr int GPL = NT + 8, EVL = EM + 1;
 template <int ABL>
-__global__ __launch_bounds__(NT) void spk_bwd_kernel(const SpkArgs a, float* __restrict__ part, float* __restrict__ de_l) {
+__global__ __launch_bounds__(NT) void spk_bwd_kernel(const SpkArgs a, float* __restrict__ part, float* __restrict__ de_l, const int g_prefetch) {
   __shared__ __attribute__((aligned(16))) float Ws[CB * EM];
   __shared__ __attribute__((aligned(16))) float gp[CB * GPL];
   __shared__ __attribute__((aligned(16))) float evs[NT * EVL];
@@ -103,50 +103,59 @@ __global__ __launch_bounds__(NT) void spk_bwd_kernel(const SpkArgs a, float* __r
   for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dacc[jb][r] = 0.f;
+  // The tile's loads are issued one tile AHEAD (round 6): right after tile k has gone from the registers into LDS, so that
+  // they are in flight while tile k's two matrix products and its partial-sum pass run -- the pass used to wait out a
+  // full HBM round trip per tile (1.4 TB/s in the step).  Same values, same order: bit-identical gradients.
+  constexpr int RW = CB / (NT / 64);
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+  f32x4 yv[RW], dv_[RW];
+  u16x8 raw[CB / 8];
+  const int f0 = 4 * lane;
+  auto load_tile = [&](int c0) __attribute__((always_inline)) {
+    const int n = min(CB, C - c0);
+    const bool c8 = L.dout_c8p != 0;
+    // wave w loads rows w, w + 4, ...: a lane takes four consecutive frames of a row as ONE 16-byte load per tensor (rows
+    // are only 4-byte aligned: T is arbitrary), so the sixteen loads of a thread are all in flight at once -- as 64
+    // four-byte loads the compiler issued them in small batches, one memory round trip each
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const int i = wave + r * (NT / 64), c = c0 + i;
+      const float* po = L.out + ((int64_t)b * C + c) * T + t0 + f0;
+      const float* pd = L.dout + (int64_t)b * L.dout_bs + (int64_t)c * L.dout_rs + t0 + f0;
+      if (i < n && ABL != 3 && t0 + f0 + 3 < T) {
+        yv[r] = *reinterpret_cast<const f32x4u*>(po);
+        if (!c8) dv_[r] = *reinterpret_cast<const f32x4u*>(pd);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool ok = i < n && ABL != 3 && t0 + f0 + k < T;
+          yv[r][k] = ok ? po[k] : 1.0f;
+          if (!c8) dv_[r][k] = ok ? pd[k] : 0.f;
+        }
+      }
+      if (c8) dv_[r] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};      // the tile first holds (1 - |out|)^2 alone
+    }
+    // c8 gradient (a bf16 tensor [B][c8p][T][8]): this thread's frame of the tile's four channel groups, 16 bytes each
+    if (c8) {
+      const unsigned short* base = reinterpret_cast<const unsigned short*>(L.dout);
+#pragma unroll
+      for (int g = 0; g < CB / 8; ++g) {
+        const bool ok = c0 + 8 * g < C && t < T && ABL != 3;
+        raw[g] = ok ? *reinterpret_cast<const u16x8*>(base + (((int64_t)b * L.dout_c8p + (c0 >> 3) + g) * T + t) * 8)
+                    : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+  };
+  load_tile(0);
   for (int c0 = 0; c0 < C; c0 += CB) {
     const int n = min(CB, C - c0);
+    if (!g_prefetch && c0 > 0) load_tile(c0);
     __syncthreads();                         // the previous tile's readers (gp, Ws, red) are done
     stage_w(L, d.E, c0, n, Ws, tid);
     for (int i = n * EM + tid; i < CB * EM; i += NT) Ws[i] = 0.f;       // rows past the layer's last: no contribution
     const bool c8 = L.dout_c8p != 0;
-    // gp tile: wave w loads rows w, w + 4, ...: a lane takes four consecutive frames of a row as ONE 16-byte load per
-    // tensor (rows are only 4-byte aligned: T is arbitrary), so the sixteen loads of a thread are all in flight at once
-    // -- as 64 four-byte loads the compiler issued them in small batches, one memory round trip each
     {
-      constexpr int RW = CB / (NT / 64);
-      typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-      f32x4 yv[RW], dv_[RW];
-      const int f0 = 4 * lane;
-#pragma unroll
-      for (int r = 0; r < RW; ++r) {
-        const int i = wave + r * (NT / 64), c = c0 + i;
-        const float* po = L.out + ((int64_t)b * C + c) * T + t0 + f0;
-        const float* pd = L.dout + (int64_t)b * L.dout_bs + (int64_t)c * L.dout_rs + t0 + f0;
-        if (i < n && ABL != 3 && t0 + f0 + 3 < T) {
-          yv[r] = *reinterpret_cast<const f32x4u*>(po);
-          if (!c8) dv_[r] = *reinterpret_cast<const f32x4u*>(pd);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const bool ok = i < n && ABL != 3 && t0 + f0 + k < T;
-            yv[r][k] = ok ? po[k] : 1.0f;
-            if (!c8) dv_[r][k] = ok ? pd[k] : 0.f;
-          }
-        }
-        if (c8) dv_[r] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};      // the tile first holds (1 - |out|)^2 alone
-      }
-      // c8 gradient (a bf16 tensor [B][c8p][T][8]): this thread's frame of the tile's four channel groups, 16 bytes each
-      typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
-      u16x8 raw[CB / 8];
-      if (c8) {
-        const unsigned short* base = reinterpret_cast<const unsigned short*>(L.dout);
-#pragma unroll
-        for (int g = 0; g < CB / 8; ++g) {
-          const bool ok = c0 + 8 * g < C && t < T && ABL != 3;
-          raw[g] = ok ? *reinterpret_cast<const u16x8*>(base + (((int64_t)b * L.dout_c8p + (c0 >> 3) + g) * T + t) * 8)
-                      : u16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-      }
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
         const int i = wave + r * (NT / 64);
@@ -170,6 +179,7 @@ __global__ __launch_bounds__(NT) void spk_bwd_kernel(const SpkArgs a, float* __r
           }
       }
     }
+    if (g_prefetch && c0 + CB < C) load_tile(c0 + CB);        // in flight during this tile's products
     __syncthreads();
     // d emb: D[e][frame] += sum_rows W[row][e] * gp[row][frame];  A[i = e][k = row], B[k = row][j = frame]
     if (ABL != 2) {
@@ -295,6 +305,7 @@ int fill_args(SpkArgs& a, const dv3_spk_desc* d, const dv3_spk_layer* layers, bo
 
 }  // namespace
 
+int g_spk_prefetch = 1;   // dv3_debug_set(54, v): the backward's tile loads one tile ahead (0 = at the top of the tile)
 int g_spk_abl = 0;   // dv3_debug_set(28, v): timing-only ablations of the backward (1 no dW, 2 no d emb, 3 no loads); make EXP=1
 
 extern "C" int dv3_speaker_bias_fwd_f32(const dv3_spk_desc* d, const dv3_spk_layer* layers, void* stream) {
@@ -338,13 +349,13 @@ extern "C" int dv3_speaker_bias_bwd_f32(const dv3_spk_desc* d, const dv3_spk_lay
   hipStream_t st = (hipStream_t)stream;
 #ifdef DV3_EXPERIMENTS
   switch (g_spk_abl) {
-    case 1: hipLaunchKernelGGL(spk_bwd_kernel<1>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l); break;
-    case 2: hipLaunchKernelGGL(spk_bwd_kernel<2>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l); break;
-    case 3: hipLaunchKernelGGL(spk_bwd_kernel<3>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l); break;
-    default: hipLaunchKernelGGL(spk_bwd_kernel<0>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l);
+    case 1: hipLaunchKernelGGL(spk_bwd_kernel<1>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l, g_spk_prefetch); break;
+    case 2: hipLaunchKernelGGL(spk_bwd_kernel<2>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l, g_spk_prefetch); break;
+    case 3: hipLaunchKernelGGL(spk_bwd_kernel<3>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l, g_spk_prefetch); break;
+    default: hipLaunchKernelGGL(spk_bwd_kernel<0>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l, g_spk_prefetch);
   }
 #else
-  hipLaunchKernelGGL(spk_bwd_kernel<0>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l);
+  hipLaunchKernelGGL(spk_bwd_kernel<0>, dim3(nT, d->B, d->n_layers), dim3(NT), 0, st, a, part, de_l, g_spk_prefetch);
 #endif
   int rc2 = dv3_check_launch("speaker_bias_bwd");
   if (rc2 != DV3_OK) return rc2;
