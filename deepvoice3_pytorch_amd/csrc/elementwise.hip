@@ -286,7 +286,7 @@ __device__ __forceinline__ void dropout_keep_c8_block(uint8_t* __restrict__ out,
     if (bits_out && ch < (uint32_t)C) bits_out[wrow] = w;      // the same decisions in the keep-bit form [B*C][rs]
   }
   __syncthreads();
-  if (ent >= n_ent) return;
+  if (ent >= n_ent || !out) return;        // (out == NULL: the keep-bit form alone, a site of dv3_dropout_keep_c8_multi)
   const uint32_t q = e;                    // bytes 4q .. 4q+3
   const uint32_t* w = words[threadIdx.x >> 3];
   const uint32_t t0 = wi * 32u + 4u * q;
@@ -796,7 +796,7 @@ extern "C" int dv3_dropout_keep_c8_multi(const dv3_dropout_site* sites, int32_t 
   int64_t total = 0;
   for (int l = 0; l < n; ++l) {
     const dv3_dropout_site& e = sites[l];
-    DV3_REQUIRE(e.keep && e.B > 0 && e.C > 0 && e.T > 0, "dropout_keep_c8_multi: bad site %d", l);
+    DV3_REQUIRE((e.keep || e.bits) && e.B > 0 && e.C > 0 && e.T > 0, "dropout_keep_c8_multi: bad site %d", l);
     DV3_REQUIRE(e.p >= 0.f && e.p < 1.f, "dropout_keep_c8_multi: p out of range (site %d)", l);
     const int rs = (e.T + 31) / 32, c8p = (e.C + 31) / 32 * 4;
     DV3_REQUIRE((int64_t)e.B * c8p * e.T < (1ll << 31), "dropout_keep_c8_multi: mask %d exceeds the 2 GB the kernel can address", l);

@@ -279,8 +279,11 @@ dropout_state = DropoutState()
 def dropout_bits(rows, T, p, device, name=None):
     """-> (bits int32 [rows][ceil(T/32)], row_stride_words). One Philox launch."""
     rs = (T + 31) // 32
-    bits = torch.empty(rows * rs, dtype=torch.int32, device=device)
     site = dropout_state.next_site()
+    hit = mask_plan.take("bits", 1, rows, T, p) if (dropout_state.record is None or name is None) else None
+    if hit is not None:
+        return hit, rs
+    bits = torch.empty(rows * rs, dtype=torch.int32, device=device)
     off = dropout_state.dev_offset
     _lib.call("dv3_dropout_bits", bits.data_ptr(), rows * rs, float(p), dropout_state.seed, site,
               _ptr(off), _stream())
@@ -634,10 +637,10 @@ class MaskPlan(object):
             arr = (Site * len(part))()
             for e, sig in zip(arr, part):
                 off, kind, B, C, T, p = sig
-                keep = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=device)
-                bits = torch.empty(B * C * ((T + 31) // 32), dtype=torch.int32, device=device) if kind == "both" else None
-                e.keep, e.bits, e.B, e.C, e.T, e.p, e.site = keep.data_ptr(), _ptr(bits), B, C, T, p, s0 + off
-                ready[off] = (sig, keep if bits is None else (bits, (T + 31) // 32, keep))
+                keep = torch.empty((B, c8_groups(C), T), dtype=torch.uint8, device=device) if kind != "bits" else None
+                bits = torch.empty(B * C * ((T + 31) // 32), dtype=torch.int32, device=device) if kind != "keep" else None
+                e.keep, e.bits, e.B, e.C, e.T, e.p, e.site = _ptr(keep), _ptr(bits), B, C, T, p, s0 + off
+                ready[off] = (sig, keep if kind == "keep" else bits if kind == "bits" else (bits, (T + 31) // 32, keep))
             tables.append(arr)
         return ready, tables
 

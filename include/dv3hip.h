@@ -480,7 +480,8 @@ int dv3_dropout_keep_c8(uint8_t* out, int32_t B, int32_t C, int32_t T, float p, 
                         const uint64_t* dev_seed_offset, void* stream);
 
 /* Several dropout sites in ONE launch (ABI 41): site l gets exactly what dv3_dropout_bits_keep(bits, keep, B, C, T, p, seed,
- * site, ...) (bits != NULL) or dv3_dropout_keep_c8(keep, ...) (bits == NULL) writes.  A training step draws 25-35 masks
+ * site, ...) (bits != NULL) or dv3_dropout_keep_c8(keep, ...) (bits == NULL) writes; keep == NULL with B = 1, C = rows:
+ * what dv3_dropout_bits(bits, rows * ceil(T/32), ...) writes.  A training step draws 25-35 masks
  * (one per Conv1dGLU / HighwayConv1d: modules.py:147,210), each a ~6 us launch on the forward's only queue; the host side
  * (ops.MaskPlan) issues them together at the start of the step once the step's list of sites has repeated.        */
 #define DV3_DROPOUT_MULTI_MAX 48

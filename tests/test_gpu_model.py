@@ -914,17 +914,24 @@ def test_dropout_sites_in_one_launch_draw_the_single_launch_masks(dev):
     number and step offset (the keep decisions of F.dropout's replacement, modules.py:147,210)"""
     import ctypes
     from deepvoice3_pytorch_amd import ops, _lib
-    sites = [("both", 3, 64, 77, 0.05, 11), ("keep", 2, 72, 150, 0.1, 12), ("both", 4, 256, 33, 0.05, 14), ("keep", 1, 8, 5, 0.5, 20)]
+    sites = [("both", 3, 64, 77, 0.05, 11), ("keep", 2, 72, 150, 0.1, 12), ("both", 4, 256, 33, 0.05, 14), ("keep", 1, 8, 5, 0.5, 20),
+             ("bits", 1, 300, 77, 0.05, 21), ("bits", 1, 37, 130, 0.2, 23)]
     off = torch.tensor([12345], dtype=torch.int64, device=dev)
     Site = ops.STRUCTS["dv3_dropout_site"]
     arr, outs = (Site * len(sites))(), []
     for e, (kind, B, C, T, p, site) in zip(arr, sites):
-        keep = torch.zeros((B, ops.c8_groups(C), T), dtype=torch.uint8, device=dev)
-        bits = torch.zeros(B * C * ((T + 31) // 32), dtype=torch.int32, device=dev) if kind == "both" else None
-        e.keep, e.bits, e.B, e.C, e.T, e.p, e.site = keep.data_ptr(), (bits.data_ptr() if bits is not None else None), B, C, T, p, site
+        keep = torch.zeros((B, ops.c8_groups(C), T), dtype=torch.uint8, device=dev) if kind != "bits" else None
+        bits = torch.zeros(B * C * ((T + 31) // 32), dtype=torch.int32, device=dev) if kind != "keep" else None
+        e.keep, e.bits = (keep.data_ptr() if keep is not None else None), (bits.data_ptr() if bits is not None else None)
+        e.B, e.C, e.T, e.p, e.site = B, C, T, p, site
         outs.append((keep, bits))
     _lib.call("dv3_dropout_keep_c8_multi", arr, len(sites), 777, off.data_ptr(), ops._stream())
     for (kind, B, C, T, p, site), (keep, bits) in zip(sites, outs):
+        if kind == "bits":          # rows = C: what dv3_dropout_bits writes
+            b1 = torch.zeros_like(bits)
+            _lib.call("dv3_dropout_bits", b1.data_ptr(), b1.numel(), p, 777, site, off.data_ptr(), ops._stream())
+            assert torch.equal(b1, bits) and 0 < int(bits.count_nonzero())
+            continue
         k1 = torch.zeros_like(keep)
         if kind == "both":
             b1 = torch.zeros_like(bits)
