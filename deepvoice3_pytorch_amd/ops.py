@@ -644,10 +644,10 @@ class MaskPlan(object):
             tables.append(arr)
         return ready, tables
 
-    def draw(self, tables, dev_offset, stream=None):
+    def draw(self, tables, dev_offset, stream=None, seed=None):
         for arr in tables:
-            _lib.call("dv3_dropout_keep_c8_multi", arr, len(arr), dropout_state.seed, _ptr(dev_offset),
-                      _stream() if stream is None else stream)
+            _lib.call("dv3_dropout_keep_c8_multi", arr, len(arr), dropout_state.seed if seed is None else seed,
+                      _ptr(dev_offset), _stream() if stream is None else stream)
             self.stats["batched_launches"] += 1
 
     def take(self, kind, B, C, T, p):

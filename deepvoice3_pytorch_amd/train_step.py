@@ -639,6 +639,7 @@ class GraphedTrainer(object):
                     os.environ.get("DV3_MASK_PREDRAW", "1") not in ("0", ""):
                 mp.static, self._mask_tables = mp.build(dev, site0)
                 self._mask_buffers = mp.static            # (this object keeps the buffers alive: the replays read them)
+                self._mask_seed = ops.dropout_state.seed  # the seed the captured single-site launches carry too
             try:
                 self._capture_segments()
             finally:
@@ -646,7 +647,7 @@ class GraphedTrainer(object):
             if self._mask_tables is not None:
                 torch.cuda.synchronize()
                 self.mask_offset = self.seed_offset.clone()      # the counter value the first replay runs under
-                mp.draw(self._mask_tables, self.mask_offset)
+                mp.draw(self._mask_tables, self.mask_offset, seed=self._mask_seed)
                 self._mask_event, self._mask_join = torch.cuda.Event(), torch.cuda.Event()
                 self._mask_event.record(torch.cuda.current_stream())
         ops.dropout_state.site = site0
@@ -812,7 +813,7 @@ class GraphedTrainer(object):
                 side.wait_event(self._mask_join)
                 with torch.cuda.stream(side):
                     self.mask_offset.add_(1)
-                    ops.mask_plan.draw(self._mask_tables, self.mask_offset)
+                    ops.mask_plan.draw(self._mask_tables, self.mask_offset, seed=self._mask_seed)
                     self._mask_event.record(side)
             self.graph2.replay()
         ops.bump_param_epoch()           # the replayed clip/Adam wrote the parameters
@@ -834,6 +835,7 @@ class GraphedTrainer(object):
         if ops.dropout_state.dev_offset is self.seed_offset:
             ops.dropout_state.dev_offset = self._prev_offset
         self._prev_offset = None
+        self._mask_tables = self._mask_buffers = None
         if self.segs:
             from . import _lib
             torch.cuda.synchronize()
