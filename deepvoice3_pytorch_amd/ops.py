@@ -1110,16 +1110,17 @@ def axpby(a, b, alpha):
 
 
 # K steps a weight-gradient workgroup gets at least.  0 = the measured rule: 8 for short reductions (B=16: more slabs
-# fill the chip), rising with the reduction length to 32 (fp32-storage kernels) / 20 (channel-blocked bf16 kernel) for the
+# fill the chip), rising with the reduction length to 32 (fp32-storage kernels) / 28 (channel-blocked bf16 kernel) for the
 # B=64 ones, where fewer, longer workgroups write fewer partial slabs for the weight-norm backward to read
 # (profiles/r06_ksplit_min_steps_ab.txt: -1.3 % / -1.5 % / -0.8 % on the B=64 / B=32 / vctk-bf16 steps; 20 forced at B=16
-# costs +1.8 %, 56 at B=64 +7 %, 32 on the bf16 kernel +2 %).
+# costs +1.8 %, 56 at B=64 +7 %; the bf16 kernel's cap was 20 while it transposed in registers -- 32 cost +2 % then -- and
+# moved to 28 with the transposing-read kernel, whose K steps are a quarter shorter: 14 costs +1.6 %, 40 +0.3 %).
 ksplit_min_steps = int(_os.environ.get("DV3_KSPLIT_MIN_STEPS", "0"))
 
 
 def _ksplit_count(total_steps, tiles, slots=512, min_steps=None, c8=False):
     if min_steps is None:
-        min_steps = ksplit_min_steps or (max(8, min(20, total_steps // 22)) if c8 else max(8, min(32, total_steps // 14)))
+        min_steps = ksplit_min_steps or (max(8, min(28, total_steps // 12)) if c8 else max(8, min(32, total_steps // 14)))
     return _ksplit_count_c(total_steps, tiles, slots, min_steps)
 
 
