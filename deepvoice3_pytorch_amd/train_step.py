@@ -616,8 +616,12 @@ class GraphedTrainer(object):
             # launches, 20 and more lose the overlap (one segment = the single graph's time); the 46-fork
             # deepvoice3_ljspeech step is 0.5 % faster at 4 (15.20 vs 15.28 ms), the 58-fork nyanko step 0.9 % faster at
             # 10 (10.80 vs 10.90 ms), batch 16 the same at both
+            # Round 6 re-scan (profiles/r06_split_chunk.txt): what separates the two was the storage mode, not the fork
+            # count -- with channel-blocked bf16 activations (short kernels) 8 (10 for the 58-fork nyanko step) is the best or within noise of it
+            # (deepvoice3_vctk bf16 -1.7 % against 4, nyanko bf16 8 ~ 10 < 6 < 16), with fp32 activations 4 is (nyanko f16x3
+            # +1.7 % at 8, and it used to get 10 by its fork count)
             n = ops.SideStream.forks_last if warmup > 0 else 0
-            self.chunk = 4 if 0 < n < 52 else 10
+            self.chunk = (8 if 0 < n < 52 else 10) if ops.storage_c8() else 4
         self.n_forks = ops.SideStream.forks_last if warmup > 0 else 0
         if not self.split:
             # a process group brings its watchdog thread: its event queries must not invalidate this thread's capture
