@@ -621,7 +621,8 @@ class GraphedTrainer(object):
             # (deepvoice3_vctk bf16 -1.7 % against 4, nyanko bf16 8 ~ 10 < 6 < 16), with fp32 activations 4 is (nyanko f16x3
             # +1.7 % at 8, and it used to get 10 by its fork count)
             n = ops.SideStream.forks_last if warmup > 0 else 0
-            self.chunk = (8 if 0 < n < 52 else 10) if ops.storage_c8() else 4
+            small = int(static_batch.mel.size(0)) < 48          # short kernels again: B = 16 / 32 want 5-6 (-0.8 % / -0.5 %)
+            self.chunk = (8 if 0 < n < 52 else 10) if ops.storage_c8() else (6 if small else 4)
         self.n_forks = ops.SideStream.forks_last if warmup > 0 else 0
         if not self.split:
             # a process group brings its watchdog thread: its event queries must not invalidate this thread's capture
