@@ -908,6 +908,91 @@ def ragged_epoch_config(dev, preset, gemm, args, n_items=13100, n_batches=10):
                         "%d of the epoch's %d batches, padded to the batch maximum as train.collate_fn does" % (n_items, len(dev_batches), len(batches)))
 
 
+def ragged_lattice_config(dev, preset, gemm, args, batch, n_items=13100, n_batches=64, lattice=(16, 8)):
+    """The ragged epoch WITHOUT the host in the loop: the same item lengths and the same sampler as
+    ragged_epoch_config, but every mini-batch is padded to the next point of a lattice of shapes (text positions to a
+    multiple of lattice[0], decoder steps to a multiple of lattice[1]) and carries its own maxima as device scalars
+    (ops.ValidLengths) -- the step computes what the reference computes on the batch padded to its own maxima
+    (tests/test_gpu_valid_lengths.py) -- so its shape is one of a few dozen and train_step.LatticeReplay replays a step
+    captured for that shape.  `n_batches` batches spread over the epoch run twice: the first pass meets every shape
+    (capture cost reported), the second is timed.  value = un-padded frames of the batches / wall time of the pass."""
+    from deepvoice3_pytorch_amd import data, train_step
+    rng = np.random.RandomState(4321)
+    frames = np.clip(rng.normal(566, 180, n_items), 120, 870).astype(np.int64)
+    text = np.clip(frames * (100.0 / 566.0) + rng.normal(0, 8, n_items), 20, 187).astype(np.int64)
+    sampler = data.LengthBucketedSampler(frames, batch_size=batch, seed=0)
+    batches = [b for b in sampler.epoch_batches() if len(b) == batch]
+    pick = [batches[i] for i in np.linspace(0, len(batches) - 1, min(n_batches, len(batches))).astype(int)]
+    run = TrainRun(dev, None, 0, 1, preset, gemm, batch, args.text_len, args.frames, graph=False)
+    rep = None
+    try:
+        hp = run.hp
+        r, ds = hp["r"], hp["downsample_step"]
+        # one pool of random features, sliced per item (the values do not matter, generating 100 batches of them does)
+        pool_n = int(batch * 880)
+        mel_pool = torch.from_numpy(rng.rand(pool_n, hp["mel_dim"]).astype(np.float32))
+        lin_pool = torch.from_numpy(rng.rand(pool_n, hp["linear_dim"]).astype(np.float32))
+        dev_batches, real, padded, padded_own = [], 0, 0, 0
+        for idx in pick:
+            tl, fl = text[idx], frames[idx]
+            ids = rng.randint(2, hp["n_vocab"], int(tl.sum())).astype(np.int64)
+            ids[np.cumsum(tl) - 1] = 1
+            n = int(fl.sum())
+            packed = data.PackedBatch(torch.from_numpy(ids), mel_pool[:n], lin_pool[:n], tl.astype(np.int64),
+                                      fl.astype(np.int64), None)
+            b = data.device_collate(packed, dev, r, ds, lattice=lattice)
+            dev_batches.append(b)
+            real += int(fl.sum())
+            padded += int(b.y.shape[0] * b.y.shape[1])
+            padded_own += int(batch * data.padded_frames(fl, r, ds)[0])
+        torch.cuda.synchronize()
+        rep = train_step.LatticeReplay(run.trainer)
+        t0 = time.perf_counter()
+        for b in dev_batches:               # first pass: every shape is met (two dry passes + a capture each), then replayed
+            rep.step(b)
+        torch.cuda.synchronize()
+        first_pass_s = time.perf_counter() - t0
+        captures, capture_s = rep.stats["captures"], rep.stats["capture_s"]
+        t0 = time.perf_counter()
+        for b in dev_batches:
+            scal = rep.step(b)
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        loss = float(scal["loss"])
+        if not math.isfinite(loss):
+            raise RuntimeError("non-finite training loss in the lattice replay")
+        if rep.stats["captures"] != captures:
+            raise RuntimeError("the timed pass captured again")
+        # host time to issue ONE step into an idle queue (TrainRun.measure: over a long loop the host's time converges to
+        # the GPU's through back-pressure, whatever it really costs)
+        t_one = 0.0
+        probe = dev_batches[:: max(1, len(dev_batches) // 6)][:6]
+        for b in probe:
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            rep.step(b)
+            t_one += time.perf_counter() - h0
+        torch.cuda.synchronize()
+    finally:
+        if rep is not None:
+            rep.close()
+        run.close()
+    return dict(value=round(real / dt, 1), unit="mel-frames/s", ms_per_step=round(dt / len(dev_batches) * 1e3, 3),
+                host_enqueue_ms_per_step=round(t_one / len(probe) * 1e3, 3),
+                host_loop_ms_per_step=round(t_issue / len(dev_batches) * 1e3, 3), steps=len(dev_batches),
+                per_gpu_batch=batch, hipgraph=True, lattice=dict(text_step=lattice[0], decoder_step=lattice[1]),
+                shapes_captured=captures, capture_s_total=round(capture_s, 2),
+                capture_s_per_shape=round(capture_s / max(captures, 1), 3),
+                capture_amortised_after_steps=int(capture_s / max(dt / len(dev_batches), 1e-9)),
+                first_pass_s=round(first_pass_s, 2),
+                real_frames=real, padded_frames=padded, padded_over_real=round(padded / float(real), 4),
+                padded_over_real_at_batch_maxima=round(padded_own / float(real), 4), final_loss=round(loss, 5),
+                lengths="%d items, frames ~ clip(N(566,180),120,870); mini-batches by data.LengthBucketedSampler (train.py:195-239), "
+                        "%d of the epoch's %d batches, each padded to the lattice and carrying its own maxima (ops.ValidLengths)"
+                        % (n_items, len(dev_batches), len(batches)))
+
+
 def ddp_world1_config(dev, preset, gemm, args, no_group_ms, steps=12, warmup=4):
     """The data-parallel step with its gradient exchange ARMED, on the one GPU a bench box has: a world-size-1 "nccl"
     (RCCL) group, dist.BucketedAllReduce's notifications, bucketed all-reduces on the collective stream, clip with
@@ -1278,6 +1363,16 @@ def main():
                 cfgs["dv3lj_b64_ragged_epoch"] = ragged_epoch_config(dev, args.preset, gemm, args)
             except Exception as e:
                 cfgs["dv3lj_b64_ragged_epoch"] = dict(error="%s: %s" % (type(e).__name__, e))
+            # the same epoch replayed from captured steps of a lattice of padded shapes (no host in the loop)
+            for key, bsz, nb in (("dv3lj_b64_ragged_epoch_lattice", args.batch, 48), ("dv3lj_b16_ragged_epoch_lattice", 16, 64)):
+                try:
+                    cfgs[key] = ragged_lattice_config(dev, args.preset, gemm, args, bsz, n_batches=nb)
+                except Exception as e:
+                    import traceback
+                    traceback.print_exc()
+                    cfgs[key] = dict(error="%s: %s" % (type(e).__name__, e))
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
             try:
                 # what one GPU can measure about the 8-GPU step's collective: a ring stand-in beside backward
                 ds = dict(note="dist.RingStandin (csrc/standin.hip) in the communicator's place: 16 persistent workgroups x 256 "

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(const dv3_softmax_des
   for (int n = lo + lane; n < hi; n += 64) sum += expf(s[n] - mx);
   sum = dv3_wave_sum(sum);
   const float inv = 1.0f / sum;
+  const float pd_scale = p.pd_scale_dev ? p.pd_scale * p.pd_scale_dev[0] : p.pd_scale;
   float* pd = p.pd ? p.pd + row * Tk : nullptr;
   for (int n = lane; n < Tk; n += 64) {
     float v = 0.f;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(const dv3_softmax_des
     if (pd) {
       float d = v;
       if (p.mask) d = dv3_keep(p.mask, row, p.mask_rs, n) ? v * p.drop_scale : 0.f;
-      pd[n] = d * p.pd_scale;
+      pd[n] = d * pd_scale;
     }
   }
 }
@@ -52,11 +53,12 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const dv3_softmax
   const float* dpd = p.dpd ? p.dpd + row * Tk : nullptr;
   const float* dpx = p.dp_direct ? p.dp_direct + row * Tk : nullptr;
   float* ds = p.ds + row * Tk;
+  const float drop_scale = p.scale_dev ? p.drop_scale * p.scale_dev[0] : p.drop_scale;
   float dot = 0.f;
   for (int n = lane; n < Tk; n += 64) {
     float d = 0.f;
     if (dpd) {
-      d = dpd[n] * p.drop_scale;   // drop_scale carries 1/(1-p) AND the forward's pd_scale
+      d = dpd[n] * drop_scale;   // drop_scale carries 1/(1-p) AND the forward's pd_scale
       if (p.mask && !dv3_keep(p.mask, row, p.mask_rs, n)) d = 0.f;
     }
     if (dpx) d += dpx[n];
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const dv3_softmax
   for (int n = lane; n < Tk; n += 64) {
     float d = 0.f;
     if (dpd) {
-      d = dpd[n] * p.drop_scale;   // drop_scale carries 1/(1-p) AND the forward's pd_scale
+      d = dpd[n] * drop_scale;   // drop_scale carries 1/(1-p) AND the forward's pd_scale
       if (p.mask && !dv3_keep(p.mask, row, p.mask_rs, n)) d = 0.f;
     }
     if (dpx) d += dpx[n];
@@ -154,13 +156,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const dv3_attn_fwd_desc p
 #pragma unroll
     for (int off = 4; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     const float inv = 1.0f / sum;
+    const float pd_scale = p.pd_scale_dev ? p.pd_scale * p.pd_scale_dev[0] : p.pd_scale;
     const int64_t grow = (int64_t)b * Tq + t;
     for (int n = sub; n < Tk; n += 8) {
       float v = 0.f;
       if (n < hi) v = expf(s[n] - mx) * inv;
       float d = v;
       if (p.mask && t < Tq) d = dv3_keep(p.mask, grow, p.mask_rs, n) ? v * p.drop_scale : 0.f;
-      d *= p.pd_scale;
+      d *= pd_scale;
       s[n] = d;
       if (t < Tq) {
         p.P[grow * Tk + n] = v;

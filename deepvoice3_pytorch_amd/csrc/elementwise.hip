@@ -972,3 +972,39 @@ extern "C" int dv3_sincos_pos_bct_f32(const int64_t* pos, const float* table, co
                      apply_sincos);
   return dv3_check_launch("sincos_pos_bct_f32");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Valid-length steps (ABI 42, include/dv3hip.h: dv3_zero_tail_b32).  A batch padded beyond its own longest item -- to a
+// lattice shape, so that a captured step can be replayed for it -- must still compute what the reference computes on the
+// batch padded to its own maximum: there a non-causal convolution reads nn.Conv1d's zero padding beyond the last frame
+// (modules.py:139-143), here it would read the previous layer's output at the surplus frames (bias, ReLU, ...).  So the
+// surplus columns of every activation of the non-causal stacks (and of their gradients in backward) are set to zero; the
+// batch's own maximum is a DEVICE scalar (a replayed graph has no host in the loop), the host promises only an upper
+// bound for the number of surplus columns.  rows * max_tail * words threads, consecutive threads on consecutive words.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void zero_tail_kernel(uint32_t* __restrict__ x, int64_t rows, int T, int words,
+                                                        const int32_t* __restrict__ t_valid, int mult, int max_tail) {
+  const int64_t per_row = (int64_t)max_tail * words;
+  const int64_t n = rows * per_row;
+  int64_t tv64 = (int64_t)t_valid[0] * mult;
+  const int tv = tv64 < 0 ? 0 : (tv64 > T ? T : (int)tv64);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / per_row;
+    const int64_t k = i - row * per_row;            // word inside the row's last max_tail columns
+    const int col = T - max_tail + (int)(k / words);
+    if (col >= tv && col >= 0) x[(row * T + col) * words + (k % words)] = 0u;
+  }
+}
+}  // namespace
+extern "C" int dv3_zero_tail_b32(void* x, int64_t rows, int32_t T, int32_t words, const int32_t* t_valid, int32_t mult,
+                                 int32_t max_tail, void* stream) {
+  DV3_REQUIRE(x && t_valid && rows >= 0 && T > 0 && words > 0 && mult > 0 && max_tail >= 0, "zero_tail: bad args");
+  if (max_tail > T) max_tail = T;
+  if (rows == 0 || max_tail == 0) return DV3_OK;
+  int64_t blocks = (rows * max_tail * words + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(zero_tail_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint32_t*)x, rows, (int)T,
+                     (int)words, t_valid, (int)mult, (int)max_tail);
+  return dv3_check_launch("zero_tail_b32");
+}

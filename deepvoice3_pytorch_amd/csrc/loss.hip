@@ -38,10 +38,17 @@ __device__ __forceinline__ void spec_bd(float yh, float y, float& z, float& dz) 
   dz = (a * __builtin_amdgcn_rcpf(ab) - y) * (ra + rb);
 }
 
+// frames that take part (ABI 42, dv3_spec_loss_desc.t_valid): the batch's own maximum when the tensors are padded further
+__device__ __forceinline__ int spec_t_valid(const dv3_spec_loss_desc& p) {
+  if (!p.t_valid) return p.T;
+  const int tv = p.t_valid[0];
+  return tv < p.T ? (tv > p.r ? tv : p.r + 1) : p.T;
+}
+
 // mask_sum as train.py:286-290 computes it: sum over the expanded (B, T-r, D) mask
 __device__ __forceinline__ float spec_mask_sum(const dv3_spec_loss_desc& p) {
   float ms = 0.f;
-  const int Tr = p.T - p.r;
+  const int Tr = spec_t_valid(p) - p.r;
   for (int b = 0; b < p.B; ++b) {
     int l = p.lengths[b] - p.r;
     l = l < 0 ? 0 : (l > Tr ? Tr : l);
@@ -52,10 +59,11 @@ __device__ __forceinline__ float spec_mask_sum(const dv3_spec_loss_desc& p) {
 
 __global__ __launch_bounds__(kLossBlock) void spec_loss_kernel(const dv3_spec_loss_desc p) {
   const int Tr = p.T - p.r, D = p.D;
+  const int Trv = spec_t_valid(p) - p.r;       // == Tr unless the batch is padded beyond its own maximum
   const int64_t n = (int64_t)p.B * Tr * D;
   const bool use_mask = p.w_masked > 0.f && p.lengths;
   const float msum = use_mask ? spec_mask_sum(p) : 1.f;
-  const float inv_n = 1.0f / (float)n;
+  const float inv_n = 1.0f / (float)((int64_t)p.B * Trv * D);
   const float wm = use_mask ? p.w_masked : 0.f;
   const float c_all = (1.f - wm) * inv_n, c_msk = use_mask ? wm / msum : 0.f;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};  // l1, l1 masked, z, z masked
@@ -77,6 +85,10 @@ __global__ __launch_bounds__(kLossBlock) void spec_loss_kernel(const dv3_spec_lo
     }
     const int64_t ih = b * p.yh_bs + t * p.yh_ts + dd * p.yh_ds;          // y_hat[:, :-r]
     const int64_t iy = b * p.y_bs + (int64_t)(t + p.r) * p.y_ts + dd * p.y_ds;  // y[:, r:]
+    if (t >= Trv) {
+      if (p.dyh) p.dyh[ih] = 0.f;
+      continue;
+    }
     const float yh = p.y_hat[ih], y = p.y[iy];
     const float m = (use_mask && (t + p.r) < p.lengths[b]) ? 1.f : 0.f;
     const float diff = yh - y;
@@ -109,10 +121,10 @@ __global__ __launch_bounds__(kLossBlock) void spec_loss_tiled_kernel(const dv3_s
                                                                      int n_tiles) {
   __shared__ float ys[64 * 65];
   const int Tr = p.T - p.r, D = p.D;
-  const int64_t n = (int64_t)p.B * Tr * D;
+  const int Trv = spec_t_valid(p) - p.r;
   const bool use_mask = p.w_masked > 0.f && p.lengths;
   const float msum = use_mask ? spec_mask_sum(p) : 1.f;
-  const float inv_n = 1.0f / (float)n;
+  const float inv_n = 1.0f / (float)((int64_t)p.B * Trv * D);
   const float wm = use_mask ? p.w_masked : 0.f;
   const float c_all = (1.f - wm) * inv_n, c_msk = use_mask ? wm / msum : 0.f;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -135,6 +147,10 @@ __global__ __launch_bounds__(kLossBlock) void spec_loss_tiled_kernel(const dv3_s
       const int t = t0 + tl, dd = d0 + dl;
       if (t >= Tr || dd >= D) continue;
       const int64_t ih = b * p.yh_bs + t + (int64_t)dd * p.yh_ds;
+      if (t >= Trv) {
+        if (p.dyh) p.dyh[ih] = 0.f;
+        continue;
+      }
       const float yh = p.y_hat[ih], y = ys[tl * 65 + dl];
       const float m = (use_mask && (t + p.r) < len_b) ? 1.f : 0.f;
       const float diff = yh - y;
@@ -182,7 +198,7 @@ __global__ __launch_bounds__(256) void spec_loss_finish_kernel(const dv3_spec_lo
   if (threadIdx.x == 0) {
     const bool use_mask = p.w_masked > 0.f && p.lengths;
     const float msum = use_mask ? spec_mask_sum(p) : 1.f;
-    const float n = (float)((int64_t)p.B * (p.T - p.r) * p.D);
+    const float n = (float)((int64_t)p.B * (spec_t_valid(p) - p.r) * p.D);
     const float wm = use_mask ? p.w_masked : 0.f;
     const float l1 = wm * (use_mask ? fin[1] / msum : 0.f) + (1.f - wm) * fin[0] / n;
     const float bd = p.w_bd > 0.f ? wm * (use_mask ? fin[3] / msum : 0.f) + (1.f - wm) * fin[2] / n : 0.f;
@@ -199,8 +215,12 @@ __global__ __launch_bounds__(256) void guided_attn_kernel(const float* __restric
                                                           const int32_t* __restrict__ out_len,
                                                           float* __restrict__ dattn,
                                                           float* __restrict__ scratch, int L, int B,
-                                                          int Tq, int Tk, float g, float gscale) {
-  const int64_t per = (int64_t)B * Tq * Tk, n = per * L;
+                                                          int Tq, int Tk, float g, float gscale,
+                                                          const int32_t* __restrict__ tq_valid,
+                                                          const int32_t* __restrict__ tk_valid) {
+  const int64_t per = (int64_t)B * Tq * Tk;
+  // the mean's element count: the tensor's, or (ABI 42) that of the batch's own maxima
+  const int64_t n = tq_valid ? (int64_t)L * B * min(tq_valid[0], Tq) * min(tk_valid[0], Tk) : per * L;
   const float inv_n = 1.0f / (float)n;
   const double inv2g2 = 1.0 / (2.0 * (double)g * (double)g);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -224,26 +244,44 @@ __global__ __launch_bounds__(256) void guided_attn_kernel(const float* __restric
   block_reduce4(acc, scratch + (int64_t)blockIdx.x * 4);
 }
 
+// out1 = (sum of the block partial sums) * scale; with va (and vb) the scale is 1 / (count * min(va[0], cap_a) [* min(vb[0], cap_b)])
 __global__ __launch_bounds__(256) void sum_finish_kernel(const float* __restrict__ scratch,
                                                          int n_blocks, float scale,
-                                                         float* __restrict__ out1) {
+                                                         float* __restrict__ out1,
+                                                         const int32_t* __restrict__ va = nullptr, int cap_a = 0,
+                                                         const int32_t* __restrict__ vb = nullptr, int cap_b = 0,
+                                                         int64_t count = 0) {
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < n_blocks; i += 256) acc[0] += scratch[(int64_t)i * 4];
   __shared__ float fin[4];
   block_reduce4(acc, fin);
   __syncthreads();
-  if (threadIdx.x == 0) out1[0] = fin[0] * scale;
+  if (threadIdx.x == 0) {
+    if (va) {
+      int64_t n = count * min(va[0], cap_a);
+      if (vb) n *= min(vb[0], cap_b);
+      scale = 1.0f / (float)n;
+    }
+    out1[0] = fin[0] * scale;
+  }
 }
 
 // ---- BCE (nn.BCELoss, mean; log clamped at -100 as torch does) ------------------------------
 __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ p,
                                                   const float* __restrict__ t,
                                                   float* __restrict__ dp, float* __restrict__ scratch,
-                                                  int64_t n, float gscale) {
+                                                  int64_t n, float gscale, int T = 0,
+                                                  const int32_t* __restrict__ t_valid = nullptr) {
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const float inv_n = 1.0f / (float)n;
+  // ABI 42: [rows][T] with only the first t_valid[0] columns taking part
+  const int Tv = t_valid ? min(t_valid[0], T) : T;
+  const float inv_n = 1.0f / (float)(t_valid ? (n / T) * Tv : n);
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    if (t_valid && (int)(i % T) >= Tv) {
+      if (dp) dp[i] = 0.f;
+      continue;
+    }
     const float x = p[i], y = t[i];
     const float lx = fmaxf(logf(x), -100.f), l1x = fmaxf(logf(1.f - x), -100.f);
     acc[0] += -(y * lx + (1.f - y) * l1x);
@@ -304,10 +342,26 @@ extern "C" int dv3_guided_attn_loss_f32(const float* attn, const int32_t* in_len
   const int64_t per = (int64_t)B * Tq * Tk;
   const int nb = loss_blocks(per);
   hipLaunchKernelGGL(guided_attn_kernel, dim3(nb), dim3(256), 0, st, attn, in_len, out_len, dattn,
-                     scratch, L, B, Tq, Tk, g, gscale);
+                     scratch, L, B, Tq, Tk, g, gscale, (const int32_t*)nullptr, (const int32_t*)nullptr);
   hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, scratch, nb,
-                     1.0f / (float)(per * L), out1);
+                     1.0f / (float)(per * L), out1, (const int32_t*)nullptr, 0, (const int32_t*)nullptr, 0, (int64_t)0);
   return dv3_check_launch("guided_attn_loss_f32");
+}
+
+extern "C" int dv3_guided_attn_loss_valid_f32(const float* attn, const int32_t* in_len, const int32_t* out_len,
+                                              float* dattn, float* out1, float* scratch, int32_t L, int32_t B,
+                                              int32_t Tq, int32_t Tk, float g, float gscale,
+                                              const int32_t* tq_valid, const int32_t* tk_valid, void* stream) {
+  DV3_REQUIRE(attn && in_len && out_len && out1 && scratch && tq_valid && tk_valid, "guided_attn_valid: null pointer");
+  DV3_REQUIRE(L > 0 && B > 0 && Tq > 0 && Tk > 0 && g > 0.f, "guided_attn_valid: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t per = (int64_t)B * Tq * Tk;
+  const int nb = loss_blocks(per);
+  hipLaunchKernelGGL(guided_attn_kernel, dim3(nb), dim3(256), 0, st, attn, in_len, out_len, dattn,
+                     scratch, L, B, Tq, Tk, g, gscale, tq_valid, tk_valid);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, scratch, nb, 0.f, out1, tq_valid, (int)Tq, tk_valid,
+                     (int)Tk, (int64_t)L * B);
+  return dv3_check_launch("guided_attn_loss_valid_f32");
 }
 
 extern "C" int dv3_bce_loss_f32(const float* p, const float* t, float* dp, float* out1,
@@ -315,7 +369,20 @@ extern "C" int dv3_bce_loss_f32(const float* p, const float* t, float* dp, float
   DV3_REQUIRE(p && t && out1 && scratch && n > 0, "bce_loss: bad args");
   hipStream_t st = (hipStream_t)stream;
   const int nb = loss_blocks(n);
-  hipLaunchKernelGGL(bce_kernel, dim3(nb), dim3(256), 0, st, p, t, dp, scratch, n, gscale);
-  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, scratch, nb, 1.0f / (float)n, out1);
+  hipLaunchKernelGGL(bce_kernel, dim3(nb), dim3(256), 0, st, p, t, dp, scratch, n, gscale, 0, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, scratch, nb, 1.0f / (float)n, out1,
+                     (const int32_t*)nullptr, 0, (const int32_t*)nullptr, 0, (int64_t)0);
   return dv3_check_launch("bce_loss_f32");
+}
+
+extern "C" int dv3_bce_loss_valid_f32(const float* p, const float* t, float* dp, float* out1, float* scratch,
+                                      int64_t rows, int32_t T, const int32_t* t_valid, float gscale, void* stream) {
+  DV3_REQUIRE(p && t && out1 && scratch && t_valid && rows > 0 && T > 0, "bce_loss_valid: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = rows * T;
+  const int nb = loss_blocks(n);
+  hipLaunchKernelGGL(bce_kernel, dim3(nb), dim3(256), 0, st, p, t, dp, scratch, n, gscale, (int)T, t_valid);
+  hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, scratch, nb, 0.f, out1, t_valid, (int)T,
+                     (const int32_t*)nullptr, 0, rows);
+  return dv3_check_launch("bce_loss_valid_f32");
 }

@@ -98,10 +98,20 @@ def padded_frames(tgt_len, outputs_per_step=1, downsample_step=4):
     return T + b_pad * ds, b_pad
 
 
-def device_collate(packed, device, outputs_per_step=1, downsample_step=4):
+def lattice_shape(max_in, max_dec, step_in=16, step_dec=8):
+    """(longest text, most decoder steps) of a batch rounded up to the lattice a LatticeReplay keeps captured steps for
+    -> (t_in, t_dec).  The surplus is at most step - 1 columns per axis."""
+    up = lambda v, s: -(-int(v) // int(s)) * int(s)
+    return up(max_in, step_in), up(max_dec, step_dec)
+
+
+def device_collate(packed, device, outputs_per_step=1, downsample_step=4, lattice=None):
     """PackedBatch -> train_step.Batch on `device`, equal bit for bit to
     `to_device_batch(collate_fn(batch), device, ...)`; the padding runs on the GPU
-    (dv3_ragged_pad_rows_b32), positions and done flags come from the length vectors."""
+    (dv3_ragged_pad_rows_b32), positions and done flags come from the length vectors.
+    lattice = (step_in, step_dec): pad to lattice_shape(...) instead of the batch's own maxima and attach those maxima
+    as `batch.valid` (ops.ValidLengths) -- a step on such a batch computes what the step on the batch padded to its own
+    maxima computes (train_step.Trainer reads `valid`), and its shape is one of a small set (train_step.LatticeReplay)."""
     from . import ops
     r, ds = int(outputs_per_step), int(downsample_step)
     n = len(packed.in_len)
@@ -109,6 +119,8 @@ def device_collate(packed, device, outputs_per_step=1, downsample_step=4):
     Tt = int(packed.in_len.max())
     Td = T // r // ds
     dev = torch.device(device)
+    if lattice is not None:
+        return _device_collate_lattice(packed, dev, r, ds, T, b_pad, Tt, Td, lattice)
     f = lambda t: t.to(dev, non_blocking=True)
     text, mel, lin = f(packed.text), f(packed.mel), f(packed.lin)
     off = lambda lens: f(torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)))
@@ -125,6 +137,64 @@ def device_collate(packed, device, outputs_per_step=1, downsample_step=4):
     done = (torch.arange(Td, device=dev)[None] >= first_done[:, None]).float()[:, :, None]
     spk = f(torch.from_numpy(packed.speaker_ids)) if packed.speaker_ids is not None else None
     return Batch(x, tpos, fpos, mel_ds, y, done, packed.in_len, packed.tgt_len, spk, r, ds, dev)
+
+
+def _device_collate_lattice(packed, dev, r, ds, T, b_pad, Tt, Td, lattice):
+    from . import ops
+    n = len(packed.in_len)
+    step_in, step_dec = lattice
+    t_in, t_dec = lattice_shape(Tt, Td, step_in, step_dec)
+    TL = t_dec * r * ds
+    f = lambda t: t.to(dev, non_blocking=True)
+    text, mel, lin = f(packed.text), f(packed.mel), f(packed.lin)
+    off = lambda lens: f(torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)))
+    toff, foff = off(packed.in_len), off(packed.tgt_len)
+    x = ops.ragged_pad_rows(text, toff, n, t_in, lead=0, t_stride=1)
+    y = ops.ragged_pad_rows(lin, foff, n, TL, lead=b_pad, t_stride=1)
+    mel_ds = ops.ragged_pad_rows(mel, foff, n, TL // ds, lead=b_pad, t_stride=ds)
+    in_len_d = f(torch.from_numpy(packed.in_len))
+    ar = torch.arange(1, t_in + 1, device=dev, dtype=torch.int64)[None]
+    tpos = ar * (ar <= in_len_d[:, None])
+    fr = torch.arange(1, t_dec + 1, device=dev, dtype=torch.int64)
+    fpos = (fr * (fr <= Td))[None].repeat(n, 1)          # surplus steps: position 0 (no frame of the batch reads them)
+    first_done = f(torch.from_numpy(np.maximum(packed.tgt_len // r // ds - 1, 0)))
+    done = (torch.arange(t_dec, device=dev)[None] >= first_done[:, None]).float()[:, :, None]
+    spk = f(torch.from_numpy(packed.speaker_ids)) if packed.speaker_ids is not None else None
+    b = Batch(x, tpos, fpos, mel_ds, y, done, packed.in_len, packed.tgt_len, spk, r, ds, dev)
+    b.valid = ops.ValidLengths.make(Tt, Td, n, t_in, t_dec, step_in - 1, step_dec - 1, r, ds, dev)
+    return b
+
+
+def pad_to_shape(batch, t_in, t_dec, tail_in=None, tail_dec=None):
+    """A Batch padded to its own maxima -> the same batch padded to (t_in text positions, t_dec decoder steps) with
+    `valid` attached (see device_collate(lattice=)).  tail_*: the promised upper bound of the surplus per axis (default:
+    the surplus itself)."""
+    from . import ops
+    B, Tt = batch.text.shape
+    Td = batch.frame_positions.shape[1]
+    r = batch.mel.shape[1] // Td
+    ds = batch.y.shape[1] // batch.mel.shape[1]
+    if t_in < Tt or t_dec < Td:
+        raise ValueError("pad_to_shape: (%d, %d) is smaller than the batch (%d, %d)" % (t_in, t_dec, Tt, Td))
+
+    def pad(t, n, dim=1):
+        if t is None or t.shape[dim] == n:
+            return t
+        shape = list(t.shape)
+        shape[dim] = n
+        out = t.new_zeros(shape)
+        out.narrow(dim, 0, t.shape[dim]).copy_(t)
+        return out
+
+    done = pad(batch.done, t_dec)
+    if t_dec > Td:
+        done[:, Td:] = 1.0
+    b = Batch(pad(batch.text, t_in), pad(batch.text_positions, t_in), pad(batch.frame_positions, t_dec),
+              pad(batch.mel, t_dec * r), pad(batch.y, t_dec * r * ds), done, batch.input_lengths_host,
+              batch.target_lengths_host, batch.speaker_ids, r, ds, batch.text.device)
+    b.valid = ops.ValidLengths.make(Tt, Td, B, t_in, t_dec, t_in - Tt if tail_in is None else tail_in,
+                                    t_dec - Td if tail_dec is None else tail_dec, r, ds, batch.text.device)
+    return b
 
 
 class PreprocessedDataset(torch.utils.data.Dataset):

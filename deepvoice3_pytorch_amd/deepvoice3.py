@@ -82,14 +82,19 @@ def _conv1d_c8(f, x, last, **kw):
     return f(x, out_c8=not last, **kw)
 
 
-def _run_stack(modules, x, speaker_embed_btc, first=0, keep_c8=False):
+def _run_stack(modules, x, speaker_embed_btc, first=0, keep_c8=False, valid_axis=None):
     """Run a ModuleList of {Conv1d, nn.ReLU, Conv1dGLU, ConvTranspose1d} on BCT x, fusing each
     Conv1d + ReLU pair into one launch.  In the bf16 GEMM mode the activations between the layers are
-    channel-blocked bf16 tensors (ops.to_c8); the result is fp32 (B, C, T) unless keep_c8."""
+    channel-blocked bf16 tensors (ops.to_c8); the result is fp32 (B, C, T) unless keep_c8.
+    valid_axis = (device int32[1], most surplus columns) for a NON-CAUSAL stack on a batch padded beyond its own
+    maximum (ops.ValidLengths): every layer's output -- and, in backward, its gradient -- is zero beyond that maximum,
+    as the zero padding of the reference's nn.Conv1d is."""
     n = len(modules)
     i = first
     C = x.size(1)               # channel count of x (a c8 tensor pads it to a multiple of 32)
     x = _c8_enter(x)
+    if valid_axis is not None:
+        x = ops.zero_tail(x, *valid_axis)
     while i < n:
         f = modules[i]
         if isinstance(f, Conv1dGLU):
@@ -111,6 +116,8 @@ def _run_stack(modules, x, speaker_embed_btc, first=0, keep_c8=False):
         else:
             x = f(x)
             C = getattr(f, "out_channels", C)
+        if valid_axis is not None:
+            x = ops.zero_tail(x, *valid_axis)
         i += 1
     return x if keep_c8 else _c8_leave(x, C)
 
@@ -166,9 +173,12 @@ class Encoder(nn.Module):
                                                 getattr(self, "_dv3_site", "enc") + ".speaker_embed")
         if speaker_embed_btc is not None:
             x = x + self._speaker_term(self.speaker_fc1, speaker_embed_btc)
+        vl = ops.valid              # the batch is padded beyond its longest text: zeros beyond it, layer by layer
+        if vl is not None:
+            x = ops.zero_tail(x, *vl.text())
         input_embedding = x
         _fuse_speaker_biases(speaker_embed_btc, self.convolutions)
-        x = _run_stack(self.convolutions, x, speaker_embed_btc)
+        x = _run_stack(self.convolutions, x, speaker_embed_btc, valid_axis=vl.text() if vl is not None else None)
         keys = x
         if speaker_embed_btc is not None:
             keys = keys + self._speaker_term(self.speaker_fc2, speaker_embed_btc)
@@ -348,6 +358,10 @@ class Decoder(nn.Module):
         key_len = None
         if self.use_memory_mask and lengths is not None:
             key_len = key_lengths_i32(lengths, keys_bct.device)
+        elif ops.valid is not None:
+            # keys beyond the batch's longest text are padding of the padded SHAPE, not of the batch: out of the softmax
+            # (the reference's softmax runs over the batch's own padded length, deepvoice3.py:159-163)
+            key_len = ops.valid.key_valid
 
         if text_positions is not None:
             w = self._rate(self.key_position_rate, self.speaker_proj1, speaker_embed)
@@ -718,6 +732,15 @@ class Converter(nn.Module):
         _fuse_speaker_biases(speaker_embed_btc, by_t.get(x.size(2), ()))
         i = 0
         x = _c8_enter(x)            # bf16 storage: channel-blocked bf16 between the layers (see _run_stack)
+        vl = ops.valid              # a batch padded beyond its own maximum: zeros beyond it after every layer (_run_stack)
+
+        def ztail(x):
+            if vl is None:
+                return x
+            ptr, tail, mult = vl.axis_for(x.size(2))
+            return ops.zero_tail(x, ptr, tail, mult)
+
+        x = ztail(x)
         while i < n:
             f = mods[i]
             if speaker_embed_btc is not None and speaker_embed_btc.size(1) != x.size(2):
@@ -741,5 +764,7 @@ class Converter(nn.Module):
                 x = _c8_enter(f(_c8_leave(x, f.in_channels)))
             else:
                 x = f(x)
+            if not last:
+                x = ztail(x)
             i += 1
         return _c8_leave(x, self.out_dim).transpose(1, 2)

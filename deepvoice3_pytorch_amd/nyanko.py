@@ -18,14 +18,25 @@ from .deepvoice3 import AttentionLayer, _c8_enter, _c8_leave, _conv1d_c8
 from .decode_program import StepTrace
 
 
-def _run_seq(mods, x):
+def _run_seq(mods, x, valid_axis=None):
     """nn.Sequential / ModuleList of {Conv1d, ReLU, Sigmoid, HighwayConv1d, ConvTranspose1d} on
-    BCT x with Conv1d+ReLU / Conv1d+Sigmoid fused."""
+    BCT x with Conv1d+ReLU / Conv1d+Sigmoid fused.
+    valid_axis (NON-CAUSAL sequences on a batch padded beyond its own maximum, ops.ValidLengths): a function
+    T -> (device int32[1], most surplus columns, multiplier) -- the surplus columns of every layer's output, and of its
+    gradient in backward, are zeroed (deepvoice3._run_stack)."""
     mods = list(mods)
     n = len(mods)
     i = 0
     C = x.size(1)           # channel count of x (a c8 tensor pads it to a multiple of 32)
     x = _c8_enter(x)        # bf16 GEMM mode: channel-blocked bf16 between the layers, fp32 (B, C, T) result
+
+    def ztail(x):
+        if valid_axis is None:
+            return x
+        ptr, tail, mult = valid_axis(x.size(2))
+        return ops.zero_tail(x, ptr, tail, mult)
+
+    x = ztail(x)
     while i < n:
         f = mods[i]
         C = getattr(f, "out_channels", C) if not isinstance(f, HighwayConv1d) else C
@@ -48,6 +59,8 @@ def _run_seq(mods, x):
             if isinstance(f, HighwayConv1d) and i + 1 < n:
                 ops.mark_sole_consumer(x)      # the next layer of the sequence is x's only consumer (ops.GateFuse)
         i += 1
+        if i < n:
+            x = ztail(x)
     return _c8_leave(x, C)
 
 
@@ -97,7 +110,8 @@ class Encoder(nn.Module):
     def forward(self, text_sequences, text_positions=None, lengths=None, speaker_embed=None):
         x = ops.embedding_bct(text_sequences, self.embed_tokens.weight, 0.0, False,
                               self.embed_tokens.padding_idx)
-        x = _run_seq(self.convnet, x)                       # (B, 2D, T)
+        vl = ops.valid          # the batch is padded beyond its longest text: zeros beyond it, layer by layer
+        x = _run_seq(self.convnet, x, (lambda T: vl.text() + (1,)) if vl is not None else None)     # (B, 2D, T)
         D = x.size(1) // 2
         keys, values = x[:, :D, :], x[:, D:, :]             # channel halves (nyanko.py:69)
         return keys.transpose(1, 2), values.transpose(1, 2)
@@ -173,6 +187,8 @@ class Decoder(nn.Module):
         key_len = None
         if self.use_memory_mask and lengths is not None:
             key_len = key_lengths_i32(lengths, keys_bct.device)
+        elif ops.valid is not None:       # keys beyond the batch's longest text: out of the softmax (deepvoice3.Decoder)
+            key_len = ops.valid.key_valid
 
         if text_positions is not None:
             keys_bct = ops.add_position_encoding(keys_bct.contiguous(), text_positions,
@@ -373,4 +389,5 @@ class Converter(nn.Module):
     def forward(self, x, speaker_embed=None):
         bct = getattr(x, "_dv3_bct", None)
         x = bct if bct is not None else x.transpose(1, 2).contiguous()
-        return _run_seq(self.convnet, x).transpose(1, 2)
+        vl = ops.valid
+        return _run_seq(self.convnet, x, vl.axis_for if vl is not None else None).transpose(1, 2)

@@ -1914,13 +1914,18 @@ class AttnCoreFn(torch.autograd.Function):
             d = _attn_fwd_desc()
             d.q, d.k, d.vT, d.key_len = q.data_ptr(), k.data_ptr(), vT.data_ptr(), _ptr(key_len)
             d.mask, d.mask_rs, d.drop_scale = _ptr(bits), bits_rs, dscale
-            d.pd_scale = Tk * math.sqrt(1.0 / Tk)
+            # deepvoice3.py:170-171: s * sqrt(1/s), s = keys of the batch -- a device scalar when the batch is padded beyond
+            # its own longest text (ValidLengths; the caller passes that length as every item's key_len)
+            vs = valid.scale if valid is not None else None
+            d.pd_scale = 1.0 if vs is not None else Tk * math.sqrt(1.0 / Tk)
+            d.pd_scale_dev = _ptr(vs)
             d.ctx, d.P, d.pd = ctxv.data_ptr(), P.data_ptr(), pd.data_ptr()
             d.B, d.E, d.Tq, d.Tk = B, E, Tq, Tk
             _lib.call("dv3_attn_fwd_f32", ctypes.byref(d), _stream())
             if any(ctx.needs_input_grad[:3]):
                 ctx.save_for_backward(q, k, v, P, pd)
                 ctx.bits, ctx.bits_rs, ctx.dscale, ctx.pd_scale = bits, bits_rs, dscale, d.pd_scale
+                ctx.scale_dev = vs
             return ctxv, P
         # scores: per-batch operand A = q[b] as [Cin=E][lda=Tq]
         S = conv_gemm(k, q, Tq, 0, B=B, Cin=E, Tin=Tk, M=Tq, Tout=Tk, a_bs=E * Tq)
@@ -1928,7 +1933,9 @@ class AttnCoreFn(torch.autograd.Function):
         d = _softmax_desc()
         d.s, d.pd, d.key_len, d.last_attended = S.data_ptr(), pd.data_ptr(), _ptr(key_len), _ptr(last_attended)
         d.mask, d.mask_rs, d.drop_scale = _ptr(bits), bits_rs, dscale
-        d.pd_scale = Tk * math.sqrt(1.0 / Tk)   # deepvoice3.py:170-171: s * sqrt(1/s)
+        vs = valid.scale if valid is not None else None
+        d.pd_scale = 1.0 if vs is not None else Tk * math.sqrt(1.0 / Tk)   # deepvoice3.py:170-171: s * sqrt(1/s)
+        d.pd_scale_dev = _ptr(vs)
         d.B, d.Tq, d.Tk, d.win_back, d.win_ahead = B, Tq, Tk, win_back, win_ahead
         _lib.call("dv3_attn_softmax_f32", ctypes.byref(d), _stream())
         P = S
@@ -1938,6 +1945,7 @@ class AttnCoreFn(torch.autograd.Function):
         if any(ctx.needs_input_grad[:3]):
             ctx.save_for_backward(q, k, v, P, pd)
             ctx.bits, ctx.bits_rs, ctx.dscale, ctx.pd_scale = bits, bits_rs, dscale, d.pd_scale
+            ctx.scale_dev = vs
         return ctxv, P
 
     @staticmethod
@@ -1956,6 +1964,7 @@ class AttnCoreFn(torch.autograd.Function):
         d.p, d.dpd, d.ds = P.data_ptr(), dpd.data_ptr(), dS.data_ptr()
         d.dp_direct = _ptr(_c(dP)) if dP is not None else None
         d.mask, d.mask_rs, d.drop_scale = _ptr(ctx.bits), ctx.bits_rs, ctx.dscale * ctx.pd_scale
+        d.scale_dev = _ptr(ctx.scale_dev)
         d.B, d.Tq, d.Tk = B, Tq, Tk
         _lib.call("dv3_attn_softmax_bwd_f32", ctypes.byref(d), _stream())
         # dq[b][e][t] = sum_n k[b][e][n] * dS[b][t][n]
@@ -2138,6 +2147,108 @@ def position_encoding(pos, table, w=None, apply_sincos=True):
 
 
 # ----------------------------------------------------------------------------------------------
+# valid-length steps: a batch padded beyond its own maxima (to a lattice shape whose captured step is replayed)
+# ----------------------------------------------------------------------------------------------
+class ValidLengths(object):
+    """What a step needs to compute, on a batch padded to (t_in, t_dec) -- text positions / decoder steps --, exactly what
+    the reference computes on the same batch padded to its OWN maxima (train.collate_fn, train.py:293-360): those maxima
+    as DEVICE scalars (a replayed hipGraph has no host in the loop) plus host-side upper bounds for the surplus.
+
+      tv        int32[4] on the device: {longest text, most decoder steps, x r (mel frames), x r x downsample (linear frames)}
+      scale     float32[1]: s * sqrt(1 / s) for s = longest text -- the context scale of AttentionLayer (deepvoice3.py:170-171)
+      key_valid int32[B], every entry the longest text: the softmax's key limit when the model uses no memory mask
+      t_in, t_dec / tail_in, tail_dec   (host) the padded sizes and the most surplus columns either axis can have
+
+    Where the surplus would change a result: the non-causal stacks (Encoder, Converter: zero_tail after every layer, and
+    on every activation gradient), the attention softmax and its sqrt(keys) scale, and every loss mean.  The causal
+    decoder stack needs nothing: its valid frames never read a later one, and the losses feed its surplus frames zeros."""
+
+    def __init__(self, tv, scale, key_valid, t_in, t_dec, tail_in, tail_dec, r, downsample_step):
+        self.tv, self.scale, self.key_valid = tv, scale, key_valid
+        self.t_in, self.t_dec, self.tail_in, self.tail_dec = int(t_in), int(t_dec), int(tail_in), int(tail_dec)
+        self.r, self.downsample_step = int(r), int(downsample_step)
+
+    @staticmethod
+    def make(max_in, max_dec, B, t_in, t_dec, tail_in, tail_dec, r, downsample_step, device):
+        max_in, max_dec = int(max_in), int(max_dec)
+        if not (0 < max_in <= t_in and 0 < max_dec <= t_dec and t_in - max_in <= tail_in and t_dec - max_dec <= tail_dec):
+            raise ValueError("ValidLengths: maxima (%d, %d) do not fit the padded shape (%d, %d) with tails (%d, %d)" % (
+                max_in, max_dec, t_in, t_dec, tail_in, tail_dec))
+        tv = torch.tensor([max_in, max_dec, max_dec * r, max_dec * r * downsample_step], dtype=torch.int32).to(device)
+        scale = torch.tensor([max_in * math.sqrt(1.0 / max_in)], dtype=torch.float32).to(device)
+        key_valid = torch.full((B,), max_in, dtype=torch.int32).to(device)
+        return ValidLengths(tv, scale, key_valid, t_in, t_dec, tail_in, tail_dec, r, downsample_step)
+
+    # (pointer tensor, host upper bound of the surplus) per time axis
+    def text(self):
+        return self.tv[0:1], self.tail_in
+
+    def dec(self):
+        return self.tv[1:2], self.tail_dec
+
+    def mel(self):
+        return self.tv[2:3], self.tail_dec * self.r
+
+    def linear(self):
+        return self.tv[3:4], self.tail_dec * self.r * self.downsample_step
+
+    def axis_for(self, T):
+        """the (pointer, tail, mult) of an activation with T columns in the converter: T is the decoder's axis or the
+        mel axis times a power of two (the ConvTranspose1d layers double it)"""
+        for ptr, tail, base in ((self.tv[1:2], self.tail_dec, self.t_dec), (self.tv[2:3], self.tail_dec * self.r, self.t_dec * self.r)):
+            if T % base == 0 and (T // base) & (T // base - 1) == 0:
+                return ptr, tail * (T // base), T // base
+        raise RuntimeError("ValidLengths: no time axis of the padded batch has %d columns" % T)
+
+
+valid = None      # a ValidLengths, set by the trainer for the duration of a step on a batch padded beyond its maxima
+
+
+def _zero_tail_raw(x, ptr, mult, max_tail):
+    """columns >= ptr[0] * mult of x ((B, C, T) fp32 or the channel-blocked bf16 [B][C8][T][8]) to zero, behind
+    autograd's back (no version bump: layers save their outputs)"""
+    if is_c8(x):
+        rows, T, words = x.shape[0] * x.shape[1], x.shape[2], 4
+    else:
+        _chk(x, "x")
+        T, words = x.shape[-1], 1
+        rows = x.numel() // T
+    if not x.is_contiguous():
+        raise RuntimeError("zero_tail: contiguous tensors only")
+    _lib.call("dv3_zero_tail_b32", x.data_ptr(), rows, T, words, ptr.data_ptr(), int(mult), int(max_tail), _stream())
+
+
+class _ZeroTailFn(torch.autograd.Function):
+    """forward: the surplus columns of x to zero, in place; backward: the same on the incoming gradient.  The result is a
+    view of x -- not x marked dirty -- because the producing layer may have saved x for its own backward (ReLU layers
+    do) and the zeroed columns are ones no valid output depends on."""
+
+    @staticmethod
+    def forward(ctx, x, ptr, mult, max_tail):
+        ctx.args = (ptr, mult, max_tail)
+        _zero_tail_raw(x, ptr, mult, max_tail)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ptr, mult, max_tail = ctx.args
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        _zero_tail_raw(dy, ptr, mult, max_tail)
+        return dy, None, None, None
+
+
+def zero_tail(x, ptr, max_tail, mult=1):
+    """see ValidLengths; ptr: device int32[1] = valid columns at mult 1"""
+    if max_tail <= 0:
+        return x
+    out = _ZeroTailFn.apply(x, ptr, mult, max_tail)
+    c = getattr(x, "_dv3_C", None)
+    if c is not None:
+        out._dv3_C = c          # a channel-blocked tensor remembers its channel count
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
 # losses (fused value + gradient; train.py:537-601,704-740)
 # ----------------------------------------------------------------------------------------------
 def _dense_or_copy(t):
@@ -2155,7 +2266,7 @@ class SpecLossFn(torch.autograd.Function):
     y_hat[:, :-r] with y[:, r:]."""
 
     @staticmethod
-    def forward(ctx, y_hat, y, lengths, r, w_masked, w_bd):
+    def forward(ctx, y_hat, y, lengths, r, w_masked, w_bd, t_valid=None):
         y_hat, y = _dense_or_copy(_chk(y_hat, "y_hat")), _dense_or_copy(_chk(y, "y"))
         B, T, D = y_hat.shape
         dev = y_hat.device
@@ -2171,6 +2282,7 @@ class SpecLossFn(torch.autograd.Function):
         d.dyh, d.out4, d.scratch = _ptr(dyh), out4.data_ptr(), scratch.data_ptr()
         d.B, d.T, d.D, d.r = B, T, D, r
         d.w_masked, d.w_bd, d.gscale = w_masked, w_bd, 1.0
+        d.t_valid = _ptr(t_valid)
         _lib.call("dv3_spec_loss_f32", ctypes.byref(d), _stream())
         ctx.dyh = dyh
         return out4
@@ -2178,11 +2290,12 @@ class SpecLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         g = ctx.dyh * dout[2] if ctx.dyh is not None else None
-        return g, None, None, None, None, None
+        return g, None, None, None, None, None, None
 
 
-def spec_loss(y_hat, y, lengths, r=1, w_masked=0.5, w_bd=0.1):
-    return SpecLossFn.apply(y_hat, y, lengths, r, w_masked, w_bd)
+def spec_loss(y_hat, y, lengths, r=1, w_masked=0.5, w_bd=0.1, t_valid=None):
+    """t_valid: device int32[1] -- only the first t_valid[0] frames take part (ValidLengths)"""
+    return SpecLossFn.apply(y_hat, y, lengths, r, w_masked, w_bd, t_valid)
 
 
 class _NoCtx(object):
@@ -2192,22 +2305,22 @@ class _NoCtx(object):
     needs_input_grad = (True,)
 
 
-def spec_loss_with_grad(y_hat, y, lengths, r=1, w_masked=0.5, w_bd=0.1):
+def spec_loss_with_grad(y_hat, y, lengths, r=1, w_masked=0.5, w_bd=0.1, t_valid=None):
     """-> (tensor[4] as spec_loss, d total / d y_hat laid out like y_hat); no autograd graph"""
     c = _NoCtx()
-    out4 = SpecLossFn.forward(c, y_hat.detach(), y, lengths, r, w_masked, w_bd)
+    out4 = SpecLossFn.forward(c, y_hat.detach(), y, lengths, r, w_masked, w_bd, t_valid)
     return out4, c.dyh
 
 
-def guided_attention_loss_with_grad(attn, in_len, out_len, g=0.2):
+def guided_attention_loss_with_grad(attn, in_len, out_len, g=0.2, tq_valid=None, tk_valid=None):
     c = _NoCtx()
-    out1 = GuidedAttnLossFn.forward(c, attn.detach(), in_len, out_len, g)
+    out1 = GuidedAttnLossFn.forward(c, attn.detach(), in_len, out_len, g, tq_valid, tk_valid)
     return out1, c.dattn
 
 
-def bce_loss_with_grad(p, t):
+def bce_loss_with_grad(p, t, t_valid=None):
     c = _NoCtx()
-    out1 = BCELossFn.forward(c, p.detach(), t)
+    out1 = BCELossFn.forward(c, p.detach(), t, t_valid)
     return out1, c.dp
 
 
@@ -2227,47 +2340,58 @@ def scaled_copy(a, alpha=1.0):
 
 class GuidedAttnLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, attn, in_len, out_len, g):
+    def forward(ctx, attn, in_len, out_len, g, tq_valid=None, tk_valid=None):
         attn = _c(_chk(attn, "attn"))
         L, B, Tq, Tk = attn.shape
         dev = attn.device
         out1 = torch.empty(1, dtype=torch.float32, device=dev)
         scratch = torch.empty(4 * 1024 + 16, dtype=torch.float32, device=dev)
         dattn = torch.empty_like(attn) if ctx.needs_input_grad[0] else None
-        _lib.call("dv3_guided_attn_loss_f32", attn.data_ptr(), in_len.data_ptr(), out_len.data_ptr(),
-                  _ptr(dattn), out1.data_ptr(), scratch.data_ptr(), L, B, Tq, Tk, float(g), 1.0, _stream())
+        if tq_valid is not None:      # the mean over the batch's own (decoder steps, text) maxima (ValidLengths)
+            _lib.call("dv3_guided_attn_loss_valid_f32", attn.data_ptr(), in_len.data_ptr(), out_len.data_ptr(),
+                      _ptr(dattn), out1.data_ptr(), scratch.data_ptr(), L, B, Tq, Tk, float(g), 1.0,
+                      tq_valid.data_ptr(), tk_valid.data_ptr(), _stream())
+        else:
+            _lib.call("dv3_guided_attn_loss_f32", attn.data_ptr(), in_len.data_ptr(), out_len.data_ptr(),
+                      _ptr(dattn), out1.data_ptr(), scratch.data_ptr(), L, B, Tq, Tk, float(g), 1.0, _stream())
         ctx.dattn = dattn
         return out1
 
     @staticmethod
     def backward(ctx, dout):
-        return (ctx.dattn * dout if ctx.dattn is not None else None), None, None, None
+        return (ctx.dattn * dout if ctx.dattn is not None else None), None, None, None, None, None
 
 
-def guided_attention_loss(attn, in_len, out_len, g=0.2):
-    return GuidedAttnLossFn.apply(attn, in_len, out_len, g)
+def guided_attention_loss(attn, in_len, out_len, g=0.2, tq_valid=None, tk_valid=None):
+    return GuidedAttnLossFn.apply(attn, in_len, out_len, g, tq_valid, tk_valid)
 
 
 class BCELossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, p, t):
+    def forward(ctx, p, t, t_valid=None):
         p, t = _c(_chk(p, "p")), _c(_chk(t, "t"))
         dev = p.device
         out1 = torch.empty(1, dtype=torch.float32, device=dev)
         scratch = torch.empty(4 * 1024 + 16, dtype=torch.float32, device=dev)
         dp = torch.empty_like(p) if ctx.needs_input_grad[0] else None
-        _lib.call("dv3_bce_loss_f32", p.data_ptr(), t.data_ptr(), _ptr(dp), out1.data_ptr(),
-                  scratch.data_ptr(), p.numel(), 1.0, _stream())
+        if t_valid is not None:       # p, t (B, T, 1): the first t_valid[0] steps of every item (ValidLengths)
+            if p.dim() != 3 or p.shape[2] != 1:
+                raise RuntimeError("bce_loss(t_valid=): (B, T, 1) tensors")
+            _lib.call("dv3_bce_loss_valid_f32", p.data_ptr(), t.data_ptr(), _ptr(dp), out1.data_ptr(),
+                      scratch.data_ptr(), p.shape[0], p.shape[1], t_valid.data_ptr(), 1.0, _stream())
+        else:
+            _lib.call("dv3_bce_loss_f32", p.data_ptr(), t.data_ptr(), _ptr(dp), out1.data_ptr(),
+                      scratch.data_ptr(), p.numel(), 1.0, _stream())
         ctx.dp = dp
         return out1
 
     @staticmethod
     def backward(ctx, dout):
-        return (ctx.dp * dout if ctx.dp is not None else None), None
+        return (ctx.dp * dout if ctx.dp is not None else None), None, None
 
 
-def bce_loss(p, t):
-    return BCELossFn.apply(p, t)
+def bce_loss(p, t, t_valid=None):
+    return BCELossFn.apply(p, t, t_valid)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -100,6 +100,9 @@ class Batch(object):
         # what the linear-domain mask is built from (train.py:669-677)
         self.linear_mask_lengths = self.target_lengths if downsample_step > 1 else self.decoder_lengths
         self.n_frames = int(self.target_lengths_host.sum())
+        # ops.ValidLengths when the tensors are padded BEYOND the batch's own maxima (data.device_collate(lattice=),
+        # data.pad_to_shape): the step then computes what it would on the batch padded to its own maxima
+        self.valid = None
 
     @staticmethod
     def from_collate(x, input_lengths, mel, y, text_positions, frame_positions, done, target_lengths,
@@ -328,6 +331,11 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         ops.prepacked = self._prepack_all()
         ops.mask_plan.begin_step(self.device)      # the step's dropout masks in one launch once its list of sites repeats
         s2s, pn = self.train_seq2seq, self.train_postnet
+        # a batch padded beyond its own maxima (data.pad_to_shape: the lattice shapes of LatticeReplay) carries those maxima
+        # as device scalars; the model's non-causal stacks, its attention and the loss means below read them
+        vl = ops.valid = getattr(batch, "valid", None)
+        v_mel, v_lin, v_dec, v_in = (vl.tv[2:3], vl.tv[3:4], vl.tv[1:2], vl.tv[0:1]) if vl is not None else (None,) * 4
+        self._valid_args = (v_mel, v_lin, v_dec, v_in)
         try:
             if s2s and pn:
                 mel_out, lin_out, attn, done_hat = self.model(
@@ -346,6 +354,7 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
                 mel_out = attn = done_hat = None
         finally:
             ops.prepacked = None
+            ops.valid = None
             ops.mask_plan.end_step()
         if not (s2s and pn):
             return self._split_losses_backward(batch, mel_out, lin_out, attn, done_hat)
@@ -357,35 +366,36 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
             # (train.py:728-740): the gradients go straight to autograd.backward below -- no select / mul / ones / add
             # nodes between the loss terms and the model outputs (round 3: 16 torch launches per step, two of them
             # 100 MB multiplications by 1.0).
-            m4, g_mel = ops.spec_loss_with_grad(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w)
-            l4, g_lin = ops.spec_loss_with_grad(lin_out, batch.y, lin_len, r, wm, w)
-            done_loss, g_done = ops.bce_loss_with_grad(done_hat, batch.done)
+            m4, g_mel = ops.spec_loss_with_grad(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w,
+                                                t_valid=v_mel)
+            l4, g_lin = ops.spec_loss_with_grad(lin_out, batch.y, lin_len, r, wm, w, t_valid=v_lin)
+            done_loss, g_done = ops.bce_loss_with_grad(done_hat, batch.done, t_valid=v_dec)
             lin_loss = l4[2]
             roots, grads = [mel_out, lin_out, done_hat], [g_mel, g_lin, g_done]
             attn_loss = None
             if c.use_guided_attention:
                 attn_loss, g_attn = ops.guided_attention_loss_with_grad(attn, batch.input_lengths, batch.decoder_lengths,
-                                                                         c.guided_attention_sigma)
+                                                                         c.guided_attention_sigma, v_dec, v_in)
                 roots.append(attn)
                 grads.append(g_attn)
             loss = ops.sum_scalars(m4[2:3], l4[2:3], done_loss, attn_loss)
         else:
-            m4 = ops.spec_loss(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w)
-            l4 = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, w)
+            m4 = ops.spec_loss(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w, v_mel)
+            l4 = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, w, v_lin)
             lin_loss = l4[2]
             if c.priority_freq_weight > 0:
                 # l1 := (1 - pw) * l1 + pw * l1(first n bins)   (train.py:562-569): two more passes of the fused loss
                 # kernel with the binary-divergence weight 0, whose third output IS the (masked) L1 and carries gradient
                 n_pri = int(c.priority_freq / (c.sample_rate * 0.5) * lin_out.size(-1))
-                l1_all = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, 0.0)[2]
-                l1_pri = ops.spec_loss(lin_out[:, :, :n_pri], batch.y[:, :, :n_pri], lin_len, r, wm, 0.0)[2]
+                l1_all = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, 0.0, v_lin)[2]
+                l1_pri = ops.spec_loss(lin_out[:, :, :n_pri], batch.y[:, :, :n_pri], lin_len, r, wm, 0.0, v_lin)[2]
                 lin_loss = lin_loss + (1.0 - w) * c.priority_freq_weight * (l1_pri - l1_all)
-            done_loss = ops.bce_loss(done_hat, batch.done)
+            done_loss = ops.bce_loss(done_hat, batch.done, v_dec)
             loss = m4[2] + lin_loss + done_loss[0]
             attn_loss = None
             if c.use_guided_attention:
                 attn_loss = ops.guided_attention_loss(attn, batch.input_lengths, batch.decoder_lengths,
-                                                      c.guided_attention_sigma)
+                                                      c.guided_attention_sigma, v_dec, v_in)
                 loss = loss + attn_loss[0]
         scal = dict(mel_l1_loss=m4[0], mel_binary_div_loss=m4[1], mel_loss=m4[2], linear_l1_loss=l4[0],
                     linear_binary_div_loss=l4[1], linear_loss=lin_loss, done_loss=done_loss[0])
@@ -423,25 +433,26 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
         of the part that ran"""
         c = self.cfg
         r, wm, w = c.outputs_per_step, c.masked_loss_weight, c.binary_divergence_weight
+        v_mel, v_lin, v_dec, v_in = self._valid_args
         scal, terms = {}, []
         if self.train_seq2seq:
-            m4 = ops.spec_loss(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w)
-            done_loss = ops.bce_loss(done_hat, batch.done)
+            m4 = ops.spec_loss(mel_out, batch.mel, batch.decoder_lengths if wm > 0 else None, r, wm, w, v_mel)
+            done_loss = ops.bce_loss(done_hat, batch.done, v_dec)
             scal.update(mel_l1_loss=m4[0], mel_binary_div_loss=m4[1], mel_loss=m4[2], done_loss=done_loss[0])
             terms += [m4[2], done_loss[0]]
             if c.use_guided_attention:
                 attn_loss = ops.guided_attention_loss(attn, batch.input_lengths, batch.decoder_lengths,
-                                                      c.guided_attention_sigma)
+                                                      c.guided_attention_sigma, v_dec, v_in)
                 scal["attn_loss"] = attn_loss[0]
                 terms.append(attn_loss[0])
         else:
             lin_len = batch.linear_mask_lengths if wm > 0 else None
-            l4 = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, w)
+            l4 = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, w, v_lin)
             lin_loss = l4[2]
             if c.priority_freq_weight > 0:
                 n_pri = int(c.priority_freq / (c.sample_rate * 0.5) * lin_out.size(-1))
-                l1_all = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, 0.0)[2]
-                l1_pri = ops.spec_loss(lin_out[:, :, :n_pri], batch.y[:, :, :n_pri], lin_len, r, wm, 0.0)[2]
+                l1_all = ops.spec_loss(lin_out, batch.y, lin_len, r, wm, 0.0, v_lin)[2]
+                l1_pri = ops.spec_loss(lin_out[:, :, :n_pri], batch.y[:, :, :n_pri], lin_len, r, wm, 0.0, v_lin)[2]
                 lin_loss = lin_loss + (1.0 - w) * c.priority_freq_weight * (l1_pri - l1_all)
             scal.update(linear_l1_loss=l4[0], linear_binary_div_loss=l4[1], linear_loss=lin_loss)
             terms.append(lin_loss)
@@ -584,9 +595,15 @@ class GraphedTrainer(object):
     benchmark's sizes.)  Without split_streams (single graph) the collectives are still captured with the step, in
     the thread-local capture mode."""
 
-    def __init__(self, trainer, static_batch, warmup=3, split_streams=None, chunk=None):
+    def __init__(self, trainer, static_batch, warmup=3, split_streams=None, chunk=None, dry_warmup=False, pool=None):
+        """dry_warmup: the warm-up passes run forward + backward only (no clip / Adam: parameters, moments and the step
+        counter stay as they are) -- what a LatticeReplay wants when it meets a new padded shape in the middle of a run.
+        pool: a torch.cuda.graph_pool_handle() shared with other GraphedTrainers of the same trainer that are never
+        replayed concurrently (LatticeReplay: one step at a time, whatever its shape) -- their activations then share
+        one set of blocks instead of holding a private set per captured shape."""
         self.t = trainer
         self.batch = static_batch
+        self._pool = pool
         trainer.check_lengths(static_batch)
         dev = trainer.device
         if split_streams is None:
@@ -604,6 +621,10 @@ class GraphedTrainer(object):
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):      # real optimisation steps (lr / bias corrections set first)
+                if dry_warmup:           # ... or forward + backward only (_set_hyper would count an Adam step)
+                    trainer._zero_grad()
+                    trainer.forward_backward(self.batch)
+                    continue
                 trainer._set_hyper()
                 self._body()
                 trainer.global_step += 1
@@ -630,6 +651,8 @@ class GraphedTrainer(object):
             self.graph = torch.cuda.CUDAGraph()
             cap = _capture_stream(self.t.device)
             ops.prepare_streamk_ws(dev, cap)       # the captured stream-K launches' workspace: not from the graph's pool
+            if self._pool is not None:
+                mode["pool"] = self._pool
             with torch.cuda.graph(self.graph, stream=cap, **mode):
                 self.scal = self._body()
         else:
@@ -665,7 +688,7 @@ class GraphedTrainer(object):
         from . import _lib
         t, SS = self.t, ops.SideStream
         side_raw = t.side_stream.cuda_stream
-        pool = torch.cuda.graph_pool_handle()
+        pool = self._pool if self._pool is not None else torch.cuda.graph_pool_handle()
         st = dict(g=None, side_open=False, forks=0)
 
         def begin_seg():
@@ -777,11 +800,19 @@ class GraphedTrainer(object):
             if (a is None) != (b is None) or (a is not None and (a.shape != b.shape or a.dtype != b.dtype)):
                 raise RuntimeError("GraphedTrainer: batch field %s %s does not fit the captured %s" % (
                     name, None if b is None else tuple(b.shape), None if a is None else tuple(a.shape)))
+        va, vb = st.valid, batch.valid
+        if (va is None) != (vb is None) or (va is not None and (
+                (va.t_in, va.t_dec, va.r, va.downsample_step) != (vb.t_in, vb.t_dec, vb.r, vb.downsample_step) or
+                vb.tail_in > va.tail_in or vb.tail_dec > va.tail_dec)):
+            raise RuntimeError("GraphedTrainer: the batch's valid lengths do not fit the captured step's")
         self.t.check_lengths(batch)
         for name in self._TENSORS:
             a = getattr(st, name)
             if a is not None:
                 a.copy_(getattr(batch, name), non_blocking=True)
+        if va is not None:       # the batch's own maxima: the device scalars the captured kernels read
+            for name in ("tv", "scale", "key_valid"):
+                getattr(va, name).copy_(getattr(vb, name), non_blocking=True)
         st.input_lengths_host, st.target_lengths_host = batch.input_lengths_host, batch.target_lengths_host
         st.decoder_lengths_host, st.n_frames = batch.decoder_lengths_host, batch.n_frames
 
@@ -848,6 +879,87 @@ class GraphedTrainer(object):
                 if ex is not None:
                     _lib.call("dv3_graph_destroy", ex)
             self.segs = []
+
+
+def clone_batch(batch):
+    """a Batch with its own copies of every device tensor (the static batch a captured step reads)"""
+    c = lambda t: t.clone() if t is not None else None
+    r = batch.mel.shape[1] // batch.frame_positions.shape[1]
+    ds = batch.y.shape[1] // batch.mel.shape[1]
+    b = Batch(c(batch.text), c(batch.text_positions), c(batch.frame_positions), c(batch.mel), c(batch.y), c(batch.done),
+              batch.input_lengths_host.copy(), batch.target_lengths_host.copy(), c(batch.speaker_ids), r, ds,
+              batch.text.device)
+    v = batch.valid
+    if v is not None:
+        b.valid = ops.ValidLengths(v.tv.clone(), v.scale.clone(), v.key_valid.clone(), v.t_in, v.t_dec, v.tail_in,
+                                   v.tail_dec, v.r, v.downsample_step)
+    return b
+
+
+class LatticeReplay(object):
+    """Ragged epochs without the host in the loop.  The reference's sampler (train.py:195-239) yields
+    about one new padded shape per batch, so a captured step never sees its shape again.  Here a batch is padded to the
+    next point of a LATTICE of shapes (data.device_collate(lattice=(step_in, step_dec)): text positions up to a multiple
+    of step_in, decoder steps up to a multiple of step_dec) and carries its own maxima as device scalars
+    (ops.ValidLengths): the step computes exactly what the reference computes on the batch padded to its own maxima
+    (tests/test_gpu_valid_lengths.py), and its shape is one of a few dozen.  One GraphedTrainer per shape, captured the
+    first time the shape is met (two forward + backward passes without an update, then the capture), replayed
+    afterwards; all of them share one block pool (a step at a time), so the memory is that of the largest shape.
+    An LRU bounds the number of live captures.
+
+    step(batch) -> the scalars of the step (device tensors of the captured step that ran; read them before the next
+    step of the same shape).  `stats`: captures, replays, capture seconds."""
+
+    def __init__(self, trainer, max_graphs=48, warmup=2):
+        import collections
+        self.t = trainer
+        self.max_graphs, self.warmup = int(max_graphs), int(warmup)
+        self.graphs = collections.OrderedDict()
+        self.pool = torch.cuda.graph_pool_handle() if trainer.device.type == "cuda" else None
+        self.stats = dict(captures=0, replays=0, capture_s=0.0, evictions=0)
+        self._n_made = 0
+
+    @staticmethod
+    def key_of(batch):
+        v = batch.valid
+        if v is None:
+            raise RuntimeError("LatticeReplay: the batch carries no valid lengths (data.device_collate(lattice=...))")
+        return (v.t_in, v.t_dec, int(batch.text.shape[0]))
+
+    def step(self, batch):
+        import time
+        key = self.key_of(batch)
+        g = self.graphs.get(key)
+        if g is None:
+            t0 = time.perf_counter()
+            if len(self.graphs) >= self.max_graphs:
+                _, old = self.graphs.popitem(last=False)
+                old.close()
+                self.stats["evictions"] += 1
+            st = ops.dropout_state
+            if st.seed is None:
+                st.manual_seed(torch.initial_seed())
+            seed0 = st.seed
+            # every capture draws from its own Philox stream: its step counter starts at zero like every other's
+            st.seed = (seed0 + 0x9E3779B1 * (self._n_made + 1)) & 0x7FFFFFFFFFFFFFFF
+            try:
+                g = GraphedTrainer(self.t, clone_batch(batch), warmup=self.warmup, dry_warmup=True, pool=self.pool)
+            finally:
+                st.seed = seed0
+            self._n_made += 1
+            self.graphs[key] = g
+            torch.cuda.synchronize()
+            self.stats["captures"] += 1
+            self.stats["capture_s"] += time.perf_counter() - t0
+        else:
+            self.graphs.move_to_end(key)
+        self.stats["replays"] += 1
+        return g.step(batch)
+
+    def close(self):
+        for g in self.graphs.values():
+            g.close()
+        self.graphs.clear()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 41
+#define DV3_ABI_VERSION 42
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -513,6 +513,8 @@ typedef struct dv3_softmax_desc {
   const uint32_t* mask; int32_t mask_rs; float drop_scale;
   float pd_scale;                            /* pd = dropout(p) * pd_scale (the sqrt(Tk) of deepvoice3.py:170-171) */
   int32_t B, Tq, Tk, win_back, win_ahead;
+  const float* pd_scale_dev;                 /* ABI 42: device float[1] multiplied into pd_scale, or NULL (valid-length
+                                              * steps: the key count of the batch is only known on the device)     */
 } dv3_softmax_desc;
 int dv3_attn_softmax_f32(const dv3_softmax_desc* d, void* stream);
 /* backward: ds = p * (dp_total - sum_k(dp_total*p)); dp_total = dpd*bit*scale + dp_direct */
@@ -520,6 +522,7 @@ typedef struct dv3_softmax_bwd_desc {
   const float* p; const float* dpd; const float* dp_direct; float* ds;
   const uint32_t* mask; int32_t mask_rs; float drop_scale;
   int32_t B, Tq, Tk;
+  const float* scale_dev;                    /* ABI 42: device float[1] multiplied into drop_scale, or NULL          */
 } dv3_softmax_bwd_desc;
 int dv3_attn_softmax_bwd_f32(const dv3_softmax_bwd_desc* d, void* stream);
 /* Fused attention forward (deepvoice3.py:143-171, teacher-forced / training: no monotonic window): scores = q^T k
@@ -534,6 +537,7 @@ typedef struct dv3_attn_fwd_desc {
   float pd_scale;
   float* ctx; float* P; float* pd;
   int32_t B, E, Tq, Tk;
+  const float* pd_scale_dev;                 /* ABI 42: as dv3_softmax_desc.pd_scale_dev                             */
 } dv3_attn_fwd_desc;
 int dv3_attn_fwd_f32(const dv3_attn_fwd_desc* d, void* stream);
 /* argmax over keys of one probability row -> last_attended (deepvoice3.py:445)          */
@@ -557,6 +561,14 @@ int dv3_memset_b8(void* p, int32_t value, int64_t bytes, void* stream);
 /* `rows` runs of row_bytes each, row_stride_bytes apart (all multiples of 16, p 16-byte aligned): the padding groups of a
  * channel-blocked tensor whose channel count is not a multiple of 32 (ops._c8_empty), one launch.                    */
 int dv3_memset_rows_b8(void* p, int32_t value, int64_t rows, int64_t row_bytes, int64_t row_stride_bytes, void* stream);
+/* ABI 42 (valid-length steps).  x is [rows][T] elements of `words` 32-bit words each (fp32 (B, C, T): words = 1; the
+ * channel-blocked bf16 [B][C8][T][8]: words = 4).  Columns t >= t_valid[0] * mult of every row are set to zero, where
+ * t_valid is a device int32[1]; the host only promises T - t_valid[0] * mult <= max_tail.  What a non-causal
+ * convolution of the reference sees beyond the batch's longest item is its own zero padding (modules.py:139-143:
+ * nn.Conv1d(padding=...)): a batch padded further (to a lattice shape, so that captured steps can be replayed) keeps
+ * that by zeroing the activations -- and, in backward, the activation gradients -- beyond the batch's own maximum.  */
+int dv3_zero_tail_b32(void* x, int64_t rows, int32_t T, int32_t words, const int32_t* t_valid, int32_t mult,
+                      int32_t max_tail, void* stream);
 /* Embedding gather into BCT with optional dropout: out[b][c][t] = W[idx[b][t]][c]
  * (deepvoice3.py:74-75, nyanko.py:63).  Backward: dense scatter-add into dW.           */
 int dv3_embedding_bct_f32(const int64_t* idx, const float* w, float* out,
@@ -619,6 +631,10 @@ typedef struct dv3_spec_loss_desc {
   int64_t yh_bs, yh_ts, yh_ds;              /* element strides of y_hat / dyh over (b,t,d):  */
   int64_t y_bs, y_ts, y_ds;                 /* BTC (T*D, D, 1) or BCT (D*T, 1, T) both fine  */
   int32_t B, T, D, r; float w_masked, w_bd, gscale;
+  const int32_t* t_valid;                   /* ABI 42: device int32[1] or NULL.  The loss is the one of the tensors cut
+                                             * to their first t_valid[0] frames (means over B * (t_valid - r) * D, zero
+                                             * gradient beyond): a batch padded beyond its own maximum (valid-length
+                                             * steps, replayed from a lattice of padded shapes)                         */
 } dv3_spec_loss_desc;
 int dv3_spec_loss_f32(const dv3_spec_loss_desc* d, void* stream);
 int dv3_spec_loss_scratch_floats(int32_t B, int32_t T, int32_t D);
@@ -629,9 +645,20 @@ int dv3_spec_loss_scratch_floats(int32_t B, int32_t T, int32_t D);
 int dv3_guided_attn_loss_f32(const float* attn, const int32_t* in_len, const int32_t* out_len,
                              float* dattn, float* out1, float* scratch, int32_t L, int32_t B,
                              int32_t Tq, int32_t Tk, float g, float gscale, void* stream);
+/* ABI 42: the same with the mean taken over L * B * tq_valid[0] * tk_valid[0] elements (device int32[1] each): the
+ * alignment of a batch padded beyond its own maxima.  W is zero outside every item's (T_b, N_b), so only the divisor
+ * differs from the call above on the padded tensor.                                                               */
+int dv3_guided_attn_loss_valid_f32(const float* attn, const int32_t* in_len, const int32_t* out_len,
+                                   float* dattn, float* out1, float* scratch, int32_t L, int32_t B,
+                                   int32_t Tq, int32_t Tk, float g, float gscale, const int32_t* tq_valid,
+                                   const int32_t* tk_valid, void* stream);
 /* BCELoss(done_hat, done) mean (train.py:614,714) + gradient                            */
 int dv3_bce_loss_f32(const float* p, const float* t, float* dp, float* out1, float* scratch,
                      int64_t n, float gscale, void* stream);
+/* ABI 42: p, t are [rows][T]; only the first t_valid[0] (device int32[1]) columns of every row take part: mean over
+ * rows * t_valid, zero gradient beyond.                                                                             */
+int dv3_bce_loss_valid_f32(const float* p, const float* t, float* dp, float* out1, float* scratch,
+                           int64_t rows, int32_t T, const int32_t* t_valid, float gscale, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Optimiser tail (train.py:755-759): clip_grad_norm_ + Adam over ONE flat fp32 arena

@@ -909,3 +909,42 @@ def test_mask_plan_state_machine():
     st.next_site()
     assert plan.take("keep", 2, 64, 50, 0.05) == "mask" and not plan.ready
     plan.end_step()
+
+
+def test_valid_lengths_host_logic():
+    """ops.ValidLengths / data.lattice_shape / data.pad_to_shape (round 6: batches padded to a lattice of shapes carry
+    their own maxima): the host side, on CPU tensors"""
+    from deepvoice3_pytorch_amd import data, ops, train_step
+    assert data.lattice_shape(33, 17, 16, 8) == (48, 24)
+    assert data.lattice_shape(32, 16, 16, 8) == (32, 16)
+    v = ops.ValidLengths.make(29, 13, 3, 32, 16, 15, 7, 1, 4, torch.device("cpu"))
+    assert v.tv.tolist() == [29, 13, 13, 52] and v.key_valid.tolist() == [29, 29, 29]
+    assert abs(float(v.scale[0]) - 29 ** 0.5) < 1e-6
+    # the converter's time axes: decoder steps x 1, 2, 4 (each ConvTranspose1d doubles)
+    for T, mult in ((16, 1), (32, 2), (64, 4)):
+        ptr, tail, m = v.axis_for(T)
+        assert int(ptr[0]) == 13 and m == mult and tail == 7 * mult
+    with pytest.raises(RuntimeError):
+        v.axis_for(48)
+    with pytest.raises(ValueError):       # the promised surplus bound must hold
+        ops.ValidLengths.make(10, 13, 3, 32, 16, 15, 7, 1, 4, torch.device("cpu"))
+    # r = 3: the mel axis is not a power of two times the decoder's
+    v3 = ops.ValidLengths.make(29, 13, 3, 32, 16, 15, 7, 3, 2, torch.device("cpu"))
+    assert v3.tv.tolist() == [29, 13, 39, 78]
+    ptr, tail, m = v3.axis_for(48 * 2)
+    assert int(ptr[0]) == 39 and m == 2 and tail == 7 * 3 * 2
+    # pad_to_shape keeps the batch and appends zeros (done flags: ones)
+    B, Tt, Td, r, ds = 2, 5, 6, 1, 4
+    b0 = train_step.Batch(torch.ones(B, Tt, dtype=torch.long), torch.ones(B, Tt, dtype=torch.long),
+                          torch.ones(B, Td, dtype=torch.long), torch.ones(B, Td * r, 3), torch.ones(B, Td * r * ds, 4),
+                          torch.zeros(B, Td, 1), np.array([5, 3]), np.array([20, 12]), None, r, ds, torch.device("cpu"))
+    b1 = data.pad_to_shape(b0, 8, 8)
+    assert b1.text.shape == (B, 8) and b1.y.shape == (B, 32, 4) and b1.mel.shape == (B, 8, 3)
+    assert int(b1.text[:, 5:].abs().sum()) == 0 and float(b1.y[:, 24:].abs().sum()) == 0
+    assert float(b1.done[:, 6:].min()) == 1.0 and float(b1.done[:, :6].max()) == 0.0
+    assert b1.valid.tv.tolist() == [5, 6, 6, 24] and (b1.valid.tail_in, b1.valid.tail_dec) == (3, 2)
+    assert train_step.LatticeReplay.key_of(b1) == (8, 8, B)
+    with pytest.raises(RuntimeError):
+        train_step.LatticeReplay.key_of(b0)
+    c = train_step.clone_batch(b1)
+    assert c.valid.tv is not b1.valid.tv and c.valid.tv.tolist() == b1.valid.tv.tolist() and c.text.data_ptr() != b1.text.data_ptr()
