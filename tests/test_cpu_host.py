@@ -948,3 +948,26 @@ def test_valid_lengths_host_logic():
         train_step.LatticeReplay.key_of(b0)
     c = train_step.clone_batch(b1)
     assert c.valid.tv is not b1.valid.tv and c.valid.tv.tolist() == b1.valid.tv.tolist() and c.text.data_ptr() != b1.text.data_ptr()
+
+
+def test_torch_library_operator_surface_is_registered():
+    """deepvoice3_pytorch_amd/torch_ops.py: every operator of SURVEY.md 8b's list is a dispatcher entry with a schema,
+    shape inference on meta tensors, and NO CPU implementation (the product path has no fallback)"""
+    from deepvoice3_pytorch_amd import torch_ops
+    for name in torch_ops.OPERATORS:
+        op = getattr(torch.ops.dv3hip, name)
+        assert op.default._schema.name == "dv3hip::" + name
+    x, v = torch.empty(2, 8, 33, device="meta"), torch.empty(16, 8, 3, device="meta")
+    y, pre, bits = torch.ops.dv3hip.conv1d_glu_fwd(x, v, None, None, None, 1, False, 0, True, 0.05, 1, 1)
+    assert y.shape == (2, 8, 33) and pre.shape == (2, 16, 33) and bits.shape == (2 * 8 * 2,)
+    assert torch.ops.dv3hip.conv1d_act_fwd(x, torch.empty(5, 8, 3, device="meta"), None, None, 0, 2, 1).shape == (2, 5, 29)
+    assert torch.ops.dv3hip.convtranspose1d_k2s2_fwd(x, torch.empty(8, 6, 2, device="meta"), None, None).shape == (2, 6, 66)
+    c, P, Pd, _ = torch.ops.dv3hip.attention_fwd(x, torch.empty(2, 8, 11, device="meta"), torch.empty(2, 11, 8, device="meta"),
+                                                 None, 0.0, 0, 0)
+    assert c.shape == (2, 8, 33) and P.shape == Pd.shape == (2, 33, 11)
+    with pytest.raises(NotImplementedError):
+        torch.ops.dv3hip.conv1d_glu_fwd(torch.zeros(2, 8, 33), torch.zeros(16, 8, 3), None, None, None, 1, False, 0, True,
+                                        0.0, 1, 1)
+    with pytest.raises(NotImplementedError):
+        torch.ops.dv3hip.fused_clip_adam(torch.zeros(4), torch.zeros(4), torch.zeros(4), torch.zeros(4), 1e-3, 1, 0.5, 0.9,
+                                         1e-6, 0.0, 0.1)

@@ -121,10 +121,20 @@ def _step_result(tr, batch):
     return {k: float(v) for k, v in scal.items()}, tr.arena.grad.detach().cpu().numpy().copy()
 
 
+@pytest.fixture
+def gemm_mode(request):
+    from deepvoice3_pytorch_amd import ops
+    prev = ops.set_gemm_precision(request.param)
+    yield request.param
+    ops.set_gemm_precision(prev)
+
+
+@pytest.mark.parametrize("gemm_mode", ["f16x3", "bf16"], indirect=True)
 @pytest.mark.parametrize("which", ["deepvoice3", "deepvoice3_mask", "multispeaker", "nyanko"])
-def test_padded_step_equals_the_step_on_the_batch_maxima(which):
+def test_padded_step_equals_the_step_on_the_batch_maxima(which, gemm_mode):
     """losses and every parameter gradient of one training step: the batch padded to a lattice shape with its maxima
-    attached against the batch as the reference's collate_fn pads it"""
+    attached against the batch as the reference's collate_fn pads it.  In the bf16 mode (BASELINE configs 3 / 4) the
+    activations between the layers are channel-blocked bf16 tensors: the same zero columns, 16-byte units."""
     from deepvoice3_pytorch_amd import data
     hp, name, speakers = dict(HP), "deepvoice3", 0
     if which == "deepvoice3_mask":
@@ -146,9 +156,11 @@ def test_padded_step_equals_the_step_on_the_batch_maxima(which):
     assert b1.text.shape[1] > Tt and b1.frame_positions.shape[1] > Td
     s0, g0 = _step_result(tr, b0)
     s1, g1 = _step_result(tr, b1)
+    # (the padded shape changes how the weight-gradient kernels cut the time axis: fp32 sums in another order)
+    tol_s, tol_g = (2e-6, 2e-5) if gemm_mode == "f16x3" else (1e-5, 1e-4)
     for k in s0:
-        assert abs(s1[k] - s0[k]) <= 2e-6 * max(1.0, abs(s0[k])), (k, s0[k], s1[k])
-    assert rel_err(g1, g0) < 2e-5
+        assert abs(s1[k] - s0[k]) <= tol_s * max(1.0, abs(s0[k])), (k, s0[k], s1[k])
+    assert rel_err(g1, g0) < tol_g
     # ... and without the maxima the padded batch is another computation (the test would pass vacuously otherwise)
     b1.valid = None
     s2, _ = _step_result(tr, b1)
