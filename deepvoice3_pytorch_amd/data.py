@@ -368,10 +368,12 @@ class Prefetcher(object):
     A producer thread walks the sampler; worker threads read the items and copy them back to back into a
     pinned staging slot (no padded bytes cross PCIe); the H2D copies and the device-side collate
     (dv3_ragged_pad_rows, positions, done flags) run on a side HIP stream; `depth` batches are kept in
-    flight.  next() makes the consumer's stream wait on the batch's event -- no host synchronisation."""
+    flight.  next() makes the consumer's stream wait on the batch's event -- no host synchronisation.
+    lattice = (step_in, step_dec): batches padded to a lattice of shapes with their maxima attached
+    (device_collate(lattice=)), what train_step.LatticeReplay.step takes."""
 
     def __init__(self, dataset, batch_sampler, device, outputs_per_step=1, downsample_step=4, depth=2, workers=2,
-                 loop=False, beside=None):
+                 loop=False, beside=None, lattice=None):
         import queue
         import threading
         from concurrent.futures import ThreadPoolExecutor
@@ -379,6 +381,7 @@ class Prefetcher(object):
         self.device = torch.device(device)
         self.r, self.ds = int(outputs_per_step), int(downsample_step)
         self.loop = loop
+        self.lattice = tuple(lattice) if lattice is not None else None
         self.cuda = self.device.type == "cuda"
         # the copy / collate stream: one that shares no hardware queue with the consumer's streams (`beside`: default the
         # current stream; pass the trainer's side stream too) -- see ops.concurrent_stream
@@ -417,12 +420,12 @@ class Prefetcher(object):
                     packed = slot.fill(items, self.pool)
                     if self.cuda:
                         with torch.cuda.stream(self.side):
-                            batch = device_collate(packed, self.device, self.r, self.ds)
+                            batch = device_collate(packed, self.device, self.r, self.ds, lattice=self.lattice)
                             ev = torch.cuda.Event()
                             ev.record(self.side)
                         slot.event = ev
                     else:
-                        batch, ev = device_collate(packed, self.device, self.r, self.ds), None
+                        batch, ev = device_collate(packed, self.device, self.r, self.ds, lattice=self.lattice), None
                     while not self._stop.is_set():
                         try:
                             self.q.put((batch, ev), timeout=0.1)
@@ -457,6 +460,8 @@ class Prefetcher(object):
                       batch.input_lengths, batch.target_lengths, batch.decoder_lengths, batch.speaker_ids):
                 if t is not None:
                     t.record_stream(cur)         # allocated on the side stream, consumed here
+            if batch.valid is not None:
+                batch.valid.buf.record_stream(cur)
         return batch
 
     def close(self):

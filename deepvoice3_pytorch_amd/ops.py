@@ -2155,6 +2155,7 @@ class ValidLengths(object):
     as DEVICE scalars (a replayed hipGraph has no host in the loop) plus host-side upper bounds for the surplus.
 
       tv        int32[4] on the device: {longest text, most decoder steps, x r (mel frames), x r x downsample (linear frames)}
+                (tv, scale and key_valid are views of one buffer `buf`)
       scale     float32[1]: s * sqrt(1 / s) for s = longest text -- the context scale of AttentionLayer (deepvoice3.py:170-171)
       key_valid int32[B], every entry the longest text: the softmax's key limit when the model uses no memory mask
       t_in, t_dec / tail_in, tail_dec   (host) the padded sizes and the most surplus columns either axis can have
@@ -2163,8 +2164,11 @@ class ValidLengths(object):
     on every activation gradient), the attention softmax and its sqrt(keys) scale, and every loss mean.  The causal
     decoder stack needs nothing: its valid frames never read a later one, and the losses feed its surplus frames zeros."""
 
-    def __init__(self, tv, scale, key_valid, t_in, t_dec, tail_in, tail_dec, r, downsample_step):
-        self.tv, self.scale, self.key_valid = tv, scale, key_valid
+    def __init__(self, buf, t_in, t_dec, tail_in, tail_dec, r, downsample_step):
+        """buf: int32[5 + B] = {tv[4], the bits of the fp32 scale, key_valid[B]} -- ONE buffer, so that a batch's maxima reach
+        the device (and a captured step's static copy) in one copy"""
+        self.buf = buf
+        self.tv, self.scale, self.key_valid = buf[0:4], buf[4:5].view(torch.float32), buf[5:]
         self.t_in, self.t_dec, self.tail_in, self.tail_dec = int(t_in), int(t_dec), int(tail_in), int(tail_dec)
         self.r, self.downsample_step = int(r), int(downsample_step)
 
@@ -2174,10 +2178,19 @@ class ValidLengths(object):
         if not (0 < max_in <= t_in and 0 < max_dec <= t_dec and t_in - max_in <= tail_in and t_dec - max_dec <= tail_dec):
             raise ValueError("ValidLengths: maxima (%d, %d) do not fit the padded shape (%d, %d) with tails (%d, %d)" % (
                 max_in, max_dec, t_in, t_dec, tail_in, tail_dec))
-        tv = torch.tensor([max_in, max_dec, max_dec * r, max_dec * r * downsample_step], dtype=torch.int32).to(device)
-        scale = torch.tensor([max_in * math.sqrt(1.0 / max_in)], dtype=torch.float32).to(device)
-        key_valid = torch.full((B,), max_in, dtype=torch.int32).to(device)
-        return ValidLengths(tv, scale, key_valid, t_in, t_dec, tail_in, tail_dec, r, downsample_step)
+        device = torch.device(device)
+        host = torch.empty(5 + B, dtype=torch.int32)
+        if device.type == "cuda":
+            host = host.pin_memory()       # an asynchronous copy: a pageable one would make the host wait for the stream
+        host[0], host[1], host[2], host[3] = max_in, max_dec, max_dec * r, max_dec * r * downsample_step
+        host[4:5].view(torch.float32)[0] = max_in * math.sqrt(1.0 / max_in)
+        host[5:] = max_in
+        v = ValidLengths(host.to(device, non_blocking=True), t_in, t_dec, tail_in, tail_dec, r, downsample_step)
+        v._host = host                     # alive until the copy has run
+        return v
+
+    def clone(self):
+        return ValidLengths(self.buf.clone(), self.t_in, self.t_dec, self.tail_in, self.tail_dec, self.r, self.downsample_step)
 
     # (pointer tensor, host upper bound of the surplus) per time axis
     def text(self):

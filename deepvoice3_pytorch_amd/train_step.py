@@ -811,8 +811,7 @@ class GraphedTrainer(object):
             if a is not None:
                 a.copy_(getattr(batch, name), non_blocking=True)
         if va is not None:       # the batch's own maxima: the device scalars the captured kernels read
-            for name in ("tv", "scale", "key_valid"):
-                getattr(va, name).copy_(getattr(vb, name), non_blocking=True)
+            va.buf.copy_(vb.buf, non_blocking=True)
         st.input_lengths_host, st.target_lengths_host = batch.input_lengths_host, batch.target_lengths_host
         st.decoder_lengths_host, st.n_frames = batch.decoder_lengths_host, batch.n_frames
 
@@ -889,10 +888,8 @@ def clone_batch(batch):
     b = Batch(c(batch.text), c(batch.text_positions), c(batch.frame_positions), c(batch.mel), c(batch.y), c(batch.done),
               batch.input_lengths_host.copy(), batch.target_lengths_host.copy(), c(batch.speaker_ids), r, ds,
               batch.text.device)
-    v = batch.valid
-    if v is not None:
-        b.valid = ops.ValidLengths(v.tv.clone(), v.scale.clone(), v.key_valid.clone(), v.t_in, v.t_dec, v.tail_in,
-                                   v.tail_dec, v.r, v.downsample_step)
+    if batch.valid is not None:
+        b.valid = batch.valid.clone()
     return b
 
 
@@ -955,6 +952,14 @@ class LatticeReplay(object):
             self.graphs.move_to_end(key)
         self.stats["replays"] += 1
         return g.step(batch)
+
+    def check_range(self):
+        """the f16x3 range guard (GraphedTrainer.check_range): > 0 = the process has moved to bf16x3, every capture of
+        this object packed f16x3 operands and is dropped -- the next step of each shape captures again"""
+        n = self.t.check_range()
+        if n:
+            self.close()
+        return n
 
     def close(self):
         for g in self.graphs.values():

@@ -20,10 +20,13 @@ def main():
     args = argparse.Namespace(batch=64, text_len=150, frames=800, preset="deepvoice3_ljspeech")
     gemm = "f16x3"
     for batch, nb in ((64, n64), (16, n16)):
+        if nb <= 0:
+            continue
         args.batch = batch
-        for name, fn in (("eager_batch_maxima", lambda: bench.ragged_epoch_config(dev, args.preset, gemm, args)),
-                         ("lattice_replay", lambda: bench.ragged_lattice_config(dev, args.preset, gemm, args, batch,
-                                                                                n_batches=nb, lattice=lat))):
+        forms = (("eager_batch_maxima", lambda: bench.ragged_epoch_config(dev, args.preset, gemm, args)),) \
+            if os.environ.get("LATTICE_ONLY", "") in ("", "0") else ()
+        for name, fn in forms + (("lattice_replay", lambda: bench.ragged_lattice_config(dev, args.preset, gemm, args, batch,
+                                                                                n_batches=nb, lattice=lat)),):
             try:
                 out = fn()
             except Exception as e:

@@ -611,6 +611,23 @@ def test_prefetcher_yields_the_collated_batches(monkeypatch):
         for name in ("text", "text_positions", "frame_positions", "mel", "y", "done", "input_lengths",
                      "target_lengths", "speaker_ids"):
             assert torch.equal(getattr(g, name), getattr(h, name)), name
+    # lattice=(16, 8): the same batches padded to the next lattice point -- zeros beyond what collate_fn pads to, the
+    # batch's own maxima attached (device_collate(lattice=) == pad_to_shape(collate(...)))
+    pf = data.Prefetcher(ds, sampler, "cpu", outputs_per_step=1, downsample_step=4, depth=2, workers=0, lattice=(16, 8))
+    got = list(pf)
+    pf.close()
+    for idx, g in zip(want, got):
+        h = data.to_device_batch(data.collate_fn([items[i] for i in idx], 1, 4), "cpu", 1, 4)
+        Tt, Td = h.text.shape[1], h.frame_positions.shape[1]
+        t_in, t_dec = data.lattice_shape(Tt, Td, 16, 8)
+        hp = data.pad_to_shape(h, t_in, t_dec, 15, 7)
+        assert g.text.shape == (len(idx), t_in) and g.y.shape[1] == t_dec * 4
+        assert g.valid.tv.tolist() == [Tt, Td, Td, Td * 4] == hp.valid.tv.tolist()
+        for name in ("text", "text_positions", "mel", "y", "input_lengths", "target_lengths", "speaker_ids"):
+            assert torch.equal(getattr(g, name), getattr(hp, name)), name
+        # frames of the batch: the same positions and done flags; the surplus steps: position 0, done 1
+        assert torch.equal(g.frame_positions[:, :Td], h.frame_positions) and int(g.frame_positions[:, Td:].abs().sum()) == 0
+        assert torch.equal(g.done[:, :Td], h.done) and (Td == t_dec or float(g.done[:, Td:].min()) == 1.0)
     pf = data.Prefetcher(ds, sampler, "cpu", depth=1, workers=0, loop=True)
     it = iter(pf)
     n = sum(1 for _ in zip(range(25), it))      # more than one epoch
