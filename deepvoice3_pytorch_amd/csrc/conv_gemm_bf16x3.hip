@@ -1048,6 +1048,7 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
 
 extern int g_wgrad_tile, g_wgrad_prio, g_wgrad_t2_abl, g_wgrad_taps2_default, g_wgrad_t2_window, g_wgrad_t2_il;   // wgrad_gemm_bf16x3.hip, wgrad_taps2.hip
 extern int g_spk_prefetch;                                                                                 // speaker_bias.hip
+extern int g_gate_vec;                                                                                     // elementwise.hip
 extern int g_wn_bwd_vec4;                                                                                  // weight_norm.hip
 extern int g_wgrad_c8_pf2, g_wgrad_c8_il, g_wgrad_c8_tr, g_spk_abl;                                                       // wgrad_c8.hip
 int dv3_planes_debug_set(int what, int value);   // conv_planes.hip
@@ -1080,6 +1081,7 @@ extern "C" int dv3_debug_set(int what, int value) {
   if (what == 51) g_wn_bwd_vec4 = value;
   if (what == 52) g_wgrad_c8_tr = value;
   if (what == 54) g_spk_prefetch = value;
+  if (what == 55) g_gate_vec = value;
   if (what == 22) g_pp2_sk = value;
   if (what == 23) g_pp2_sk_overhead = value;
   if (what == 24) g_pp2_sk_gain = value;

@@ -9,6 +9,10 @@ namespace {
 // Gate backward.  One wave per (b, channel) row, lanes along time (coalesced); row sums of the
 // pre-activation gradients are written per (b, row) for the deterministic bias / speaker-bias
 // reduction.  Autograd of modules.py:157-164 (GLU) and :224-226 (highway).
+// VEC4: 16 bytes per lane and access for ANY T -- the tensors' bases are 16-byte aligned and every operand's row starts
+// at the same element phase (row * T) & 3 (checked by the launcher: C % 4 == 0 in the gated modes), so a row is
+// [head: up to 3 elements][quads at 16-byte boundaries][tail: up to 3 elements]; the head and tail elements are one
+// 4-byte access of the first lanes.  T % 4 == 0 has no head or tail and sums in the order it always did.
 // ------------------------------------------------------------------------------------------
 template <bool VEC4>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p) {
@@ -38,19 +42,38 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
       dv3_gate_deriv(dyv * k, av, gv, xv, glu, va, vg, vr);
     };
     if (VEC4) {
-      // rows are 16-byte aligned and T % 4 == 0 (checked by the launcher): 16 bytes per lane and access
-      const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
-      const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
-      const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
-      const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-      f32x4* da4 = reinterpret_cast<f32x4*>(da);
-      f32x4* dg4 = reinterpret_cast<f32x4*>(dg);
-      f32x4* dres4 = reinterpret_cast<f32x4*>(dres);
-      for (int q = lane; q < (T >> 2); q += 64) {
+      const int head = min(T, (int)((4 - ((row * T) & 3)) & 3));     // elements before the row's first 16-byte boundary
+      const int nq = (T - head) >> 2;
+      const int n_edge = T - 4 * nq;                                  // head + tail elements: at most 6
+      if (lane < n_edge) {
+        const int t = lane < head ? lane : 4 * nq + lane;             // tail element j sits at head + 4 nq + j
+        float va, vg, vr;
+        const float at = ab16 ? __uint_as_float((uint32_t)a16[t] << 16) : a[t];
+        const float gt = ab16 ? __uint_as_float((uint32_t)g16[t] << 16) : g[t];
+        elem(dy[t], at, gt, glu ? 0.f : x[t], va, vg, vr);
+        if (dres) dres[t] = vr;
+        if (p.dab_pair) {
+          reinterpret_cast<uint32_t*>(da)[t] = dv3_pair_word(va);
+          reinterpret_cast<uint32_t*>(dg)[t] = dv3_pair_word(vg);
+        } else {
+          da[t] = va;
+          dg[t] = vg;
+        }
+        sa += va;
+        sg += vg;
+      }
+      const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy + head);
+      const f32x4* a4 = reinterpret_cast<const f32x4*>(a + head);
+      const f32x4* g4 = reinterpret_cast<const f32x4*>(g + head);
+      const f32x4* x4 = reinterpret_cast<const f32x4*>(x + head);
+      f32x4* da4 = reinterpret_cast<f32x4*>(da + head);
+      f32x4* dg4 = reinterpret_cast<f32x4*>(dg + head);
+      f32x4* dres4 = reinterpret_cast<f32x4*>(dres + head);
+      for (int q = lane; q < nq; q += 64) {
         const f32x4 dv = dy4[q];
         f32x4 av, gv;
         if (ab16) {         // 4 bf16 = 8 bytes per lane and operand
-          const uint2 ua = reinterpret_cast<const uint2*>(a16)[q], ug = reinterpret_cast<const uint2*>(g16)[q];
+          const uint2 ua = reinterpret_cast<const uint2*>(a16 + head)[q], ug = reinterpret_cast<const uint2*>(g16 + head)[q];
           av = f32x4{__uint_as_float(ua.x << 16), __uint_as_float(ua.x & 0xffff0000u), __uint_as_float(ua.y << 16), __uint_as_float(ua.y & 0xffff0000u)};
           gv = f32x4{__uint_as_float(ug.x << 16), __uint_as_float(ug.x & 0xffff0000u), __uint_as_float(ug.y << 16), __uint_as_float(ug.y & 0xffff0000u)};
         } else {
@@ -70,8 +93,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
         }
         if (p.dab_pair) {      // (uniform) the pre-gate gradient as the bf16 hi / lo pair its consumers would build from it
           typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-          reinterpret_cast<u32x4_*>(da)[q] = u32x4_{dv3_pair_word(oa[0]), dv3_pair_word(oa[1]), dv3_pair_word(oa[2]), dv3_pair_word(oa[3])};
-          reinterpret_cast<u32x4_*>(dg)[q] = u32x4_{dv3_pair_word(og[0]), dv3_pair_word(og[1]), dv3_pair_word(og[2]), dv3_pair_word(og[3])};
+          reinterpret_cast<u32x4_*>(da + head)[q] = u32x4_{dv3_pair_word(oa[0]), dv3_pair_word(oa[1]), dv3_pair_word(oa[2]), dv3_pair_word(oa[3])};
+          reinterpret_cast<u32x4_*>(dg + head)[q] = u32x4_{dv3_pair_word(og[0]), dv3_pair_word(og[1]), dv3_pair_word(og[2]), dv3_pair_word(og[3])};
         } else {
           da4[q] = oa;
           dg4[q] = og;
@@ -105,13 +128,46 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
   } else {
     const float* y = p.ab_or_y ? p.ab_or_y + row * T : nullptr;
     float* dpre = p.dab ? p.dab + row * T : nullptr;
-    for (int t = lane; t < T; t += 64) {
-      float d = dy[t] * p.alpha;
-      if (p.mode == DV3_EPI_RELU) d = y[t] > 0.f ? d : 0.f;
-      else if (p.mode == DV3_EPI_SIGMOID) d = d * y[t] * (1.0f - y[t]);
-      else if (p.mode == DV3_EPI_SOFTSIGN) { const float q = 1.0f - fabsf(y[t]); d = d * q * q; }
-      if (dpre) dpre[t] = d;
-      sa += d;
+    const int mode = p.mode;
+    const float alpha = p.alpha;
+    auto act = [&](float dyv, float yv) {
+      float d = dyv * alpha;
+      if (mode == DV3_EPI_RELU) d = yv > 0.f ? d : 0.f;
+      else if (mode == DV3_EPI_SIGMOID) d = d * yv * (1.0f - yv);
+      else if (mode == DV3_EPI_SOFTSIGN) { const float q = 1.0f - fabsf(yv); d = d * q * q; }
+      return d;
+    };
+    if (VEC4) {
+      const int head = min(T, (int)((4 - ((row * T) & 3)) & 3));
+      const int nq = (T - head) >> 2;
+      const int n_edge = T - 4 * nq;
+      if (lane < n_edge) {
+        const int t = lane < head ? lane : 4 * nq + lane;
+        const float d = act(dy[t], y ? y[t] : 0.f);
+        if (dpre) dpre[t] = d;
+        sa += d;
+      }
+      const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy + head);
+      const f32x4* y4 = reinterpret_cast<const f32x4*>(y + head);
+      f32x4* dpre4 = reinterpret_cast<f32x4*>(dpre + head);
+      for (int q = lane; q < nq; q += 64) {
+        const f32x4 dv = dy4[q];
+        f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+        if (y) yv = y4[q];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = act(dv[e], yv[e]);
+          sa += o[e];
+        }
+        if (dpre) dpre4[q] = o;
+      }
+    } else {
+      for (int t = lane; t < T; t += 64) {
+        const float d = act(dy[t], y ? y[t] : 0.f);
+        if (dpre) dpre[t] = d;
+        sa += d;
+      }
     }
     sa = dv3_wave_sum(sa);
     if (lane == 0 && p.bias_part) p.bias_part[row] = sa;
@@ -721,6 +777,8 @@ extern "C" int dv3_sincos_pos_table_bwd_f32(const int64_t* pos, const float* tab
   return dv3_check_launch("sincos_pos_table_bwd_f32");
 }
 
+int g_gate_vec = 1;   // dv3_debug_set(55, v): 0 = 16-byte accesses only for gated layers with T % 4 == 0 (rounds 3-6a), the rest 4-byte
+
 extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
   DV3_REQUIRE(d && d->dy, "gate_bwd: null dy");
   DV3_REQUIRE(d->B > 0 && d->C > 0 && d->T > 0, "gate_bwd: bad dims");
@@ -742,11 +800,11 @@ extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
     hipLaunchKernelGGL(gate_bwd_c8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d);
     return dv3_check_launch("gate_bwd_c8");
   }
-  // 16 bytes per lane when every row starts 16-byte aligned (gated modes; the others are small)
+  // 16 bytes per lane whenever the bases are 16-byte aligned and the operands' rows share their element phase
   const uintptr_t ptrs = (uintptr_t)d->dy | (uintptr_t)d->ab_or_y | (uintptr_t)d->dab | (uintptr_t)d->x | (uintptr_t)d->dres;
   DV3_REQUIRE(!d->ab_bf16 || gated, "gate_bwd: ab_bf16 is for the gated modes");
   DV3_REQUIRE(!d->dab_pair || (gated && !d->c8), "gate_bwd: pair words are written by the gated modes on fp32 tensors");
-  if (gated && (d->T & 3) == 0 && (ptrs & 15) == 0)
+  if ((ptrs & 15) == 0 && (g_gate_vec ? (!gated || (d->C & 3) == 0) : (gated && (d->T & 3) == 0)))
     hipLaunchKernelGGL(gate_bwd_kernel<true>, dim3((unsigned)dv3_cdiv64(rows, 4)), dim3(256), 0,
                        (hipStream_t)stream, *d);
   else

@@ -926,6 +926,69 @@ def test_weight_norm_backward_16_byte_gather_is_the_4_byte_one(dev, O_, I, J, S,
     assert rel_err(dbias.cpu().numpy(), part.double().sum(0).cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("mode,B,C,T", [("glu", 3, 64, 201), ("glu", 2, 128, 150), ("glu", 2, 8, 3), ("glu", 5, 4, 1),
+                                       ("glu16", 3, 64, 203), ("highway", 2, 96, 67), ("relu", 3, 65, 201),
+                                       ("sigmoid", 2, 513, 81), ("linear", 3, 80, 7), ("softsign", 2, 33, 2),
+                                       ("glu", 2, 64, 64)])
+@pytest.mark.parametrize("pair", [False, True])
+def test_gate_backward_16_byte_rows_of_any_length(dev, mode, B, C, T, pair):
+    """dv3_gate_bwd_f32 reads and writes 16 bytes per lane for ANY T (head / aligned quads / tail of a row whose start is
+    only 4-byte aligned; round 6, default) -- element gradients must be the bits of the 4-byte form (dv3_debug_set(55, 0)),
+    the row sums differ by the order of their additions only, and both are the autograd of modules.py:157-164 / :224-226."""
+    from deepvoice3_pytorch_amd import ops, _lib
+    gated = mode in ("glu", "glu16", "highway")
+    if pair and not gated:
+        pytest.skip("pair words are the gated layers' pre-gate gradient")
+    M = {"glu": ops.EPI_GLU, "glu16": ops.EPI_GLU, "highway": ops.EPI_HIGHWAY, "relu": ops.EPI_RELU,
+         "sigmoid": ops.EPI_SIGMOID, "linear": ops.EPI_LINEAR, "softsign": ops.EPI_SOFTSIGN}[mode]
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + C + T)
+    dy = torch.randn(B, C, T, generator=g).to(dev)
+    ab = torch.randn(B, 2 * C if gated else C, T, generator=g).to(dev)
+    if mode == "sigmoid":
+        ab = torch.sigmoid(ab)
+    if mode == "softsign":
+        ab = ab / (1 + ab.abs())
+    if mode == "glu16":
+        ab = ab.to(torch.bfloat16)
+    x = torch.randn(B, C, T, generator=g).to(dev) if mode == "highway" else None
+    res = []
+    for sw in (0, 1):
+        _lib.lib().dv3_debug_set(55, sw)
+        try:
+            res.append(ops.gate_bwd(dy, None if mode == "linear" else ab, x, B=B, C=C, T=T, mode=M,
+                                    residual=1 if mode.startswith("glu") else 0, pair=pair, want_dres=mode == "highway",
+                                    alpha=1.0 if gated else 0.7))
+        finally:
+            _lib.lib().dv3_debug_set(55, 1)
+    for a, b in zip(res[0][:2], res[1][:2]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert float((res[0][2] - res[1][2]).abs().max()) <= 4e-6 * max(1.0, float(res[0][2].abs().max()))
+    # against autograd in double precision
+    dab, dres, part = res[1]
+    if pair:
+        w = dab.view(torch.int32)
+        dab = ((w & -65536).view(torch.float32) + (w << 16).view(torch.float32))
+    abd, dyd = ab.double(), dy.double()
+    if gated:
+        a, gt = abd[:, :C], abd[:, C:]
+        s = torch.sigmoid(gt)
+        if mode == "highway":
+            d = dyd
+            want = torch.cat([d * s, d * (a - x.double()) * s * (1 - s)], 1)
+            assert rel_err(dres.cpu().numpy(), (d * (1 - s)).cpu().numpy()) < 1e-5
+        else:
+            d = dyd * math.sqrt(0.5)
+            want = torch.cat([d * s, d * a * s * (1 - s)], 1)
+    else:
+        d = dyd * 0.7
+        want = {"relu": d * (abd > 0), "sigmoid": d * abd * (1 - abd), "linear": d,
+                "softsign": d * (1 - abd.abs()) ** 2}[mode]
+    assert rel_err(dab.cpu().numpy(), want.cpu().numpy()) < (3e-5 if pair else 1e-5)
+    assert rel_err(part.cpu().numpy(), want.sum(2).cpu().numpy()) < 2e-5
+
+
 def test_memset_is_a_fill_kernel_with_exact_extent(dev):
     """dv3_memset_b8 (ops.zero_: the gradient arena, padded c8 tensors) fills exactly [p, p + bytes) for every alignment of
     both ends -- it is a kernel since round 6 (the runtime's memset node replayed with a corrupt pattern inside a captured
