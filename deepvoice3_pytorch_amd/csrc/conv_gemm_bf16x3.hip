@@ -1048,6 +1048,8 @@ int dv3_conv_gemm_bf16x3_dispatch(const dv3_conv_desc* d, hipStream_t st) {
 
 extern int g_wgrad_tile, g_wgrad_prio, g_wgrad_t2_abl, g_wgrad_taps2_default, g_wgrad_t2_window, g_wgrad_t2_il;   // wgrad_gemm_bf16x3.hip, wgrad_taps2.hip
 extern int g_spk_prefetch;                                                                                 // speaker_bias.hip
+extern int g_gate_c8_fast;                                                                                 // elementwise.hip
+extern int g_loss_fast_log;                                                                                // loss.hip
 extern int g_gate_vec;                                                                                     // elementwise.hip
 extern int g_wn_bwd_vec4;                                                                                  // weight_norm.hip
 extern int g_wgrad_c8_pf2, g_wgrad_c8_il, g_wgrad_c8_tr, g_spk_abl;                                                       // wgrad_c8.hip
@@ -1082,6 +1084,8 @@ extern "C" int dv3_debug_set(int what, int value) {
   if (what == 52) g_wgrad_c8_tr = value;
   if (what == 54) g_spk_prefetch = value;
   if (what == 55) g_gate_vec = value;
+  if (what == 56) g_gate_c8_fast = value;
+  if (what == 57) g_loss_fast_log = value;
   if (what == 22) g_pp2_sk = value;
   if (what == 23) g_pp2_sk_overhead = value;
   if (what == 24) g_pp2_sk_gain = value;

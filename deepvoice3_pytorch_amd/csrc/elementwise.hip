@@ -179,7 +179,11 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const dv3_gate_bwd_desc p
 // (b, 8-channel group), threads along time: every access is a whole 16-byte unit; the eight per-channel row sums
 // (x2 for the gate half) are reduced across the workgroup for the deterministic bias reduction.
 // ------------------------------------------------------------------------------------------
+// FAST (default, dv3_debug_set(56, 0) = the libm forms of rounds 3-6): the sigmoid by v_exp_f32 + v_rcp_f32 as in the
+// forward tails and the fp32 kernel above -- with expf and a true division the kernel was bound by its vector work
+// (~45 instructions per element against 10 bytes: 55 % of the HBM rate stand-alone); the results are bf16 anyway.
 typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+template <bool FAST>
 __global__ __launch_bounds__(256) void gate_bwd_c8_kernel(const dv3_gate_bwd_desc p) {
   __shared__ float part[16][256];
   const int C = p.C, T = p.T, G = (C + 7) >> 3;     // channels >= C of the last group are zero in every c8 tensor
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) void gate_bwd_c8_kernel(const dv3_gate_bwd_des
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float d = (float)dv[e] * k;
-        const float sgm = 1.0f / (1.0f + expf(-(float)gv[e]));
+        const float sgm = FAST ? __builtin_amdgcn_rcpf(1.0f + __expf(-(float)gv[e])) : 1.0f / (1.0f + expf(-(float)gv[e]));
         const float va = d * sgm;
         float vg, vr;
         if (glu) {
@@ -777,6 +781,7 @@ extern "C" int dv3_sincos_pos_table_bwd_f32(const int64_t* pos, const float* tab
   return dv3_check_launch("sincos_pos_table_bwd_f32");
 }
 
+int g_gate_c8_fast = 1;   // dv3_debug_set(56, v): gate_bwd_c8's sigmoid by v_exp_f32 + v_rcp_f32 (0 = expf and a division)
 int g_gate_vec = 1;   // dv3_debug_set(55, v): 0 = 16-byte accesses only for gated layers with T % 4 == 0 (rounds 3-6a), the rest 4-byte
 
 extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
@@ -797,7 +802,8 @@ extern "C" int dv3_gate_bwd_f32(const dv3_gate_bwd_desc* d, void* stream) {
                 "gate_bwd: c8 tensors need 16-byte alignment and, in the gated modes, C % 8 == 0");
     const int64_t blocks = (int64_t)d->B * ((d->C + 7) / 8);
     DV3_REQUIRE(blocks < (1ll << 31), "gate_bwd: grid too large");
-    hipLaunchKernelGGL(gate_bwd_c8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d);
+    if (g_gate_c8_fast) hipLaunchKernelGGL(gate_bwd_c8_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(gate_bwd_c8_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *d);
     return dv3_check_launch("gate_bwd_c8");
   }
   // 16 bytes per lane whenever the bases are 16-byte aligned and the operands' rows share their element phase

@@ -28,12 +28,17 @@ __device__ __forceinline__ void block_reduce4(float v[4], float* out /* [4] per 
 // With a = y_hat + eps, b = 1 - y_hat + eps:  exp(L) = a / b,  log1p(exp(L)) = log(a + b) - log(b),
 // sigmoid(L) = a / (a + b): two logarithms and two reciprocals instead of four transcendental calls -- the loss kernels
 // were VALU-bound on them (round 2: 145 us per launch whatever the access pattern).  a + b = 1 + 2 eps.
+// FAST (the tiled kernel, default; dv3_debug_set(57, 0) = libm): the three logarithms by v_log_f32 (__logf: 1 ulp of
+// log2 x, i.e. ~1e-7 absolute here) -- with logf the tiled kernel was still bound by its vector work (~100 instructions per
+// element; 103 us for the 64 x 804 x 513 linear-spectrogram loss, round 6).  The gradient takes no logarithm.
+template <bool FAST = false>
 __device__ __forceinline__ void spec_bd(float yh, float y, float& z, float& dz) {
   const float eps = 1e-8f;
   const float a = yh + eps, b = 1.f - yh + eps;
-  const float la = logf(a), lb = logf(b);
+  constexpr float LN2 = 0.69314718055994530942f;
+  const float la = FAST ? __builtin_amdgcn_logf(a) * LN2 : logf(a), lb = FAST ? __builtin_amdgcn_logf(b) * LN2 : logf(b);
   const float ab = a + b;
-  z = -y * (la - lb) + (logf(ab) - lb);
+  z = -y * (la - lb) + ((FAST ? __builtin_amdgcn_logf(ab) * LN2 : logf(ab)) - lb);
   const float ra = __builtin_amdgcn_rcpf(a), rb = __builtin_amdgcn_rcpf(b);
   dz = (a * __builtin_amdgcn_rcpf(ab) - y) * (ra + rb);
 }
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(kLossBlock) void spec_loss_kernel(const dv3_spec_lo
 // takes 64 frames x 64 bins at a time: the target tile is read bin-fastest into LDS, then every thread works
 // frame-fastest -- prediction read, gradient write and the LDS reads (row stride 65) are all unit-stride.  Persistent
 // grid (tiles are walked with a grid stride) so that the block partial sums fit the caller's scratch.
+template <bool FAST>
 __global__ __launch_bounds__(kLossBlock) void spec_loss_tiled_kernel(const dv3_spec_loss_desc p, int t_tiles, int d_tiles,
                                                                      int n_tiles) {
   __shared__ float ys[64 * 65];
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(kLossBlock) void spec_loss_tiled_kernel(const dv3_s
       float dz = 0.f;
       if (p.w_bd > 0.f) {
         float z;
-        spec_bd(yh, y, z, dz);
+        spec_bd<FAST>(yh, y, z, dz);
         acc[2] += z;
         acc[3] += m * z;
       }
@@ -299,6 +305,8 @@ inline int loss_blocks(int64_t n) {
 
 }  // namespace
 
+int g_loss_fast_log = 1;   // dv3_debug_set(57, v): the tiled spectrogram loss takes its logarithms by v_log_f32 (0 = logf)
+
 extern "C" int dv3_spec_loss_scratch_floats(int32_t B, int32_t T, int32_t D) {
   // block partial sums of either form: the flat grid, or one block per 64 x 64 tile (at most 1024)
   int64_t tiles = (int64_t)B * dv3_cdiv(T, 64) * dv3_cdiv(D, 64);
@@ -319,7 +327,8 @@ extern "C" int dv3_spec_loss_f32(const dv3_spec_loss_desc* d, void* stream) {
     const int t_tiles = dv3_cdiv(d->T - d->r, 64), d_tiles = dv3_cdiv(d->D, 64);
     const int64_t nt = (int64_t)d->B * t_tiles * d_tiles;
     nb = (int)(nt < 1024 ? nt : 1024);
-    hipLaunchKernelGGL(spec_loss_tiled_kernel, dim3(nb), dim3(kLossBlock), 0, st, *d, t_tiles, d_tiles, (int)nt);
+    if (g_loss_fast_log) hipLaunchKernelGGL(spec_loss_tiled_kernel<true>, dim3(nb), dim3(kLossBlock), 0, st, *d, t_tiles, d_tiles, (int)nt);
+    else hipLaunchKernelGGL(spec_loss_tiled_kernel<false>, dim3(nb), dim3(kLossBlock), 0, st, *d, t_tiles, d_tiles, (int)nt);
   } else {
     hipLaunchKernelGGL(spec_loss_kernel, dim3(nb), dim3(kLossBlock), 0, st, *d);
   }

@@ -1214,6 +1214,17 @@ class SideStream(object):
             SideStream._release_point()
             return False
 
+    class _MainSection(object):
+        """a fork point whose weight gradient stays on the step stream (DV3_SIDE_MAIN: balance of the two queues)"""
+
+        def __enter__(self):
+            pass
+
+        def __exit__(self, *exc):
+            SideStream._release_point()
+            return False
+
+    main_rule, _main_spec = (frozenset(), 0), ""       # (set of fork numbers, every-k) from DV3_SIDE_MAIN
     forks_last = 0         # ... of the step before
     forks = 0              # fork points since the last join (GraphedTrainer sizes its segments from a warm-up step's count)
 
@@ -1221,6 +1232,10 @@ class SideStream(object):
     def fork(cls, *tensors):
         # the section's inputs are complete on the step stream: the side stream waits for exactly that point
         cls.forks += 1
+        spec = _os.environ.get("DV3_SIDE_MAIN", "")
+        if spec != cls._main_spec:
+            cls._main_spec, cls.main_rule = spec, _parse_side_main(spec)
+        on_main = cls.forks in cls.main_rule[0] or (cls.main_rule[1] and cls.forks % cls.main_rule[1] == 0)
         if cls.split_capture:
             # two separate captures: nothing ties them here; GraphedTrainer closes both every few fork points and the
             # replay orders step-stream segment j before side segment j with an ordinary event
@@ -1229,7 +1244,7 @@ class SideStream(object):
         else:
             _lib.call("dv3_stream_fork", cls.main.cuda_stream, cls.stream.cuda_stream)
         cls.keep.append([None, [tensors]])
-        return cls._section
+        return cls._main_section if on_main else cls._section
 
     @classmethod
     def retain(cls, *tensors):
@@ -1284,6 +1299,19 @@ class SideStream(object):
 
 
 SideStream._section = SideStream._Section()
+SideStream._main_section = SideStream._MainSection()
+
+
+def _parse_side_main(spec):
+    """DV3_SIDE_MAIN = "3,7,11" (fork numbers of a step, 1-based) and / or "every:k": those weight gradients are issued on
+    the step stream instead of the second one"""
+    nums, every = set(), 0
+    for tok in spec.replace(" ", "").split(","):
+        if tok.startswith("every:"):
+            every = int(tok[6:])
+        elif tok:
+            nums.add(int(tok))
+    return nums, every
 
 
 # Round 6: the gate backward of a gated layer runs in the tail of its consumer's input-gradient launch (GateFuse) when the
