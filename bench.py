@@ -692,6 +692,10 @@ class TrainRun(object):
     def graph_form(self):
         if not self.use_graph or self.runner is None:
             return None
+        if getattr(self.runner, "flag_sync", False):
+            return ("forward graph | backward graph on the step stream beside ONE weight-gradient graph on the second stream, "
+                    "their %d fork points ordered by a device flag (dv3_flag_signal / dv3_flag_wait, ABI 43) | optimiser graph"
+                    % self.runner.n_forks)
         if getattr(self.runner, "split", False):
             return ("%d segment hipGraphs on the step stream, each followed by its weight-gradient segment on the second "
                     "stream (and, under a process group, by the host-issued all-reduces of the buckets it completes) | "

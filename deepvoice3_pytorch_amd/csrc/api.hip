@@ -107,6 +107,47 @@ extern "C" int dv3_graph_side_end(void* side_stream, void** exec_out, int32_t* n
   *exec_out = (void*)exec;
   return DV3_OK;
 }
+// ---- ABI 43: fork points of a captured backward ordered by a device flag (include/dv3hip.h) ----
+namespace {
+__global__ void flag_signal_kernel(unsigned long long* flag, unsigned long long* epoch, int j, int bump) {
+  unsigned long long e = *epoch;
+  if (bump) {
+    e += 1;
+    *epoch = e;
+  }
+  __hip_atomic_store(flag, e * 4096ull + (unsigned long long)j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void flag_wait_kernel(const unsigned long long* flag, unsigned long long* epoch, int j, int bump, unsigned* err,
+                                 long long timeout_ticks) {
+  unsigned long long e = *epoch;
+  if (bump) {
+    e += 1;
+    *epoch = e;
+  }
+  const unsigned long long want = e * 4096ull + (unsigned long long)j;
+  const long long t0 = (long long)wall_clock64();     // the 100 MHz constant clock
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    __builtin_amdgcn_s_sleep(16);
+    if ((long long)wall_clock64() - t0 > timeout_ticks) {
+      atomicAdd(err, 1u);
+      break;
+    }
+  }
+}
+}  // namespace
+extern "C" int dv3_flag_signal(uint64_t* flag, uint64_t* epoch, int32_t j, int32_t bump, void* stream) {
+  DV3_REQUIRE(flag && epoch && j > 0 && j < 4096, "flag_signal: bad arguments");
+  hipLaunchKernelGGL(flag_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)flag,
+                     (unsigned long long*)epoch, (int)j, (int)bump);
+  return dv3_check_launch("flag_signal");
+}
+extern "C" int dv3_flag_wait(const uint64_t* flag, uint64_t* epoch, int32_t j, int32_t bump, uint32_t* err,
+                             int32_t timeout_ms, void* stream) {
+  DV3_REQUIRE(flag && epoch && err && j > 0 && j < 4096 && timeout_ms > 0, "flag_wait: bad arguments");
+  hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned long long*)flag,
+                     (unsigned long long*)epoch, (int)j, (int)bump, (unsigned*)err, (long long)timeout_ms * 100000ll);
+  return dv3_check_launch("flag_wait");
+}
 extern "C" int dv3_graph_launch(void* exec, void* stream) {
   DV3_REQUIRE(exec, "graph_launch: null graph");
   hipError_t e = hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)stream);

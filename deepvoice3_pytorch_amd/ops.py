@@ -100,6 +100,7 @@ def _stream():
     return _raw_stream(_cur_device())
 
 
+reserved_stream_handles = set()      # raw handles new_stream() must not hand out again (capture streams)
 stream_probe_log = []      # one record per concurrent_stream() call: bench.py prints them as `stream_queues`
 _hip_rt = None
 
@@ -111,7 +112,15 @@ def new_stream(priority="normal"):
     backward: profiles/r05_step_timeline.txt -- the input-gradient chain on the step stream is the critical path, the
     weight-gradient queue is 68-84 % busy).  Never destroyed (a handful per process)."""
     if priority != "low":
-        return torch.cuda.Stream()
+        # torch hands its 32 pool streams out round robin: after enough calls (every probe of concurrent_stream takes up
+        # to a dozen) the pool comes back to a handle this process has set aside -- the capture stream of
+        # train_step._capture_stream: a trainer whose second backward stream IS the capture stream cannot be captured
+        # ("operation cannot be performed in the present state")
+        for _ in range(40):
+            s = torch.cuda.Stream()
+            if s.cuda_stream not in reserved_stream_handles:
+                return s
+        return s
     import ctypes
     global _hip_rt
     if _hip_rt is None:

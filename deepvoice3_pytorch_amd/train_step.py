@@ -546,7 +546,7 @@ Please set a larger value for ``max_position`` in hyper parameters.""".format(ma
 _CAPTURE_STREAMS = {}
 
 
-def _capture_stream(device):
+def _capture_stream(device, avoid=()):
     """ONE capture stream per device for every GraphedTrainer of the process: ops._sk_ws keeps a permanent
     67 MB stream-K workspace per (device, stream) -- a fresh torch.cuda.Stream() per capture cycled through torch's 32
     pool streams and pinned up to 2 GB, and a pool handle shared with an unrelated eager user would have shared the
@@ -554,8 +554,14 @@ def _capture_stream(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     st = _CAPTURE_STREAMS.get(key)
     if st is None:
+        taken = set(a.cuda_stream for a in avoid if a is not None)     # (the first capture's trainer already has its streams)
         with torch.cuda.device(key):
-            st = _CAPTURE_STREAMS[key] = torch.cuda.Stream()
+            for _ in range(40):
+                st = ops.new_stream()
+                if st.cuda_stream not in taken:
+                    break
+        _CAPTURE_STREAMS[key] = st
+        ops.reserved_stream_handles.add(st.cuda_stream)      # no later side / prefetch / collective stream gets this handle
     return st
 
 
@@ -614,10 +620,25 @@ class GraphedTrainer(object):
         self.tail_fine = int(os.environ.get("DV3_SPLIT_TAIL", "6"))     # the last N fork points end a segment each (0 = off)
         self.head_fine = int(os.environ.get("DV3_SPLIT_HEAD", "0"))     # ... and the first N (0 = off)
         self.n_forks = 0
+        # ABI 43 (round 6, last part): backward as ONE graph per stream, its fork points ordered by a device flag
+        # (include/dv3hip.h: dv3_flag_signal / dv3_flag_wait) instead of segment boundaries.  Not under a process group:
+        # the host-issued collectives of the segmented form need the segments.  DV3_FLAG_SYNC=0: the segments.
+        # By rule (profiles/r06i_flag_sync.txt): it wins where the segment boundaries are a visible share of the step --
+        # fp32 activations below batch 48 (deepvoice3_ljspeech B = 16: -1.1 ... -1.8 %) -- is even at B = 64 (the boundaries'
+        # 0.23 ms against 44 signal kernels on the critical queue) and LOSES with channel-blocked bf16 activations
+        # (+2.4 ... +3.6 %: 58 signal kernels of ~3 us each on a 9 ms step's critical queue, and weight gradients that start
+        # the moment their operands exist take compute units from the input-gradient chain).  DV3_FLAG_SYNC=1 / 0 force it.
+        fs = os.environ.get("DV3_FLAG_SYNC", "rule")
+        small = int(static_batch.mel.size(0)) < 48
+        self.flag_sync = (self.split and trainer.comm is None and
+                          (fs == "1" or (fs not in ("0", "") and small and not ops.storage_c8())))
+        self._flag = torch.zeros(4, dtype=torch.int64, device=dev) if self.flag_sync else None   # flag, epochs, err
+        self._flag_checked = False
+        self.flag_lag = int(os.environ.get("DV3_FLAG_LAG", "0"))
         self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
         self._prev_offset = ops.dropout_state.dev_offset        # restored by close()
         ops.dropout_state.dev_offset = self.seed_offset
-        s = _capture_stream(dev)           # (the warm-up steps' stream-K launches take their workspace per stream too)
+        s = _capture_stream(dev, avoid=(trainer.side_stream, torch.cuda.current_stream()))   # (the warm-up steps' stream-K launches take their workspace per stream too)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):      # real optimisation steps (lr / bias corrections set first)
@@ -707,6 +728,28 @@ class GraphedTrainer(object):
             self.segs.append((g, ex if (ex.value and n.value > 0) else None))
             self.seg_buckets.append(t.comm.take_completed() if t.comm is not None else [])
 
+        flag = self._flag
+        timeout_ms = int(os.environ.get("DV3_FLAG_TIMEOUT_MS", "2000"))
+
+        def on_fork_flag():
+            # the first fork point ends the graph of zero_grad + forward + losses (the replay orders the side graph after
+            # it with an ordinary event, so the side stream does not sit in a wait kernel for the whole forward); from
+            # there on both captures run to the end of backward, tied at every fork point by the flag
+            st["forks"] += 1
+            j = st["forks"]
+            if j == 1:
+                end_seg()
+                begin_seg()
+            if j >= 4096:
+                raise RuntimeError("GraphedTrainer(flag_sync): more than 4095 fork points in a step")
+            p = flag.data_ptr()
+            _lib.call("dv3_flag_signal", p, p + 8, j, int(j == 1), SS.main.cuda_stream)
+            # the weight gradient of fork point j starts when the step stream has reached fork point j + lag: the
+            # input-gradient chain is the critical path, and weight gradients that start the moment their operands exist
+            # take compute units from it (the segments' lag of one segment, without their boundaries)
+            jw = min(j + self.flag_lag, self.n_forks) if self.n_forks >= j else j
+            _lib.call("dv3_flag_wait", p, p + 16, jw, int(j == 1), p + 24, timeout_ms, side_raw)
+
         def on_fork():
             st["forks"] += 1
             # data parallel (round 6): a bucket that became complete inside this segment ends it -- its all-reduce is
@@ -733,7 +776,7 @@ class GraphedTrainer(object):
         cap = _capture_stream(self.t.device)
         ops.prepare_streamk_ws(t.device, cap)       # the captured stream-K launches' workspace: not from the graphs' pool
         cap.wait_stream(torch.cuda.current_stream())
-        SS.split_capture, SS.split_on_fork = True, on_fork
+        SS.split_capture, SS.split_on_fork = True, (on_fork_flag if self.flag_sync else on_fork)
         try:
             with torch.cuda.stream(cap):
                 begin_seg()
@@ -828,7 +871,13 @@ class GraphedTrainer(object):
             comm = self.t.comm
             if self._mask_tables is not None:
                 cur.wait_event(self._mask_event)            # this step's masks (drawn beside the previous step's tail)
-            for j, ((g, ex), ev) in enumerate(zip(self.segs, self._seg_events)):
+            segs = self.segs
+            if self.flag_sync:
+                # [forward graph] -> event -> the side stream; then [backward graph] on the step stream and [the
+                # weight-gradient graph] on the side stream side by side, ordered at every fork point by the device flag
+                # (the segments before the last one -- the forward -- go through the loop below as always)
+                segs = self.segs[:-1]
+            for j, ((g, ex), ev) in enumerate(zip(segs, self._seg_events)):
                 g.replay()
                 if ex is not None:        # side segment j reads what step segment j wrote: an ordinary event orders them
                     ev.record(cur)
@@ -836,6 +885,14 @@ class GraphedTrainer(object):
                     _lib.call("dv3_graph_launch", ex, side_raw)
                 if comm is not None and self.seg_buckets[j]:
                     comm.launch_after(self.seg_buckets[j], (cur, side))
+            if self.flag_sync:
+                g, ex = self.segs[-1]
+                ev = self._seg_events[-1]
+                ev.record(cur)                 # the end of the forward graph(s)
+                side.wait_event(ev)
+                g.replay()
+                if ex is not None:
+                    _lib.call("dv3_graph_launch", ex, side_raw)
             self._join_event.record(side)
             cur.wait_event(self._join_event)
             if comm is not None:
@@ -853,7 +910,21 @@ class GraphedTrainer(object):
             self.graph2.replay()
         ops.bump_param_epoch()           # the replayed clip/Adam wrote the parameters
         self.t.global_step += 1
+        if self.flag_sync and not self._flag_checked:
+            # once, after the first replay: a wait that gave up means the two streams share a hardware queue (or a signal
+            # was lost) -- the step then ran with its weight gradients out of order
+            self._flag_checked = True
+            n = self.flag_timeouts()
+            if n:
+                raise RuntimeError("GraphedTrainer(flag_sync): %d fork-point waits timed out in the first replay -- the two "
+                                   "backward streams do not run side by side here; set DV3_FLAG_SYNC=0" % n)
         return self.scal
+
+    def flag_timeouts(self):
+        """fork-point waits of the replayed steps that gave up (host sync); 0 in a healthy run"""
+        if self._flag is None:
+            return 0
+        return int(self._flag[3].item()) & 0xFFFFFFFF
 
     def check_range(self):
         """The f16x3 range guard for replayed steps.  A captured graph cannot change its GEMM mode and its clip / Adam

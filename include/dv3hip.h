@@ -30,7 +30,7 @@ extern "C" {
 #define DV3_ELAUNCH (-2)  /* hipLaunch / runtime error        */
 
 /* ABI version, bumped on any struct change; checked by the Python loader. */
-#define DV3_ABI_VERSION 42
+#define DV3_ABI_VERSION 43
 int dv3_abi_version(void);
 const char* dv3_last_error(void);
 /* Fills name (<=255 chars) of device `dev`, number of CUs; returns 0/err. */
@@ -275,6 +275,26 @@ int dv3_graph_side_begin(void* side_stream);
 int dv3_graph_side_end(void* side_stream, void** exec_out, int32_t* n_nodes_out);
 int dv3_graph_launch(void* exec, void* stream);
 int dv3_graph_destroy(void* exec);
+
+/* ABI 43: the two branches of a captured backward ordered by a DEVICE flag instead of segment boundaries.  With the
+ * segments above every fork-point dependency costs two graph launches and an event pair, the step queue idles 15-40 us at
+ * every boundary and side segment j cannot start before step segment j has run to its END.  Here backward is ONE graph
+ * per stream: at fork point j the step stream's capture holds a one-thread kernel that publishes (epoch, j) in `flag`, the
+ * side stream's capture a one-thread kernel that waits until the flag has reached (epoch, j) -- the weight gradient of a
+ * layer starts when its operands exist, whatever else the step stream still has to do.
+ *   flag   device uint64, zero before the first use; value = epoch * 4096 + j, monotonic over the steps
+ *   epoch  device uint64 OWNED BY THE STREAM that launches the kernel (one for the step stream, one for the side stream),
+ *          zero before the first use; `bump` != 0 (the first fork point of a step) increments it first -- both graphs are
+ *          replayed once per step, so the two epochs agree
+ *   j      fork point of the step, 1 .. 4095
+ *   err    device uint32 counting waits that gave up after `timeout_ms` (a lost signal must not hang the GPU); the host
+ *          reads it when it reads the step's scalars
+ * Release / acquire at agent scope: what the step stream wrote before the signal is visible to the side stream's kernels
+ * after the wait (kernel boundaries write back and invalidate as they always do).  The two streams must run on different
+ * hardware queues (ops.concurrent_stream probes for that).  Replaces: nothing in the reference. */
+int dv3_flag_signal(uint64_t* flag, uint64_t* epoch, int32_t j, int32_t bump, void* stream);
+int dv3_flag_wait(const uint64_t* flag, uint64_t* epoch, int32_t j, int32_t bump, uint32_t* err, int32_t timeout_ms,
+                  void* stream);
 
 #define DV3_SPLIT_DTYPE_BF16 0
 #define DV3_SPLIT_DTYPE_F16 1

@@ -739,7 +739,8 @@ def test_archived_bench_line_meets_the_contract():
     assert cb["kind"] in ("reference", "port")
     assert abs(d["value"] - d["config"]["global_batch"] * 800 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
     # round 3: the host's issue time and the launch-mode probe are reported for the headline and for every side config
-    flat = ("synth_rtf", "ddp_world1", "dv3lj_b64_ragged_epoch", "ddp_standin")
+    flat = ("synth_rtf", "ddp_world1", "dv3lj_b64_ragged_epoch", "ddp_standin", "dv3lj_b64_ragged_epoch_lattice",
+            "dv3lj_b16_ragged_epoch_lattice")
     for cfg in [d["config"]] + [c["config"] for k, c in d["configs"].items() if k not in flat]:
         assert cfg["host_enqueue_ms_per_step"] > 0 and "hipgraph" in cfg and "launch_bound" in cfg
         assert cfg["launch_probe"] is None or {"eager_ms_per_step", "hipgraph_ms_per_step"} <= set(cfg["launch_probe"])
@@ -753,6 +754,11 @@ def test_archived_bench_line_meets_the_contract():
     ep = d["configs"].get("dv3lj_b64_ragged_epoch")
     if ep is not None:
         assert ep["value"] > 0 and ep["hipgraph"] is False and ep["real_frames"] > 0 and ep["host_enqueue_ms_per_step"] > 0
+    # round 6: the same epoch replayed from captured steps of a lattice of padded shapes (train_step.LatticeReplay)
+    for k in ("dv3lj_b64_ragged_epoch_lattice", "dv3lj_b16_ragged_epoch_lattice"):
+        lt = d["configs"].get(k)
+        if lt is not None and "value" in lt:
+            assert lt["value"] > 0 and lt["hipgraph"] is True and lt["host_enqueue_ms_per_step"] > 0
     # round 6: the data-parallel step beside a ring stand-in (dist.RingStandin): step inflation, exposed wait, the bucket
     # schedule and the weak-scaling efficiency they predict, for the three presets and the preset's own batch
     sd = d["configs"].get("ddp_standin")

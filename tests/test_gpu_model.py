@@ -474,12 +474,29 @@ def test_split_stream_graph_replay_is_bit_identical(dev, gemm_mode, B, Tt, frame
             finally:
                 ops.dropout_state.dev_offset = prev
         else:
-            g = train_step.GraphedTrainer(tr, batch, warmup=warm, split_streams=(kind == "split"))
-            assert g.split == (kind == "split")
+            # "split": backward as one graph per stream, fork points ordered by the device flag (ABI 43, the default);
+            # "segments": the chain of segment graphs ordered by host-issued events (DV3_FLAG_SYNC=0; what a process
+            # group still replays)
+            prev_env = os.environ.get("DV3_FLAG_SYNC")
+            os.environ["DV3_FLAG_SYNC"] = "0" if kind == "segments" else "1"
+            try:
+                g = train_step.GraphedTrainer(tr, batch, warmup=warm, split_streams=(kind != "single"))
+            finally:
+                if prev_env is None:
+                    del os.environ["DV3_FLAG_SYNC"]
+                else:
+                    os.environ["DV3_FLAG_SYNC"] = prev_env
+            assert g.split == (kind != "single")
+            assert g.flag_sync == (kind == "split")
             if kind == "split":
+                assert len(g.segs) == 2 and g.segs[-1][1] is not None       # forward | backward + its weight-gradient graph
+            elif kind == "segments":
+                assert len(g.segs) > 2
+            if kind != "single":
                 assert (g._mask_tables is not None) == (warm >= 2)
             for _ in range(steps - 1):
                 norms.append(float(g.step()["grad_norm"]))
+            assert g.flag_timeouts() == 0
             g.close()
         torch.cuda.synchronize()
         w = tr.arena.flat.detach().cpu().clone()
@@ -490,6 +507,9 @@ def test_split_stream_graph_replay_is_bit_identical(dev, gemm_mode, B, Tt, frame
     assert all(math.isfinite(x) for x in n1 + n3), (n1, n3)
     assert n1 == n3, (n1, n3)
     assert torch.equal(w1, w3), float((w1 - w3).abs().max())
+    w4, n4 = run("segments")
+    assert n4 == n3, (n4, n3)
+    assert torch.equal(w4, w3), float((w4 - w3).abs().max())
     we, ne = run("eager")
     assert torch.equal(we, w3), (float((we - w3).abs().max()), ne, n3)
 
