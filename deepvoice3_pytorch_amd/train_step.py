@@ -220,11 +220,16 @@ class Trainer(object):
         # second stream for the weight-gradient branch of backward (ops.SideStream); DV3_WGRAD_STREAM=0 keeps one stream
         # (a stream that shares no hardware queue with the step stream: ops.concurrent_stream)
         self.side_stream = None
+        self.side_stream_beside = False
         if dev.type == "cuda" and os.environ.get("DV3_WGRAD_STREAM", "1") not in ("0", ""):
             with torch.cuda.device(dev):
                 # DV3_SIDE_PRIORITY=low: the weight-gradient stream at the device's least stream priority (ops.new_stream)
                 self.side_stream = ops.concurrent_stream([torch.cuda.current_stream()], role="weight-gradient",
                                                          priority=os.environ.get("DV3_SIDE_PRIORITY", "normal"))
+                # did the probe SEE this stream run beside the step stream?  (GraphedTrainer.flag_sync needs that: a wait
+                # kernel on a queue it shares with its signal would sit out its time-out)
+                rec = ops.stream_probe_log[-1] if ops.stream_probe_log else {}
+                self.side_stream_beside = bool(rec.get("probed") and rec.get("found"))
         self.pg = process_group
         self.world = 1
         self.comm = None
@@ -631,10 +636,14 @@ class GraphedTrainer(object):
         fs = os.environ.get("DV3_FLAG_SYNC", "rule")
         small = int(static_batch.mel.size(0)) < 48
         self.flag_sync = (self.split and trainer.comm is None and
-                          (fs == "1" or (fs not in ("0", "") and small and not ops.storage_c8())))
+                          (fs == "1" or (fs not in ("0", "") and small and not ops.storage_c8() and
+                                         getattr(trainer, "side_stream_beside", False))))
         self._flag = torch.zeros(4, dtype=torch.int64, device=dev) if self.flag_sync else None   # flag, epochs, err
         self._flag_checked = False
         self.flag_lag = int(os.environ.get("DV3_FLAG_LAG", "0"))
+        # a signal kernel at every k-th fork point only (profiles/r06i_flag_sync.txt: k = 2 brings the bf16 presets to parity
+        # and B = 64 to -0.5 %, at -1.3 % instead of -1.8 % for B = 16, which is what the rule serves: k = 1)
+        self.flag_every = int(os.environ.get("DV3_FLAG_EVERY", "1"))
         self.seed_offset = torch.zeros(1, dtype=torch.int64, device=dev)
         self._prev_offset = ops.dropout_state.dev_offset        # restored by close()
         ops.dropout_state.dev_offset = self.seed_offset
@@ -743,6 +752,15 @@ class GraphedTrainer(object):
             if j >= 4096:
                 raise RuntimeError("GraphedTrainer(flag_sync): more than 4095 fork points in a step")
             p = flag.data_ptr()
+            k = self.flag_every
+            if k > 1 and self.n_forks >= j:
+                # a signal at every k-th fork point only (and at the first and the last): fewer one-thread kernels on the
+                # critical queue; a weight gradient then waits for the next signal at or after its own fork point
+                if j == 1 or j % k == 0 or j == self.n_forks:
+                    _lib.call("dv3_flag_signal", p, p + 8, j, int(j == 1), SS.main.cuda_stream)
+                jw = j if j == 1 else min(-(-j // k) * k, self.n_forks)
+                _lib.call("dv3_flag_wait", p, p + 16, jw, int(j == 1), p + 24, timeout_ms, side_raw)
+                return
             _lib.call("dv3_flag_signal", p, p + 8, j, int(j == 1), SS.main.cuda_stream)
             # the weight gradient of fork point j starts when the step stream has reached fork point j + lag: the
             # input-gradient chain is the critical path, and weight gradients that start the moment their operands exist
