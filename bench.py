@@ -689,6 +689,36 @@ class TrainRun(object):
                 torch.cuda.synchronize()
                 torch.cuda.empty_cache()
 
+        # The flag-ordered backward (train_step.GraphedTrainer.flag_sync, ABI 43) is opt-in in the library; where its rule
+        # applies (fp32 activations below batch 48, no process group, a second stream seen beside the step stream) it is
+        # probed here against the segments the same way, and kept only when it is the faster form IN THIS PROCESS.
+        if (self.use_graph and self.runner is not None and getattr(self.runner, "split", False) and pg is None
+                and os.environ.get("DV3_FLAG_SYNC") is None and int(self.batch.mel.size(0)) < 48
+                and not ops.storage_c8() and getattr(self.trainer, "side_stream_beside", False)):
+            t_seg = self._probe(4)
+            seg_runner = self.runner
+            seg_runner.close()
+            self.runner = None
+            os.environ["DV3_FLAG_SYNC"] = "1"
+            try:
+                self.runner = train_step.GraphedTrainer(self.trainer, self.batch, warmup=2)
+                t_flag = self._probe(4)
+                bad = self.runner.flag_timeouts()
+            except Exception as e:
+                t_flag, bad = float("inf"), -1
+                if rank == 0:
+                    print("flag-ordered capture failed (%s: %s); keeping the segments" % (type(e).__name__, e), file=sys.stderr)
+            finally:
+                del os.environ["DV3_FLAG_SYNC"]
+            if self.launch_probe is None:      # (--graph: no eager probe was run)
+                self.launch_probe = dict(eager_ms_per_step=None, hipgraph_ms_per_step=round(t_seg, 3), steps=4)
+            self.launch_probe.update(segments_ms_per_step=round(t_seg, 3),
+                                     flag_ordered_ms_per_step=(round(t_flag, 3) if math.isfinite(t_flag) else None))
+            if not (t_flag < 0.995 * t_seg and bad == 0):
+                if self.runner is not None:
+                    self.runner.close()
+                self.runner = train_step.GraphedTrainer(self.trainer, self.batch, warmup=2)
+
     def graph_form(self):
         if not self.use_graph or self.runner is None:
             return None

@@ -632,8 +632,12 @@ class GraphedTrainer(object):
         # fp32 activations below batch 48 (deepvoice3_ljspeech B = 16: -1.1 ... -1.8 %) -- is even at B = 64 (the boundaries'
         # 0.23 ms against 44 signal kernels on the critical queue) and LOSES with channel-blocked bf16 activations
         # (+2.4 ... +3.6 %: 58 signal kernels of ~3 us each on a 9 ms step's critical queue, and weight gradients that start
-        # the moment their operands exist take compute units from the input-gradient chain).  DV3_FLAG_SYNC=1 / 0 force it.
-        fs = os.environ.get("DV3_FLAG_SYNC", "rule")
+        # the moment their operands exist take compute units from the input-gradient chain).
+        # OPT-IN (DV3_FLAG_SYNC=rule: by that rule; =1: always; default 0: the segments): HIP maps streams to hardware
+        # queues dynamically, and one bench process showed a replay of this form at 11 ms against 6.2 ms -- two graphs whose
+        # streams share a queue run one after the other, where the segments only lose their overlap.  bench.py probes it per
+        # configuration (like eager against the replay) and keeps it where it is the faster form in that process.
+        fs = os.environ.get("DV3_FLAG_SYNC", "0")
         small = int(static_batch.mel.size(0)) < 48
         self.flag_sync = (self.split and trainer.comm is None and
                           (fs == "1" or (fs not in ("0", "") and small and not ops.storage_c8() and
